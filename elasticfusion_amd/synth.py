@@ -1,0 +1,128 @@
+"""Synthetic RGB-D sequences with analytic geometry and scripted SE(3) motion.
+
+Scene: interior of a 4 x 2.5 x 3 m box with three spheres, closed-form ray casting => exact depth.
+Depth is ``round(1000 z)`` uint16 mm, kept only inside the accepted 300..3000 mm band (0 = invalid,
+depth_bilateral.frag:34 / MainController.cpp:70).  Colour is a world-anchored procedural albedo
+(sinusoid mixture + value noise, period ~8-40 px) with no zero bytes (0 means "invalid" to the
+tracker, reduce.cu:647,679).  Trajectory: smooth Lissajous, <= 8 mm and <= 0.4 deg per frame.
+
+This module only *generates inputs* (it is what a .klg replay would feed processFrame); it is not a
+checker and does not touch oracle/.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+DEFAULT_INTRINSICS = dict(width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0)  # MainController.cpp:37-43
+
+
+def _rot_xyz(rx: float, ry: float, rz: float) -> np.ndarray:
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+class Sequence:
+    """Frames k = 0.. of one synthetic sequence.  ``seed`` 0xEF0001..0xEF0008 select the 8 bench sequences."""
+
+    def __init__(self, seed: int = 0xEF0001, width: int = 640, height: int = 480, fx: float | None = None,
+                 fy: float | None = None, cx: float | None = None, cy: float | None = None, noise: bool = False,
+                 speed: float = 1.0):
+        s = width / 640.0
+        self.width, self.height = width, height
+        self.fx = 528.0 * s if fx is None else fx
+        self.fy = 528.0 * s if fy is None else fy
+        self.cx = 320.0 * s if cx is None else cx
+        self.cy = 240.0 * s if cy is None else cy
+        self.noise = noise
+        self.speed = speed
+        rng = np.random.RandomState(seed & 0x7FFFFFFF)
+        self._phase = rng.uniform(0, 2 * np.pi, size=6)
+        self._amp_t = np.array([0.25, 0.10, 0.18]) * rng.uniform(0.8, 1.0, size=3)
+        self._amp_r = np.array([0.12, 0.30, 0.08]) * rng.uniform(0.8, 1.0, size=3)
+        self._per = np.array([400.0, 300.0, 500.0, 350.0, 450.0, 600.0]) * rng.uniform(0.9, 1.1, size=6)
+        self._noise_rng = np.random.RandomState(0xEF5107)
+        # box half extents (x, y, z) and spheres (centre, radius), world frame = camera frame at k = 0
+        self.box = np.array([2.0, 1.25, 1.5])
+        self.spheres = [(np.array([-0.7, 0.45, 1.0]), 0.35), (np.array([0.6, 0.6, 0.9]), 0.30),
+                        (np.array([0.1, -0.35, 1.15]), 0.25)]
+        v, u = np.mgrid[0:height, 0:width]
+        self._dirs = np.stack([(u - self.cx) / self.fx, (v - self.cy) / self.fy, np.ones_like(u, dtype=np.float64)], -1)
+        self._T0_inv = np.linalg.inv(self._abs_pose(0))
+        # value-noise lattice
+        self._lattice = rng.uniform(-1, 1, size=(32, 32, 32, 3))
+
+    # -- trajectory -------------------------------------------------------------------------------
+    def _abs_pose(self, k: int) -> np.ndarray:
+        kk = k * self.speed
+        a = 2 * np.pi * kk / self._per + self._phase
+        t = self._amp_t * np.sin(a[:3])
+        r = self._amp_r * np.sin(a[3:])
+        T = np.eye(4)
+        T[:3, :3] = _rot_xyz(*r)
+        T[:3, 3] = t
+        return T
+
+    def pose(self, k: int) -> np.ndarray:
+        """Ground-truth T_wc of frame k with the world frame = camera frame of frame 0 (4x4 float64)."""
+        return self._T0_inv @ self._abs_pose(k)
+
+    # -- rendering --------------------------------------------------------------------------------
+    def _albedo(self, p: np.ndarray) -> np.ndarray:
+        x, y, z = p[..., 0], p[..., 1], p[..., 2]
+        out = np.empty(p.shape[:-1] + (3,), dtype=np.float64)
+        # angular frequencies in rad/m: spatial periods ~3-12 cm == ~10-40 px at 1.5 m (1 px ~ 2.8 mm)
+        freqs = [((55.1, 23.7, 31.3), (97.3, -61.1, 44.9), (-46.7, 123.1, 72.3)),
+                 ((47.7, 58.9, -34.1), (-83.9, 45.1, 109.7), (135.3, 47.3, -59.1)),
+                 ((35.9, -46.1, 59.7), (111.1, 84.3, -56.3), (-58.3, -97.9, 85.1))]
+        # trilinear value noise on a 4 cm lattice
+        q = p / 0.04
+        q0 = np.floor(q).astype(np.int64)
+        f = q - q0
+        f = f * f * (3 - 2 * f)
+        L = self._lattice
+
+        def lat(dx, dy, dz):
+            return L[(q0[..., 0] + dx) % 32, (q0[..., 1] + dy) % 32, (q0[..., 2] + dz) % 32]
+
+        fx, fy, fz = f[..., 0:1], f[..., 1:2], f[..., 2:3]
+        n = (((lat(0, 0, 0) * (1 - fx) + lat(1, 0, 0) * fx) * (1 - fy) + (lat(0, 1, 0) * (1 - fx) + lat(1, 1, 0) * fx) * fy) * (1 - fz)
+             + ((lat(0, 0, 1) * (1 - fx) + lat(1, 0, 1) * fx) * (1 - fy) + (lat(0, 1, 1) * (1 - fx) + lat(1, 1, 1) * fx) * fy) * fz)
+        for c in range(3):
+            acc = 0.0
+            for (a, b, d), wgt in zip(freqs[c], (38.0, 26.0, 18.0)):
+                acc = acc + wgt * np.sin(a * x + b * y + d * z + c)
+            out[..., c] = 128.0 + acc + 30.0 * n[..., c]
+        return np.clip(np.rint(out), 1, 255).astype(np.uint8)
+
+    def frame(self, k: int):
+        """Returns (rgb uint8 [H,W,3], depth uint16 [H,W] in mm, T_wc 4x4) for frame k."""
+        T = self._abs_pose(k)
+        R, o = T[:3, :3], T[:3, 3]
+        d = self._dirs @ R.T  # world ray directions; parameter t == camera-space z
+        # box (we are inside): per axis the exit plane
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tb = np.where(d > 0, (self.box - o) / d, (-self.box - o) / d)
+        tb = np.where(np.isfinite(tb), tb, np.inf)
+        t = tb.min(-1)
+        for c, r in self.spheres:
+            oc = o - c
+            a = (d * d).sum(-1)
+            b = 2 * (d @ oc)
+            cc = oc @ oc - r * r
+            disc = b * b - 4 * a * cc
+            ok = disc > 0
+            sq = np.sqrt(np.where(ok, disc, 0))
+            ts = (-b - sq) / (2 * a)
+            ts = np.where(ok & (ts > 1e-6), ts, np.inf)
+            t = np.minimum(t, ts)
+        p = o + d * t[..., None]
+        rgb = self._albedo(p)
+        z = t.copy()
+        if self.noise:
+            z = z + self._noise_rng.normal(0, 1.0, size=z.shape) * 0.0012 * z * z
+        mm = np.rint(1000.0 * z)
+        depth = np.where((mm >= 300) & (mm <= 3000), mm, 0).astype(np.uint16)
+        return rgb, depth, self.pose(k)

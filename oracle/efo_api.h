@@ -1,0 +1,118 @@
+/* TEST INFRASTRUCTURE — CPU oracle C API (host pointers only). See oracle/README.md.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library. */
+#ifndef EFO_API_H_
+#define EFO_API_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- tracking operators (Core/Cuda/cudafuncs.cu, reduce.cu) ---- */
+void efo_pyr_down_u16(const uint16_t* src, int scols, int srows, uint16_t* dst);
+void efo_create_vmap(const uint16_t* depth, int cols, int rows, float fx, float fy, float cx, float cy,
+                     float depthCutoff, float* vmap);
+void efo_create_nmap(const float* vmap, int cols, int rows, float* nmap);
+void efo_transform_maps(float* vmap, float* nmap, int cols, int rows, const float* R9, const float* t3);
+void efo_copy_maps(const float* vtex, const float* ntex, int cols, int rows, float* vmaps_tmp, float* vmap, float* nmap);
+void efo_resize_map(const float* in, int scols, int srows, float* out, int normalize);
+void efo_pyr_down_gauss_f(const float* src, int scols, int srows, float* dst);
+void efo_pyr_down_uchar_gauss(const uint8_t* src, int scols, int srows, uint8_t* dst);
+void efo_vertices_to_depth(const float* vmaps_tmp, int cols, int rows, float cutOff, float* dst);
+void efo_bgr_to_intensity(const uint8_t* rgba, int cols, int rows, uint8_t* dst);
+void efo_derivative_images(const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy);
+void efo_project_to_point_cloud(const float* depth, int cols, int rows, float fx, float fy, float cx, float cy, float* cloud);
+void efo_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr, const float* nmap_curr,
+                  const float* Rprev_inv, const float* tprev, float fx, float fy, float cx, float cy,
+                  const float* vmap_g_prev, const float* nmap_g_prev, float distThres, float angleThres, int cols,
+                  int rows, float* A36, float* b6, float* residual2);
+void efo_rgb_residual(float minScale, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
+                      const float* nextDepth, const uint8_t* lastImage, const uint8_t* nextImage, void* corres_out,
+                      float maxDepthDelta, const float* kt3, const float* krkinv9, int cols, int rows, int* sigmaSum,
+                      int* count);
+void efo_rgb_step(const void* corres_in, float sigma, const float* cloud, float fx, float fy, const int16_t* dIdx,
+                  const int16_t* dIdy, float sobelScale, int cols, int rows, float* A36, float* b6);
+void efo_so3_step(const uint8_t* lastImage, const uint8_t* nextImage, const float* imageBasis9, const float* kinv9,
+                  const float* krlr9, int cols, int rows, float* A9, float* b3, float* residual2);
+
+/* ---- tracking driver (Core/Utils/RGBDOdometry.cpp) ---- */
+typedef struct efo_odometry efo_odometry;
+efo_odometry* efo_odom_create(int w, int h, float cx, float cy, float fx, float fy);
+void efo_odom_destroy(efo_odometry*);
+void efo_odom_init_icp(efo_odometry*, const uint16_t* filteredDepth, float depthCutoff);
+void efo_odom_init_icp_model(efo_odometry*, const float* vtex, const float* ntex, const double* T_wc16);
+void efo_odom_init_rgb_model(efo_odometry*, const uint8_t* rgba);
+void efo_odom_init_rgb(efo_odometry*, const uint8_t* rgba);
+void efo_odom_init_first_rgb(efo_odometry*, const uint8_t* rgba);
+void efo_odom_track(efo_odometry*, double* T_wc16, int rgbOnly, float icpWeight, int pyramid, int fastOdom, int so3);
+void efo_odom_stats(const efo_odometry*, float* out6, double* lastA36, double* lastb6);
+const void* efo_odom_buffer(const efo_odometry*, int which, int level);
+
+/* ---- small linear algebra (Eigen / Sophus restatement) for known-answer tests ---- */
+void efo_ldlt6(const double* A36, const double* b6, double* x6);
+void efo_ldlt3f(const float* A9, const float* b3, float* x3);
+void efo_polar3(const double* A9, double* R9);
+void efo_rodrigues(const double* v3, double* R9);
+void efo_se3_inverse(const double* T16, double* out16);
+double efo_se3_log_norm(const double* T16, double* out6);
+float efo_expf_spec(float x);
+
+/* ---- pre-processing + surfel map (Core/Shaders GLSL passes, IndexMap.cpp, GlobalModel.cpp) ---- */
+void efo_filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered);
+void efo_metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out);
+
+typedef struct efo_cam { int cols, rows; float fx, fy, cx, cy; } efo_cam;
+
+/* surfels are the reference's 3 x vec4 = 12 floats: {x,y,z,conf} {colour,0,initTime,lastTime} {nx,ny,nz,radius} */
+int efo_seed_map(const efo_cam* cam, const uint8_t* rgb, const float* depthMetric, const float* depthMetricFiltered,
+                 int time, float maxDepth, float* surfels_out /* cols*rows*12 */);
+void efo_predict_indices(const efo_cam* cam, const double* T_wc16, int time, const float* surfels, int count,
+                         float maxDepth, int timeDelta, uint32_t* indexMap, float* vertConf, float* colorTime,
+                         float* normRad);
+void efo_combined_predict(const efo_cam* cam, const double* T_wc16, const float* surfels, int count, float maxDepth,
+                          float confThreshold, int time, int maxTime, int timeDelta, uint8_t* image_rgba,
+                          float* vertex, float* normal, uint16_t* timeMap);
+void efo_fill_in(const efo_cam* cam, const uint8_t* image_rgba, const float* vertex, const float* normal,
+                 const uint16_t* depthFiltered, const uint8_t* rgb, int passthrough, int passthroughImage,
+                 uint8_t* fill_image_rgba, float* fill_vertex, float* fill_normal);
+int efo_dense_enough(const efo_cam* cam, const uint8_t* image_rgba);
+/* fuse data pass + update pass; surfels updated in place; new unstable candidates (tags -1/-2 in colour.w)
+ * written to newUnstable (<= cols*rows*12 floats) in draw (column-major) order; returns their number */
+int efo_fuse(const efo_cam* cam, const double* T_wc16, int time, const uint8_t* rgb, const float* depthMetric,
+             const float* depthMetricFiltered, const uint32_t* indexMap, const float* vertConf,
+             const float* colorTime, const float* normRad, float maxDepth, float weighting, float* surfels,
+             int count, float* newUnstable);
+/* clean: old surfels then newUnstable through copy_unstable.{vert,geom}; returns new count */
+int efo_clean(const efo_cam* cam, const double* T_wc16, int time, const uint32_t* indexMap, const float* vertConf,
+              const float* colorTime, const float* normRad, float confThreshold, int timeDelta, float maxDepth,
+              const float* surfels, int count, const float* newUnstable, int newCount, float* surfels_out);
+
+/* ---- whole-frame orchestration (Core/ElasticFusion.cpp:270-653, open loop) ---- */
+typedef struct efo_fusion efo_fusion;
+typedef struct efo_fusion_params {
+  int width, height;
+  float fx, fy, cx, cy;
+  int timeDelta;
+  float confidence, depthCut, icpWeight;
+  int fastOdom, so3, frameToFrameRGB, pyramid, rgbOnly;
+  int maxSurfels;
+} efo_fusion_params;
+void efo_fusion_default_params(efo_fusion_params*);
+efo_fusion* efo_fusion_create(const efo_fusion_params*);
+void efo_fusion_destroy(efo_fusion*);
+void efo_fusion_process_frame(efo_fusion*, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp,
+                              float weightMultiplier, const double* in_T_wc16_or_null);
+void efo_fusion_get_pose(const efo_fusion*, double* T_wc16);
+int efo_fusion_map_count(const efo_fusion*);
+void efo_fusion_map_download(const efo_fusion*, float* surfels /* count*12 */);
+int efo_fusion_tick(const efo_fusion*);
+void efo_fusion_stats(const efo_fusion*, float* out6);
+/* which: 0 image_rgba(u8x4) 1 vertex(f4) 2 normal(f4) 3 time(u16) 4 fill_image 5 fill_vertex 6 fill_normal
+ * 7 indexMap(u32) 8 vertConf 9 colorTime 10 normRad 11 depthFiltered(u16) 12 depthMetric 13 depthMetricFiltered */
+const void* efo_fusion_buffer(const efo_fusion*, int which);
+efo_odometry* efo_fusion_odometry(efo_fusion*);
+/* tracking-only timing hook for bench.py cpu_baseline: runs initICP/initRGB/track on the current state */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,183 @@
+// TEST INFRASTRUCTURE — CPU oracle. Not part of the product path (see oracle/README.md).
+//
+// CPU restatement of ElasticFusion::processFrame (Core/ElasticFusion.cpp:270-607) and predict()
+// (:621-653) in open-loop mode (closeLoops = false, reloc = false): the loop-closure branches
+// (:391-534), Ferns::addFrame (:601-619) and the deformation-graph sampling (:593-595) have no effect
+// on pose or map in that mode and are omitted.
+#include "efo_common.h"
+#include "efo_linalg.h"
+#include "efo_api.h"
+#include <vector>
+
+using namespace efo;
+
+struct efo_fusion {
+  efo_fusion_params p;
+  efo_cam cam;
+  efo_odometry* frameToModel;
+  int tick = 1;
+  SE3 T_wc = se3_identity();
+  const float maxDepthProcessed = 20.0f;  // ElasticFusion.cpp:83
+  // "textures"
+  std::vector<uint8_t> rgb;              // RGB8 as uploaded
+  std::vector<uint8_t> rgba;             // the GL_RGBA texture contents (alpha 255)
+  std::vector<uint16_t> depthRaw, depthFiltered;
+  std::vector<float> depthMetric, depthMetricFiltered;
+  // IndexMap
+  std::vector<uint32_t> indexMap;
+  std::vector<float> vertConf, colorTime, normRad;
+  std::vector<uint8_t> image;
+  std::vector<float> vertex, normal;
+  std::vector<uint16_t> timeMap;
+  // FillIn
+  std::vector<uint8_t> fimage;
+  std::vector<float> fvertex, fnormal;
+  // GlobalModel
+  std::vector<float> surfels, surfelsTmp, newUnstable;
+  int count = 0;
+  float lastWeighting = 0;
+
+  explicit efo_fusion(const efo_fusion_params& pp) : p(pp) {
+    cam = efo_cam{p.width, p.height, p.fx, p.fy, p.cx, p.cy};
+    frameToModel = efo_odom_create(p.width, p.height, p.cx, p.cy, p.fx, p.fy);
+    size_t P = (size_t)p.width * p.height;
+    rgb.assign(P * 3, 0); rgba.assign(P * 4, 0);
+    depthRaw.assign(P, 0); depthFiltered.assign(P, 0);
+    depthMetric.assign(P, 0.f); depthMetricFiltered.assign(P, 0.f);
+    indexMap.assign(P, 0); vertConf.assign(P * 4, 0.f); colorTime.assign(P * 4, 0.f); normRad.assign(P * 4, 0.f);
+    image.assign(P * 4, 0); vertex.assign(P * 4, 0.f); normal.assign(P * 4, 0.f); timeMap.assign(P, 0);
+    fimage.assign(P * 4, 0); fvertex.assign(P * 4, 0.f); fnormal.assign(P * 4, 0.f);
+    surfels.assign((size_t)p.maxSurfels * 12, 0.f);
+    surfelsTmp.assign((size_t)p.maxSurfels * 12, 0.f);
+    newUnstable.assign(P * 12, 0.f);
+  }
+  ~efo_fusion() { efo_odom_destroy(frameToModel); }
+
+  void pose16(double* M) const { M4d m = se3_matrix(T_wc); std::memcpy(M, m.m, sizeof(m.m)); }
+
+  // ElasticFusion::predict(), ElasticFusion.cpp:621-653 (lost == false)
+  void predict() {
+    double M[16];
+    pose16(M);
+    efo_combined_predict(&cam, M, surfels.data(), count, maxDepthProcessed, p.confidence, tick, tick, p.timeDelta,
+                         image.data(), vertex.data(), normal.data(), timeMap.data());
+    efo_fill_in(&cam, image.data(), vertex.data(), normal.data(), depthFiltered.data(), rgb.data(), 0,
+                p.frameToFrameRGB ? 1 : 0, fimage.data(), fvertex.data(), fnormal.data());
+  }
+
+  void processFrame(const uint8_t* rgb_in, const uint16_t* depth_in, int64_t, float weightMultiplier, const double* in_T_wc) {
+    const size_t P = (size_t)p.width * p.height;
+    std::memcpy(depthRaw.data(), depth_in, P * 2);       // :278-280
+    std::memcpy(rgb.data(), rgb_in, P * 3);
+    for (size_t i = 0; i < P; ++i) { rgba[i * 4] = rgb[i * 3]; rgba[i * 4 + 1] = rgb[i * 3 + 1]; rgba[i * 4 + 2] = rgb[i * 3 + 2]; rgba[i * 4 + 3] = 255; }
+    efo_filter_depth(depthRaw.data(), p.width, p.height, p.depthCut, depthFiltered.data());                 // :284
+    efo_metricise_depth(depthRaw.data(), p.width, p.height, p.depthCut, depthMetric.data());                // :285
+    efo_metricise_depth(depthFiltered.data(), p.width, p.height, p.depthCut, depthMetricFiltered.data());
+
+    if (tick == 1) {  // :290-296
+      count = efo_seed_map(&cam, rgb.data(), depthMetric.data(), depthMetricFiltered.data(), tick, maxDepthProcessed, surfels.data());
+      efo_odom_init_first_rgb(frameToModel, rgba.data());
+    } else {
+      const SE3 T_prev = T_wc;
+      if (!in_T_wc) {
+        bool shouldFillIn = !efo_dense_enough(&cam, image.data());  // :304-305
+        double M[16];
+        pose16(M);
+        efo_odom_init_icp_model(frameToModel, shouldFillIn ? fvertex.data() : vertex.data(),
+                                shouldFillIn ? fnormal.data() : normal.data(), M);                           // :310-313
+        efo_odom_init_rgb_model(frameToModel, (shouldFillIn || p.frameToFrameRGB) ? fimage.data() : image.data());
+        efo_odom_init_icp(frameToModel, depthFiltered.data(), maxDepthProcessed);                            // :317
+        efo_odom_init_rgb(frameToModel, rgba.data());                                                        // :318
+        efo_odom_track(frameToModel, M, p.rgbOnly, p.icpWeight, p.pyramid, p.fastOdom, p.so3);               // :322-323
+        T_wc = se3_from_matrix(M);
+      } else {
+        T_wc = se3_from_matrix(in_T_wc);
+      }
+      // velocity weighting, :369-383
+      SE3 T_curr_prev = se3_mul(se3_inverse(T_wc), T_prev);
+      double tn = std::sqrt(T_curr_prev.t[0] * T_curr_prev.t[0] + T_curr_prev.t[1] * T_curr_prev.t[1] + T_curr_prev.t[2] * T_curr_prev.t[2]);
+      float weighting = (float)std::max(tn, se3_log_norm(T_curr_prev));
+      float largest = 0.01f, minWeight = 0.5f;
+      if (weighting > largest) weighting = largest;
+      weighting = std::max(1.0f - (weighting / largest), minWeight) * weightMultiplier;
+      lastWeighting = weighting;
+
+      predict();  // :387 (result unused when closeLoops == false; kept for fidelity)
+
+      if (!p.rgbOnly) {  // :536-585 (trackingOk && !lost always hold without reloc)
+        double M[16];
+        pose16(M);
+        efo_predict_indices(&cam, M, tick, surfels.data(), count, maxDepthProcessed, p.timeDelta, indexMap.data(),
+                            vertConf.data(), colorTime.data(), normRad.data());
+        int nNew = efo_fuse(&cam, M, tick, rgb.data(), depthMetric.data(), depthMetricFiltered.data(), indexMap.data(),
+                            vertConf.data(), colorTime.data(), normRad.data(), maxDepthProcessed, weighting,
+                            surfels.data(), count, newUnstable.data());
+        efo_predict_indices(&cam, M, tick, surfels.data(), count, maxDepthProcessed, p.timeDelta, indexMap.data(),
+                            vertConf.data(), colorTime.data(), normRad.data());
+        int room = p.maxSurfels;
+        (void)room;
+        count = efo_clean(&cam, M, tick, indexMap.data(), vertConf.data(), colorTime.data(), normRad.data(),
+                          p.confidence, p.timeDelta, maxDepthProcessed, surfels.data(), count, newUnstable.data(), nNew,
+                          surfelsTmp.data());
+        surfels.swap(surfelsTmp);
+      }
+    }
+    predict();  // :599
+    tick++;     // :603 (lost is never set without reloc)
+  }
+};
+
+extern "C" {
+
+void efo_fusion_default_params(efo_fusion_params* p) {
+  // MainController.cpp:37-43,69-104 front-end defaults, with -o (open loop): timeDelta = INT_MAX/2 (:179-183)
+  p->width = 640; p->height = 480;
+  p->fx = 528; p->fy = 528; p->cx = 320; p->cy = 240;
+  p->timeDelta = 2147483647 / 2;
+  p->confidence = 10.0f; p->depthCut = 3.0f; p->icpWeight = 10.0f;
+  p->fastOdom = 0; p->so3 = 1; p->frameToFrameRGB = 0; p->pyramid = 1; p->rgbOnly = 0;
+  p->maxSurfels = 2 * 1024 * 1024;
+}
+efo_fusion* efo_fusion_create(const efo_fusion_params* p) { return new efo_fusion(*p); }
+void efo_fusion_destroy(efo_fusion* f) { delete f; }
+void efo_fusion_process_frame(efo_fusion* f, const uint8_t* rgb, const uint16_t* depth, int64_t ts, float wm, const double* T) {
+  f->processFrame(rgb, depth, ts, wm, T);
+}
+void efo_fusion_get_pose(const efo_fusion* f, double* T) { f->pose16(T); }
+int efo_fusion_map_count(const efo_fusion* f) { return f->count; }
+void efo_fusion_map_download(const efo_fusion* f, float* s) { std::memcpy(s, f->surfels.data(), (size_t)f->count * 48); }
+int efo_fusion_tick(const efo_fusion* f) { return f->tick; }
+void efo_fusion_stats(const efo_fusion* f, float* out6) {
+  efo_odom_stats(f->frameToModel, out6, nullptr, nullptr);
+}
+const void* efo_fusion_buffer(const efo_fusion* f, int which) {
+  switch (which) {
+    case 0: return f->image.data();
+    case 1: return f->vertex.data();
+    case 2: return f->normal.data();
+    case 3: return f->timeMap.data();
+    case 4: return f->fimage.data();
+    case 5: return f->fvertex.data();
+    case 6: return f->fnormal.data();
+    case 7: return f->indexMap.data();
+    case 8: return f->vertConf.data();
+    case 9: return f->colorTime.data();
+    case 10: return f->normRad.data();
+    case 11: return f->depthFiltered.data();
+    case 12: return f->depthMetric.data();
+    case 13: return f->depthMetricFiltered.data();
+  }
+  return nullptr;
+}
+efo_odometry* efo_fusion_odometry(efo_fusion* f) { return f->frameToModel; }
+
+// ---- linalg exports for known-answer tests ----
+void efo_ldlt6(const double* A, const double* b, double* x) { ldlt_solve<double, 6>(A, b, x); }
+void efo_ldlt3f(const float* A, const float* b, float* x) { ldlt_solve<float, 3>(A, b, x); }
+void efo_polar3(const double* A, double* R) { M3d a; std::memcpy(a.m, A, sizeof(a.m)); M3d r = polar3(a); std::memcpy(R, r.m, sizeof(r.m)); }
+void efo_rodrigues(const double* v, double* R) { M3d r = rodrigues(V3d{{v[0], v[1], v[2]}}); std::memcpy(R, r.m, sizeof(r.m)); }
+void efo_se3_inverse(const double* T, double* out) { M4d m = se3_matrix(se3_inverse(se3_from_matrix(T))); std::memcpy(out, m.m, sizeof(m.m)); }
+double efo_se3_log_norm(const double* T, double* out6) { return se3_log_norm(se3_from_matrix(T), out6); }
+float efo_expf_spec(float x) { return efo_expf(x); }
+
+}  // extern "C"

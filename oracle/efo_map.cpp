@@ -1,0 +1,500 @@
+// TEST INFRASTRUCTURE — CPU oracle. Not part of the product path (see oracle/README.md).
+//
+// CPU restatement of the reference's GLSL "compute" passes and the surfel-map maintenance:
+//   Core/Shaders/depth_bilateral.frag, depth_metric.frag            (G1, G2)
+//   vertex_feedback.{vert,geom}, init_unstable.vert, surfels.glsl, geometry.glsl, color.glsl (G3)
+//   index_map.{vert,frag}                      via IndexMap::predictIndices   (G4)
+//   splat.vert + combo_splat.frag              via IndexMap::combinedPredict  (G5)
+//   fill_{vertex,normal,rgb}.frag              via FillIn                     (G7)
+//   resize.frag + ElasticFusion::denseEnough                                  (G8)
+//   data.{vert,geom,frag}, update.vert         via GlobalModel::fuse          (G9, G10)
+//   copy_unstable.{vert,geom}                  via GlobalModel::clean         (G11)
+// GL-defined behaviour that cannot be observed here is *specified* (SURVEY.md §8a N1-N5):
+//   N1 size-1 point -> pixel (floor u, floor v), culled when the centre is outside the viewport
+//   N2 depth test on the float camera-space z, ties -> lower surfel index (draw order, GL_LESS)
+//   N3 sprite = pixel centres in [u-s/2, u+s/2) x [v-s/2, v+s/2), s clamped to [1, 2047]
+//   N4 NEAREST sampling, CLAMP_TO_EDGE; the 4 taps/axis of data.vert / copy_unstable.vert sit at
+//      pixel offsets {-1,-1/2,0,+1/2} -> texel floor(x+off)
+//   N5 update-map collisions: first pixel in draw (column-major) order wins
+// parity unpinned: no reference vectors exist and the GL/driver stack cannot run here.
+#include "efo_common.h"
+#include "efo_linalg.h"
+#include "efo_api.h"
+#include <algorithm>
+#include <vector>
+
+using namespace efo;
+
+namespace {
+
+constexpr int kTexDim = 3072;  // GlobalModel::TEXTURE_DIMENSION, GlobalModel.cpp:22
+
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// uv attribute of FeedbackBuffer.cpp:44-52 / GlobalModel.cpp:109-117 and x = texcoord.x * cols
+inline float pix_coord(int i, int n) {
+  float u = (float)((double)((float)i / (float)n) + 1.0 / (double)(2 * (float)n));
+  return u * (float)n;
+}
+
+struct Mat4f { float m[16]; };  // row-major
+// T_wc.inverse().matrix().cast<float>()  (IndexMap.cpp:208, GlobalModel.cpp:567)
+inline Mat4f T_cw_float(const double* T_wc16) {
+  SE3 T = se3_from_matrix(T_wc16);
+  M4d Mi = se3_matrix(se3_inverse(T));
+  Mat4f r;
+  for (int i = 0; i < 16; ++i) r.m[i] = (float)Mi.m[i];
+  return r;
+}
+// T_wc.cast<float>().matrix()  (GlobalModel.cpp:403): quaternion cast to float, renormalised in float,
+// rotation matrix evaluated in float (Sophus SO3 ctor + Eigen toRotationMatrix).
+inline Mat4f pose_castf(const double* T_wc16) {
+  SE3 T = se3_from_matrix(T_wc16);
+  float q[4] = {(float)T.q[0], (float)T.q[1], (float)T.q[2], (float)T.q[3]};
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) q[i] /= n;
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  float tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  float twx = tx * w, twy = ty * w, twz = tz * w;
+  float txx = tx * x, txy = ty * x, txz = tz * x;
+  float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  Mat4f r{};
+  r.m[0] = 1 - (tyy + tzz); r.m[1] = txy - twz;       r.m[2] = txz + twy;       r.m[3] = (float)T.t[0];
+  r.m[4] = txy + twz;       r.m[5] = 1 - (txx + tzz); r.m[6] = tyz - twx;       r.m[7] = (float)T.t[1];
+  r.m[8] = txz - twy;       r.m[9] = tyz + twx;       r.m[10] = 1 - (txx + tyy); r.m[11] = (float)T.t[2];
+  r.m[15] = 1;
+  return r;
+}
+inline m33 rot_of(const Mat4f& M) {
+  return m33{{{M.m[0], M.m[1], M.m[2]}, {M.m[4], M.m[5], M.m[6]}, {M.m[8], M.m[9], M.m[10]}}};
+}
+inline f3 trans_of(const Mat4f& M) { return {M.m[3], M.m[7], M.m[11]}; }
+// mat4 * vec4(p,1): fma chain per row, then + translation column
+inline f3 xform(const Mat4f& M, f3 p) { return mul(rot_of(M), p) + trans_of(M); }
+
+// color.glsl:19-34
+inline float encodeColor(f3 c) {
+  int rgb = (int)roundf(c.x * 255.0f);
+  rgb = (rgb << 8) + (int)roundf(c.y * 255.0f);
+  rgb = (rgb << 8) + (int)roundf(c.z * 255.0f);
+  return (float)rgb;
+}
+inline f3 decodeColor(float c) {
+  int ic = (int)c;
+  return {(float)((ic >> 16) & 0xFF) / 255.0f, (float)((ic >> 8) & 0xFF) / 255.0f, (float)(ic & 0xFF) / 255.0f};
+}
+// surfels.glsl:19-34 ; cam.z = 1/fx, cam.w = 1/fy
+inline float getRadius(float depth, float norm_z, float inv_fx, float inv_fy) {
+  float meanFocal = ((1.0f / fabsf(inv_fx)) + (1.0f / fabsf(inv_fy))) / 2.0f;
+  const float sqrt2 = 1.41421356237f;
+  float radius = (depth / meanFocal) * sqrt2;
+  float radius_n = radius / fabsf(norm_z);
+  return fminf(2.0f * radius, radius_n);
+}
+// surfels.glsl:36-46
+inline float confidence(float x, float y, float cx, float cy, float weighting) {
+  const float maxRadDist = 400, twoSigmaSquared = 0.72f;
+  float px = x - cx, py = y - cy;
+  float radialDist = sqrtf(px * px + py * py) / maxRadDist;
+  return efo_expf(-(radialDist * radialDist) / twoSigmaSquared) * weighting;
+}
+
+struct DepthF {  // float depth texture, NEAREST + CLAMP_TO_EDGE
+  const float* d; int cols, rows;
+  float at(int x, int y) const { return d[clampi(y, 0, rows - 1) * cols + clampi(x, 0, cols - 1)]; }
+};
+// geometry.glsl:21-25 (float depth): vertex at float pixel coords (x,y) from texel (ix,iy)
+inline f3 getVertexF(const DepthF& D, int ix, int iy, float x, float y, float cx, float cy, float inv_fx, float inv_fy) {
+  float z = D.at(ix, iy);
+  return {(x - cx) * z * inv_fx, (y - cy) * z * inv_fy, z};
+}
+// geometry.glsl:28-40 central difference
+inline f3 getNormalF(const DepthF& D, f3 vPosition, int ix, int iy, float x, float y, float cx, float cy, float inv_fx, float inv_fy) {
+  f3 xf = getVertexF(D, ix + 1, iy, x + 1, y, cx, cy, inv_fx, inv_fy);
+  f3 xb = getVertexF(D, ix - 1, iy, x - 1, y, cx, cy, inv_fx, inv_fy);
+  f3 yf = getVertexF(D, ix, iy + 1, x, y + 1, cx, cy, inv_fx, inv_fy);
+  f3 yb = getVertexF(D, ix, iy - 1, x, y - 1, cx, cy, inv_fx, inv_fy);
+  auto half = [](f3 a, f3 b) { return f3{(a.x + b.x) / 2, (a.y + b.y) / 2, (a.z + b.z) / 2}; };
+  f3 del_x = half(xb, vPosition) - half(xf, vPosition);
+  f3 del_y = half(yb, vPosition) - half(yf, vPosition);
+  return normalized(cross(del_x, del_y));
+}
+
+}  // namespace
+
+extern "C" {
+
+// depth_bilateral.frag:30-76 (G1)
+void efo_filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered) {
+  const float sigma_space2_inv_half = 0.024691358f, sigma_color2_inv_half = 0.000555556f;
+  const int R = 6, D = R * 2 + 1;
+  const unsigned maxv = (unsigned)(maxD * 1000.0f);
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      unsigned value = raw[y * cols + x];
+      if (value > maxv || value < 300U) { filtered[y * cols + x] = 0; continue; }
+      int tx = std::min(x - D / 2 + D, cols), ty = std::min(y - D / 2 + D, rows);
+      float sum1 = 0, sum2 = 0;
+      for (int cy = std::max(y - D / 2, 0); cy < ty; ++cy)
+        for (int cx = std::max(x - D / 2, 0); cx < tx; ++cx) {
+          unsigned tmp = raw[cy * cols + cx];
+          float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) + ((float)y - (float)cy) * ((float)y - (float)cy);
+          float color2 = ((float)value - (float)tmp) * ((float)value - (float)tmp);
+          float weight = efo_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+          sum1 += (float)tmp * weight;
+          sum2 += weight;
+        }
+      filtered[y * cols + x] = (uint16_t)(unsigned)roundf(sum1 / sum2);
+    }
+}
+
+// depth_metric.frag:28-40 (G2)
+void efo_metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out) {
+  const unsigned maxv = (unsigned)(maxD * 1000.0f);
+  for (int i = 0; i < cols * rows; ++i) {
+    unsigned value = in[i];
+    out[i] = (value > maxv || value < 300U) ? 0.0f : (float)value / 1000.0f;
+  }
+}
+
+// vertex_feedback.{vert,geom} run twice (raw, filtered) + init_unstable.vert (G3).
+// ElasticFusion.cpp:240-254, FeedbackBuffer.cpp:81-138, GlobalModel.cpp:229-284.
+// The two transform-feedback streams are compacted independently and zipped by output index, exactly
+// as the reference binds attribute 0/1 from RAW and attribute 2 from FILTERED.
+int efo_seed_map(const efo_cam* cam, const uint8_t* rgb, const float* depthMetric, const float* depthMetricFiltered,
+                 int time, float maxDepth, float* out) {
+  const int cols = cam->cols, rows = cam->rows;
+  const float inv_fx = 1.0f / cam->fx, inv_fy = 1.0f / cam->fy;  // FeedbackBuffer.cpp:91-95
+  std::vector<float> rawStream, filtStream;  // 12 floats per emitted vertex
+  for (int pass = 0; pass < 2; ++pass) {
+    DepthF D{pass == 0 ? depthMetric : depthMetricFiltered, cols, rows};
+    std::vector<float>& S = pass == 0 ? rawStream : filtStream;
+    for (int i = 0; i < cols; ++i)
+      for (int j = 0; j < rows; ++j) {
+        float x = pix_coord(i, cols), y = pix_coord(j, rows);
+        f3 v = getVertexF(D, i, j, x, y, cam->cx, cam->cy, inv_fx, inv_fy);
+        f3 n = getNormalF(D, v, i, j, x, y, cam->cx, cam->cy, inv_fx, inv_fy);
+        float zVal = (v.z <= 0 || v.z > maxDepth) ? 0.f : v.z;
+        if (!(zVal > 0)) continue;
+        const uint8_t* c = rgb + (size_t)(j * cols + i) * 3;
+        f3 col{(float)c[0] / 255.0f, (float)c[1] / 255.0f, (float)c[2] / 255.0f};
+        float rec[12] = {v.x, v.y, v.z, confidence(x, y, cam->cx, cam->cy, 1.0f),
+                         encodeColor(col), 0.f, col.z, (float)time,
+                         n.x, n.y, n.z, getRadius(v.z, n.z, inv_fx, inv_fy)};
+        S.insert(S.end(), rec, rec + 12);
+      }
+  }
+  const int count = (int)(rawStream.size() / 12);
+  filtStream.resize((size_t)std::max<size_t>(filtStream.size(), rawStream.size()), 0.f);  // stale zeros beyond its end
+  for (int k = 0; k < count; ++k) {
+    float* o = out + (size_t)k * 12;
+    for (int c = 0; c < 8; ++c) o[c] = rawStream[(size_t)k * 12 + c];
+    o[5] = 0;  // init_unstable.vert:33-34
+    o[6] = 1;
+    for (int c = 8; c < 12; ++c) o[c] = filtStream[(size_t)k * 12 + c];
+  }
+  return count;
+}
+
+// IndexMap::predictIndices + index_map.{vert,frag} (G4)
+void efo_predict_indices(const efo_cam* cam, const double* T_wc16, int time, const float* surfels, int count,
+                         float maxDepth, int timeDelta, uint32_t* indexMap, float* vertConf, float* colorTime,
+                         float* normRad) {
+  const int cols = cam->cols, rows = cam->rows, P = cols * rows;
+  const Mat4f T = T_cw_float(T_wc16);
+  const m33 R = rot_of(T);
+  std::vector<float> zbuf(P, std::numeric_limits<float>::infinity());
+  std::fill(indexMap, indexMap + P, 0u);
+  std::fill(vertConf, vertConf + 4 * (size_t)P, 0.f);
+  std::fill(colorTime, colorTime + 4 * (size_t)P, 0.f);
+  std::fill(normRad, normRad + 4 * (size_t)P, 0.f);
+  for (int id = 0; id < count; ++id) {
+    const float* s = surfels + (size_t)id * 12;
+    f3 p = xform(T, f3{s[0], s[1], s[2]});
+    if (p.z > maxDepth || p.z < 0 || (float)time - s[7] > (float)timeDelta) continue;
+    float u = ((cam->fx * p.x) / p.z) + cam->cx;
+    float v = ((cam->fy * p.y) / p.z) + cam->cy;
+    if (!(u >= 0 && u < (float)cols && v >= 0 && v < (float)rows)) continue;  // N1
+    int px = (int)floorf(u), py = (int)floorf(v);
+    int pi = py * cols + px;
+    if (!(p.z < zbuf[pi])) continue;  // N2 (strict: earlier id keeps ties)
+    zbuf[pi] = p.z;
+    indexMap[pi] = (uint32_t)id;
+    float* vc = vertConf + (size_t)pi * 4;
+    vc[0] = p.x; vc[1] = p.y; vc[2] = p.z; vc[3] = s[3];
+    std::memcpy(colorTime + (size_t)pi * 4, s + 4, 16);
+    f3 n = normalized(mul(R, f3{s[8], s[9], s[10]}));
+    float* nr = normRad + (size_t)pi * 4;
+    nr[0] = n.x; nr[1] = n.y; nr[2] = n.z; nr[3] = s[11];
+  }
+}
+
+// IndexMap::combinedPredict + splat.vert + combo_splat.frag (G5)
+void efo_combined_predict(const efo_cam* cam, const double* T_wc16, const float* surfels, int count, float maxDepth,
+                          float confThreshold, int time, int maxTime, int timeDelta, uint8_t* image, float* vertex,
+                          float* normal, uint16_t* timeMap) {
+  const int cols = cam->cols, rows = cam->rows, P = cols * rows;
+  const Mat4f T = T_cw_float(T_wc16);
+  const m33 R = rot_of(T);
+  const float fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
+  std::vector<float> zbuf(P, std::numeric_limits<float>::infinity());
+  std::fill(image, image + 4 * (size_t)P, (uint8_t)0);
+  std::fill(vertex, vertex + 4 * (size_t)P, 0.f);
+  std::fill(normal, normal + 4 * (size_t)P, 0.f);
+  std::fill(timeMap, timeMap + P, (uint16_t)0);
+  auto projImage = [&](f3 p) { return f3{((fx * p.x) / p.z) + cx, ((fy * p.y) / p.z) + cy, p.z}; };
+  for (int id = 0; id < count; ++id) {
+    const float* s = surfels + (size_t)id * 12;
+    f3 p = xform(T, f3{s[0], s[1], s[2]});
+    if (p.z > maxDepth || p.z < 0 || s[3] < confThreshold || (float)time - s[7] > (float)timeDelta || s[7] > (float)maxTime)
+      continue;
+    f3 n = normalized(mul(R, f3{s[8], s[9], s[10]}));
+    float rad = s[11];
+    // splat.vert:70  normalize(..) * normRad.w * 1.41421356  ==  (t*r)*c per component
+    f3 t1 = normalized(f3{n.y - n.z, -n.x, n.x});
+    f3 x1{(t1.x * rad) * 1.41421356f, (t1.y * rad) * 1.41421356f, (t1.z * rad) * 1.41421356f};
+    f3 y1 = cross(n, x1);
+    f3 q1 = projImage(p + x1), q2 = projImage(p + y1), q3 = projImage(p - y1), q4 = projImage(p - x1);
+    float xmin = fminf(q1.x, fminf(q2.x, fminf(q3.x, q4.x))), xmax = fmaxf(q1.x, fmaxf(q2.x, fmaxf(q3.x, q4.x)));
+    float ymin = fminf(q1.y, fminf(q2.y, fminf(q3.y, q4.y))), ymax = fmaxf(q1.y, fmaxf(q2.y, fmaxf(q3.y, q4.y)));
+    float size = fmaxf(0.f, fmaxf(fabsf(xmax - xmin), fabsf(ymax - ymin)));
+    if (std::isnan(size) || std::isnan(xmin) || std::isnan(ymin)) continue;  // degenerate sprite axis: specified skip
+    size = fminf(fmaxf(size, 1.0f), 2047.0f);                                // N3
+    float u = ((fx * p.x) / p.z) + cx, v = ((fy * p.y) / p.z) + cy;
+    if (!(u >= 0 && u < (float)cols && v >= 0 && v < (float)rows)) continue;  // point clipped by its centre
+    float hs = size * 0.5f;
+    int px0 = std::max(0, (int)ceilf(u - hs - 0.5f)), px1 = std::min(cols - 1, (int)ceilf(u + hs - 0.5f) - 1);
+    int py0 = std::max(0, (int)ceilf(v - hs - 0.5f)), py1 = std::min(rows - 1, (int)ceilf(v + hs - 0.5f) - 1);
+    const float sqrRad = rad * rad;
+    const float pn = dot(p, n);
+    f3 colr = decodeColor(s[4]);
+    for (int py = py0; py <= py1; ++py)
+      for (int px = px0; px <= px1; ++px) {
+        float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;  // gl_FragCoord
+        f3 l = normalized(f3{(fcx - cx) / fx, (fcy - cy) / fy, 1.0f});
+        float k = pn / dot(l, n);
+        f3 cp{k * l.x, k * l.y, k * l.z};
+        f3 diff = cp - p;
+        if (!(dot(diff, diff) <= sqrRad)) continue;  // discard (also on NaN)
+        float z = cp.z;
+        int pi = py * cols + px;
+        if (!(z < zbuf[pi])) continue;  // N2
+        zbuf[pi] = z;
+        uint8_t* im = image + (size_t)pi * 4;
+        im[0] = (uint8_t)roundf(colr.x * 255.0f); im[1] = (uint8_t)roundf(colr.y * 255.0f);
+        im[2] = (uint8_t)roundf(colr.z * 255.0f); im[3] = 255;
+        float* vt = vertex + (size_t)pi * 4;
+        vt[0] = (fcx - cx) * z * (1.f / fx); vt[1] = (fcy - cy) * z * (1.f / fy); vt[2] = z; vt[3] = s[3];
+        float* nm = normal + (size_t)pi * 4;
+        nm[0] = n.x; nm[1] = n.y; nm[2] = n.z; nm[3] = rad;
+        timeMap[pi] = (uint16_t)(unsigned)s[6];
+      }
+  }
+}
+
+// FillIn::{vertex,normal,image} + fill_*.frag (G7).  cam = (cx, cy, 1/fx, 1/fy), FillIn.cpp:115-119
+void efo_fill_in(const efo_cam* cam, const uint8_t* image, const float* vertex, const float* normal,
+                 const uint16_t* depthFiltered, const uint8_t* rgb, int passthrough, int passthroughImage,
+                 uint8_t* fimage, float* fvertex, float* fnormal) {
+  const int cols = cam->cols, rows = cam->rows;
+  const float cx = cam->cx, cy = cam->cy, inv_fx = 1.0f / cam->fx, inv_fy = 1.0f / cam->fy;
+  auto depthAt = [&](int x, int y) { return (float)depthFiltered[clampi(y, 0, rows - 1) * cols + clampi(x, 0, cols - 1)] / 1000.0f; };
+  auto vtx = [&](int sx, int sy, int x, int y) {  // geometry.glsl:44-48 (int pixel coords, Q4)
+    float z = depthAt(sx, sy);
+    return f3{((float)x - cx) * z * inv_fx, ((float)y - cy) * z * inv_fy, z};
+  };
+  for (int y = 0; y < rows; ++y)
+    for (int x = 0; x < cols; ++x) {
+      size_t pi = (size_t)y * cols + x;
+      const float* sv = vertex + pi * 4;
+      float* ov = fvertex + pi * 4;
+      if (sv[2] == 0 || passthrough) {
+        f3 v = vtx(x, y, x, y);
+        ov[0] = v.x; ov[1] = v.y; ov[2] = v.z; ov[3] = 1;
+      } else std::memcpy(ov, sv, 16);
+      const float* sn = normal + pi * 4;
+      float* on = fnormal + pi * 4;
+      if (sn[2] == 0 || passthrough) {  // fill_normal.frag tests the normal image's own z
+        f3 v = vtx(x, y, x, y);
+        f3 vx = vtx(x + 1, y, x + 1, y), vy = vtx(x, y + 1, x, y + 1);  // geometry.glsl:52-60 forward difference
+        f3 nn = normalized(cross(vx - v, vy - v));
+        on[0] = nn.x; on[1] = nn.y; on[2] = nn.z; on[3] = 1;
+      } else std::memcpy(on, sn, 16);
+      const uint8_t* si = image + pi * 4;
+      uint8_t* oi = fimage + pi * 4;
+      float sum = (float)si[0] / 255.0f + (float)si[1] / 255.0f + (float)si[2] / 255.0f;
+      if (sum == 0 || passthroughImage) {
+        oi[0] = rgb[pi * 3]; oi[1] = rgb[pi * 3 + 1]; oi[2] = rgb[pi * 3 + 2]; oi[3] = 255;
+      } else std::memcpy(oi, si, 4);
+    }
+}
+
+// Resize::image + ElasticFusion::denseEnough (G8), consSample = 20 (ElasticFusion.cpp:62-70,256-268)
+int efo_dense_enough(const efo_cam* cam, const uint8_t* image) {
+  const int dc = cam->cols / 20, dr = cam->rows / 20;
+  int sum = 0;
+  for (int b = 0; b < dr; ++b)
+    for (int a = 0; a < dc; ++a) {
+      const uint8_t* t = image + ((size_t)(20 * b + 10) * cam->cols + (20 * a + 10)) * 4;
+      sum += (t[0] > 0 && t[1] > 0 && t[2] > 0);
+    }
+  return (float)sum / (float)(dr * dc) > 0.75f;
+}
+
+// GlobalModel::fuse = data pass (data.vert/geom/frag) + update pass (update.vert)  (G9, G10)
+int efo_fuse(const efo_cam* cam, const double* T_wc16, int time, const uint8_t* rgb, const float* depthMetric,
+             const float* depthMetricFiltered, const uint32_t* indexMap, const float* vertConf,
+             const float* colorTime, const float* normRad, float maxDepth, float weighting, float* surfels, int count,
+             float* newUnstable) {
+  (void)colorTime;
+  const int cols = cam->cols, rows = cam->rows;
+  const float cx = cam->cx, cy = cam->cy;
+  const float inv_fx = (float)(1.0 / (double)cam->fx), inv_fy = (float)(1.0 / (double)cam->fy);  // GlobalModel.cpp:397-398
+  const Mat4f pose = pose_castf(T_wc16);
+  const m33 Rp = rot_of(pose);
+  const DepthF DR{depthMetric, cols, rows}, DF{depthMetricFiltered, cols, rows};
+  const float ftime = (float)time;
+  // update "textures": one winner per surfel id (N5)
+  std::vector<int> winner(count > 0 ? count : 1, -1);
+  std::vector<float> upd;  // 12 floats per winner, indexed through winner[]
+  int nNew = 0;
+  for (int i = 0; i < cols; ++i)
+    for (int j = 0; j < rows; ++j) {
+      float x = pix_coord(i, cols), y = pix_coord(j, rows);
+      f3 vPosLocal = getVertexF(DR, i, j, x, y, cx, cy, inv_fx, inv_fy);
+      if (!((int)x % 2 == (int)ftime % 2 && (int)y % 2 == (int)ftime % 2)) continue;
+      // checkNeighbours, data.vert:50-69
+      if (DR.at(i - 1, j) == 0 || DR.at(i, j - 1) == 0 || DR.at(i + 1, j) == 0 || DR.at(i, j + 1) == 0) continue;
+      if (!(vPosLocal.z > 0 && vPosLocal.z <= maxDepth)) continue;
+      f3 vPos = xform(pose, vPosLocal);
+      f3 vPosition_f = getVertexF(DF, i, j, x, y, cx, cy, inv_fx, inv_fy);
+      const uint8_t* c = rgb + (size_t)(j * cols + i) * 3;
+      f3 col{(float)c[0] / 255.0f, (float)c[1] / 255.0f, (float)c[2] / 255.0f};
+      f3 vNormLocal = getNormalF(DF, vPosition_f, i, j, x, y, cx, cy, inv_fx, inv_fy);
+      f3 nW = mul(Rp, vNormLocal);
+      float rec[12] = {vPos.x, vPos.y, vPos.z, confidence(x, y, cx, cy, weighting),
+                       encodeColor(col), 0.f, ftime, 0.f,
+                       nW.x, nW.y, nW.z, getRadius(vPosition_f.z, vNormLocal.z, inv_fx, inv_fy)};
+      // association, data.vert:114-158
+      int counter = 0;
+      uint32_t best = 0;
+      float bestDist = 1000;
+      float xl = (x - cx) * inv_fx, yl = (y - cy) * inv_fy;
+      float lambda = sqrtf(xl * xl + yl * yl + 1);
+      f3 ray{xl, yl, 1};
+      const float lenRay = sqrtf(dot(ray, ray));
+      static const int tapOff[4] = {-1, 0, 0, 1};  // N4: pixel offsets {-1,-1/2,0,+1/2} from the centre i+0.5
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+          int tx = clampi(i + tapOff[a], 0, cols - 1), ty = clampi(j + tapOff[b], 0, rows - 1);
+          size_t ti = (size_t)ty * cols + tx;
+          uint32_t current = indexMap[ti];
+          if (current > 0U) {
+            const float* vc = vertConf + ti * 4;
+            if (fabsf((vc[2] * lambda) - (vPosLocal.z * lambda)) < 0.05f) {
+              f3 cr = cross(ray, f3{vc[0], vc[1], vc[2]});
+              float dist = sqrtf(dot(cr, cr)) / lenRay;
+              const float* nr = normRad + ti * 4;
+              f3 nn{nr[0], nr[1], nr[2]};
+              // abs(acos(c)) < 0.5  <=>  cos(0.5) < c <= 1   (acos(c>1) is NaN -> false)
+              float cang = dot(nn, vNormLocal) / (sqrtf(dot(nn, nn)) * sqrtf(dot(vNormLocal, vNormLocal)));
+              bool angOk = (cang > 0.87758255f && cang <= 1.0f);
+              if (dist < bestDist && (fabsf(nr[2]) < 0.75f || angOk)) {
+                counter++;
+                bestDist = dist;
+                best = current;
+              }
+            }
+          }
+        }
+      if (counter > 0) {
+        rec[7] = -1;
+        if ((int)best < count && winner[best] < 0) {  // first in draw order wins the update texel (N5)
+          winner[best] = (int)(upd.size() / 12);
+          upd.insert(upd.end(), rec, rec + 12);
+        }
+      } else {
+        rec[7] = -2;
+      }
+      std::memcpy(newUnstable + (size_t)nNew * 12, rec, sizeof(rec));  // data.geom:37-48 emits both kinds
+      ++nNew;
+    }
+  // update.vert:37-92
+  for (int id = 0; id < count; ++id) {
+    if (winner[id] < 0) continue;
+    const float* u = &upd[(size_t)winner[id] * 12];
+    float* s = surfels + (size_t)id * 12;
+    float c_k = s[3], a = u[3];
+    if (u[11] < (1.0f + 0.5f) * s[11]) {
+      for (int k = 0; k < 3; ++k) s[k] = ((c_k * s[k]) + (a * u[k])) / (c_k + a);
+      s[3] = c_k + a;
+      f3 oldCol = decodeColor(s[4]), newCol = decodeColor(u[4]);
+      f3 avg{((c_k * oldCol.x) + (a * newCol.x)) / (c_k + a), ((c_k * oldCol.y) + (a * newCol.y)) / (c_k + a),
+             ((c_k * oldCol.z) + (a * newCol.z)) / (c_k + a)};
+      s[4] = encodeColor(avg);
+      s[7] = ftime;
+      float nr[4];
+      for (int k = 0; k < 4; ++k) nr[k] = ((c_k * s[8 + k]) + (a * u[8 + k])) / (c_k + a);
+      f3 nn = normalized(f3{nr[0], nr[1], nr[2]});
+      s[8] = nn.x; s[9] = nn.y; s[10] = nn.z; s[11] = nr[3];
+    } else {
+      s[3] = c_k + a;
+      s[7] = ftime;
+    }
+  }
+  return nNew;
+}
+
+// GlobalModel::clean + copy_unstable.{vert,geom}, nodes == 0 (G11)
+int efo_clean(const efo_cam* cam, const double* T_wc16, int time, const uint32_t* indexMap, const float* vertConf,
+              const float* colorTime, const float* normRad, float confThreshold, int timeDelta, float maxDepth,
+              const float* surfels, int count, const float* newUnstable, int newCount, float* out) {
+  (void)normRad; (void)maxDepth;
+  const int cols = cam->cols, rows = cam->rows;
+  const float fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
+  const Mat4f T = T_cw_float(T_wc16);
+  const m33 R = rot_of(T);
+  const float ftime = (float)time, ftd = (float)timeDelta;
+  int outCount = 0;
+  static const float tapOff[4] = {-1.0f, -0.5f, 0.0f, 0.5f};  // N4
+  for (int k = 0; k < count + newCount; ++k) {
+    const float* s = k < count ? surfels + (size_t)k * 12 : newUnstable + (size_t)(k - count) * 12;
+    float v[12];
+    std::memcpy(v, s, sizeof(v));
+    int test = 1;
+    f3 localPos = xform(T, f3{v[0], v[1], v[2]});
+    float x = ((fx * localPos.x) / localPos.z) + cx;
+    float y = ((fy * localPos.y) / localPos.z) + cy;
+    f3 localNorm = normalized(mul(R, f3{v[8], v[9], v[10]}));
+    int cnt = 0, zCount = 0;
+    if (ftime - v[7] < ftd && localPos.z > 0 && x > 0 && y > 0 && x < (float)cols && y < (float)rows) {
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) {
+          int tx = clampi((int)floorf(x + tapOff[a]), 0, cols - 1), ty = clampi((int)floorf(y + tapOff[b]), 0, rows - 1);
+          size_t ti = (size_t)ty * cols + tx;
+          if (indexMap[ti] > 0U) {
+            const float* vc = vertConf + ti * 4;
+            const float* ct = colorTime + ti * 4;
+            float dx = vc[0] - localPos.x, dy = vc[1] - localPos.y;
+            if (ct[2] < v[6] && vc[3] > confThreshold && vc[2] > localPos.z && vc[2] - localPos.z < 0.01f &&
+                sqrtf(dx * dx + dy * dy) < v[11] * 1.4f)
+              cnt++;
+            if (ct[3] == ftime && vc[3] > confThreshold && vc[2] > localPos.z && vc[2] - localPos.z > 0.01f &&
+                fabsf(localNorm.z) > 0.85f)
+              zCount++;
+          }
+        }
+    }
+    if (cnt > 8 || zCount > 4) test = 0;
+    if (v[7] == -2) v[7] = ftime;                                        // new unstable point
+    if (v[7] == -1 || ((ftime - v[7]) > 20 && v[3] < confThreshold)) test = 0;
+    if (v[7] > 0 && ftime - v[7] > ftd) test = 1;
+    if (test) {
+      std::memcpy(out + (size_t)outCount * 12, v, sizeof(v));
+      ++outCount;
+    }
+  }
+  return outCount;
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+"""ctypes binding of the CPU oracle (oracle/libefo_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+c_f = C.c_float
+c_i = C.c_int
+P = C.c_void_p
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(ORACLE_DIR, "libefo_oracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".h")) or f == "Makefile"]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libefo_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.efo_odom_create.restype = P
+        _LIB.efo_odom_buffer.restype = P
+        _LIB.efo_fusion_create.restype = P
+        _LIB.efo_fusion_buffer.restype = P
+        _LIB.efo_fusion_odometry.restype = P
+        _LIB.efo_se3_log_norm.restype = C.c_double
+        _LIB.efo_expf_spec.restype = c_f
+        _LIB.efo_expf_spec.argtypes = [c_f]
+    return _LIB
+
+
+def ptr(a: np.ndarray):
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(P)
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Cam(C.Structure):
+    _fields_ = [("cols", c_i), ("rows", c_i), ("fx", c_f), ("fy", c_f), ("cx", c_f), ("cy", c_f)]
+
+
+class FusionParams(C.Structure):
+    _fields_ = [("width", c_i), ("height", c_i), ("fx", c_f), ("fy", c_f), ("cx", c_f), ("cy", c_f),
+                ("timeDelta", c_i), ("confidence", c_f), ("depthCut", c_f), ("icpWeight", c_f),
+                ("fastOdom", c_i), ("so3", c_i), ("frameToFrameRGB", c_i), ("pyramid", c_i), ("rgbOnly", c_i),
+                ("maxSurfels", c_i)]
+
+
+DATATERM = np.dtype([("zero", np.int16, 2), ("one", np.int16, 2), ("diff", np.float32), ("valid", np.uint8),
+                     ("pad", np.uint8, 3)])
+assert DATATERM.itemsize == 16
+
+# ------------------------------------------------------------------------------------------------
+# operator wrappers (numpy in / numpy out)
+# ------------------------------------------------------------------------------------------------
+
+
+def pyr_down_u16(src):
+    h, w = src.shape
+    dst = np.zeros((h // 2, w // 2), np.uint16)
+    lib().efo_pyr_down_u16(ptr(src), c_i(w), c_i(h), ptr(dst))
+    return dst
+
+
+def create_vmap(depth, fx, fy, cx, cy, cutoff, vmap=None):
+    h, w = depth.shape
+    vmap = np.zeros((3 * h, w), np.float32) if vmap is None else vmap
+    lib().efo_create_vmap(ptr(depth), c_i(w), c_i(h), c_f(fx), c_f(fy), c_f(cx), c_f(cy), c_f(cutoff), ptr(vmap))
+    return vmap
+
+
+def create_nmap(vmap, nmap=None):
+    h3, w = vmap.shape
+    nmap = np.zeros((h3, w), np.float32) if nmap is None else nmap
+    lib().efo_create_nmap(ptr(vmap), c_i(w), c_i(h3 // 3), ptr(nmap))
+    return nmap
+
+
+def transform_maps(vmap, nmap, R, t):
+    v, n = vmap.copy(), nmap.copy()
+    lib().efo_transform_maps(ptr(v), ptr(n), c_i(v.shape[1]), c_i(v.shape[0] // 3), ptr(f32(R).reshape(9)), ptr(f32(t)))
+    return v, n
+
+
+def copy_maps(vtex, ntex):
+    h, w, _ = vtex.shape
+    tmp = np.zeros((h, w, 4), np.float32)
+    vm = np.zeros((3 * h, w), np.float32)
+    nm = np.zeros((3 * h, w), np.float32)
+    lib().efo_copy_maps(ptr(vtex), ptr(ntex), c_i(w), c_i(h), ptr(tmp), ptr(vm), ptr(nm))
+    return tmp, vm, nm
+
+
+def resize_map(src, normalize, out=None):
+    h3, w = src.shape
+    out = np.zeros((h3 // 2, w // 2), np.float32) if out is None else out
+    lib().efo_resize_map(ptr(src), c_i(w), c_i(h3 // 3), ptr(out), c_i(int(normalize)))
+    return out
+
+
+def pyr_down_gauss_f(src):
+    h, w = src.shape
+    dst = np.zeros((h // 2, w // 2), np.float32)
+    lib().efo_pyr_down_gauss_f(ptr(src), c_i(w), c_i(h), ptr(dst))
+    return dst
+
+
+def pyr_down_uchar_gauss(src):
+    h, w = src.shape
+    dst = np.zeros((h // 2, w // 2), np.uint8)
+    lib().efo_pyr_down_uchar_gauss(ptr(src), c_i(w), c_i(h), ptr(dst))
+    return dst
+
+
+def vertices_to_depth(vmaps_tmp, cutoff):
+    h, w, _ = vmaps_tmp.shape
+    dst = np.zeros((h, w), np.float32)
+    lib().efo_vertices_to_depth(ptr(vmaps_tmp), c_i(w), c_i(h), c_f(cutoff), ptr(dst))
+    return dst
+
+
+def bgr_to_intensity(rgba):
+    h, w, _ = rgba.shape
+    dst = np.zeros((h, w), np.uint8)
+    lib().efo_bgr_to_intensity(ptr(rgba), c_i(w), c_i(h), ptr(dst))
+    return dst
+
+
+def derivative_images(img):
+    h, w = img.shape
+    dx = np.zeros((h, w), np.int16)
+    dy = np.zeros((h, w), np.int16)
+    lib().efo_derivative_images(ptr(img), c_i(w), c_i(h), ptr(dx), ptr(dy))
+    return dx, dy
+
+
+def project_to_point_cloud(depth, fx, fy, cx, cy):
+    h, w = depth.shape
+    cloud = np.zeros((h, w, 3), np.float32)
+    lib().efo_project_to_point_cloud(ptr(depth), c_i(w), c_i(h), c_f(fx), c_f(fy), c_f(cx), c_f(cy), ptr(cloud))
+    return cloud
+
+
+def icp_step(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, distThres, angleThres):
+    h3, w = vmap_curr.shape
+    A = np.zeros((6, 6), np.float32)
+    b = np.zeros(6, np.float32)
+    res = np.zeros(2, np.float32)
+    fx, fy, cx, cy = intr
+    lib().efo_icp_step(ptr(f32(Rcurr).reshape(9)), ptr(f32(tcurr)), ptr(vmap_curr), ptr(nmap_curr),
+                       ptr(f32(Rprev_inv).reshape(9)), ptr(f32(tprev)), c_f(fx), c_f(fy), c_f(cx), c_f(cy),
+                       ptr(vmap_g_prev), ptr(nmap_g_prev), c_f(distThres), c_f(angleThres), c_i(w), c_i(h3 // 3),
+                       ptr(A), ptr(b), ptr(res))
+    return A, b, res
+
+
+def rgb_residual(minScale, dIdx, dIdy, lastDepth, nextDepth, lastImage, nextImage, maxDepthDelta, kt, krkinv):
+    h, w = nextImage.shape
+    corres = np.zeros((h, w), DATATERM)
+    sigma = c_i(0)
+    count = c_i(0)
+    lib().efo_rgb_residual(c_f(minScale), ptr(dIdx), ptr(dIdy), ptr(lastDepth), ptr(nextDepth), ptr(lastImage),
+                           ptr(nextImage), ptr(corres), c_f(maxDepthDelta), ptr(f32(kt)), ptr(f32(krkinv).reshape(9)),
+                           c_i(w), c_i(h), C.byref(sigma), C.byref(count))
+    return corres, sigma.value, count.value
+
+
+def rgb_step(corres, sigma, cloud, fx, fy, dIdx, dIdy, sobelScale):
+    h, w = corres.shape
+    A = np.zeros((6, 6), np.float32)
+    b = np.zeros(6, np.float32)
+    lib().efo_rgb_step(ptr(corres), c_f(sigma), ptr(cloud), c_f(fx), c_f(fy), ptr(dIdx), ptr(dIdy), c_f(sobelScale),
+                       c_i(w), c_i(h), ptr(A), ptr(b))
+    return A, b
+
+
+def so3_step(lastImage, nextImage, imageBasis, kinv, krlr):
+    h, w = nextImage.shape
+    A = np.zeros((3, 3), np.float32)
+    b = np.zeros(3, np.float32)
+    res = np.zeros(2, np.float32)
+    lib().efo_so3_step(ptr(lastImage), ptr(nextImage), ptr(f32(imageBasis).reshape(9)), ptr(f32(kinv).reshape(9)),
+                       ptr(f32(krlr).reshape(9)), c_i(w), c_i(h), ptr(A), ptr(b), ptr(res))
+    return A, b, res
+
+
+def filter_depth(raw, maxD):
+    h, w = raw.shape
+    out = np.zeros((h, w), np.uint16)
+    lib().efo_filter_depth(ptr(raw), c_i(w), c_i(h), c_f(maxD), ptr(out))
+    return out
+
+
+def metricise_depth(d, maxD):
+    h, w = d.shape
+    out = np.zeros((h, w), np.float32)
+    lib().efo_metricise_depth(ptr(d), c_i(w), c_i(h), c_f(maxD), ptr(out))
+    return out
+
+
+def make_cam(w, h, fx, fy, cx, cy):
+    return Cam(w, h, fx, fy, cx, cy)
+
+
+def seed_map(cam, rgb, dm, dmf, time, maxDepth):
+    out = np.zeros((cam.cols * cam.rows, 12), np.float32)
+    n = lib().efo_seed_map(C.byref(cam), ptr(rgb), ptr(dm), ptr(dmf), c_i(time), c_f(maxDepth), ptr(out))
+    return out[:n].copy()
+
+
+def _T(T):
+    return np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+
+
+def predict_indices(cam, T_wc, time, surfels, maxDepth, timeDelta):
+    Pn = cam.cols * cam.rows
+    idx = np.zeros((cam.rows, cam.cols), np.uint32)
+    vc = np.zeros((cam.rows, cam.cols, 4), np.float32)
+    ct = np.zeros((cam.rows, cam.cols, 4), np.float32)
+    nr = np.zeros((cam.rows, cam.cols, 4), np.float32)
+    s = f32(surfels)
+    lib().efo_predict_indices(C.byref(cam), ptr(_T(T_wc)), c_i(time), ptr(s), c_i(len(s)), c_f(maxDepth), c_i(timeDelta),
+                              ptr(idx), ptr(vc), ptr(ct), ptr(nr))
+    return idx, vc, ct, nr
+
+
+def combined_predict(cam, T_wc, surfels, maxDepth, confThreshold, time, maxTime, timeDelta):
+    img = np.zeros((cam.rows, cam.cols, 4), np.uint8)
+    vt = np.zeros((cam.rows, cam.cols, 4), np.float32)
+    nm = np.zeros((cam.rows, cam.cols, 4), np.float32)
+    tm = np.zeros((cam.rows, cam.cols), np.uint16)
+    s = f32(surfels)
+    lib().efo_combined_predict(C.byref(cam), ptr(_T(T_wc)), ptr(s), c_i(len(s)), c_f(maxDepth), c_f(confThreshold),
+                               c_i(time), c_i(maxTime), c_i(timeDelta), ptr(img), ptr(vt), ptr(nm), ptr(tm))
+    return img, vt, nm, tm
+
+
+def fill_in(cam, image, vertex, normal, depthFiltered, rgb, passthrough=0, passthroughImage=0):
+    fi = np.zeros_like(image)
+    fv = np.zeros_like(vertex)
+    fn = np.zeros_like(normal)
+    lib().efo_fill_in(C.byref(cam), ptr(image), ptr(vertex), ptr(normal), ptr(depthFiltered), ptr(rgb),
+                      c_i(passthrough), c_i(passthroughImage), ptr(fi), ptr(fv), ptr(fn))
+    return fi, fv, fn
+
+
+def dense_enough(cam, image):
+    return bool(lib().efo_dense_enough(C.byref(cam), ptr(image)))
+
+
+def fuse(cam, T_wc, time, rgb, dm, dmf, idx, vc, ct, nr, maxDepth, weighting, surfels):
+    s = f32(surfels).copy()
+    newu = np.zeros((cam.cols * cam.rows, 12), np.float32)
+    n = lib().efo_fuse(C.byref(cam), ptr(_T(T_wc)), c_i(time), ptr(rgb), ptr(dm), ptr(dmf), ptr(idx), ptr(vc), ptr(ct),
+                       ptr(nr), c_f(maxDepth), c_f(weighting), ptr(s), c_i(len(s)), ptr(newu))
+    return s, newu[:n].copy()
+
+
+def clean(cam, T_wc, time, idx, vc, ct, nr, confThreshold, timeDelta, maxDepth, surfels, newUnstable):
+    s = f32(surfels)
+    nu = f32(newUnstable).reshape(-1, 12)
+    out = np.zeros((len(s) + len(nu), 12), np.float32)
+    n = lib().efo_clean(C.byref(cam), ptr(_T(T_wc)), c_i(time), ptr(idx), ptr(vc), ptr(ct), ptr(nr), c_f(confThreshold),
+                        c_i(timeDelta), c_f(maxDepth), ptr(s), c_i(len(s)), ptr(nu), c_i(len(nu)), ptr(out))
+    return out[:n].copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# tracking driver + whole-frame objects
+# ------------------------------------------------------------------------------------------------
+class Odometry:
+    BUF = dict(vmap_curr=(0, np.float32, 3), nmap_curr=(1, np.float32, 3), vmap_g_prev=(2, np.float32, 3),
+               nmap_g_prev=(3, np.float32, 3), lastDepth=(4, np.float32, 1), nextDepth=(5, np.float32, 1),
+               lastImage=(6, np.uint8, 1), nextImage=(7, np.uint8, 1), lastNextImage=(8, np.uint8, 1),
+               dIdx=(9, np.int16, 1), dIdy=(10, np.int16, 1), depth_tmp=(11, np.uint16, 1))
+
+    def __init__(self, w, h, cx, cy, fx, fy, handle=None):
+        self.w, self.h = w, h
+        self.own = handle is None
+        self.h_ = P(lib().efo_odom_create(c_i(w), c_i(h), c_f(cx), c_f(cy), c_f(fx), c_f(fy))) if handle is None else P(handle)
+
+    def __del__(self):
+        if getattr(self, "own", False) and self.h_:
+            lib().efo_odom_destroy(self.h_)
+            self.h_ = None
+
+    def init_icp(self, depth_filtered, cutoff):
+        lib().efo_odom_init_icp(self.h_, ptr(depth_filtered), c_f(cutoff))
+
+    def init_icp_model(self, vtex, ntex, T_wc):
+        lib().efo_odom_init_icp_model(self.h_, ptr(f32(vtex)), ptr(f32(ntex)), ptr(_T(T_wc)))
+
+    def init_rgb_model(self, rgba):
+        lib().efo_odom_init_rgb_model(self.h_, ptr(rgba))
+
+    def init_rgb(self, rgba):
+        lib().efo_odom_init_rgb(self.h_, ptr(rgba))
+
+    def init_first_rgb(self, rgba):
+        lib().efo_odom_init_first_rgb(self.h_, ptr(rgba))
+
+    def track(self, T_wc, rgbOnly=False, icpWeight=10.0, pyramid=True, fastOdom=False, so3=True):
+        T = _T(T_wc).copy()
+        lib().efo_odom_track(self.h_, ptr(T), c_i(int(rgbOnly)), c_f(icpWeight), c_i(int(pyramid)), c_i(int(fastOdom)), c_i(int(so3)))
+        return T.reshape(4, 4)
+
+    def stats(self):
+        out = np.zeros(6, np.float32)
+        A = np.zeros((6, 6), np.float64)
+        b = np.zeros(6, np.float64)
+        lib().efo_odom_stats(self.h_, ptr(out), ptr(A), ptr(b))
+        return out, A, b
+
+    def buffer(self, name, level=0):
+        which, dt, planes = self.BUF[name]
+        w, h = self.w >> level, self.h >> level
+        addr = lib().efo_odom_buffer(self.h_, c_i(which), c_i(level))
+        n = w * h * planes
+        arr = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,))
+        return arr.view(dt).reshape(h * planes, w).copy()
+
+
+class Fusion:
+    def __init__(self, **kw):
+        self.p = FusionParams()
+        lib().efo_fusion_default_params(C.byref(self.p))
+        for k, v in kw.items():
+            assert hasattr(self.p, k), k
+            setattr(self.p, k, v)
+        self.h_ = P(lib().efo_fusion_create(C.byref(self.p)))
+
+    def __del__(self):
+        if getattr(self, "h_", None):
+            lib().efo_fusion_destroy(self.h_)
+            self.h_ = None
+
+    def process_frame(self, rgb, depth, ts=0, weight=1.0, T_wc=None):
+        lib().efo_fusion_process_frame(self.h_, ptr(rgb), ptr(depth), C.c_int64(ts), c_f(weight),
+                                       ptr(_T(T_wc)) if T_wc is not None else None)
+
+    def pose(self):
+        T = np.zeros(16, np.float64)
+        lib().efo_fusion_get_pose(self.h_, ptr(T))
+        return T.reshape(4, 4)
+
+    def map_count(self):
+        return lib().efo_fusion_map_count(self.h_)
+
+    def map(self):
+        n = self.map_count()
+        out = np.zeros((n, 12), np.float32)
+        lib().efo_fusion_map_download(self.h_, ptr(out))
+        return out
+
+    def tick(self):
+        return lib().efo_fusion_tick(self.h_)
+
+    def stats(self):
+        out = np.zeros(6, np.float32)
+        lib().efo_fusion_stats(self.h_, ptr(out))
+        return out
+
+    def odometry(self):
+        return Odometry(self.p.width, self.p.height, self.p.cx, self.p.cy, self.p.fx, self.p.fy,
+                        handle=lib().efo_fusion_odometry(self.h_))
+
+    _BUF = {0: (np.uint8, 4), 1: (np.float32, 4), 2: (np.float32, 4), 3: (np.uint16, 1), 4: (np.uint8, 4),
+            5: (np.float32, 4), 6: (np.float32, 4), 7: (np.uint32, 1), 8: (np.float32, 4), 9: (np.float32, 4),
+            10: (np.float32, 4), 11: (np.uint16, 1), 12: (np.float32, 1), 13: (np.float32, 1)}
+    NAMES = dict(image=0, vertex=1, normal=2, time=3, fill_image=4, fill_vertex=5, fill_normal=6, index=7,
+                 vertConf=8, colorTime=9, normRad=10, depthFiltered=11, depthMetric=12, depthMetricFiltered=13)
+
+    def buffer(self, name):
+        which = self.NAMES[name]
+        dt, ch = self._BUF[which]
+        addr = lib().efo_fusion_buffer(self.h_, c_i(which))
+        n = self.p.width * self.p.height * ch
+        arr = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,))
+        a = arr.view(dt).copy()
+        return a.reshape(self.p.height, self.p.width, ch) if ch > 1 else a.reshape(self.p.height, self.p.width)
