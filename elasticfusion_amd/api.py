@@ -1,0 +1,504 @@
+"""Host-side mirror of the reference interface over the C ABI of libefusion_hip.so (include/ef_hip.h).
+
+``ElasticFusion`` keeps the reference's public names (Core/ElasticFusion.h:40-255): processFrame, predict,
+get_T_wc, getTick/setTick, getTimeDelta, getConfidenceThreshold, setRgbOnly/..., savePly; the ctor takes the
+reference's argument names plus the Resolution / Intrinsics singletons as plain arguments.
+``ops`` exposes the operator tier (the cudafuncs.cuh free functions and the GLSL passes) on numpy arrays:
+each call uploads, runs the HIP kernel(s) through the C ABI and downloads — it is what the parity tests use.
+
+There is NO fallback: if the shared library is missing or no GPU is present, everything here raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libefusion_hip.so")
+_lib = None
+
+c_f, c_i, c_u32, P = C.c_float, C.c_int, C.c_uint32, C.c_void_p
+
+
+class EFError(RuntimeError):
+    pass
+
+
+class ef_config(C.Structure):
+    _fields_ = [("width", c_i), ("height", c_i), ("fx", c_f), ("fy", c_f), ("cx", c_f), ("cy", c_f),
+                ("time_delta", c_i), ("confidence", c_f), ("depth_cut", c_f), ("icp_weight", c_f),
+                ("fast_odom", c_i), ("so3", c_i), ("frame_to_frame_rgb", c_i), ("pyramid", c_i), ("rgb_only", c_i),
+                ("close_loops", c_i), ("max_surfels", c_u32), ("device", c_i), ("stream", P)]
+
+
+class ef_intr(C.Structure):
+    _fields_ = [("fx", c_f), ("fy", c_f), ("cx", c_f), ("cy", c_f)]
+
+
+class ef_cam(C.Structure):
+    _fields_ = [("cols", c_i), ("rows", c_i), ("fx", c_f), ("fy", c_f), ("cx", c_f), ("cy", c_f)]
+
+
+class ef_timing(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", c_f)]
+
+
+DATATERM = np.dtype([("zero", np.int16, 2), ("one", np.int16, 2), ("diff", np.float32), ("valid", np.uint8),
+                     ("pad", np.uint8, 3)])
+
+
+def lib():
+    """Loads libefusion_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EFError(f"{LIB_PATH} not built: run `python -m elasticfusion_amd.build` (hipcc, gfx950). "
+                          "There is no CPU fallback for this engine.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ef_last_error.restype = C.c_char_p
+        _lib.ef_last_error.argtypes = [P]
+        _lib.ef_stream.restype = P
+        _lib.ef_stream.argtypes = [P]
+    return _lib
+
+
+def _chk(rc: int, ctx=None):
+    if rc != 0:
+        msg = lib().ef_last_error(ctx)
+        raise EFError(f"libefusion_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def device_count() -> int:
+    n = c_i(0)
+    rc = lib().ef_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _ptr(a: np.ndarray):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(P)
+
+
+class DevBuf:
+    """A raw HIP allocation owned through the C ABI (ef_dev_alloc / ef_dev_free)."""
+
+    def __init__(self, nbytes: int, fill: int | None = 0):
+        self.p = P()
+        self.nbytes = int(nbytes)
+        _chk(lib().ef_dev_alloc(C.byref(self.p), C.c_size_t(self.nbytes)))
+        if fill is not None:
+            _chk(lib().ef_dev_memset(self.p, c_i(fill), C.c_size_t(self.nbytes)))
+
+    @classmethod
+    def from_array(cls, a: np.ndarray) -> "DevBuf":
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes, fill=None)
+        if a.nbytes:
+            _chk(lib().ef_dev_upload(b.p, _ptr(a), C.c_size_t(a.nbytes)))
+        return b
+
+    def to_array(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes, (out.nbytes, self.nbytes)
+        if out.nbytes:
+            _chk(lib().ef_dev_download(_ptr(out), self.p, C.c_size_t(out.nbytes)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            try:
+                lib().ef_dev_free(self.p)
+            except Exception:
+                pass
+            self.p = None
+
+
+def default_config(**kw) -> ef_config:
+    cfg = ef_config()
+    lib().ef_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown config field {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+class ElasticFusion:
+    """Mirror of ``class ElasticFusion`` (Core/ElasticFusion.h) over the C ABI."""
+
+    IMAGES = dict(depth_filtered=(0, np.uint16, 1), depth_metric=(1, np.float32, 1), depth_metric_filtered=(2, np.float32, 1),
+                  image=(3, np.uint8, 4), vertex=(4, np.float32, 4), normal=(5, np.float32, 4), time=(6, np.uint16, 1),
+                  fill_image=(7, np.uint8, 4), fill_vertex=(8, np.float32, 4), fill_normal=(9, np.float32, 4),
+                  index=(10, np.uint32, 1), vertConf=(11, np.float32, 4), colorTime=(12, np.float32, 4), normRad=(13, np.float32, 4))
+    TRACKER = dict(vmap_curr=(0, np.float32, 3), nmap_curr=(1, np.float32, 3), vmap_g_prev=(2, np.float32, 3),
+                   nmap_g_prev=(3, np.float32, 3), lastDepth=(4, np.float32, 1), nextDepth=(5, np.float32, 1),
+                   lastImage=(6, np.uint8, 1), nextImage=(7, np.uint8, 1), lastNextImage=(8, np.uint8, 1),
+                   dIdx=(9, np.int16, 1), dIdy=(10, np.int16, 1), depth_tmp=(11, np.uint16, 1))
+
+    def __init__(self, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, timeDelta=2147483647 // 2,
+                 confidence=10.0, depthCut=3.0, icpThresh=10.0, fastOdom=False, so3=True, frameToFrameRGB=False,
+                 closeLoops=False, maxSurfels=4 * 1024 * 1024, device=0, stream=None):
+        cfg = default_config(width=width, height=height, fx=fx, fy=fy, cx=cx, cy=cy, time_delta=timeDelta,
+                             confidence=confidence, depth_cut=depthCut, icp_weight=icpThresh, fast_odom=int(fastOdom),
+                             so3=int(so3), frame_to_frame_rgb=int(frameToFrameRGB), close_loops=int(closeLoops),
+                             max_surfels=maxSurfels, device=device, stream=stream)
+        self.cfg = cfg
+        self.h = P()
+        _chk(lib().ef_create(C.byref(cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ef_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # --- frame tier ---
+    def processFrame(self, rgb: np.ndarray, depth: np.ndarray, timestamp: int = 0, weightMultiplier: float = 1.0, in_T_wc=None):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        assert rgb.size == self.cfg.width * self.cfg.height * 3 and depth.size == self.cfg.width * self.cfg.height
+        T = None if in_T_wc is None else np.ascontiguousarray(in_T_wc, np.float64).reshape(16)
+        _chk(lib().ef_process_frame(self.h, _ptr(rgb), _ptr(depth), C.c_int64(timestamp), c_f(weightMultiplier),
+                                    _ptr(T) if T is not None else None), self.h)
+
+    def processFrameDevice(self, rgb_dev, depth_dev, timestamp: int = 0, weightMultiplier: float = 1.0, in_T_wc=None):
+        """rgb_dev / depth_dev: raw device pointers (int or c_void_p) of frames already resident in HBM."""
+        T = None if in_T_wc is None else np.ascontiguousarray(in_T_wc, np.float64).reshape(16)
+        _chk(lib().ef_process_frame_dev(self.h, P(int(rgb_dev)), P(int(depth_dev)), C.c_int64(timestamp), c_f(weightMultiplier),
+                                        _ptr(T) if T is not None else None), self.h)
+
+    def predict(self):
+        _chk(lib().ef_predict(self.h), self.h)
+
+    def synchronize(self):
+        _chk(lib().ef_synchronize(self.h), self.h)
+
+    def stream(self) -> int:
+        return int(lib().ef_stream(self.h) or 0)
+
+    def get_T_wc(self) -> np.ndarray:
+        T = np.zeros(16, np.float64)
+        _chk(lib().ef_get_pose(self.h, _ptr(T)), self.h)
+        return T.reshape(4, 4)
+
+    def getTick(self) -> int:
+        t = c_i(0)
+        _chk(lib().ef_get_tick(self.h, C.byref(t)), self.h)
+        return t.value
+
+    def setTick(self, v: int):
+        _chk(lib().ef_set_tick(self.h, c_i(v)), self.h)
+
+    def getTimeDelta(self) -> int:
+        return self.cfg.time_delta
+
+    def getConfidenceThreshold(self) -> float:
+        return self.cfg.confidence
+
+    def getMaxDepthProcessed(self) -> float:
+        return 20.0
+
+    def trackingStats(self):
+        out = np.zeros(6, np.float32)
+        A = np.zeros((6, 6), np.float64)
+        b = np.zeros(6, np.float64)
+        _chk(lib().ef_get_tracking_stats(self.h, _ptr(out), _ptr(A), _ptr(b)), self.h)
+        return out, A, b
+
+    def trajectory(self):
+        n = c_i(0)
+        _chk(lib().ef_get_trajectory(self.h, None, None, c_i(0), C.byref(n)), self.h)
+        cap = 1 << 16
+        T = np.zeros((cap, 16), np.float64)
+        ts = np.zeros(cap, np.int64)
+        _chk(lib().ef_get_trajectory(self.h, _ptr(T), _ptr(ts), c_i(cap), C.byref(n)), self.h)
+        return T[:n.value].reshape(-1, 4, 4).copy(), ts[:n.value].copy()
+
+    def lastCount(self) -> int:
+        n = c_u32(0)
+        _chk(lib().ef_map_count(self.h, C.byref(n)), self.h)
+        return n.value
+
+    def downloadMap(self) -> np.ndarray:
+        n = self.lastCount()
+        out = np.zeros((max(n, 1), 12), np.float32)
+        got = c_u32(0)
+        _chk(lib().ef_map_download(self.h, _ptr(out), c_u32(n), C.byref(got)), self.h)
+        return out[:got.value].copy()
+
+    def uploadMap(self, surfels: np.ndarray):
+        s = np.ascontiguousarray(surfels, np.float32).reshape(-1, 12)
+        _chk(lib().ef_map_upload(self.h, _ptr(s), c_u32(len(s))), self.h)
+
+    def savePly(self, path: str):
+        _chk(lib().ef_save_ply(self.h, path.encode()), self.h)
+
+    def saveFreiburg(self, path: str):
+        _chk(lib().ef_save_freiburg(self.h, path.encode()), self.h)
+
+    def setRgbOnly(self, v): _chk(lib().ef_set_rgb_only(self.h, c_i(int(v))), self.h)
+    def setIcpWeight(self, v): _chk(lib().ef_set_icp_weight(self.h, c_f(v)), self.h)
+    def setPyramid(self, v): _chk(lib().ef_set_pyramid(self.h, c_i(int(v))), self.h)
+    def setFastOdom(self, v): _chk(lib().ef_set_fast_odom(self.h, c_i(int(v))), self.h)
+    def setSo3(self, v): _chk(lib().ef_set_so3(self.h, c_i(int(v))), self.h)
+    def setFrameToFrameRGB(self, v): _chk(lib().ef_set_frame_to_frame_rgb(self.h, c_i(int(v))), self.h)
+    def setConfidenceThreshold(self, v): _chk(lib().ef_set_confidence_threshold(self.h, c_f(v)), self.h)
+    def setDepthCutoff(self, v): _chk(lib().ef_set_depth_cutoff(self.h, c_f(v)), self.h)
+
+    def image(self, name: str) -> np.ndarray:
+        which, dt, ch = self.IMAGES[name]
+        W, H = self.cfg.width, self.cfg.height
+        out = np.zeros((H, W, ch) if ch > 1 else (H, W), dt)
+        _chk(lib().ef_get_image(self.h, c_i(which), _ptr(out), C.c_size_t(out.nbytes)), self.h)
+        return out
+
+    def trackerBuffer(self, name: str, level: int = 0) -> np.ndarray:
+        which, dt, planes = self.TRACKER[name]
+        w, h = self.cfg.width >> level, self.cfg.height >> level
+        out = np.zeros((h * planes, w), dt)
+        _chk(lib().ef_get_tracker_buffer(self.h, c_i(which), c_i(level), _ptr(out), C.c_size_t(out.nbytes)), self.h)
+        return out
+
+    def enableTiming(self, on=True):
+        _chk(lib().ef_enable_timing(self.h, c_i(int(on))), self.h)
+
+    def timings(self) -> dict:
+        arr = (ef_timing * 32)()
+        n = c_i(0)
+        _chk(lib().ef_get_timings(self.h, arr, c_i(32), C.byref(n)), self.h)
+        return {arr[i].name.decode(): arr[i].ms for i in range(n.value)}
+
+
+# ------------------------------------------------------------------------------------------------
+# operator tier on numpy arrays (upload -> HIP kernel via the C ABI -> download)
+# ------------------------------------------------------------------------------------------------
+class ops:
+    @staticmethod
+    def _f32(a):
+        return np.ascontiguousarray(a, np.float32)
+
+    @staticmethod
+    def pyr_down(src):
+        h, w = src.shape
+        s, d = DevBuf.from_array(src), DevBuf((h // 2) * (w // 2) * 2)
+        _chk(lib().ef_op_pyr_down(s.p, c_i(w), c_i(h), d.p, None))
+        return d.to_array(np.uint16, (h // 2, w // 2))
+
+    @staticmethod
+    def create_vmap(depth, fx, fy, cx, cy, cutoff, init=None):
+        h, w = depth.shape
+        d = DevBuf.from_array(depth)
+        v = DevBuf.from_array(np.zeros((3 * h, w), np.float32) if init is None else init)
+        k = ef_intr(fx, fy, cx, cy)
+        _chk(lib().ef_op_create_vmap(C.byref(k), d.p, c_i(w), c_i(h), c_f(cutoff), v.p, None))
+        return v.to_array(np.float32, (3 * h, w))
+
+    @staticmethod
+    def create_nmap(vmap, init=None):
+        h3, w = vmap.shape
+        v = DevBuf.from_array(vmap)
+        n = DevBuf.from_array(np.zeros((h3, w), np.float32) if init is None else init)
+        _chk(lib().ef_op_create_nmap(v.p, c_i(w), c_i(h3 // 3), n.p, None))
+        return n.to_array(np.float32, (h3, w))
+
+    @staticmethod
+    def transform_maps(vmap, nmap, R, t):
+        h3, w = vmap.shape
+        v, n = DevBuf.from_array(vmap), DevBuf.from_array(nmap)
+        R9, t3 = ops._f32(R).reshape(9), ops._f32(t).reshape(3)
+        _chk(lib().ef_op_transform_maps(v.p, n.p, c_i(w), c_i(h3 // 3), _ptr(R9), _ptr(t3), v.p, n.p, None))
+        return v.to_array(np.float32, (h3, w)), n.to_array(np.float32, (h3, w))
+
+    @staticmethod
+    def copy_maps(vtex, ntex):
+        h, w, _ = vtex.shape
+        v4, n4 = DevBuf.from_array(ops._f32(vtex)), DevBuf.from_array(ops._f32(ntex))
+        tmp, vm, nm = DevBuf(h * w * 16), DevBuf(h * w * 12), DevBuf(h * w * 12)
+        _chk(lib().ef_op_copy_maps(v4.p, n4.p, c_i(w), c_i(h), tmp.p, vm.p, nm.p, None))
+        return tmp.to_array(np.float32, (h, w, 4)), vm.to_array(np.float32, (3 * h, w)), nm.to_array(np.float32, (3 * h, w))
+
+    @staticmethod
+    def resize_map(src, normalize, init=None):
+        h3, w = src.shape
+        s = DevBuf.from_array(src)
+        o = DevBuf.from_array(np.zeros((h3 // 2, w // 2), np.float32) if init is None else init)
+        fn = lib().ef_op_resize_nmap if normalize else lib().ef_op_resize_vmap
+        _chk(fn(s.p, c_i(w), c_i(h3 // 3), o.p, None))
+        return o.to_array(np.float32, (h3 // 2, w // 2))
+
+    @staticmethod
+    def pyr_down_gauss_f(src):
+        h, w = src.shape
+        s, d = DevBuf.from_array(src), DevBuf((h // 2) * (w // 2) * 4)
+        _chk(lib().ef_op_pyr_down_gauss_f(s.p, c_i(w), c_i(h), d.p, None))
+        return d.to_array(np.float32, (h // 2, w // 2))
+
+    @staticmethod
+    def pyr_down_uchar_gauss(src):
+        h, w = src.shape
+        s, d = DevBuf.from_array(src), DevBuf((h // 2) * (w // 2))
+        _chk(lib().ef_op_pyr_down_uchar_gauss(s.p, c_i(w), c_i(h), d.p, None))
+        return d.to_array(np.uint8, (h // 2, w // 2))
+
+    @staticmethod
+    def vertices_to_depth(vmaps_tmp, cutoff):
+        h, w, _ = vmaps_tmp.shape
+        s, d = DevBuf.from_array(ops._f32(vmaps_tmp)), DevBuf(h * w * 4)
+        _chk(lib().ef_op_vertices_to_depth(s.p, c_i(w), c_i(h), c_f(cutoff), d.p, None))
+        return d.to_array(np.float32, (h, w))
+
+    @staticmethod
+    def bgr_to_intensity(rgba):
+        h, w, _ = rgba.shape
+        s, d = DevBuf.from_array(rgba), DevBuf(h * w)
+        _chk(lib().ef_op_image_bgr_to_intensity(s.p, c_i(w), c_i(h), d.p, None))
+        return d.to_array(np.uint8, (h, w))
+
+    @staticmethod
+    def derivative_images(img):
+        h, w = img.shape
+        s, dx, dy = DevBuf.from_array(img), DevBuf(h * w * 2), DevBuf(h * w * 2)
+        _chk(lib().ef_op_compute_derivative_images(s.p, c_i(w), c_i(h), dx.p, dy.p, None))
+        return dx.to_array(np.int16, (h, w)), dy.to_array(np.int16, (h, w))
+
+    @staticmethod
+    def project_to_point_cloud(depth, fx, fy, cx, cy, level=0):
+        h, w = depth.shape
+        s, d = DevBuf.from_array(depth), DevBuf(h * w * 12)
+        k = ef_intr(fx, fy, cx, cy)
+        _chk(lib().ef_op_project_to_point_cloud(s.p, c_i(w), c_i(h), C.byref(k), c_i(level), d.p, None))
+        return d.to_array(np.float32, (h, w, 3))
+
+    @staticmethod
+    def icp_step(Rcurr, tcurr, vmap_curr, nmap_curr, Rprev_inv, tprev, intr, vmap_g_prev, nmap_g_prev, distThres, angleThres):
+        h3, w = vmap_curr.shape
+        bufs = [DevBuf.from_array(a) for a in (vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev)]
+        A, b, res = np.zeros((6, 6), np.float32), np.zeros(6, np.float32), np.zeros(2, np.float32)
+        k = ef_intr(*intr)
+        _chk(lib().ef_op_icp_step(_ptr(ops._f32(Rcurr).reshape(9)), _ptr(ops._f32(tcurr)), bufs[0].p, bufs[1].p,
+                                  _ptr(ops._f32(Rprev_inv).reshape(9)), _ptr(ops._f32(tprev)), C.byref(k), bufs[2].p, bufs[3].p,
+                                  c_f(distThres), c_f(angleThres), c_i(w), c_i(h3 // 3), _ptr(A), _ptr(b), _ptr(res), None))
+        return A, b, res
+
+    @staticmethod
+    def rgb_residual(minScale, dIdx, dIdy, lastDepth, nextDepth, lastImage, nextImage, maxDepthDelta, kt, krkinv):
+        h, w = nextImage.shape
+        bufs = [DevBuf.from_array(a) for a in (dIdx, dIdy, lastDepth, nextDepth, lastImage, nextImage)]
+        corres = DevBuf(h * w * 16)
+        sigma, count = c_i(0), c_i(0)
+        _chk(lib().ef_op_compute_rgb_residual(c_f(minScale), bufs[0].p, bufs[1].p, bufs[2].p, bufs[3].p, bufs[4].p, bufs[5].p, corres.p,
+                                              c_f(maxDepthDelta), _ptr(ops._f32(kt)), _ptr(ops._f32(krkinv).reshape(9)), c_i(w), c_i(h),
+                                              C.byref(sigma), C.byref(count), None))
+        return corres.to_array(DATATERM, (h, w)), sigma.value, count.value
+
+    @staticmethod
+    def rgb_step(corres, sigma, cloud, fx, fy, dIdx, dIdy, sobelScale):
+        h, w = corres.shape
+        bufs = [DevBuf.from_array(a) for a in (corres, ops._f32(cloud), dIdx, dIdy)]
+        A, b = np.zeros((6, 6), np.float32), np.zeros(6, np.float32)
+        _chk(lib().ef_op_rgb_step(bufs[0].p, c_f(sigma), bufs[1].p, c_f(fx), c_f(fy), bufs[2].p, bufs[3].p, c_f(sobelScale), c_i(w), c_i(h),
+                                  _ptr(A), _ptr(b), None))
+        return A, b
+
+    @staticmethod
+    def so3_step(lastImage, nextImage, imageBasis, kinv, krlr):
+        h, w = nextImage.shape
+        li, ni = DevBuf.from_array(lastImage), DevBuf.from_array(nextImage)
+        A, b, res = np.zeros((3, 3), np.float32), np.zeros(3, np.float32), np.zeros(2, np.float32)
+        _chk(lib().ef_op_so3_step(li.p, ni.p, _ptr(ops._f32(imageBasis).reshape(9)), _ptr(ops._f32(kinv).reshape(9)),
+                                  _ptr(ops._f32(krlr).reshape(9)), c_i(w), c_i(h), _ptr(A), _ptr(b), _ptr(res), None))
+        return A, b, res
+
+    @staticmethod
+    def filter_depth(raw, maxD):
+        h, w = raw.shape
+        s, d = DevBuf.from_array(raw), DevBuf(h * w * 2)
+        _chk(lib().ef_op_filter_depth(s.p, c_i(w), c_i(h), c_f(maxD), d.p, None))
+        return d.to_array(np.uint16, (h, w))
+
+    @staticmethod
+    def metricise_depth(d_in, maxD):
+        h, w = d_in.shape
+        s, d = DevBuf.from_array(d_in), DevBuf(h * w * 4)
+        _chk(lib().ef_op_metricise_depth(s.p, c_i(w), c_i(h), c_f(maxD), d.p, None))
+        return d.to_array(np.float32, (h, w))
+
+    @staticmethod
+    def seed_map(cam, rgb, dm, dmf, time, maxDepth):
+        Pn = cam.cols * cam.rows
+        bufs = [DevBuf.from_array(a) for a in (rgb, dm, dmf)]
+        out = DevBuf(Pn * 48)
+        n = c_u32(0)
+        _chk(lib().ef_op_seed_map(C.byref(cam), bufs[0].p, bufs[1].p, bufs[2].p, c_i(time), c_f(maxDepth), out.p, C.byref(n), None))
+        return out.to_array(np.float32, (n.value, 12))
+
+    @staticmethod
+    def _T(T):
+        return np.ascontiguousarray(T, np.float64).reshape(16)
+
+    @staticmethod
+    def predict_indices(cam, T_wc, time, surfels, maxDepth, timeDelta):
+        s = ops._f32(surfels).reshape(-1, 12)
+        Pn = cam.cols * cam.rows
+        sb = DevBuf.from_array(s)
+        idx, vc, ct, nr = DevBuf(Pn * 4), DevBuf(Pn * 16), DevBuf(Pn * 16), DevBuf(Pn * 16)
+        _chk(lib().ef_op_predict_indices(C.byref(cam), _ptr(ops._T(T_wc)), c_i(time), sb.p, c_u32(len(s)), c_f(maxDepth), c_i(timeDelta),
+                                         idx.p, vc.p, ct.p, nr.p, None))
+        shp = (cam.rows, cam.cols)
+        return (idx.to_array(np.uint32, shp), vc.to_array(np.float32, shp + (4,)), ct.to_array(np.float32, shp + (4,)),
+                nr.to_array(np.float32, shp + (4,)))
+
+    @staticmethod
+    def combined_predict(cam, T_wc, surfels, maxDepth, confThreshold, time, maxTime, timeDelta):
+        s = ops._f32(surfels).reshape(-1, 12)
+        Pn = cam.cols * cam.rows
+        sb = DevBuf.from_array(s)
+        img, vt, nm, tm = DevBuf(Pn * 4), DevBuf(Pn * 16), DevBuf(Pn * 16), DevBuf(Pn * 2)
+        _chk(lib().ef_op_combined_predict(C.byref(cam), _ptr(ops._T(T_wc)), sb.p, c_u32(len(s)), c_f(maxDepth), c_f(confThreshold),
+                                          c_i(time), c_i(maxTime), c_i(timeDelta), img.p, vt.p, nm.p, tm.p, None))
+        shp = (cam.rows, cam.cols)
+        return (img.to_array(np.uint8, shp + (4,)), vt.to_array(np.float32, shp + (4,)), nm.to_array(np.float32, shp + (4,)),
+                tm.to_array(np.uint16, shp))
+
+    @staticmethod
+    def fill_in(cam, image, vertex, normal, depthFiltered, rgb, passthrough=0, passthroughImage=0):
+        bufs = [DevBuf.from_array(a) for a in (image, ops._f32(vertex), ops._f32(normal), depthFiltered, rgb)]
+        Pn = cam.cols * cam.rows
+        fi, fv, fn = DevBuf(Pn * 4), DevBuf(Pn * 16), DevBuf(Pn * 16)
+        _chk(lib().ef_op_fill_in(C.byref(cam), bufs[0].p, bufs[1].p, bufs[2].p, bufs[3].p, bufs[4].p, c_i(passthrough), c_i(passthroughImage),
+                                 fi.p, fv.p, fn.p, None))
+        shp = (cam.rows, cam.cols)
+        return fi.to_array(np.uint8, shp + (4,)), fv.to_array(np.float32, shp + (4,)), fn.to_array(np.float32, shp + (4,))
+
+    @staticmethod
+    def dense_enough(cam, image):
+        b = DevBuf.from_array(image)
+        d = c_i(0)
+        _chk(lib().ef_op_dense_enough(C.byref(cam), b.p, C.byref(d), None))
+        return bool(d.value)
+
+    @staticmethod
+    def fuse(cam, T_wc, time, rgb, dm, dmf, idx, vc, ct, nr, maxDepth, weighting, surfels):
+        s = ops._f32(surfels).reshape(-1, 12)
+        bufs = [DevBuf.from_array(a) for a in (rgb, dm, dmf, idx, ops._f32(vc), ops._f32(ct), ops._f32(nr))]
+        sb = DevBuf.from_array(s)
+        nu = DevBuf((cam.cols // 2) * (cam.rows // 2) * 48)
+        n = c_u32(0)
+        _chk(lib().ef_op_fuse(C.byref(cam), _ptr(ops._T(T_wc)), c_i(time), bufs[0].p, bufs[1].p, bufs[2].p, bufs[3].p, bufs[4].p, bufs[5].p,
+                              bufs[6].p, c_f(maxDepth), c_f(weighting), sb.p, c_u32(len(s)), nu.p, C.byref(n), None))
+        return sb.to_array(np.float32, (len(s), 12)), nu.to_array(np.float32, (n.value, 12))
+
+    @staticmethod
+    def clean(cam, T_wc, time, idx, vc, ct, nr, confThreshold, timeDelta, maxDepth, surfels, newUnstable):
+        s = ops._f32(surfels).reshape(-1, 12)
+        nu = ops._f32(newUnstable).reshape(-1, 12)
+        bufs = [DevBuf.from_array(a) for a in (idx, ops._f32(vc), ops._f32(ct), ops._f32(nr))]
+        sb, nb = DevBuf.from_array(s), DevBuf.from_array(nu if len(nu) else np.zeros((1, 12), np.float32))
+        out = DevBuf((len(s) + len(nu) + 1) * 48)
+        n = c_u32(0)
+        _chk(lib().ef_op_clean(C.byref(cam), _ptr(ops._T(T_wc)), c_i(time), bufs[0].p, bufs[1].p, bufs[2].p, bufs[3].p, c_f(confThreshold),
+                               c_i(timeDelta), c_f(maxDepth), sb.p, c_u32(len(s)), nb.p, c_u32(len(nu)), out.p, C.byref(n), None))
+        return out.to_array(np.float32, (n.value, 12))

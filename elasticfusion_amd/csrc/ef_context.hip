@@ -1,0 +1,984 @@
+// libefusion_hip: context, per-frame driver and the C ABI of include/ef_hip.h.
+// The frame script follows ElasticFusion::processFrame (Core/ElasticFusion.cpp:270-607) for the open-loop
+// configuration; every stage is only ENQUEUED on the context's stream — pose, surfel count, fill-in
+// decision and fusion weight all live in a device-resident state block, so a frame costs zero
+// host<->device round trips (the reference has ~70 blocking ones).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ef_hip.h"
+#include "ef_linalg_dev.hpp"
+#include "ef_map.hpp"
+#include "ef_track.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct StageTimer {
+  const char* name;
+  hipEvent_t a, b;
+  bool used;
+};
+
+}  // namespace
+
+struct ef_ctx {
+  ef_config cfg;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  efm::Cam cam;
+  eft::Intr intr;
+  const float maxDepthProcessed = 20.0f;  // ElasticFusion.cpp:83
+  // frame images
+  uint8_t* rgb = nullptr;
+  uint16_t* depth_raw = nullptr;
+  uint16_t* depth_filtered = nullptr;
+  float* depth_metric = nullptr;
+  float* depth_metric_filtered = nullptr;
+  uint8_t* h_rgb = nullptr;      // pinned staging
+  uint16_t* h_depth = nullptr;
+  // tracker
+  eft::Pyramid pyr{};
+  eft::TrackState* st = nullptr;
+  // model prediction
+  efm::IndexMaps im{};
+  efm::PredictMaps pm{};
+  efm::FillMaps fm{};
+  unsigned long long* zbuf = nullptr;
+  unsigned* dense_counter = nullptr;
+  // global model
+  efm::SurfelSoA maps[2]{};
+  int cur = 0;
+  uint32_t capacity = 0;
+  uint32_t* winner = nullptr;
+  efm::Candidates cand{};
+  efm::CompactScratch cs{};
+  int* overflow = nullptr;
+  // trajectory (device log + host timestamps)
+  double* traj = nullptr;  // 16 doubles per frame
+  int traj_cap = 0;
+  std::vector<int64_t> stamps;
+  int tick = 1;
+  std::vector<void*> allocs;
+  // timing
+  bool timing = false;
+  std::vector<StageTimer> timers;
+};
+
+namespace {
+
+#define EF_HIP(ctx, expr)                                                                       \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                           \
+      return EF_EHIP;                                                                           \
+    }                                                                                           \
+  } while (0)
+
+template <typename T>
+int dev_alloc(ef_ctx* c, T** p, size_t n, int fill = 0) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, n * sizeof(T));
+  if (e != hipSuccess) {
+    c->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return EF_ENOMEM;
+  }
+  e = hipMemsetAsync(q, fill, n * sizeof(T), c->stream);
+  if (e != hipSuccess) {
+    c->err = std::string("hipMemset: ") + hipGetErrorString(e);
+    return EF_EHIP;
+  }
+  c->allocs.push_back(q);
+  *p = (T*)q;
+  return EF_OK;
+}
+#define EF_ALLOC(c, p, n, ...)                                   \
+  do {                                                           \
+    int _r = dev_alloc((c), &(p), (size_t)(n), ##__VA_ARGS__);   \
+    if (_r != EF_OK) return _r;                                  \
+  } while (0)
+
+// scalar per-frame bookkeeping kernels -----------------------------------------------------------
+// !denseEnough(): float(sum)/float(rows*cols) > 0.75f over the (W/20)x(H/20) samples (ElasticFusion.cpp:256-268)
+__global__ void k_frame_begin(eft::TrackState* st, unsigned* dense_counter, int samples) {
+  if (threadIdx.x != 0) return;
+  const unsigned sum = *dense_counter;
+  *dense_counter = 0;
+  st->should_fill_in = !((float)sum / (float)samples > 0.75f);
+}
+__global__ void k_set_pose(eft::TrackState* st, efl::SE3 T) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 4; ++i) st->q[i] = T.q[i];
+  for (int i = 0; i < 3; ++i) st->t[i] = T.t[i];
+}
+__global__ void k_log_pose(const eft::TrackState* st, double* traj, int slot) {
+  if (threadIdx.x != 0) return;
+  efl::SE3 T;
+  for (int i = 0; i < 4; ++i) T.q[i] = st->q[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = st->t[i];
+  efl::se3_matrix(T, traj + (size_t)slot * 16);
+}
+__global__ void k_set_count(unsigned* count_dev, unsigned v) {
+  if (threadIdx.x == 0) *count_dev = v;
+}
+
+void timer_begin(ef_ctx* c, const char* name) {
+  if (!c->timing) return;
+  for (auto& t : c->timers)
+    if (t.name == name || !strcmp(t.name, name)) { (void)hipEventRecord(t.a, c->stream); t.used = true; return; }
+  StageTimer t{name, nullptr, nullptr, true};
+  (void)hipEventCreate(&t.a);
+  (void)hipEventCreate(&t.b);
+  (void)hipEventRecord(t.a, c->stream);
+  c->timers.push_back(t);
+}
+void timer_end(ef_ctx* c, const char* name) {
+  if (!c->timing) return;
+  for (auto& t : c->timers)
+    if (!strcmp(t.name, name)) { (void)hipEventRecord(t.b, c->stream); return; }
+}
+
+int do_predict(ef_ctx* c) {
+  // ElasticFusion::predict(), ElasticFusion.cpp:621-653: combinedPredict(ACTIVE) + FillIn (fused into the resolve)
+  efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_count, c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick,
+                        c->cfg.time_delta, c->zbuf, c->pm, c->fm, c->depth_filtered, c->rgb, c->cfg.frame_to_frame_rgb != 0,
+                        c->dense_counter, c->stream);
+  return EF_OK;
+}
+
+int process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_dev, int64_t timestamp, float weightMultiplier,
+                      const double* in_T_wc) {
+  hipStream_t s = c->stream;
+  const int W = c->cam.cols, H = c->cam.rows;
+  // the frame images are referenced by later stages of this frame and by the next frame's tracker
+  // (fill-in / predict read depth_filtered + rgb), so they are copied into context-owned buffers (D2D)
+  if (rgb_dev != c->rgb) EF_HIP(c, hipMemcpyAsync(c->rgb, rgb_dev, (size_t)W * H * 3, hipMemcpyDeviceToDevice, s));
+  if (depth_dev != c->depth_raw) EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_dev, (size_t)W * H * 2, hipMemcpyDeviceToDevice, s));
+
+  timer_begin(c, "Preprocess");
+  efm::preprocess_depth(c->depth_raw, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, s);
+  timer_end(c, "Preprocess");
+  hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, s, c->st, c->dense_counter, (W / 20) * (H / 20));
+
+  const bool rgbOnly = c->cfg.rgb_only != 0;
+  if (c->tick == 1) {  // ElasticFusion.cpp:290-296
+    timer_begin(c, "feedbackBuffers");
+    efm::seed_map(c->cam, c->rgb, c->depth_metric, c->depth_metric_filtered, c->tick, c->maxDepthProcessed, c->maps[c->cur],
+                  &c->st->map_count, c->cs, s);
+    eft::init_first_rgb(c->pyr, c->rgb, s);
+    timer_end(c, "feedbackBuffers");
+  } else {
+    if (!in_T_wc) {
+      eft::TrackParams tp;
+      tp.rgbOnly = rgbOnly;
+      tp.pyramid = c->cfg.pyramid != 0;
+      tp.fastOdom = c->cfg.fast_odom != 0;
+      tp.so3 = c->cfg.so3 != 0;
+      tp.icpWeight = c->cfg.icp_weight;
+      tp.distThres = 0.10f;                                   // RGBDOdometry.h:41
+      tp.angleThres = sinf(20.f * 3.14159254f / 180.f);       // RGBDOdometry.h:42
+      const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
+      timer_begin(c, "odomInit");
+      eft::init_icp_model(c->pyr, (const float*)c->pm.vertex, (const float*)c->pm.normal, (const float*)c->fm.vertex,
+                          (const float*)c->fm.normal, c->st, 6.0f /* maxDepthRGB, RGBDOdometry.cpp:42 */, s);
+      eft::init_icp(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, s);
+      eft::init_rgb(c->pyr, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, c->rgb, c->st, rgb, s);
+      timer_end(c, "odomInit");
+      timer_begin(c, "odom");
+      eft::track(c->pyr, c->st, c->intr, tp, s);
+      eft::track_end(c->st, rgb, weightMultiplier, s);
+      timer_end(c, "odom");
+    } else {
+      eft::save_prev_pose(c->st, s);
+      hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->st, efl::se3_from_matrix(in_T_wc));
+      eft::pose_injected(c->st, weightMultiplier, true, s);
+    }
+    // mid-frame predict() of ElasticFusion.cpp:387 is dead work without loop closure: skipped
+    if (!rgbOnly) {  // ElasticFusion.cpp:536-585
+      timer_begin(c, "indexMap");
+      efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_count, c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
+                           c->im, s);
+      timer_end(c, "indexMap");
+      timer_begin(c, "Fuse::Data+Update");
+      efm::fuse(c->cam, c->st->pose_f, c->tick, c->rgb, c->depth_metric, c->depth_metric_filtered, c->im, c->maxDepthProcessed,
+                &c->st->weighting, c->maps[c->cur], &c->st->map_count, c->cand, c->winner, s);
+      timer_end(c, "Fuse::Data+Update");
+      timer_begin(c, "indexMap2");
+      efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_count, c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
+                           c->im, s);
+      timer_end(c, "indexMap2");
+      timer_begin(c, "Fuse::Copy");
+      efm::clean(c->cam, c->st->T_cw, c->tick, c->im, c->cfg.confidence, c->cfg.time_delta, c->maps[c->cur], &c->st->map_count, c->cand,
+                 c->winner, c->maps[c->cur ^ 1], c->capacity, c->cs, c->overflow, s);
+      c->cur ^= 1;
+      timer_end(c, "Fuse::Copy");
+    }
+  }
+  // t_T_wc.push_back / poseLogTimes.push_back, ElasticFusion.cpp:588-589
+  if ((int)c->stamps.size() < c->traj_cap) {
+    hipLaunchKernelGGL(k_log_pose, dim3(1), dim3(64), 0, s, (const eft::TrackState*)c->st, c->traj, (int)c->stamps.size());
+    c->stamps.push_back(timestamp);
+  }
+  timer_begin(c, "IndexMap::ACTIVE");
+  do_predict(c);  // ElasticFusion.cpp:599
+  timer_end(c, "IndexMap::ACTIVE");
+  c->tick++;
+  EF_HIP(c, hipGetLastError());
+  return EF_OK;
+}
+
+int ctx_init(ef_ctx* c) {
+  const ef_config& g = c->cfg;
+  const int W = g.width, H = g.height;
+  const size_t P = (size_t)W * H;
+  hipStream_t s = c->stream;
+  EF_ALLOC(c, c->rgb, P * 3);
+  EF_ALLOC(c, c->depth_raw, P);
+  EF_ALLOC(c, c->depth_filtered, P);
+  EF_ALLOC(c, c->depth_metric, P);
+  EF_ALLOC(c, c->depth_metric_filtered, P);
+  EF_HIP(c, hipHostMalloc((void**)&c->h_rgb, P * 3));
+  EF_HIP(c, hipHostMalloc((void**)&c->h_depth, P * 2));
+  // tracker pyramids (zero-filled: the stale y/z planes of quirk Q3 are then deterministic)
+  c->pyr.width = W;
+  c->pyr.height = H;
+  for (int i = 0; i < eft::NUM_PYRS; ++i) {
+    const size_t n = (size_t)(W >> i) * (H >> i);
+    EF_ALLOC(c, c->pyr.depth_tmp[i], n);
+    EF_ALLOC(c, c->pyr.vmap_curr[i], 3 * n);
+    EF_ALLOC(c, c->pyr.nmap_curr[i], 3 * n);
+    EF_ALLOC(c, c->pyr.vmap_g_prev[i], 3 * n);
+    EF_ALLOC(c, c->pyr.nmap_g_prev[i], 3 * n);
+    EF_ALLOC(c, c->pyr.lastDepth[i], n);
+    EF_ALLOC(c, c->pyr.lastImage[i], n);
+    EF_ALLOC(c, c->pyr.nextImage[i], n);
+    EF_ALLOC(c, c->pyr.lastNextImage[i], n);
+    EF_ALLOC(c, c->pyr.dIdx[i], n);
+    EF_ALLOC(c, c->pyr.dIdy[i], n);
+    uint8_t* corr;
+    EF_ALLOC(c, corr, n * 16);
+    c->pyr.corresImg[i] = corr;
+  }
+  EF_ALLOC(c, c->pyr.partials, (size_t)eft::MAX_PARTIAL_BLOCKS * eft::PARTIAL_STRIDE);
+  EF_ALLOC(c, c->st, 1);
+  // prediction images
+  EF_ALLOC(c, c->im.index, P);
+  EF_ALLOC(c, c->im.vert_conf, P);
+  EF_ALLOC(c, c->im.color_time, P);
+  EF_ALLOC(c, c->im.norm_rad, P);
+  EF_ALLOC(c, c->pm.image, P);
+  EF_ALLOC(c, c->pm.vertex, P);
+  EF_ALLOC(c, c->pm.normal, P);
+  EF_ALLOC(c, c->pm.time, P);
+  EF_ALLOC(c, c->fm.image, P);
+  EF_ALLOC(c, c->fm.vertex, P);
+  EF_ALLOC(c, c->fm.normal, P);
+  EF_ALLOC(c, c->zbuf, P, 0xFF);
+  EF_ALLOC(c, c->dense_counter, 1);
+  EF_ALLOC(c, c->overflow, 1);
+  // global model
+  c->capacity = g.max_surfels;
+  for (int k = 0; k < 2; ++k) {
+    EF_ALLOC(c, c->maps[k].pos_conf, c->capacity);
+    EF_ALLOC(c, c->maps[k].col_time, c->capacity);
+    EF_ALLOC(c, c->maps[k].nrm_rad, c->capacity);
+  }
+  EF_ALLOC(c, c->winner, c->capacity, 0xFF);
+  c->cand.n = (W / 2) * (H / 2);
+  EF_ALLOC(c, c->cand.pos_conf, c->cand.n);
+  EF_ALLOC(c, c->cand.col_time, c->cand.n);
+  EF_ALLOC(c, c->cand.nrm_rad, c->cand.n);
+  EF_ALLOC(c, c->cand.best, c->cand.n);
+  c->cs.max_chunks = (int)((c->capacity + (size_t)c->cand.n + 2 * P) / efm::CHUNK + 8);
+  EF_ALLOC(c, c->cs.flags, (size_t)c->capacity + c->cand.n + 2 * P);
+  EF_ALLOC(c, c->cs.chunk_count, c->cs.max_chunks);
+  EF_ALLOC(c, c->cs.chunk_offset, c->cs.max_chunks);
+  EF_ALLOC(c, c->cs.totals, 8);
+  c->traj_cap = 1 << 16;
+  EF_ALLOC(c, c->traj, (size_t)c->traj_cap * 16);
+  // T_wc = identity (ElasticFusion.h: T_wc_curr default) -> publish the float matrices
+  efl::SE3 I{{0, 0, 0, 1}, {0, 0, 0}};
+  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->st, I);
+  eft::save_prev_pose(c->st, s);
+  eft::pose_injected(c->st, 1.0f, false, s);
+  EF_HIP(c, hipStreamSynchronize(s));
+  return EF_OK;
+}
+
+void ctx_free(ef_ctx* c) {
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->h_rgb) (void)hipHostFree(c->h_rgb);
+  if (c->h_depth) (void)hipHostFree(c->h_depth);
+  for (auto& t : c->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+void ef_default_config(ef_config* cfg) {
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->width = 640; cfg->height = 480;                          // MainController.cpp:37
+  cfg->fx = 528; cfg->fy = 528; cfg->cx = 320; cfg->cy = 240;   // MainController.cpp:42
+  cfg->time_delta = 2147483647 / 2;                             // -o, MainController.cpp:179-183
+  cfg->confidence = 10.0f;                                      // MainController.cpp:69
+  cfg->depth_cut = 3.0f;                                        // MainController.cpp:70
+  cfg->icp_weight = 10.0f;                                      // MainController.cpp:71
+  cfg->fast_odom = 0; cfg->so3 = 1; cfg->frame_to_frame_rgb = 0; cfg->pyramid = 1; cfg->rgb_only = 0;
+  cfg->close_loops = 0;
+  cfg->max_surfels = 4u * 1024u * 1024u;
+  cfg->device = 0;
+  cfg->stream = nullptr;
+}
+
+int ef_create(const ef_config* cfg, ef_ctx** out) {
+  if (!cfg || !out) { g_create_error = "null argument"; return EF_EINVAL; }
+  if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width % 4) || (cfg->height % 4) || cfg->fx <= 0 || cfg->fy <= 0) {
+    g_create_error = "width/height must be positive multiples of 4 and focal lengths positive";
+    return EF_EINVAL;
+  }
+  if (cfg->close_loops) { g_create_error = "close_loops=1: loop closure is out of scope of this engine (SURVEY.md §8f)"; return EF_EINVAL; }
+  if ((size_t)cfg->max_surfels < (size_t)cfg->width * cfg->height) { g_create_error = "max_surfels must be >= width*height"; return EF_EINVAL; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    g_create_error = std::string("no HIP device: ") + hipGetErrorString(e);
+    return EF_EHIP;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "bad device ordinal"; return EF_EINVAL; }
+  e = hipSetDevice(cfg->device);
+  if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return EF_EHIP; }
+  ef_ctx* c = new ef_ctx();
+  c->cfg = *cfg;
+  c->cam = efm::Cam{cfg->width, cfg->height, cfg->fx, cfg->fy, cfg->cx, cfg->cy};
+  c->intr = eft::Intr{cfg->fx, cfg->fy, cfg->cx, cfg->cy};
+  if (cfg->stream) {
+    c->stream = (hipStream_t)cfg->stream;
+  } else {
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return EF_EHIP; }
+    c->own_stream = true;
+  }
+  const int r = ctx_init(c);
+  if (r != EF_OK) {
+    g_create_error = c->err;
+    ctx_free(c);
+    delete c;
+    return r;
+  }
+  *out = c;
+  return EF_OK;
+}
+
+void ef_destroy(ef_ctx* c) {
+  if (!c) return;
+  ctx_free(c);
+  delete c;
+}
+const char* ef_last_error(const ef_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+void* ef_stream(ef_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int ef_synchronize(ef_ctx* c) {
+  if (!c) return EF_EINVAL;
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  return EF_OK;
+}
+
+int ef_process_frame(ef_ctx* c, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, float wm, const double* T) {
+  if (!c || !rgb || !depth) return EF_EINVAL;
+  const size_t P = (size_t)c->cam.cols * c->cam.rows;
+  // the staging buffers may still be in flight from the previous frame's async copy
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  memcpy(c->h_rgb, rgb, P * 3);
+  memcpy(c->h_depth, depth, P * 2);
+  EF_HIP(c, hipMemcpyAsync(c->rgb, c->h_rgb, P * 3, hipMemcpyHostToDevice, c->stream));
+  EF_HIP(c, hipMemcpyAsync(c->depth_raw, c->h_depth, P * 2, hipMemcpyHostToDevice, c->stream));
+  return process_frame_dev(c, c->rgb, c->depth_raw, timestamp, wm, T);
+}
+int ef_process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_dev, int64_t timestamp, float wm, const double* T) {
+  if (!c || !rgb_dev || !depth_dev) return EF_EINVAL;
+  return process_frame_dev(c, rgb_dev, depth_dev, timestamp, wm, T);
+}
+int ef_predict(ef_ctx* c) {
+  if (!c) return EF_EINVAL;
+  EF_HIP(c, hipMemsetAsync(c->dense_counter, 0, sizeof(unsigned), c->stream));
+  return do_predict(c);
+}
+int ef_get_pose(ef_ctx* c, double* T16) {
+  if (!c || !T16) return EF_EINVAL;
+  eft::TrackState h;
+  EF_HIP(c, hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  efl::SE3 T;
+  for (int i = 0; i < 4; ++i) T.q[i] = h.q[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = h.t[i];
+  efl::se3_matrix(T, T16);
+  return EF_OK;
+}
+int ef_get_tick(ef_ctx* c, int* tick) { if (!c || !tick) return EF_EINVAL; *tick = c->tick; return EF_OK; }
+int ef_set_tick(ef_ctx* c, int tick) { if (!c) return EF_EINVAL; c->tick = tick; return EF_OK; }
+int ef_get_tracking_stats(ef_ctx* c, float* out6, double* A36, double* b6) {
+  if (!c || !out6) return EF_EINVAL;
+  eft::TrackState h;
+  EF_HIP(c, hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  out6[0] = h.lastICPError; out6[1] = h.lastICPCount; out6[2] = h.lastRGBError;
+  out6[3] = h.lastRGBCount; out6[4] = h.lastSO3Error; out6[5] = h.lastSO3Count;
+  if (A36) memcpy(A36, h.lastA, sizeof(h.lastA));
+  if (b6) memcpy(b6, h.lastb, sizeof(h.lastb));
+  return EF_OK;
+}
+int ef_get_trajectory(ef_ctx* c, double* T16s, int64_t* stamps, int max_frames, int* n_frames) {
+  if (!c || !n_frames) return EF_EINVAL;
+  int n = (int)c->stamps.size();
+  if (n > max_frames) n = max_frames;
+  if (T16s && n) {
+    EF_HIP(c, hipMemcpyAsync(T16s, c->traj, (size_t)n * 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    EF_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  if (stamps) for (int i = 0; i < n; ++i) stamps[i] = c->stamps[i];
+  *n_frames = n;
+  return EF_OK;
+}
+int ef_map_count(ef_ctx* c, uint32_t* count) {
+  if (!c || !count) return EF_EINVAL;
+  EF_HIP(c, hipMemcpyAsync(count, &c->st->map_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  return EF_OK;
+}
+int ef_map_download(ef_ctx* c, float* surfels, uint32_t max_surfels, uint32_t* count) {
+  if (!c || !count) return EF_EINVAL;
+  uint32_t n = 0;
+  int r = ef_map_count(c, &n);
+  if (r != EF_OK) return r;
+  if (n > max_surfels) n = max_surfels;
+  *count = n;
+  if (!surfels || !n) return EF_OK;
+  // NB the reference's downloadMap() reads the pre-clean ping-pong buffer (quirk Q14); this returns model()
+  float* tmp = nullptr;
+  EF_HIP(c, hipMalloc((void**)&tmp, (size_t)n * 48));
+  efm::soa_to_aos(c->maps[c->cur], n, tmp, c->stream);
+  hipError_t e = hipMemcpyAsync(surfels, tmp, (size_t)n * 48, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
+  EF_HIP(c, e);
+  return EF_OK;
+}
+int ef_map_upload(ef_ctx* c, const float* surfels, uint32_t count) {
+  if (!c || (!surfels && count)) return EF_EINVAL;
+  if (count > c->capacity) { c->err = "ef_map_upload: count exceeds max_surfels"; return EF_ECAPACITY; }
+  float* tmp = nullptr;
+  if (count) {
+    EF_HIP(c, hipMalloc((void**)&tmp, (size_t)count * 48));
+    hipError_t e = hipMemcpyAsync(tmp, surfels, (size_t)count * 48, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+      efm::aos_to_soa(tmp, count, c->maps[c->cur], c->stream);
+      e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(tmp);
+    EF_HIP(c, e);
+  }
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, c->stream, &c->st->map_count, count);
+  return EF_OK;
+}
+int ef_save_freiburg(ef_ctx* c, const char* path) {
+  if (!c || !path) return EF_EINVAL;
+  const int n = (int)c->stamps.size();
+  std::vector<double> T((size_t)n * 16);
+  int got = 0;
+  int r = ef_get_trajectory(c, T.data(), nullptr, n, &got);
+  if (r != EF_OK) return r;
+  FILE* f = fopen(path, "w");
+  if (!f) { c->err = std::string("cannot open ") + path; return EF_EINVAL; }
+  // "timestamp tx ty tz qx qy qz qw", timestamp = microseconds / 1e6 (ElasticFusion.cpp:112-139)
+  for (int i = 0; i < got; ++i) {
+    const efl::SE3 S = efl::se3_from_matrix(&T[(size_t)i * 16]);
+    fprintf(f, "%.6f %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", (double)c->stamps[i] / 1000000.0, S.t[0], S.t[1], S.t[2], S.q[0], S.q[1], S.q[2], S.q[3]);
+  }
+  fclose(f);
+  return EF_OK;
+}
+int ef_save_ply(ef_ctx* c, const char* path) {
+  if (!c || !path) return EF_EINVAL;
+  uint32_t n = 0;
+  int r = ef_map_count(c, &n);
+  if (r != EF_OK) return r;
+  std::vector<float> m((size_t)n * 12);
+  r = ef_map_download(c, m.data(), n, &n);
+  if (r != EF_OK) return r;
+  uint32_t valid = 0;
+  for (uint32_t i = 0; i < n; ++i) valid += m[(size_t)i * 12 + 3] > c->cfg.confidence;
+  FILE* f = fopen(path, "wb");
+  if (!f) { c->err = std::string("cannot open ") + path; return EF_EINVAL; }
+  // header + binary little-endian records of ElasticFusion::savePly (ElasticFusion.cpp:684-781)
+  fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %u\nproperty float x\nproperty float y\nproperty float z\n"
+             "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty float nx\nproperty float ny\nproperty float nz\n"
+             "property float radius\nend_header\n", valid);
+  for (uint32_t i = 0; i < n; ++i) {
+    const float* s = &m[(size_t)i * 12];
+    if (!(s[3] > c->cfg.confidence)) continue;
+    const int col = (int)s[4];
+    const unsigned char rgbc[3] = {(unsigned char)((col >> 16) & 0xFF), (unsigned char)((col >> 8) & 0xFF), (unsigned char)(col & 0xFF)};
+    fwrite(s, sizeof(float), 3, f);
+    fwrite(rgbc, 1, 3, f);
+    fwrite(s + 8, sizeof(float), 4, f);
+  }
+  fclose(f);
+  return EF_OK;
+}
+
+int ef_set_rgb_only(ef_ctx* c, int v) { if (!c) return EF_EINVAL; c->cfg.rgb_only = v; return EF_OK; }
+int ef_set_icp_weight(ef_ctx* c, float v) { if (!c) return EF_EINVAL; c->cfg.icp_weight = v; return EF_OK; }
+int ef_set_pyramid(ef_ctx* c, int v) { if (!c) return EF_EINVAL; c->cfg.pyramid = v; return EF_OK; }
+int ef_set_fast_odom(ef_ctx* c, int v) { if (!c) return EF_EINVAL; c->cfg.fast_odom = v; return EF_OK; }
+int ef_set_so3(ef_ctx* c, int v) { if (!c) return EF_EINVAL; c->cfg.so3 = v; return EF_OK; }
+int ef_set_frame_to_frame_rgb(ef_ctx* c, int v) { if (!c) return EF_EINVAL; c->cfg.frame_to_frame_rgb = v; return EF_OK; }
+int ef_set_confidence_threshold(ef_ctx* c, float v) { if (!c) return EF_EINVAL; c->cfg.confidence = v; return EF_OK; }
+int ef_set_depth_cutoff(ef_ctx* c, float v) { if (!c) return EF_EINVAL; c->cfg.depth_cut = v; return EF_OK; }
+
+int ef_get_image(ef_ctx* c, int which, void* dst, size_t bytes) {
+  if (!c || !dst) return EF_EINVAL;
+  const size_t P = (size_t)c->cam.cols * c->cam.rows;
+  const void* src = nullptr;
+  size_t need = 0;
+  switch (which) {
+    case EF_IMG_DEPTH_FILTERED: src = c->depth_filtered; need = P * 2; break;
+    case EF_IMG_DEPTH_METRIC: src = c->depth_metric; need = P * 4; break;
+    case EF_IMG_DEPTH_METRIC_FILTERED: src = c->depth_metric_filtered; need = P * 4; break;
+    case EF_IMG_PREDICT_IMAGE: src = c->pm.image; need = P * 4; break;
+    case EF_IMG_PREDICT_VERTEX: src = c->pm.vertex; need = P * 16; break;
+    case EF_IMG_PREDICT_NORMAL: src = c->pm.normal; need = P * 16; break;
+    case EF_IMG_PREDICT_TIME: src = c->pm.time; need = P * 2; break;
+    case EF_IMG_FILL_IMAGE: src = c->fm.image; need = P * 4; break;
+    case EF_IMG_FILL_VERTEX: src = c->fm.vertex; need = P * 16; break;
+    case EF_IMG_FILL_NORMAL: src = c->fm.normal; need = P * 16; break;
+    case EF_IMG_INDEX: src = c->im.index; need = P * 4; break;
+    case EF_IMG_VERT_CONF: src = c->im.vert_conf; need = P * 16; break;
+    case EF_IMG_COLOR_TIME: src = c->im.color_time; need = P * 16; break;
+    case EF_IMG_NORM_RAD: src = c->im.norm_rad; need = P * 16; break;
+    default: c->err = "ef_get_image: unknown image"; return EF_EINVAL;
+  }
+  if (bytes < need) { c->err = "ef_get_image: destination too small"; return EF_EINVAL; }
+  EF_HIP(c, hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  return EF_OK;
+}
+int ef_get_tracker_buffer(ef_ctx* c, int which, int level, void* dst, size_t bytes) {
+  if (!c || !dst || level < 0 || level >= eft::NUM_PYRS) return EF_EINVAL;
+  const size_t n = (size_t)(c->cam.cols >> level) * (c->cam.rows >> level);
+  const void* src = nullptr;
+  size_t need = 0;
+  const eft::Pyramid& p = c->pyr;
+  switch (which) {
+    case 0: src = p.vmap_curr[level]; need = n * 12; break;
+    case 1: src = p.nmap_curr[level]; need = n * 12; break;
+    case 2: src = p.vmap_g_prev[level]; need = n * 12; break;
+    case 3: src = p.nmap_g_prev[level]; need = n * 12; break;
+    case 4: case 5: src = p.lastDepth[level]; need = n * 4; break;
+    case 6: src = p.lastImage[level]; need = n; break;
+    case 7: src = p.nextImage[level]; need = n; break;
+    case 8: src = p.lastNextImage[level]; need = n; break;
+    case 9: src = p.dIdx[level]; need = n * 2; break;
+    case 10: src = p.dIdy[level]; need = n * 2; break;
+    case 11: src = level == 0 ? c->depth_filtered : p.depth_tmp[level]; need = n * 2; break;
+    default: c->err = "ef_get_tracker_buffer: unknown buffer"; return EF_EINVAL;
+  }
+  if (bytes < need) { c->err = "ef_get_tracker_buffer: destination too small"; return EF_EINVAL; }
+  EF_HIP(c, hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  return EF_OK;
+}
+
+int ef_enable_timing(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->timing = on != 0; return EF_OK; }
+int ef_get_timings(ef_ctx* c, ef_timing* out, int max, int* n) {
+  if (!c || !n) return EF_EINVAL;
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  int k = 0;
+  for (auto& t : c->timers) {
+    if (!t.used || k >= max) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) ms = -1.f;
+    if (out) { out[k].name = t.name; out[k].ms = ms; }
+    ++k;
+  }
+  *n = k;
+  return EF_OK;
+}
+
+// ---- device helpers ----
+int ef_dev_alloc(void** dev, size_t bytes) { return hipMalloc(dev, bytes ? bytes : 1) == hipSuccess ? EF_OK : EF_ENOMEM; }
+int ef_dev_free(void* dev) { return hipFree(dev) == hipSuccess ? EF_OK : EF_EHIP; }
+int ef_dev_upload(void* dev, const void* host, size_t bytes) { return hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) == hipSuccess ? EF_OK : EF_EHIP; }
+int ef_dev_download(void* host, const void* dev, size_t bytes) { return hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost) == hipSuccess ? EF_OK : EF_EHIP; }
+int ef_dev_memset(void* dev, int value, size_t bytes) { return hipMemset(dev, value, bytes) == hipSuccess ? EF_OK : EF_EHIP; }
+int ef_dev_sync(void) { return hipDeviceSynchronize() == hipSuccess ? EF_OK : EF_EHIP; }
+int ef_device_count(int* n) { return hipGetDeviceCount(n) == hipSuccess ? EF_OK : EF_EHIP; }
+int ef_set_device(int d) { return hipSetDevice(d) == hipSuccess ? EF_OK : EF_EHIP; }
+
+// ---- operator tier: tracking ----
+#define OP_TAIL(s)                                                         \
+  do {                                                                     \
+    hipError_t _e = hipGetLastError();                                     \
+    if (_e != hipSuccess) { g_create_error = hipGetErrorString(_e); return EF_EHIP; } \
+    return EF_OK;                                                          \
+  } while (0)
+#define OP_SYNC(s)                                                         \
+  do {                                                                     \
+    hipError_t _e = hipStreamSynchronize((hipStream_t)(s));                \
+    if (_e == hipSuccess) _e = hipGetLastError();                          \
+    if (_e != hipSuccess) { g_create_error = hipGetErrorString(_e); return EF_EHIP; } \
+  } while (0)
+
+int ef_op_pyr_down(const uint16_t* src, int sc, int sr, uint16_t* dst, void* s) { eft::pyr_down_u16(src, sc, sr, dst, (hipStream_t)s); OP_TAIL(s); }
+int ef_op_create_vmap(const ef_intr* k, const uint16_t* depth, int cols, int rows, float cutoff, float* vmap, void* s) {
+  eft::create_vmap(depth, cols, rows, eft::Intr{k->fx, k->fy, k->cx, k->cy}, cutoff, vmap, (hipStream_t)s);
+  OP_TAIL(s);
+}
+int ef_op_create_nmap(const float* vmap, int cols, int rows, float* nmap, void* s) { eft::create_nmap(vmap, cols, rows, nmap, (hipStream_t)s); OP_TAIL(s); }
+int ef_op_transform_maps(const float* vs, const float* ns, int cols, int rows, const float* R9, const float* t3, float* vd, float* nd, void* s) {
+  float* rt = nullptr;
+  if (hipMalloc((void**)&rt, 12 * sizeof(float)) != hipSuccess) return EF_ENOMEM;
+  float h[12];
+  memcpy(h, R9, 36);
+  memcpy(h + 9, t3, 12);
+  (void)hipMemcpyAsync(rt, h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)s);
+  eft::transform_maps(vs, ns, cols, rows, rt, rt + 9, vd, nd, (hipStream_t)s);
+  (void)hipStreamSynchronize((hipStream_t)s);
+  (void)hipFree(rt);
+  OP_TAIL(s);
+}
+int ef_op_copy_maps(const float* v4, const float* n4, int cols, int rows, float* tmp, float* vd, float* nd, void* s) {
+  eft::copy_maps(v4, n4, cols, rows, tmp, vd, nd, (hipStream_t)s);
+  OP_TAIL(s);
+}
+int ef_op_resize_vmap(const float* in, int sc, int sr, float* out, void* s) { eft::resize_map(in, sc, sr, out, false, (hipStream_t)s); OP_TAIL(s); }
+int ef_op_resize_nmap(const float* in, int sc, int sr, float* out, void* s) { eft::resize_map(in, sc, sr, out, true, (hipStream_t)s); OP_TAIL(s); }
+int ef_op_pyr_down_gauss_f(const float* src, int sc, int sr, float* dst, void* s) { eft::pyr_down_gauss_f(src, sc, sr, dst, (hipStream_t)s); OP_TAIL(s); }
+int ef_op_pyr_down_uchar_gauss(const uint8_t* src, int sc, int sr, uint8_t* dst, void* s) { eft::pyr_down_uchar_gauss(src, sc, sr, dst, (hipStream_t)s); OP_TAIL(s); }
+int ef_op_vertices_to_depth(const float* tmp, int cols, int rows, float cutoff, float* dst, void* s) { eft::vertices_to_depth(tmp, cols, rows, cutoff, dst, (hipStream_t)s); OP_TAIL(s); }
+int ef_op_image_bgr_to_intensity(const uint8_t* rgba, int cols, int rows, uint8_t* dst, void* s) { eft::bgr_to_intensity(rgba, 4, cols, rows, dst, (hipStream_t)s); OP_TAIL(s); }
+int ef_op_compute_derivative_images(const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy, void* s) {
+  eft::derivative_images(src, cols, rows, dx, dy, (hipStream_t)s);
+  OP_TAIL(s);
+}
+int ef_op_project_to_point_cloud(const float* depth, int cols, int rows, const ef_intr* k0, int level, float* cloud, void* s) {
+  eft::project_to_point_cloud(depth, cols, rows, eft::intr_level(eft::Intr{k0->fx, k0->fy, k0->cx, k0->cy}, level), cloud, (hipStream_t)s);
+  OP_TAIL(s);
+}
+
+static int op_scratch(float** partials, float** out, int nfloats_out) {
+  if (hipMalloc((void**)partials, (size_t)eft::MAX_PARTIAL_BLOCKS * 8 * eft::PARTIAL_STRIDE * sizeof(float)) != hipSuccess) return EF_ENOMEM;
+  if (hipMalloc((void**)out, nfloats_out * sizeof(float)) != hipSuccess) { (void)hipFree(*partials); return EF_ENOMEM; }
+  return EF_OK;
+}
+static void unpack29_host(const float* h, float* A, float* b) {
+  int shift = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j) {
+      const float v = h[shift++];
+      if (j == 6) b[i] = v;
+      else A[j * 6 + i] = A[i * 6 + j] = v;
+    }
+}
+int ef_op_icp_step(const float* Rc, const float* tc, const float* vc, const float* nc, const float* Rpi, const float* tp, const ef_intr* k,
+                   const float* vg, const float* ng, float dist, float ang, int cols, int rows, float* A, float* b, float* res, void* s) {
+  if ((cols * rows + eft::REDUCE_BLOCK - 1) / eft::REDUCE_BLOCK > eft::MAX_PARTIAL_BLOCKS * 8) return EF_EINVAL;
+  eft::IcpArgs a;
+  memcpy(a.Rcurr, Rc, 36); memcpy(a.tcurr, tc, 12); memcpy(a.Rprev_inv, Rpi, 36); memcpy(a.tprev, tp, 12);
+  a.k = eft::Intr{k->fx, k->fy, k->cx, k->cy};
+  a.distThres = dist; a.angleThres = ang;
+  float *partials, *out;
+  int r = op_scratch(&partials, &out, 32);
+  if (r != EF_OK) return r;
+  eft::icp_step_op(a, vc, nc, vg, ng, cols, rows, partials, out, (hipStream_t)s);
+  float h[32];
+  (void)hipMemcpyAsync(h, out, 29 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)s);
+  hipError_t e = hipStreamSynchronize((hipStream_t)s);
+  (void)hipFree(partials); (void)hipFree(out);
+  if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return EF_EHIP; }
+  unpack29_host(h, A, b);
+  res[0] = h[27]; res[1] = h[28];
+  return EF_OK;
+}
+int ef_op_compute_rgb_residual(float minScale, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth, const float* nextDepth,
+                               const uint8_t* lastImage, const uint8_t* nextImage, void* corres, float maxDepthDelta, const float* kt,
+                               const float* krkinv, int cols, int rows, int* sigma, int* count, void* s) {
+  eft::RgbResidualArgs a;
+  a.minScale = minScale; a.maxDepthDelta = maxDepthDelta;
+  memcpy(a.kt, kt, 12); memcpy(a.krkinv, krkinv, 36);
+  int* out;
+  if (hipMalloc((void**)&out, 2 * sizeof(int)) != hipSuccess) return EF_ENOMEM;
+  eft::rgb_residual_op(a, dIdx, dIdy, lastDepth, nextDepth, lastImage, nextImage, corres, cols, rows, out, (hipStream_t)s);
+  int h[2] = {0, 0};
+  hipError_t e = hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(out);
+  if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return EF_EHIP; }
+  *count = h[0];
+  *sigma = h[1];
+  return EF_OK;
+}
+int ef_op_rgb_step(const void* corres, float sigma, const float* cloud, float fx, float fy, const int16_t* dIdx, const int16_t* dIdy,
+                   float sobelScale, int cols, int rows, float* A, float* b, void* s) {
+  float *partials, *out;
+  int r = op_scratch(&partials, &out, 32);
+  if (r != EF_OK) return r;
+  eft::rgb_step_op(corres, sigma, cloud, fx, fy, dIdx, dIdy, sobelScale, cols, rows, partials, out, (hipStream_t)s);
+  float h[32];
+  (void)hipMemcpyAsync(h, out, 29 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)s);
+  hipError_t e = hipStreamSynchronize((hipStream_t)s);
+  (void)hipFree(partials); (void)hipFree(out);
+  if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return EF_EHIP; }
+  unpack29_host(h, A, b);
+  return EF_OK;
+}
+int ef_op_so3_step(const uint8_t* lastImage, const uint8_t* nextImage, const float* ib, const float* kinv, const float* krlr, int cols,
+                   int rows, float* A, float* b, float* res, void* s) {
+  eft::So3Args a;
+  memcpy(a.imageBasis, ib, 36); memcpy(a.kinv, kinv, 36); memcpy(a.krlr, krlr, 36);
+  float* out;
+  if (hipMalloc((void**)&out, 16 * sizeof(float)) != hipSuccess) return EF_ENOMEM;
+  eft::so3_step_op(a, lastImage, nextImage, cols, rows, out, (hipStream_t)s);
+  float h[11];
+  (void)hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)s);
+  hipError_t e = hipStreamSynchronize((hipStream_t)s);
+  (void)hipFree(out);
+  if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return EF_EHIP; }
+  int shift = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = i; j < 4; ++j) {
+      const float v = h[shift++];
+      if (j == 3) b[i] = v;
+      else A[j * 3 + i] = A[i * 3 + j] = v;
+    }
+  res[0] = h[9]; res[1] = h[10];
+  return EF_OK;
+}
+
+// ---- operator tier: pre-processing + map ----
+int ef_op_filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, void* s) {
+  efm::filter_depth(raw, cols, rows, maxD, filtered, (hipStream_t)s);
+  OP_TAIL(s);
+}
+int ef_op_metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, void* s) {
+  efm::metricise_depth(in, cols, rows, maxD, out, (hipStream_t)s);
+  OP_TAIL(s);
+}
+
+}  // extern "C"
+namespace {
+struct OpMap {  // temporary SoA mirror of an AoS surfel list + scratch, for the operator tier
+  std::vector<void*> allocs;
+  template <typename T>
+  T* alloc(size_t n, int fill = 0) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (n ? n : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    (void)hipMemset(p, fill, (n ? n : 1) * sizeof(T));
+    allocs.push_back(p);
+    return (T*)p;
+  }
+  efm::SurfelSoA soa(size_t n) { return efm::SurfelSoA{alloc<float4>(n), alloc<float4>(n), alloc<float4>(n)}; }
+  ~OpMap() { for (void* p : allocs) (void)hipFree(p); }
+};
+efm::Cam to_cam(const ef_cam* c) { return efm::Cam{c->cols, c->rows, c->fx, c->fy, c->cx, c->cy}; }
+// device copies of the two float pose matrices derived from a double T_wc
+void pose_mats(const double* T16, float* Tcw_host, float* pose_host) {
+  const efl::SE3 T = efl::se3_from_matrix(T16);
+  efl::se3_inverse_matrix_f(T, Tcw_host);
+  efl::se3_castf_matrix(T, pose_host);
+}
+}  // namespace
+extern "C" {
+
+int ef_op_seed_map(const ef_cam* cam, const uint8_t* rgb, const float* dm, const float* dmf, int time, float maxDepth, float* surfels,
+                   uint32_t* count_host, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  OpMap m;
+  const size_t P = (size_t)cam->cols * cam->rows;
+  efm::SurfelSoA soa = m.soa(P);
+  efm::CompactScratch cs;
+  cs.max_chunks = (int)(2 * P / efm::CHUNK + 8);
+  cs.flags = m.alloc<uint8_t>(2 * P);
+  cs.chunk_count = m.alloc<uint32_t>(cs.max_chunks);
+  cs.chunk_offset = m.alloc<uint32_t>(cs.max_chunks);
+  cs.totals = m.alloc<uint32_t>(8);
+  unsigned* cnt = m.alloc<unsigned>(1);
+  efm::seed_map(to_cam(cam), rgb, dm, dmf, time, maxDepth, soa, cnt, cs, s);
+  unsigned h = 0;
+  (void)hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, s);
+  OP_SYNC(s);
+  efm::soa_to_aos(soa, h, surfels, s);
+  OP_SYNC(s);
+  *count_host = h;
+  return EF_OK;
+}
+
+int ef_op_predict_indices(const ef_cam* cam, const double* T16, int time, const float* surfels, uint32_t count, float maxDepth, int timeDelta,
+                          uint32_t* index, float* vc, float* ct, float* nr, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  OpMap m;
+  const size_t P = (size_t)cam->cols * cam->rows;
+  efm::SurfelSoA soa = m.soa(count);
+  efm::aos_to_soa(surfels, count, soa, s);
+  float h[32];
+  pose_mats(T16, h, h + 16);
+  float* mats = m.alloc<float>(32);
+  (void)hipMemcpyAsync(mats, h, sizeof(h), hipMemcpyHostToDevice, s);
+  unsigned* cnt = m.alloc<unsigned>(1);
+  (void)hipMemcpyAsync(cnt, &count, sizeof(unsigned), hipMemcpyHostToDevice, s);
+  unsigned long long* zbuf = m.alloc<unsigned long long>(P, 0xFF);
+  efm::IndexMaps im{index, (float4*)vc, (float4*)ct, (float4*)nr};
+  efm::predict_indices(to_cam(cam), mats, time, soa, cnt, maxDepth, timeDelta, zbuf, im, s);
+  OP_SYNC(s);
+  return EF_OK;
+}
+
+int ef_op_combined_predict(const ef_cam* cam, const double* T16, const float* surfels, uint32_t count, float maxDepth, float confThreshold,
+                           int time, int maxTime, int timeDelta, uint8_t* image, float* vertex, float* normal, uint16_t* timeMap, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  OpMap m;
+  const size_t P = (size_t)cam->cols * cam->rows;
+  efm::SurfelSoA soa = m.soa(count);
+  efm::aos_to_soa(surfels, count, soa, s);
+  float h[32];
+  pose_mats(T16, h, h + 16);
+  float* mats = m.alloc<float>(32);
+  (void)hipMemcpyAsync(mats, h, sizeof(h), hipMemcpyHostToDevice, s);
+  unsigned* cnt = m.alloc<unsigned>(1);
+  (void)hipMemcpyAsync(cnt, &count, sizeof(unsigned), hipMemcpyHostToDevice, s);
+  unsigned long long* zbuf = m.alloc<unsigned long long>(P, 0xFF);
+  efm::PredictMaps pm{(uchar4*)image, (float4*)vertex, (float4*)normal, timeMap};
+  efm::FillMaps none{nullptr, nullptr, nullptr};
+  efm::combined_predict(to_cam(cam), mats, soa, cnt, maxDepth, confThreshold, time, maxTime, timeDelta, zbuf, pm, none, nullptr, nullptr, false,
+                        nullptr, s);
+  OP_SYNC(s);
+  return EF_OK;
+}
+
+int ef_op_fill_in(const ef_cam* cam, const uint8_t* image, const float* vertex, const float* normal, const uint16_t* depthFiltered,
+                  const uint8_t* rgb, int passthrough, int passthroughImage, uint8_t* fimage, float* fvertex, float* fnormal, void* s_) {
+  efm::PredictMaps pm{(uchar4*)image, (float4*)vertex, (float4*)normal, nullptr};
+  efm::FillMaps fm{(uchar4*)fimage, (float4*)fvertex, (float4*)fnormal};
+  efm::fill_in(to_cam(cam), pm, depthFiltered, rgb, passthrough != 0, passthroughImage != 0, fm, (hipStream_t)s_);
+  OP_TAIL(s_);
+}
+
+int ef_op_dense_enough(const ef_cam* cam, const uint8_t* image, int* dense_host, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  OpMap m;
+  unsigned* cnt = m.alloc<unsigned>(1);
+  efm::dense_count(to_cam(cam), (const uchar4*)image, cnt, s);
+  unsigned h = 0;
+  (void)hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, s);
+  OP_SYNC(s);
+  *dense_host = ((float)h / (float)((cam->cols / 20) * (cam->rows / 20)) > 0.75f) ? 1 : 0;
+  return EF_OK;
+}
+
+int ef_op_fuse(const ef_cam* cam, const double* T16, int time, const uint8_t* rgb, const float* dm, const float* dmf, const uint32_t* index,
+               const float* vc, const float* ct, const float* nr, float maxDepth, float weighting, float* surfels, uint32_t count,
+               float* newUnstable, uint32_t* newCount, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  OpMap m;
+  efm::SurfelSoA soa = m.soa(count);
+  efm::aos_to_soa(surfels, count, soa, s);
+  float h[33];
+  pose_mats(T16, h, h + 16);
+  h[32] = weighting;
+  float* mats = m.alloc<float>(33);
+  (void)hipMemcpyAsync(mats, h, sizeof(h), hipMemcpyHostToDevice, s);
+  unsigned* cnt = m.alloc<unsigned>(2);
+  (void)hipMemcpyAsync(cnt, &count, sizeof(unsigned), hipMemcpyHostToDevice, s);
+  efm::Candidates cand;
+  cand.n = (cam->cols / 2) * (cam->rows / 2);
+  cand.pos_conf = m.alloc<float4>(cand.n);
+  cand.col_time = m.alloc<float4>(cand.n);
+  cand.nrm_rad = m.alloc<float4>(cand.n);
+  cand.best = m.alloc<uint32_t>(cand.n);
+  uint32_t* winner = m.alloc<uint32_t>(count, 0xFF);
+  efm::IndexMaps im{(uint32_t*)index, (float4*)vc, (float4*)ct, (float4*)nr};
+  efm::fuse(to_cam(cam), mats + 16, time, rgb, dm, dmf, im, maxDepth, mats + 32, soa, cnt, cand, winner, s);
+  efm::soa_to_aos(soa, count, surfels, s);
+  efm::CompactScratch cs;
+  cs.max_chunks = cand.n / efm::CHUNK + 8;
+  cs.flags = m.alloc<uint8_t>(cand.n);
+  cs.chunk_count = m.alloc<uint32_t>(cs.max_chunks);
+  cs.chunk_offset = m.alloc<uint32_t>(cs.max_chunks);
+  cs.totals = m.alloc<uint32_t>(8);
+  efm::candidates_to_aos(cand, newUnstable, cnt + 1, cs, s);
+  unsigned hn = 0;
+  (void)hipMemcpyAsync(&hn, cnt + 1, sizeof(hn), hipMemcpyDeviceToHost, s);
+  OP_SYNC(s);
+  *newCount = hn;
+  return EF_OK;
+}
+
+}  // extern "C"
+namespace {
+// scatter an AoS "newUnstable" list (draw order) back into candidate slots 0..n-1: the clean kernels only
+// need the relative order, which consecutive slots preserve
+__global__ void k_aos_to_cand(const float4* __restrict__ aos, uint32_t n, efm::Candidates cand) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint32_t)cand.n) return;
+  if (i < n) {
+    cand.pos_conf[i] = aos[(size_t)i * 3];
+    cand.col_time[i] = aos[(size_t)i * 3 + 1];
+    cand.nrm_rad[i] = aos[(size_t)i * 3 + 2];
+  } else {
+    cand.col_time[i] = make_float4(0, 0, 0, 0);
+  }
+}
+}  // namespace
+extern "C" {
+
+int ef_op_clean(const ef_cam* cam, const double* T16, int time, const uint32_t* index, const float* vc, const float* ct, const float* nr,
+                float confThreshold, int timeDelta, float maxDepth, const float* surfels, uint32_t count, const float* newUnstable,
+                uint32_t newCount, float* surfels_out, uint32_t* outCount, void* s_) {
+  (void)maxDepth;
+  hipStream_t s = (hipStream_t)s_;
+  OpMap m;
+  const uint32_t cap = count + newCount;
+  efm::SurfelSoA soa = m.soa(count), out = m.soa(cap);
+  efm::aos_to_soa(surfels, count, soa, s);
+  float h[32];
+  pose_mats(T16, h, h + 16);
+  float* mats = m.alloc<float>(32);
+  (void)hipMemcpyAsync(mats, h, sizeof(h), hipMemcpyHostToDevice, s);
+  unsigned* cnt = m.alloc<unsigned>(1);
+  (void)hipMemcpyAsync(cnt, &count, sizeof(unsigned), hipMemcpyHostToDevice, s);
+  efm::Candidates cand;
+  cand.n = (int)(newCount ? newCount : 1);
+  cand.pos_conf = m.alloc<float4>(cand.n);
+  cand.col_time = m.alloc<float4>(cand.n);
+  cand.nrm_rad = m.alloc<float4>(cand.n);
+  cand.best = m.alloc<uint32_t>(cand.n);
+  hipLaunchKernelGGL(k_aos_to_cand, dim3((cand.n + 255) / 256), dim3(256), 0, s, (const float4*)newUnstable, newCount, cand);
+  uint32_t* winner = m.alloc<uint32_t>(count, 0xFF);
+  efm::CompactScratch cs;
+  cs.max_chunks = (int)((cap + 1) / efm::CHUNK + 8);
+  cs.flags = m.alloc<uint8_t>((size_t)cap + 1);
+  cs.chunk_count = m.alloc<uint32_t>(cs.max_chunks);
+  cs.chunk_offset = m.alloc<uint32_t>(cs.max_chunks);
+  cs.totals = m.alloc<uint32_t>(8);
+  efm::IndexMaps im{(uint32_t*)index, (float4*)vc, (float4*)ct, (float4*)nr};
+  efm::clean(to_cam(cam), mats, time, im, confThreshold, timeDelta, soa, cnt, cand, winner, out, cap, cs, nullptr, s);
+  unsigned hn = 0;
+  (void)hipMemcpyAsync(&hn, cnt, sizeof(hn), hipMemcpyDeviceToHost, s);
+  OP_SYNC(s);
+  efm::soa_to_aos(out, hn, surfels_out, s);
+  OP_SYNC(s);
+  *outCount = hn;
+  return EF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// Map side of libefusion_hip: depth pre-processing and surfel-map maintenance as HIP compute.
+// Replaces the reference's GLSL transform-feedback / FBO passes (Core/IndexMap.cpp, Core/GlobalModel.cpp,
+// Core/Shaders/{ComputePack,FillIn,FeedbackBuffer,Resize}.cpp and their shaders): no GL, no interop.
+//
+// HBM layout: surfels are three float4 streams (SoA) {x,y,z,conf} {colour,0,initTime,lastTime}
+// {nx,ny,nz,radius}: every per-surfel pass issues perfectly coalesced 16-byte loads, and passes that
+// cull on position/time never touch the normal stream.  The 48-byte AoS records of the reference
+// (Core/Shaders/Vertex.cpp:74) exist only at the download / upload boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ef_track.hpp"
+
+namespace efm {
+
+struct Cam { int cols, rows; float fx, fy, cx, cy; };
+
+struct SurfelSoA {
+  float4* pos_conf;
+  float4* col_time;
+  float4* nrm_rad;
+};
+
+constexpr unsigned long long ZBUF_EMPTY = 0xFFFFFFFFFFFFFFFFull;
+constexpr unsigned WINNER_EMPTY = 0xFFFFFFFFu;
+constexpr int CHUNK = 1024;  // elements per compaction chunk (256 threads x 4)
+
+// per-pixel model prediction products
+struct IndexMaps {   // IndexMap::predictIndices outputs (IndexMap.h:74-88)
+  uint32_t* index;
+  float4* vert_conf;
+  float4* color_time;
+  float4* norm_rad;
+};
+struct PredictMaps { // IndexMap::combinedPredict outputs (IndexMap.h:98-112)
+  uchar4* image;
+  float4* vertex;
+  float4* normal;
+  uint16_t* time;
+};
+struct FillMaps {    // FillIn textures (FillIn.h)
+  uchar4* image;
+  float4* vertex;
+  float4* normal;
+};
+// association products of one frame: one slot per fused pixel (W/2 x H/2, quirk Q12), in draw order
+struct Candidates {
+  float4* pos_conf;
+  float4* col_time;   // .w tag: -1 matched, -2 new unstable, 0 not emitted
+  float4* nrm_rad;
+  uint32_t* best;     // surfel id chosen by the association (tag -1)
+  int n;              // (W/2)*(H/2)
+};
+struct CompactScratch {
+  uint8_t* flags;          // capacity + n_candidates (or 2 x pixels for seeding)
+  uint32_t* chunk_count;   // per chunk
+  uint32_t* chunk_offset;  // exclusive scan
+  uint32_t* totals;        // small scratch (>= 4 u32)
+  int max_chunks;
+};
+
+// ---- pre-processing (ComputePack FILTER / METRIC / METRIC_FILTERED, ElasticFusion.cpp:655-673) ----
+void filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s);
+void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, hipStream_t s);
+// fused: bilateral + both metric conversions in one pass over the raw depth
+void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric,
+                      float* metric_filtered, hipStream_t s);
+
+// ---- layout conversion at the API boundary ----
+void aos_to_soa(const float* aos, uint32_t count, SurfelSoA soa, hipStream_t s);
+void soa_to_aos(SurfelSoA soa, uint32_t count, float* aos, hipStream_t s);
+
+// ---- first frame (vertex_feedback x2 + init_unstable) ----
+void seed_map(const Cam& cam, const uint8_t* rgb3, const float* depth_metric, const float* depth_metric_filtered, int time,
+              float maxDepth, SurfelSoA out, unsigned* count_dev, const CompactScratch& cs, hipStream_t s);
+
+// ---- model prediction ----
+// T_cw16_dev: device pointer to the float 4x4 T_wc^-1; count_dev: device surfel count
+void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSoA map, const unsigned* count_dev, float maxDepth,
+                     int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s);
+void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
+                      float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, PredictMaps out,
+                      // optional fused fill-in + denseEnough sampling (null fill.image => skipped)
+                      FillMaps fill, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthroughImage,
+                      unsigned* dense_counter, hipStream_t s);
+void fill_in(const Cam& cam, PredictMaps pred, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthrough,
+             bool passthroughImage, FillMaps out, hipStream_t s);
+// counts the (W/20)x(H/20) sample texels with r,g,b > 0 into *counter (Resize::image + denseEnough)
+void dense_count(const Cam& cam, const uchar4* image, unsigned* counter, hipStream_t s);
+
+// ---- fusion ----
+// pose_f16_dev: float T_wc (cast<float>().matrix()); weighting_dev: device float
+void fuse(const Cam& cam, const float* pose_f16_dev, int time, const uint8_t* rgb3, const float* depth_metric,
+          const float* depth_metric_filtered, IndexMaps im, float maxDepth, const float* weighting_dev, SurfelSoA map,
+          const unsigned* count_dev, Candidates cand, uint32_t* winner, hipStream_t s);
+// clean + append; writes the compacted map to `out` and the new count to *count_dev (clamped to capacity)
+void clean(const Cam& cam, const float* T_cw16_dev, int time, IndexMaps im, float confThreshold, int timeDelta, SurfelSoA map,
+           unsigned* count_dev, Candidates cand, uint32_t* winner, SurfelSoA out, uint32_t capacity, const CompactScratch& cs,
+           int* overflow_flag, hipStream_t s);
+// candidates -> AoS "newUnstable" list in draw order (operator tier / tests)
+void candidates_to_aos(Candidates cand, float* aos, unsigned* count_dev, const CompactScratch& cs, hipStream_t s);
+
+}  // namespace efm

@@ -1,0 +1,888 @@
+// HIP kernels (gfx950, wave64) for depth pre-processing and surfel-map maintenance.
+// What the reference does with GLSL draws (point rasterisation + GL_LESS depth test + transform
+// feedback) is done here with a 64-bit atomic z-buffer in HBM — key = (orderable depth bits << 32) | id,
+// resolved by atomicMin, so "nearest wins, ties go to the lower surfel index" == GL draw order — and
+// with order-preserving chunked stream compaction instead of transform feedback.
+// GL-defined behaviour is specified as N1-N5 in SURVEY.md §8a (restated in DESIGN.md).
+#include "ef_device.hpp"
+#include "ef_map.hpp"
+
+using namespace ef;
+
+namespace efm {
+
+namespace {
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+constexpr int SURFEL_GRID = 1024;   // grid-stride workgroups for per-surfel passes (count lives on the device)
+constexpr int BLK = 256;
+
+__device__ __forceinline__ uint32_t depth_key(float z) {  // order-preserving float -> uint
+  const uint32_t b = __float_as_uint(z);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long zkey(float z, uint32_t id) { return ((unsigned long long)depth_key(z) << 32) | id; }
+
+// uv attribute (FeedbackBuffer.cpp:44-52, GlobalModel.cpp:109-117) and x = texcoord.x * cols
+__device__ __forceinline__ float pix_coord(int i, int n) {
+  const float u = (float)((double)((float)i / (float)n) + 1.0 / (double)(2 * (float)n));
+  return u * (float)n;
+}
+// color.glsl:19-34
+__device__ __forceinline__ float encodeColor(f3 c) {
+  int rgb = (int)roundf(c.x * 255.0f);
+  rgb = (rgb << 8) + (int)roundf(c.y * 255.0f);
+  rgb = (rgb << 8) + (int)roundf(c.z * 255.0f);
+  return (float)rgb;
+}
+__device__ __forceinline__ f3 decodeColor(float c) {
+  const int ic = (int)c;
+  return {(float)((ic >> 16) & 0xFF) / 255.0f, (float)((ic >> 8) & 0xFF) / 255.0f, (float)(ic & 0xFF) / 255.0f};
+}
+// surfels.glsl:19-34
+__device__ __forceinline__ float getRadius(float depth, float norm_z, float inv_fx, float inv_fy) {
+  const float meanFocal = ((1.0f / fabsf(inv_fx)) + (1.0f / fabsf(inv_fy))) / 2.0f;
+  const float sqrt2 = 1.41421356237f;
+  const float radius = (depth / meanFocal) * sqrt2;
+  const float radius_n = radius / fabsf(norm_z);
+  return fminf(2.0f * radius, radius_n);
+}
+// surfels.glsl:36-46
+__device__ __forceinline__ float confidence(float x, float y, float cx, float cy, float weighting) {
+  const float maxRadDist = 400, twoSigmaSquared = 0.72f;
+  const float px = x - cx, py = y - cy;
+  const float radialDist = sqrtf(px * px + py * py) / maxRadDist;
+  return ef_expf(-(radialDist * radialDist) / twoSigmaSquared) * weighting;
+}
+struct DepthF {  // float depth image, NEAREST + CLAMP_TO_EDGE (N4)
+  const float* d; int cols, rows;
+  __device__ __forceinline__ float at(int x, int y) const { return d[clampi(y, 0, rows - 1) * cols + clampi(x, 0, cols - 1)]; }
+};
+// geometry.glsl:21-40
+__device__ __forceinline__ f3 getVertexF(const DepthF& D, int ix, int iy, float x, float y, float cx, float cy, float inv_fx, float inv_fy) {
+  const float z = D.at(ix, iy);
+  return {(x - cx) * z * inv_fx, (y - cy) * z * inv_fy, z};
+}
+__device__ __forceinline__ f3 half_sum(f3 a, f3 b) { return {(a.x + b.x) / 2, (a.y + b.y) / 2, (a.z + b.z) / 2}; }
+__device__ __forceinline__ f3 getNormalF(const DepthF& D, f3 vPosition, int ix, int iy, float x, float y, float cx, float cy,
+                                         float inv_fx, float inv_fy) {
+  const f3 xf = getVertexF(D, ix + 1, iy, x + 1, y, cx, cy, inv_fx, inv_fy);
+  const f3 xb = getVertexF(D, ix - 1, iy, x - 1, y, cx, cy, inv_fx, inv_fy);
+  const f3 yf = getVertexF(D, ix, iy + 1, x, y + 1, cx, cy, inv_fx, inv_fy);
+  const f3 yb = getVertexF(D, ix, iy - 1, x, y - 1, cx, cy, inv_fx, inv_fy);
+  const f3 del_x = half_sum(xb, vPosition) - half_sum(xf, vPosition);
+  const f3 del_y = half_sum(yb, vPosition) - half_sum(yf, vPosition);
+  return normalized(cross(del_x, del_y));
+}
+
+// exclusive scan of one value per thread over a 256-thread workgroup (wave64 shuffles + 4-entry LDS)
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* lds, unsigned& total) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  unsigned x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  __syncthreads();
+  if (lane == 63) lds[w] = x;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < BLK / 64; ++i) {
+    const unsigned s = lds[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  total = tot;
+  return base + x - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// pre-processing: depth_bilateral.frag:30-76 + depth_metric.frag:28-40
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t bilateral_px(const uint16_t* __restrict__ raw, int cols, int rows, int x, int y, unsigned maxv) {
+  const unsigned value = raw[y * cols + x];
+  if (value > maxv || value < 300U) return 0;
+  const float sigma_space2_inv_half = 0.024691358f, sigma_color2_inv_half = 0.000555556f;
+  const int R = 6, D = R * 2 + 1;
+  const int tx = min(x - D / 2 + D, cols), ty = min(y - D / 2 + D, rows);
+  float sum1 = 0, sum2 = 0;
+  for (int cy = max(y - D / 2, 0); cy < ty; ++cy)
+    for (int cx = max(x - D / 2, 0); cx < tx; ++cx) {
+      const unsigned tmp = raw[cy * cols + cx];
+      const float space2 = ((float)x - (float)cx) * ((float)x - (float)cx) + ((float)y - (float)cy) * ((float)y - (float)cy);
+      const float color2 = ((float)value - (float)tmp) * ((float)value - (float)tmp);
+      const float weight = ef_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half));
+      sum1 += (float)tmp * weight;
+      sum2 += weight;
+    }
+  return (uint16_t)(unsigned)roundf(sum1 / sum2);
+}
+__device__ __forceinline__ float metric_px(unsigned value, unsigned maxv) {
+  return (value > maxv || value < 300U) ? 0.0f : (float)value / 1000.0f;
+}
+template <bool WITH_METRIC>
+__global__ void k_preprocess(const uint16_t* __restrict__ raw, int cols, int rows, unsigned maxv, uint16_t* __restrict__ filtered,
+                             float* __restrict__ metric, float* __restrict__ metric_filtered) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  const uint16_t f = bilateral_px(raw, cols, rows, x, y, maxv);
+  filtered[y * cols + x] = f;
+  if (WITH_METRIC) {
+    metric[y * cols + x] = metric_px(raw[y * cols + x], maxv);
+    metric_filtered[y * cols + x] = metric_px(f, maxv);
+  }
+}
+__global__ void k_metricise(const uint16_t* __restrict__ in, int n, unsigned maxv, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = metric_px(in[i], maxv);
+}
+
+// ------------------------------------------------------------------------------------------
+// layout conversion
+// ------------------------------------------------------------------------------------------
+__global__ void k_aos_to_soa(const float4* __restrict__ aos, uint32_t count, SurfelSoA soa) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  soa.pos_conf[i] = aos[(size_t)i * 3];
+  soa.col_time[i] = aos[(size_t)i * 3 + 1];
+  soa.nrm_rad[i] = aos[(size_t)i * 3 + 2];
+}
+__global__ void k_soa_to_aos(SurfelSoA soa, uint32_t count, float4* __restrict__ aos) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  aos[(size_t)i * 3] = soa.pos_conf[i];
+  aos[(size_t)i * 3 + 1] = soa.col_time[i];
+  aos[(size_t)i * 3 + 2] = soa.nrm_rad[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// chunked order-preserving compaction: flags (1 byte / element) -> per-chunk counts -> scan -> scatter
+// ------------------------------------------------------------------------------------------
+// n = *count_dev + extra (count_dev may be null => n = extra)
+__device__ __forceinline__ unsigned dyn_n(const unsigned* count_dev, unsigned extra) { return (count_dev ? *count_dev : 0u) + extra; }
+
+__global__ void __launch_bounds__(1024) k_scan_chunks(const uint32_t* __restrict__ counts, const unsigned* count_dev, unsigned extra,
+                                                       uint32_t* __restrict__ offsets, uint32_t* total_out) {
+  __shared__ unsigned wsum[16];
+  __shared__ unsigned carry_s;
+  const unsigned n = dyn_n(count_dev, extra);
+  const unsigned nchunks = (n + CHUNK - 1) / CHUNK;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (unsigned base = 0; base < nchunks; base += 1024) {
+    const unsigned i = base + t;
+    const unsigned v = i < nchunks ? counts[i] : 0u;
+    unsigned x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    unsigned wb = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+      const unsigned s = wsum[k];
+      if (k < w) wb += s;
+      tot += s;
+    }
+    const unsigned carry = carry_s;
+    if (i < nchunks) offsets[i] = carry + wb + x - v;
+    __syncthreads();
+    if (t == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (t == 0) *total_out = carry_s;
+}
+
+// ------------------------------------------------------------------------------------------
+// first-frame seeding (G3)
+// ------------------------------------------------------------------------------------------
+struct SeedArgs {
+  Cam cam;
+  const uint8_t* rgb3;
+  const float* dm;
+  const float* dmf;
+  int time;
+  float maxDepth;
+};
+// element e in column-major pixel order (the uv buffer's order): i = e / rows, j = e % rows
+__global__ void __launch_bounds__(BLK) k_seed_flags(const SeedArgs A, uint8_t* __restrict__ flags_raw, uint8_t* __restrict__ flags_filt,
+                                                     uint32_t* __restrict__ cnt_raw, uint32_t* __restrict__ cnt_filt) {
+  __shared__ unsigned lds[BLK / 64];
+  const int P = A.cam.cols * A.cam.rows;
+  const int c = blockIdx.x;
+  unsigned nr = 0, nf = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = c * CHUNK + threadIdx.x * 4 + k;
+    if (e < P) {
+      const int i = e / A.cam.rows, j = e - i * A.cam.rows;
+      const float zr = A.dm[j * A.cam.cols + i], zf = A.dmf[j * A.cam.cols + i];
+      const uint8_t fr = !(zr <= 0 || zr > A.maxDepth), ff = !(zf <= 0 || zf > A.maxDepth);
+      flags_raw[e] = fr; flags_filt[e] = ff;
+      nr += fr; nf += ff;
+    }
+  }
+  unsigned tot;
+  block_excl_scan(nr, lds, tot);
+  if (threadIdx.x == 0) cnt_raw[c] = tot;
+  block_excl_scan(nf, lds, tot);
+  if (threadIdx.x == 0) cnt_filt[c] = tot;
+}
+__global__ void __launch_bounds__(BLK) k_seed_scatter(const SeedArgs A, const uint8_t* __restrict__ flags_raw,
+                                                       const uint8_t* __restrict__ flags_filt, const uint32_t* __restrict__ off_raw,
+                                                       const uint32_t* __restrict__ off_filt, const uint32_t* __restrict__ total_raw,
+                                                       SurfelSoA out, unsigned* count_dev) {
+  __shared__ unsigned lds[BLK / 64];
+  const Cam cam = A.cam;
+  const int P = cam.cols * cam.rows;
+  const int c = blockIdx.x;
+  const float inv_fx = 1.0f / cam.fx, inv_fy = 1.0f / cam.fy;  // FeedbackBuffer.cpp:91-95
+  uint8_t fr[4], ff[4];
+  unsigned nr = 0, nf = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = c * CHUNK + threadIdx.x * 4 + k;
+    fr[k] = e < P ? flags_raw[e] : 0;
+    ff[k] = e < P ? flags_filt[e] : 0;
+    nr += fr[k]; nf += ff[k];
+  }
+  unsigned tot;
+  unsigned pr = off_raw[c] + block_excl_scan(nr, lds, tot);
+  unsigned pf = off_filt[c] + block_excl_scan(nf, lds, tot);
+  const unsigned rawTotal = *total_raw;
+  if (c == 0 && threadIdx.x == 0) *count_dev = rawTotal;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = c * CHUNK + threadIdx.x * 4 + k;
+    if (e >= P) break;
+    if (!fr[k] && !ff[k]) continue;
+    const int i = e / cam.rows, j = e - i * cam.rows;
+    const float x = pix_coord(i, cam.cols), y = pix_coord(j, cam.rows);
+    if (fr[k]) {
+      const DepthF D{A.dm, cam.cols, cam.rows};
+      const f3 v = getVertexF(D, i, j, x, y, cam.cx, cam.cy, inv_fx, inv_fy);
+      const uint8_t* cc = A.rgb3 + (size_t)(j * cam.cols + i) * 3;
+      const f3 col{(float)cc[0] / 255.0f, (float)cc[1] / 255.0f, (float)cc[2] / 255.0f};
+      out.pos_conf[pr] = make_float4(v.x, v.y, v.z, confidence(x, y, cam.cx, cam.cy, 1.0f));
+      out.col_time[pr] = make_float4(encodeColor(col), 0.f, 1.f, (float)A.time);  // init_unstable.vert:33-34
+      ++pr;
+    }
+    if (ff[k]) {
+      const DepthF D{A.dmf, cam.cols, cam.rows};
+      const f3 v = getVertexF(D, i, j, x, y, cam.cx, cam.cy, inv_fx, inv_fy);
+      const f3 n = getNormalF(D, v, i, j, x, y, cam.cx, cam.cy, inv_fx, inv_fy);
+      if (pf < rawTotal) out.nrm_rad[pf] = make_float4(n.x, n.y, n.z, getRadius(v.z, n.z, inv_fx, inv_fy));
+      ++pf;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// IndexMap::predictIndices (G4): 1-pixel splat -> resolve
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLK) k_index_splat(const Cam cam, const float* __restrict__ T16, int time, SurfelSoA map,
+                                                      const unsigned* __restrict__ count_dev, float maxDepth, int timeDelta,
+                                                      unsigned long long* zbuf) {
+  const rt34 T = rt34_load16(T16);
+  const unsigned count = *count_dev;
+  const float ftime = (float)time, ftd = (float)timeDelta;
+  for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < count; id += gridDim.x * blockDim.x) {
+    const float4 pc = map.pos_conf[id];
+    const float4 ct = map.col_time[id];
+    const f3 p = xform(T, f3{pc.x, pc.y, pc.z});
+    if (p.z > maxDepth || p.z < 0 || ftime - ct.w > ftd) continue;
+    const float u = ((cam.fx * p.x) / p.z) + cam.cx;
+    const float v = ((cam.fy * p.y) / p.z) + cam.cy;
+    if (!(u >= 0 && u < (float)cam.cols && v >= 0 && v < (float)cam.rows)) continue;  // N1
+    const int px = (int)floorf(u), py = (int)floorf(v);
+    atomicMin(&zbuf[py * cam.cols + px], zkey(p.z, id));                              // N2
+  }
+}
+__global__ void __launch_bounds__(BLK) k_index_resolve(const Cam cam, const float* __restrict__ T16, SurfelSoA map,
+                                                        unsigned long long* zbuf, IndexMaps out) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= cam.cols * cam.rows) return;
+  const unsigned long long key = zbuf[pi];
+  if (key == ZBUF_EMPTY) {
+    out.index[pi] = 0u;
+    out.vert_conf[pi] = make_float4(0, 0, 0, 0);
+    out.color_time[pi] = make_float4(0, 0, 0, 0);
+    out.norm_rad[pi] = make_float4(0, 0, 0, 0);
+    return;
+  }
+  zbuf[pi] = ZBUF_EMPTY;  // leave the buffer clean for the next splat: no separate clear pass
+  const uint32_t id = (uint32_t)key;
+  const rt34 T = rt34_load16(T16);
+  const float4 pc = map.pos_conf[id];
+  const float4 nr = map.nrm_rad[id];
+  const f3 p = xform(T, f3{pc.x, pc.y, pc.z});
+  const f3 n = normalized(mul(T.R, f3{nr.x, nr.y, nr.z}));
+  out.index[pi] = id;
+  out.vert_conf[pi] = make_float4(p.x, p.y, p.z, pc.w);
+  out.color_time[pi] = map.col_time[id];
+  out.norm_rad[pi] = make_float4(n.x, n.y, n.z, nr.w);
+}
+
+// ------------------------------------------------------------------------------------------
+// IndexMap::combinedPredict (G5): oriented-disc splat -> resolve (+ fill-in G7, + denseEnough samples G8)
+// ------------------------------------------------------------------------------------------
+struct Sprite {
+  f3 p, n;
+  float rad, conf;
+  float u, v, hs;
+  bool ok;
+};
+// splat.vert:53-87 for one surfel
+__device__ __forceinline__ Sprite make_sprite(const Cam& cam, const rt34& T, float4 pc, float4 ct, float4 nr, float maxDepth,
+                                              float confThreshold, float ftime, float fmaxTime, float ftd) {
+  Sprite S;
+  S.ok = false;
+  S.p = xform(T, f3{pc.x, pc.y, pc.z});
+  if (S.p.z > maxDepth || S.p.z < 0 || pc.w < confThreshold || ftime - ct.w > ftd || ct.w > fmaxTime) return S;
+  S.n = normalized(mul(T.R, f3{nr.x, nr.y, nr.z}));
+  S.rad = nr.w;
+  S.conf = pc.w;
+  const f3 t1 = normalized(f3{S.n.y - S.n.z, -S.n.x, S.n.x});
+  const f3 x1{(t1.x * S.rad) * 1.41421356f, (t1.y * S.rad) * 1.41421356f, (t1.z * S.rad) * 1.41421356f};
+  const f3 y1 = cross(S.n, x1);
+  const float fx = cam.fx, fy = cam.fy, cx = cam.cx, cy = cam.cy;
+  const f3 a = S.p + x1, b = S.p + y1, c = S.p - y1, d = S.p - x1;
+  const float q1x = ((fx * a.x) / a.z) + cx, q1y = ((fy * a.y) / a.z) + cy;
+  const float q2x = ((fx * b.x) / b.z) + cx, q2y = ((fy * b.y) / b.z) + cy;
+  const float q3x = ((fx * c.x) / c.z) + cx, q3y = ((fy * c.y) / c.z) + cy;
+  const float q4x = ((fx * d.x) / d.z) + cx, q4y = ((fy * d.y) / d.z) + cy;
+  const float xmin = fminf(q1x, fminf(q2x, fminf(q3x, q4x))), xmax = fmaxf(q1x, fmaxf(q2x, fmaxf(q3x, q4x)));
+  const float ymin = fminf(q1y, fminf(q2y, fminf(q3y, q4y))), ymax = fmaxf(q1y, fmaxf(q2y, fmaxf(q3y, q4y)));
+  // fminf/fmaxf drop NaNs, so test the operands themselves: any NaN corner => degenerate sprite, skipped (spec)
+  if (q1x != q1x || q2x != q2x || q3x != q3x || q4x != q4x || q1y != q1y || q2y != q2y || q3y != q3y || q4y != q4y) return S;
+  float size = fmaxf(0.f, fmaxf(fabsf(xmax - xmin), fabsf(ymax - ymin)));
+  if (size != size) return S;
+  size = fminf(fmaxf(size, 1.0f), 2047.0f);  // N3
+  S.u = ((fx * S.p.x) / S.p.z) + cx;
+  S.v = ((fy * S.p.y) / S.p.z) + cy;
+  if (!(S.u >= 0 && S.u < (float)cam.cols && S.v >= 0 && S.v < (float)cam.rows)) return S;
+  S.hs = size * 0.5f;
+  S.ok = true;
+  return S;
+}
+// combo_splat.frag:35-61 for one fragment; returns false when discarded
+__device__ __forceinline__ bool sprite_fragment(const Cam& cam, const Sprite& S, int px, int py, float& z) {
+  const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+  const f3 l = normalized(f3{(fcx - cam.cx) / cam.fx, (fcy - cam.cy) / cam.fy, 1.0f});
+  const float k = dot(S.p, S.n) / dot(l, S.n);
+  const f3 cp{k * l.x, k * l.y, k * l.z};
+  const f3 diff = cp - S.p;
+  if (!(dot(diff, diff) <= S.rad * S.rad)) return false;
+  z = cp.z;
+  return true;
+}
+__global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const float* __restrict__ T16, SurfelSoA map,
+                                                        const unsigned* __restrict__ count_dev, float maxDepth, float confThreshold,
+                                                        int time, int maxTime, int timeDelta, unsigned long long* zbuf) {
+  const rt34 T = rt34_load16(T16);
+  const unsigned count = *count_dev;
+  for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < count; id += gridDim.x * blockDim.x) {
+    const float4 pc = map.pos_conf[id];
+    if (pc.w < confThreshold) continue;  // unstable surfels (the bulk of a young map) never reach the normal stream
+    const float4 ct = map.col_time[id];
+    const float4 nr = map.nrm_rad[id];
+    const Sprite S = make_sprite(cam, T, pc, ct, nr, maxDepth, confThreshold, (float)time, (float)maxTime, (float)timeDelta);
+    if (!S.ok) continue;
+    const int px0 = max(0, (int)ceilf(S.u - S.hs - 0.5f)), px1 = min(cam.cols - 1, (int)ceilf(S.u + S.hs - 0.5f) - 1);
+    const int py0 = max(0, (int)ceilf(S.v - S.hs - 0.5f)), py1 = min(cam.rows - 1, (int)ceilf(S.v + S.hs - 0.5f) - 1);
+    for (int py = py0; py <= py1; ++py)
+      for (int px = px0; px <= px1; ++px) {
+        float z;
+        if (!sprite_fragment(cam, S, px, py, z)) continue;
+        if (z != z) continue;
+        atomicMin(&zbuf[py * cam.cols + px], zkey(z, id));
+      }
+  }
+}
+
+// geometry.glsl:44-60 on the filtered u16 depth (integer pixel coords, forward differences; quirk Q4)
+__device__ __forceinline__ f3 fill_vertex_at(const uint16_t* __restrict__ d, const Cam& cam, int sx, int sy, int x, int y, float inv_fx,
+                                             float inv_fy) {
+  const float z = (float)d[clampi(sy, 0, cam.rows - 1) * cam.cols + clampi(sx, 0, cam.cols - 1)] / 1000.0f;
+  return {((float)x - cam.cx) * z * inv_fx, ((float)y - cam.cy) * z * inv_fy, z};
+}
+__device__ __forceinline__ void fill_in_px(const Cam& cam, int x, int y, uchar4 si, float4 sv, float4 sn,
+                                           const uint16_t* __restrict__ depth_filtered, const uint8_t* __restrict__ rgb3, bool passthrough,
+                                           bool passthroughImage, FillMaps out) {
+  const int pi = y * cam.cols + x;
+  const float inv_fx = 1.0f / cam.fx, inv_fy = 1.0f / cam.fy;  // FillIn.cpp:115-119
+  if (sv.z == 0 || passthrough) {
+    const f3 v = fill_vertex_at(depth_filtered, cam, x, y, x, y, inv_fx, inv_fy);
+    out.vertex[pi] = make_float4(v.x, v.y, v.z, 1.f);
+  } else {
+    out.vertex[pi] = sv;
+  }
+  if (sn.z == 0 || passthrough) {
+    const f3 v = fill_vertex_at(depth_filtered, cam, x, y, x, y, inv_fx, inv_fy);
+    const f3 vx = fill_vertex_at(depth_filtered, cam, x + 1, y, x + 1, y, inv_fx, inv_fy);
+    const f3 vy = fill_vertex_at(depth_filtered, cam, x, y + 1, x, y + 1, inv_fx, inv_fy);
+    const f3 nn = normalized(cross(vx - v, vy - v));
+    out.normal[pi] = make_float4(nn.x, nn.y, nn.z, 1.f);
+  } else {
+    out.normal[pi] = sn;
+  }
+  if ((si.x == 0 && si.y == 0 && si.z == 0) || passthroughImage) {
+    out.image[pi] = make_uchar4(rgb3[(size_t)pi * 3], rgb3[(size_t)pi * 3 + 1], rgb3[(size_t)pi * 3 + 2], 255);
+  } else {
+    out.image[pi] = si;
+  }
+}
+__device__ __forceinline__ void dense_sample(const Cam& cam, int x, int y, uchar4 si, unsigned* counter) {
+  // Resize::image: dest (a,b) <- source texel (20a+10, 20b+10), consSample = 20 (ElasticFusion.cpp:62-70)
+  if (x % 20 == 10 && y % 20 == 10 && x / 20 < cam.cols / 20 && y / 20 < cam.rows / 20)
+    if (si.x > 0 && si.y > 0 && si.z > 0) atomicAdd(counter, 1u);
+}
+
+template <bool FUSE_FILL>
+__global__ void __launch_bounds__(BLK) k_surface_resolve(const Cam cam, const float* __restrict__ T16, SurfelSoA map, float maxDepth,
+                                                          float confThreshold, int time, int maxTime, int timeDelta,
+                                                          unsigned long long* zbuf, PredictMaps out, FillMaps fill,
+                                                          const uint16_t* __restrict__ depth_filtered, const uint8_t* __restrict__ rgb3,
+                                                          bool passthroughImage, unsigned* dense_counter) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= cam.cols * cam.rows) return;
+  const int py = pi / cam.cols, px = pi - py * cam.cols;
+  const unsigned long long key = zbuf[pi];
+  uchar4 im = make_uchar4(0, 0, 0, 0);
+  float4 vt = make_float4(0, 0, 0, 0), nm = make_float4(0, 0, 0, 0);
+  uint16_t tm = 0;
+  if (key != ZBUF_EMPTY) {
+    zbuf[pi] = ZBUF_EMPTY;
+    const uint32_t id = (uint32_t)key;
+    const rt34 T = rt34_load16(T16);
+    const float4 pc = map.pos_conf[id], ct = map.col_time[id], nr = map.nrm_rad[id];
+    const Sprite S = make_sprite(cam, T, pc, ct, nr, maxDepth, confThreshold, (float)time, (float)maxTime, (float)timeDelta);
+    float z = 0.f;
+    sprite_fragment(cam, S, px, py, z);  // same operations as the splat => same bits
+    const f3 col = decodeColor(ct.x);
+    im = make_uchar4((uint8_t)roundf(col.x * 255.0f), (uint8_t)roundf(col.y * 255.0f), (uint8_t)roundf(col.z * 255.0f), 255);
+    const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
+    vt = make_float4((fcx - cam.cx) * z * (1.f / cam.fx), (fcy - cam.cy) * z * (1.f / cam.fy), z, pc.w);
+    nm = make_float4(S.n.x, S.n.y, S.n.z, nr.w);
+    tm = (uint16_t)(unsigned)ct.z;
+  }
+  out.image[pi] = im;
+  out.vertex[pi] = vt;
+  out.normal[pi] = nm;
+  out.time[pi] = tm;
+  if (FUSE_FILL) {
+    fill_in_px(cam, px, py, im, vt, nm, depth_filtered, rgb3, false, passthroughImage, fill);
+    dense_sample(cam, px, py, im, dense_counter);
+  }
+}
+__global__ void __launch_bounds__(BLK) k_fill_in(const Cam cam, PredictMaps pred, const uint16_t* __restrict__ depth_filtered,
+                                                  const uint8_t* __restrict__ rgb3, bool passthrough, bool passthroughImage, FillMaps out) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= cam.cols * cam.rows) return;
+  const int py = pi / cam.cols, px = pi - py * cam.cols;
+  fill_in_px(cam, px, py, pred.image[pi], pred.vertex[pi], pred.normal[pi], depth_filtered, rgb3, passthrough, passthroughImage, out);
+}
+__global__ void k_dense_count(const Cam cam, const uchar4* __restrict__ image, unsigned* counter) {
+  const int dc = cam.cols / 20, dr = cam.rows / 20;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dc * dr) return;
+  const int b = i / dc, a = i - b * dc;
+  const uchar4 t = image[(20 * b + 10) * cam.cols + (20 * a + 10)];
+  if (t.x > 0 && t.y > 0 && t.z > 0) atomicAdd(counter, 1u);
+}
+
+// ------------------------------------------------------------------------------------------
+// GlobalModel::fuse (G9 data pass, G10 update pass)
+// ------------------------------------------------------------------------------------------
+struct FuseArgs {
+  Cam cam;
+  const float* pose16;
+  int time;
+  const uint8_t* rgb3;
+  const float* dm;
+  const float* dmf;
+  IndexMaps im;
+  float maxDepth;
+  const float* weighting;
+};
+// data.vert:76-193.  One thread per fused pixel (W/2 x H/2, parity-selected: quirk Q12), threads walk rows
+// (coalesced taps); the candidate lands in slot r = column-major rank == the reference's draw order.
+__global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates cand, uint32_t* winner) {
+  const Cam cam = A.cam;
+  const int qc = cam.cols / 2, qr = cam.rows / 2;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= qc * qr) return;
+  const int qy = q / qc, qx = q - qy * qc;
+  const int par = A.time % 2;
+  const int i = 2 * qx + par, j = 2 * qy + par;
+  const int r = qx * qr + qy;
+  float4 c_col = make_float4(0, 0, 0, 0);  // tag 0: nothing emitted
+  if (i < cam.cols && j < cam.rows) {
+    const float cx = cam.cx, cy = cam.cy;
+    const float inv_fx = (float)(1.0 / (double)cam.fx), inv_fy = (float)(1.0 / (double)cam.fy);  // GlobalModel.cpp:397-398
+    const DepthF DR{A.dm, cam.cols, cam.rows}, DF{A.dmf, cam.cols, cam.rows};
+    const float x = pix_coord(i, cam.cols), y = pix_coord(j, cam.rows);
+    const float ftime = (float)A.time;
+    const f3 vPosLocal = getVertexF(DR, i, j, x, y, cx, cy, inv_fx, inv_fy);
+    const bool sel = ((int)x % 2 == (int)ftime % 2 && (int)y % 2 == (int)ftime % 2);
+    const bool nb = !(DR.at(i - 1, j) == 0 || DR.at(i, j - 1) == 0 || DR.at(i + 1, j) == 0 || DR.at(i, j + 1) == 0);
+    if (sel && nb && vPosLocal.z > 0 && vPosLocal.z <= A.maxDepth) {
+      const rt34 pose = rt34_load16(A.pose16);
+      const f3 vPos = xform(pose, vPosLocal);
+      const f3 vPosition_f = getVertexF(DF, i, j, x, y, cx, cy, inv_fx, inv_fy);
+      const uint8_t* c = A.rgb3 + (size_t)(j * cam.cols + i) * 3;
+      const f3 col{(float)c[0] / 255.0f, (float)c[1] / 255.0f, (float)c[2] / 255.0f};
+      const f3 vNormLocal = getNormalF(DF, vPosition_f, i, j, x, y, cx, cy, inv_fx, inv_fy);
+      const f3 nW = mul(pose.R, vNormLocal);
+      int counter = 0;
+      uint32_t best = 0;
+      float bestDist = 1000;
+      const float xl = (x - cx) * inv_fx, yl = (y - cy) * inv_fy;
+      const float lambda = sqrtf(xl * xl + yl * yl + 1);
+      const f3 ray{xl, yl, 1};
+      const float lenRay = sqrtf(dot(ray, ray));
+      const float lenN = sqrtf(dot(vNormLocal, vNormLocal));
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int tx = clampi(i + (a == 0 ? -1 : (a == 3 ? 1 : 0)), 0, cam.cols - 1);  // N4 taps {-1,0,0,+1}
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int ty = clampi(j + (b == 0 ? -1 : (b == 3 ? 1 : 0)), 0, cam.rows - 1);
+          const int ti = ty * cam.cols + tx;
+          const uint32_t current = A.im.index[ti];
+          if (current > 0U) {
+            const float4 vc = A.im.vert_conf[ti];
+            if (fabsf((vc.z * lambda) - (vPosLocal.z * lambda)) < 0.05f) {
+              const f3 cr = cross(ray, f3{vc.x, vc.y, vc.z});
+              const float dist = sqrtf(dot(cr, cr)) / lenRay;
+              const float4 nr = A.im.norm_rad[ti];
+              const f3 nn{nr.x, nr.y, nr.z};
+              const float cang = dot(nn, vNormLocal) / (sqrtf(dot(nn, nn)) * lenN);
+              const bool angOk = (cang > 0.87758255f && cang <= 1.0f);  // abs(acos(c)) < 0.5, NaN-false
+              if (dist < bestDist && (fabsf(nr.z) < 0.75f || angOk)) {
+                counter++;
+                bestDist = dist;
+                best = current;
+              }
+            }
+          }
+        }
+      }
+      const float tag = counter > 0 ? -1.0f : -2.0f;
+      cand.pos_conf[r] = make_float4(vPos.x, vPos.y, vPos.z, confidence(x, y, cx, cy, *A.weighting));
+      cand.nrm_rad[r] = make_float4(nW.x, nW.y, nW.z, getRadius(vPosition_f.z, vNormLocal.z, inv_fx, inv_fy));
+      c_col = make_float4(encodeColor(col), 0.f, ftime, tag);
+      cand.best[r] = best;
+      if (counter > 0) atomicMin(&winner[best], (uint32_t)r);  // N5: first pixel in draw order owns the update texel
+    }
+  }
+  cand.col_time[r] = c_col;
+}
+// update.vert:37-92, in place, only for the surfels that won an association
+__global__ void __launch_bounds__(BLK) k_merge(Candidates cand, const uint32_t* __restrict__ winner, SurfelSoA map, int time) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= cand.n) return;
+  const float4 ucol = cand.col_time[r];
+  if (ucol.w != -1.0f) return;
+  const uint32_t id = cand.best[r];
+  if (winner[id] != (uint32_t)r) return;
+  const float4 u = cand.pos_conf[r], un = cand.nrm_rad[r];
+  float4 s = map.pos_conf[id], sc = map.col_time[id], sn = map.nrm_rad[id];
+  const float c_k = s.w, a = u.w, ftime = (float)time;
+  if (un.w < (1.0f + 0.5f) * sn.w) {
+    s.x = ((c_k * s.x) + (a * u.x)) / (c_k + a);
+    s.y = ((c_k * s.y) + (a * u.y)) / (c_k + a);
+    s.z = ((c_k * s.z) + (a * u.z)) / (c_k + a);
+    s.w = c_k + a;
+    const f3 oldCol = decodeColor(sc.x), newCol = decodeColor(ucol.x);
+    const f3 avg{((c_k * oldCol.x) + (a * newCol.x)) / (c_k + a), ((c_k * oldCol.y) + (a * newCol.y)) / (c_k + a),
+                 ((c_k * oldCol.z) + (a * newCol.z)) / (c_k + a)};
+    sc.x = encodeColor(avg);
+    sc.w = ftime;
+    const float nx = ((c_k * sn.x) + (a * un.x)) / (c_k + a), ny = ((c_k * sn.y) + (a * un.y)) / (c_k + a),
+                nz = ((c_k * sn.z) + (a * un.z)) / (c_k + a), nw = ((c_k * sn.w) + (a * un.w)) / (c_k + a);
+    const f3 nn = normalized(f3{nx, ny, nz});
+    sn = make_float4(nn.x, nn.y, nn.z, nw);
+    map.pos_conf[id] = s;
+    map.col_time[id] = sc;
+    map.nrm_rad[id] = sn;
+  } else {
+    s.w = c_k + a;
+    sc.w = ftime;
+    map.pos_conf[id] = s;
+    map.col_time[id] = sc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// GlobalModel::clean (G11): keep-test -> flags, then stable compaction of [old surfels | candidates]
+// ------------------------------------------------------------------------------------------
+struct CleanArgs {
+  Cam cam;
+  const float* T16;
+  int time;
+  IndexMaps im;
+  float confThreshold;
+  int timeDelta;
+};
+// copy_unstable.vert:49-130 (nodes == 0); returns keep flag; ct.w tag -2 is rewritten to time by the caller
+__device__ __forceinline__ bool clean_test(const CleanArgs& A, const rt34& T, float4 pc, float4 ct, float4 nr) {
+  const Cam& cam = A.cam;
+  const float ftime = (float)A.time, ftd = (float)A.timeDelta;
+  int test = 1;
+  const f3 localPos = xform(T, f3{pc.x, pc.y, pc.z});
+  const float x = ((cam.fx * localPos.x) / localPos.z) + cam.cx;
+  const float y = ((cam.fy * localPos.y) / localPos.z) + cam.cy;
+  const f3 localNorm = normalized(mul(T.R, f3{nr.x, nr.y, nr.z}));
+  int cnt = 0, zCount = 0;
+  if (ftime - ct.w < ftd && localPos.z > 0 && x > 0 && y > 0 && x < (float)cam.cols && y < (float)cam.rows) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int tx = clampi((int)floorf(x + (-1.0f + 0.5f * a)), 0, cam.cols - 1);  // N4 offsets {-1,-.5,0,+.5}
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int ty = clampi((int)floorf(y + (-1.0f + 0.5f * b)), 0, cam.rows - 1);
+        const int ti = ty * cam.cols + tx;
+        if (A.im.index[ti] > 0U) {
+          const float4 vc = A.im.vert_conf[ti];
+          const float4 c2 = A.im.color_time[ti];
+          const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
+          if (c2.z < ct.z && vc.w > A.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
+              sqrtf(dx * dx + dy * dy) < nr.w * 1.4f)
+            cnt++;
+          if (c2.w == ftime && vc.w > A.confThreshold && vc.z > localPos.z && vc.z - localPos.z > 0.01f && fabsf(localNorm.z) > 0.85f)
+            zCount++;
+        }
+      }
+    }
+  }
+  if (cnt > 8 || zCount > 4) test = 0;
+  float lastTime = ct.w;
+  if (lastTime == -2) lastTime = ftime;
+  if (lastTime == -1 || ((ftime - lastTime) > 20 && pc.w < A.confThreshold)) test = 0;
+  if (lastTime > 0 && ftime - lastTime > ftd) test = 1;
+  return test != 0;
+}
+__device__ __forceinline__ bool load_element(const SurfelSoA& map, const Candidates& cand, unsigned count, unsigned e, float4& pc,
+                                             float4& ct, float4& nr) {
+  if (e < count) {
+    pc = map.pos_conf[e]; ct = map.col_time[e]; nr = map.nrm_rad[e];
+    return true;
+  }
+  const unsigned r = e - count;
+  ct = cand.col_time[r];
+  if (ct.w == 0.0f) return false;  // slot never emitted by the data pass
+  pc = cand.pos_conf[r]; nr = cand.nrm_rad[r];
+  return true;
+}
+__global__ void __launch_bounds__(BLK) k_clean_flags(const CleanArgs A, SurfelSoA map, const unsigned* __restrict__ count_dev,
+                                                      Candidates cand, uint32_t* winner, uint8_t* __restrict__ flags,
+                                                      uint32_t* __restrict__ chunk_count) {
+  __shared__ unsigned lds[BLK / 64];
+  const unsigned count = *count_dev;
+  const unsigned n = count + (unsigned)cand.n;
+  const unsigned nchunks = (n + CHUNK - 1) / CHUNK;
+  const rt34 T = rt34_load16(A.T16);
+  for (unsigned c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    unsigned keep = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // element order inside a chunk: k*256 + t keeps loads coalesced; ranks are recovered the same way in scatter
+      const unsigned e = c * CHUNK + k * BLK + threadIdx.x;
+      if (e < n) {
+        float4 pc, ct, nr;
+        uint8_t f = 0;
+        if (load_element(map, cand, count, e, pc, ct, nr)) f = clean_test(A, T, pc, ct, nr) ? 1 : 0;
+        if (e < count) winner[e] = WINNER_EMPTY;  // re-arm the association winners for the next frame
+        flags[e] = f;
+        keep += f;
+      }
+    }
+    unsigned tot;
+    block_excl_scan(keep, lds, tot);
+    if (threadIdx.x == 0) chunk_count[c] = tot;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(BLK) k_clean_scatter(SurfelSoA map, const unsigned* __restrict__ count_dev, Candidates cand,
+                                                        const uint8_t* __restrict__ flags, const uint32_t* __restrict__ chunk_offset,
+                                                        int time, SurfelSoA out, uint32_t capacity) {
+  __shared__ unsigned lds[BLK / 64];
+  const unsigned count = *count_dev;
+  const unsigned n = count + (unsigned)cand.n;
+  const unsigned nchunks = (n + CHUNK - 1) / CHUNK;
+  for (unsigned c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    unsigned base = chunk_offset[c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // four 256-element rows per chunk, each scanned in element order
+      const unsigned e = c * CHUNK + k * BLK + threadIdx.x;
+      const unsigned f = (e < n) ? flags[e] : 0u;
+      unsigned tot;
+      const unsigned pos = base + block_excl_scan(f, lds, tot);
+      if (f && pos < capacity) {
+        float4 pc, ct, nr;
+        load_element(map, cand, count, e, pc, ct, nr);
+        if (ct.w == -2.0f) ct.w = (float)time;  // copy_unstable.vert:114-117
+        out.pos_conf[pos] = pc;
+        out.col_time[pos] = ct;
+        out.nrm_rad[pos] = nr;
+      }
+      base += tot;
+      __syncthreads();
+    }
+  }
+}
+__global__ void k_clean_finish(const uint32_t* total, unsigned* count_dev, uint32_t capacity, int* overflow_flag) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned t = *total;
+  if (t > capacity) { t = capacity; if (overflow_flag) *overflow_flag = 1; }
+  *count_dev = t;
+}
+
+// candidates (tag != 0) -> AoS list in draw order
+__global__ void __launch_bounds__(BLK) k_cand_flags(Candidates cand, uint8_t* __restrict__ flags, uint32_t* __restrict__ chunk_count) {
+  __shared__ unsigned lds[BLK / 64];
+  const unsigned n = cand.n, c = blockIdx.x;
+  unsigned keep = 0;
+  for (int k = 0; k < 4; ++k) {
+    const unsigned e = c * CHUNK + k * BLK + threadIdx.x;
+    if (e < n) {
+      const uint8_t f = cand.col_time[e].w != 0.0f;
+      flags[e] = f;
+      keep += f;
+    }
+  }
+  unsigned tot;
+  block_excl_scan(keep, lds, tot);
+  if (threadIdx.x == 0) chunk_count[c] = tot;
+}
+__global__ void __launch_bounds__(BLK) k_cand_scatter(Candidates cand, const uint8_t* __restrict__ flags,
+                                                       const uint32_t* __restrict__ chunk_offset, float4* __restrict__ aos) {
+  __shared__ unsigned lds[BLK / 64];
+  const unsigned n = cand.n, c = blockIdx.x;
+  unsigned base = chunk_offset[c];
+  for (int k = 0; k < 4; ++k) {
+    const unsigned e = c * CHUNK + k * BLK + threadIdx.x;
+    const unsigned f = (e < n) ? flags[e] : 0u;
+    unsigned tot;
+    const unsigned pos = base + block_excl_scan(f, lds, tot);
+    if (f) {
+      aos[(size_t)pos * 3] = cand.pos_conf[e];
+      aos[(size_t)pos * 3 + 1] = cand.col_time[e];
+      aos[(size_t)pos * 3 + 2] = cand.nrm_rad[e];
+    }
+    base += tot;
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline dim3 tgrid(int cols, int rows) { return dim3(ceil_div(cols, 64), ceil_div(rows, 4)); }
+
+void filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s) {
+  hipLaunchKernelGGL(k_preprocess<false>, tgrid(cols, rows), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered,
+                     (float*)nullptr, (float*)nullptr);
+}
+void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_metricise, dim3(ceil_div(cols * rows, 256)), dim3(256), 0, s, in, cols * rows, (unsigned)(maxD * 1000.0f), out);
+}
+void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric, float* metric_filtered,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(k_preprocess<true>, tgrid(cols, rows), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered, metric,
+                     metric_filtered);
+}
+void aos_to_soa(const float* aos, uint32_t count, SurfelSoA soa, hipStream_t s) {
+  if (count) hipLaunchKernelGGL(k_aos_to_soa, dim3(ceil_div((int)count, 256)), dim3(256), 0, s, (const float4*)aos, count, soa);
+}
+void soa_to_aos(SurfelSoA soa, uint32_t count, float* aos, hipStream_t s) {
+  if (count) hipLaunchKernelGGL(k_soa_to_aos, dim3(ceil_div((int)count, 256)), dim3(256), 0, s, soa, count, (float4*)aos);
+}
+
+void seed_map(const Cam& cam, const uint8_t* rgb3, const float* dm, const float* dmf, int time, float maxDepth, SurfelSoA out,
+              unsigned* count_dev, const CompactScratch& cs, hipStream_t s) {
+  const int P = cam.cols * cam.rows;
+  const int nch = ceil_div(P, CHUNK);
+  SeedArgs A{cam, rgb3, dm, dmf, time, maxDepth};
+  uint8_t* fr = cs.flags;
+  uint8_t* ff = cs.flags + P;
+  uint32_t* cr = cs.chunk_count;
+  uint32_t* cf = cs.chunk_count + nch;
+  uint32_t* orw = cs.chunk_offset;
+  uint32_t* ofl = cs.chunk_offset + nch;
+  (void)hipMemsetAsync(out.nrm_rad, 0, (size_t)P * sizeof(float4), s);  // "stale zeros" past the end of the filtered stream
+  hipLaunchKernelGGL(k_seed_flags, dim3(nch), dim3(BLK), 0, s, A, fr, ff, cr, cf);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, (const uint32_t*)cr, (const unsigned*)nullptr, (unsigned)P, orw, cs.totals);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, (const uint32_t*)cf, (const unsigned*)nullptr, (unsigned)P, ofl, cs.totals + 1);
+  hipLaunchKernelGGL(k_seed_scatter, dim3(nch), dim3(BLK), 0, s, A, (const uint8_t*)fr, (const uint8_t*)ff, (const uint32_t*)orw,
+                     (const uint32_t*)ofl, (const uint32_t*)cs.totals, out, count_dev);
+}
+
+void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSoA map, const unsigned* count_dev, float maxDepth,
+                     int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s) {
+  hipLaunchKernelGGL(k_index_splat, dim3(SURFEL_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, time, map, count_dev, maxDepth, timeDelta, zbuf);
+  hipLaunchKernelGGL(k_index_resolve, dim3(ceil_div(cam.cols * cam.rows, BLK)), dim3(BLK), 0, s, cam, T_cw16_dev, map, zbuf, out);
+}
+
+void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
+                      float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, PredictMaps out, FillMaps fill,
+                      const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthroughImage, unsigned* dense_counter, hipStream_t s) {
+  hipLaunchKernelGGL(k_surface_splat, dim3(SURFEL_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold, time,
+                     maxTime, timeDelta, zbuf);
+  const dim3 g(ceil_div(cam.cols * cam.rows, BLK));
+  if (fill.image)
+    hipLaunchKernelGGL(k_surface_resolve<true>, g, dim3(BLK), 0, s, cam, T_cw16_dev, map, maxDepth, confThreshold, time, maxTime, timeDelta,
+                       zbuf, out, fill, depth_filtered, rgb3, passthroughImage, dense_counter);
+  else
+    hipLaunchKernelGGL(k_surface_resolve<false>, g, dim3(BLK), 0, s, cam, T_cw16_dev, map, maxDepth, confThreshold, time, maxTime, timeDelta,
+                       zbuf, out, fill, depth_filtered, rgb3, passthroughImage, dense_counter);
+}
+void fill_in(const Cam& cam, PredictMaps pred, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthrough, bool passthroughImage,
+             FillMaps out, hipStream_t s) {
+  hipLaunchKernelGGL(k_fill_in, dim3(ceil_div(cam.cols * cam.rows, BLK)), dim3(BLK), 0, s, cam, pred, depth_filtered, rgb3, passthrough,
+                     passthroughImage, out);
+}
+void dense_count(const Cam& cam, const uchar4* image, unsigned* counter, hipStream_t s) {
+  const int n = (cam.cols / 20) * (cam.rows / 20);
+  hipLaunchKernelGGL(k_dense_count, dim3(ceil_div(n, 256)), dim3(256), 0, s, cam, image, counter);
+}
+
+void fuse(const Cam& cam, const float* pose_f16_dev, int time, const uint8_t* rgb3, const float* dm, const float* dmf, IndexMaps im,
+          float maxDepth, const float* weighting_dev, SurfelSoA map, const unsigned* count_dev, Candidates cand, uint32_t* winner,
+          hipStream_t s) {
+  (void)count_dev;
+  FuseArgs A{cam, pose_f16_dev, time, rgb3, dm, dmf, im, maxDepth, weighting_dev};
+  hipLaunchKernelGGL(k_associate, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, A, cand, winner);
+  hipLaunchKernelGGL(k_merge, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, cand, (const uint32_t*)winner, map, time);
+}
+
+void clean(const Cam& cam, const float* T_cw16_dev, int time, IndexMaps im, float confThreshold, int timeDelta, SurfelSoA map,
+           unsigned* count_dev, Candidates cand, uint32_t* winner, SurfelSoA out, uint32_t capacity, const CompactScratch& cs,
+           int* overflow_flag, hipStream_t s) {
+  CleanArgs A{cam, T_cw16_dev, time, im, confThreshold, timeDelta};
+  hipLaunchKernelGGL(k_clean_flags, dim3(SURFEL_GRID), dim3(BLK), 0, s, A, map, (const unsigned*)count_dev, cand, winner, cs.flags,
+                     cs.chunk_count);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, (const uint32_t*)cs.chunk_count, (const unsigned*)count_dev, (unsigned)cand.n,
+                     cs.chunk_offset, cs.totals);
+  hipLaunchKernelGGL(k_clean_scatter, dim3(SURFEL_GRID), dim3(BLK), 0, s, map, (const unsigned*)count_dev, cand, (const uint8_t*)cs.flags,
+                     (const uint32_t*)cs.chunk_offset, time, out, capacity);
+  hipLaunchKernelGGL(k_clean_finish, dim3(1), dim3(64), 0, s, (const uint32_t*)cs.totals, count_dev, capacity, overflow_flag);
+}
+
+void candidates_to_aos(Candidates cand, float* aos, unsigned* count_dev, const CompactScratch& cs, hipStream_t s) {
+  const int nch = ceil_div(cand.n, CHUNK);
+  hipLaunchKernelGGL(k_cand_flags, dim3(nch), dim3(BLK), 0, s, cand, cs.flags, cs.chunk_count);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, (const uint32_t*)cs.chunk_count, (const unsigned*)nullptr, (unsigned)cand.n,
+                     cs.chunk_offset, count_dev);
+  hipLaunchKernelGGL(k_cand_scatter, dim3(nch), dim3(BLK), 0, s, cand, (const uint8_t*)cs.flags, (const uint32_t*)cs.chunk_offset, (float4*)aos);
+}
+
+}  // namespace efm

@@ -1,0 +1,135 @@
+// Tracking side of libefusion_hip: device-resident Gauss-Newton state + launchers.
+// Replaces Core/Utils/RGBDOdometry.{h,cpp} and the CUDA operators of Core/Cuda/{cudafuncs,reduce}.cu.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eft {
+
+constexpr int NUM_PYRS = 3;          // RGBDOdometry.h:114
+constexpr int REDUCE_BLOCK = 256;    // threads per reduction workgroup (4 waves)
+constexpr int PARTIAL_STRIDE = 64;   // floats per block partial: [0..28] ICP, [32..60] RGB
+constexpr int MAX_PARTIAL_BLOCKS = 2048;
+
+struct Intr { float fx, fy, cx, cy; };
+__host__ __device__ inline Intr intr_level(const Intr& k, int level) {  // CameraModel::operator()(level), types.cuh:92-95
+  const int div = 1 << level;
+  return Intr{k.fx / div, k.fy / div, k.cx / div, k.cy / div};
+}
+
+// Everything the 19-iteration loop mutates lives here, in HBM, so that no iteration needs the host
+// (the reference round-trips 3x per iteration: RGBDOdometry.cpp:424-512).
+struct TrackState {
+  // camera pose, Sophus-style (unit quaternion xyzw + translation), double
+  double q[4];
+  double t[3];
+  double q_prev[4];   // pose before this frame's tracking (velocity weighting, ElasticFusion.cpp:369-383)
+  double t_prev[3];
+  // constants of one getIncrementalTransformation call
+  float Rprev[9], tprev[3], Rprev_inv[9];
+  // Gauss-Newton variables
+  float Rcurr[9], tcurr[3];
+  double resultRt[16];
+  float krkinv[9], kt[3];     // K R K^-1 and K t of the coming iteration (RGBDOdometry.cpp:407-417)
+  int rgb_sum[2];             // {count, sum diff^2}: integer atomics => order independent (reduce.cu:687-709)
+  float lastRGBErrorLevel;    // rgbOnly early-exit bookkeeping (RGBDOdometry.cpp:445-450)
+  int rgb_broken;
+  // outputs (RGBDOdometry.h:74-82)
+  float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
+  double lastA[36], lastb[6];
+  int so3_iterations;
+  // per-frame scalars produced on the device
+  float weighting;            // fusion weight (ElasticFusion.cpp:371-383)
+  int should_fill_in;         // !denseEnough (ElasticFusion.cpp:304-305)
+  int tick;
+  unsigned map_count;         // live surfels
+  unsigned new_count;         // fuse candidates this frame
+  // float matrices consumed by the map kernels
+  float T_cw[16];             // T_wc.inverse().matrix().cast<float>()  (IndexMap.cpp:208)
+  float pose_f[16];           // T_wc.cast<float>().matrix()            (GlobalModel.cpp:403)
+  float R_wc_f[9], t_wc_f[3]; // T_wc.rotationMatrix().cast<float>()    (RGBDOdometry.cpp:192-193)
+};
+
+struct Pyramid {               // one RGBDOdometry instance's device buffers (RGBDOdometry.h:87-140)
+  int width, height;
+  uint16_t* depth_tmp[NUM_PYRS];
+  float* vmap_curr[NUM_PYRS];
+  float* nmap_curr[NUM_PYRS];
+  float* vmap_g_prev[NUM_PYRS];
+  float* nmap_g_prev[NUM_PYRS];
+  float* lastDepth[NUM_PYRS];      // == nextDepth in frame-to-model tracking (quirk Q1): one buffer
+  uint8_t* lastImage[NUM_PYRS];
+  uint8_t* nextImage[NUM_PYRS];
+  uint8_t* lastNextImage[NUM_PYRS];
+  int16_t* dIdx[NUM_PYRS];
+  int16_t* dIdy[NUM_PYRS];
+  void* corresImg[NUM_PYRS];       // DataTerm[rows][cols]
+  float* partials;                 // MAX_PARTIAL_BLOCKS x PARTIAL_STRIDE
+  int W(int l) const { return width >> l; }
+  int H(int l) const { return height >> l; }
+};
+
+struct TrackParams {           // host-side knobs of getIncrementalTransformation
+  bool rgbOnly, pyramid, fastOdom, so3;
+  float icpWeight;
+  float distThres, angleThres; // RGBDOdometry.h:41-42
+};
+
+// ---- operator-tier launchers (raw device pointers) ----
+void pyr_down_u16(const uint16_t* src, int scols, int srows, uint16_t* dst, hipStream_t s);
+void create_vmap(const uint16_t* depth, int cols, int rows, Intr k, float cutoff, float* vmap, hipStream_t s);
+void create_nmap(const float* vmap, int cols, int rows, float* nmap, hipStream_t s);
+void transform_maps(const float* vsrc, const float* nsrc, int cols, int rows, const float* R9_dev, const float* t3_dev,
+                    float* vdst, float* ndst, hipStream_t s);
+void copy_maps(const float* vtex, const float* ntex, int cols, int rows, float* vmaps_tmp, float* vmap, float* nmap, hipStream_t s);
+void resize_map(const float* in, int scols, int srows, float* out, bool normalize, hipStream_t s);
+void pyr_down_gauss_f(const float* src, int scols, int srows, float* dst, hipStream_t s);
+void pyr_down_uchar_gauss(const uint8_t* src, int scols, int srows, uint8_t* dst, hipStream_t s);
+void vertices_to_depth(const float* vmaps_tmp, int cols, int rows, float cutoff, float* dst, hipStream_t s);
+void bgr_to_intensity(const uint8_t* src, int channels, int cols, int rows, uint8_t* dst, hipStream_t s);
+void derivative_images(const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy, hipStream_t s);
+void project_to_point_cloud(const float* depth, int cols, int rows, Intr k, float* cloud, hipStream_t s);
+
+// reductions with explicit parameters (operator tier); results left in out_dev (29 / 29 / 11 floats, 2 ints)
+struct IcpArgs {
+  float Rcurr[9], tcurr[3], Rprev_inv[9], tprev[3];
+  Intr k;
+  float distThres, angleThres;
+};
+void icp_step_op(const IcpArgs& a, const float* vmap_curr, const float* nmap_curr, const float* vmap_g_prev,
+                 const float* nmap_g_prev, int cols, int rows, float* partials, float* out29_dev, hipStream_t s);
+struct RgbResidualArgs {
+  float minScale, maxDepthDelta;
+  float kt[3], krkinv[9];
+};
+void rgb_residual_op(const RgbResidualArgs& a, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
+                     const float* nextDepth, const uint8_t* lastImage, const uint8_t* nextImage, void* corres, int cols,
+                     int rows, int* out2_dev, hipStream_t s);
+void rgb_step_op(const void* corres, float sigma, const float* cloud, float fx, float fy, const int16_t* dIdx,
+                 const int16_t* dIdy, float sobelScale, int cols, int rows, float* partials, float* out29_dev, hipStream_t s);
+struct So3Args { float imageBasis[9], kinv[9], krlr[9]; };
+void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* nextImage, int cols, int rows, float* out11_dev,
+                 hipStream_t s);
+
+// ---- frame-tier launchers (device-resident state; nothing here synchronises) ----
+// RGBDOdometry::initICP(filteredDepth, cutoff): u16 pyramid + vertex/normal maps, RGBDOdometry.cpp:121-147
+void init_icp(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, hipStream_t s);
+// initICPModel + initRGBModel's depth half: predicted (or fill-in, chosen by st->should_fill_in) float4 maps ->
+// world-frame planar pyramids + model depth L0.  RGBDOdometry.cpp:171-210, :217
+void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
+                    const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s);
+// the rest of populateRGBDData for both the model ("last") and the frame ("next"): Gaussian depth pyramid,
+// intensity pyramids; then Sobel on the "next" pyramid.  RGBDOdometry.cpp:212-244, :275-279
+void init_rgb(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* fill_image_rgba, bool frameToFrameRGB,
+              const uint8_t* rgb3, const TrackState* st, bool with_sobel, hipStream_t s);
+// initFirstRGB, RGBDOdometry.cpp:246-257
+void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
+// getIncrementalTransformation, RGBDOdometry.cpp:259-571, entirely enqueued
+void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s);
+// tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +
+// velocity weighting (ElasticFusion.cpp:369-383) + the float matrices of the map passes
+void track_end(TrackState* st, bool rgb, float weightMultiplier, hipStream_t s);
+void pose_injected(TrackState* st, float weightMultiplier, bool with_weighting, hipStream_t s);
+void save_prev_pose(TrackState* st, hipStream_t s);
+
+}  // namespace eft

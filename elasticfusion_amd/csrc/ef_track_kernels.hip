@@ -1,0 +1,1252 @@
+// HIP kernels (gfx950, wave64) for the tracking pyramid and the Gauss-Newton reductions.
+// Reference behaviour: Core/Cuda/cudafuncs.cu (image operators), Core/Cuda/reduce.cu (icpStep,
+// computeRgbResidual, rgbStep, so3Step), Core/Utils/RGBDOdometry.cpp (driver).  The CUDA versions are
+// warp32 / 64x256-thread grid-stride / host-in-the-loop; here every reduction is a 256-thread
+// (4-wave) workgroup with LDS-staged column sums, one partial row per workgroup summed in fixed
+// order, and the 6x6 solve + SE(3) update run in a single-lane double-precision kernel so the
+// 19 iterations are enqueued back to back with no host round trip.
+#include "ef_device.hpp"
+#include "ef_linalg_dev.hpp"
+#include "ef_track.hpp"
+
+using namespace ef;
+
+namespace eft {
+
+namespace {
+
+constexpr int TILE_X = 64, TILE_Y = 4;  // 256-thread image tile: one wave per row segment, coalesced in x
+
+inline dim3 tile_grid(int cols, int rows) { return dim3((cols + TILE_X - 1) / TILE_X, (rows + TILE_Y - 1) / TILE_Y); }
+inline dim3 tile_block() { return dim3(TILE_X, TILE_Y); }
+
+// ------------------------------------------------------------------------------------------
+// image operators
+// ------------------------------------------------------------------------------------------
+
+// pyrDownGaussKernel, cudafuncs.cu:75-109
+__global__ void k_pyr_down_u16(const uint16_t* __restrict__ src, int scols, int srows, uint16_t* __restrict__ dst) {
+  const int dcols = scols / 2, drows = srows / 2;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dcols || y >= drows) return;
+  const int D = 5;
+  const float sigma_color = 30.f;
+  const int center = src[(2 * y) * scols + 2 * x];
+  const int x_mi = max(0, 2 * x - D / 2) - 2 * x, y_mi = max(0, 2 * y - D / 2) - 2 * y;
+  const int x_ma = min(scols, 2 * x - D / 2 + D) - 2 * x, y_ma = min(srows, 2 * y - D / 2 + D) - 2 * y;
+  float sum = 0, wall = 0;
+  for (int yi = y_mi; yi < y_ma; ++yi)
+    for (int xi = x_mi; xi < x_ma; ++xi) {
+      const int val = src[(2 * y + yi) * scols + 2 * x + xi];
+      if (abs(val - center) < 3 * sigma_color) {
+        const int ax = abs(xi), ay = abs(yi);
+        const float wx = ax == 0 ? 0.375f : (ax == 1 ? 0.25f : 0.0625f);
+        const float wy = ay == 0 ? 0.375f : (ay == 1 ? 0.25f : 0.0625f);
+        sum += (float)val * wx * wy;
+        wall += wx * wy;
+      }
+    }
+  dst[y * dcols + x] = (uint16_t) static_cast<int>(sum / wall);
+}
+
+// computeVmapKernel, cudafuncs.cu:123-149
+__device__ __forceinline__ bool vmap_point(int d, int u, int v, float fx_inv, float fy_inv, float cx, float cy, float cutoff, f3& p) {
+  const float z = d / 1000.f;
+  if (z != 0 && z < cutoff) {
+    p = {z * (u - cx) * fx_inv, z * (v - cy) * fy_inv, z};
+    return true;
+  }
+  return false;
+}
+__global__ void k_create_vmap(const uint16_t* __restrict__ depth, int cols, int rows, float fx_inv, float fy_inv, float cx,
+                              float cy, float cutoff, float* __restrict__ vmap) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y * blockDim.y + threadIdx.y;
+  if (u >= cols || v >= rows) return;
+  f3 p;
+  if (vmap_point(depth[v * cols + u], u, v, fx_inv, fy_inv, cx, cy, cutoff, p)) {
+    vmap[v * cols + u] = p.x;
+    vmap[(v + rows) * cols + u] = p.y;
+    vmap[(v + 2 * rows) * cols + u] = p.z;
+  } else {
+    vmap[v * cols + u] = qnan();
+  }
+}
+// computeNmapKernel, cudafuncs.cu:170-204
+__global__ void k_create_nmap(const float* __restrict__ vmap, int cols, int rows, float* __restrict__ nmap) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y * blockDim.y + threadIdx.y;
+  if (u >= cols || v >= rows) return;
+  if (u == cols - 1 || v == rows - 1) { nmap[v * cols + u] = qnan(); return; }
+  const float x00 = vmap[v * cols + u], x01 = vmap[v * cols + u + 1], x10 = vmap[(v + 1) * cols + u];
+  if (!isnan(x00) && !isnan(x01) && !isnan(x10)) {
+    const f3 v00{x00, vmap[(v + rows) * cols + u], vmap[(v + 2 * rows) * cols + u]};
+    const f3 v01{x01, vmap[(v + rows) * cols + u + 1], vmap[(v + 2 * rows) * cols + u + 1]};
+    const f3 v10{x10, vmap[(v + 1 + rows) * cols + u], vmap[(v + 1 + 2 * rows) * cols + u]};
+    const f3 r = normalized(cross(v01 - v00, v10 - v00));
+    nmap[v * cols + u] = r.x;
+    nmap[(v + rows) * cols + u] = r.y;
+    nmap[(v + 2 * rows) * cols + u] = r.z;
+  } else {
+    nmap[v * cols + u] = qnan();
+  }
+}
+
+// Fused createVMap + createNMap for all three levels in ONE launch (blockIdx.z = level): the normal is
+// evaluated straight from the three depth samples with the same operations createVMap would have used,
+// so the planar maps come out bit-identical to the two-kernel path without re-reading the vertex map.
+struct VNLevels {
+  const uint16_t* depth[NUM_PYRS];
+  float* vmap[NUM_PYRS];
+  float* nmap[NUM_PYRS];
+  int cols[NUM_PYRS], rows[NUM_PYRS];
+  Intr k[NUM_PYRS];
+  float cutoff;
+};
+__global__ void k_vmap_nmap_levels(const VNLevels L) {
+  const int l = blockIdx.z;
+  const int cols = L.cols[l], rows = L.rows[l];
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y * blockDim.y + threadIdx.y;
+  if (u >= cols || v >= rows) return;
+  const uint16_t* __restrict__ depth = L.depth[l];
+  float* __restrict__ vmap = L.vmap[l];
+  float* __restrict__ nmap = L.nmap[l];
+  const float fx_inv = 1.f / L.k[l].fx, fy_inv = 1.f / L.k[l].fy, cx = L.k[l].cx, cy = L.k[l].cy;
+  f3 v00, v01, v10;
+  const bool ok00 = vmap_point(depth[v * cols + u], u, v, fx_inv, fy_inv, cx, cy, L.cutoff, v00);
+  if (ok00) {
+    vmap[v * cols + u] = v00.x;
+    vmap[(v + rows) * cols + u] = v00.y;
+    vmap[(v + 2 * rows) * cols + u] = v00.z;
+  } else {
+    vmap[v * cols + u] = qnan();
+  }
+  if (u == cols - 1 || v == rows - 1) { nmap[v * cols + u] = qnan(); return; }
+  const bool ok01 = vmap_point(depth[v * cols + u + 1], u + 1, v, fx_inv, fy_inv, cx, cy, L.cutoff, v01);
+  const bool ok10 = vmap_point(depth[(v + 1) * cols + u], u, v + 1, fx_inv, fy_inv, cx, cy, L.cutoff, v10);
+  if (ok00 && ok01 && ok10) {
+    const f3 r = normalized(cross(v01 - v00, v10 - v00));
+    nmap[v * cols + u] = r.x;
+    nmap[(v + rows) * cols + u] = r.y;
+    nmap[(v + 2 * rows) * cols + u] = r.z;
+  } else {
+    nmap[v * cols + u] = qnan();
+  }
+}
+
+// tranformMapsKernel, cudafuncs.cu:221-270 (R, t read from device memory)
+__global__ void k_transform_maps(const float* __restrict__ vsrc, const float* __restrict__ nsrc, int cols, int rows,
+                                 const float* __restrict__ Rp, const float* __restrict__ tp, float* vdst, float* ndst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  const m33 R = m33_load(Rp);
+  const f3 t{tp[0], tp[1], tp[2]};
+  float ox = qnan();
+  const float vx = vsrc[y * cols + x];
+  if (!isnan(vx)) {
+    const f3 vs{vx, vsrc[(y + rows) * cols + x], vsrc[(y + 2 * rows) * cols + x]};
+    const f3 vd = mul(R, vs) + t;
+    vdst[(y + rows) * cols + x] = vd.y;
+    vdst[(y + 2 * rows) * cols + x] = vd.z;
+    ox = vd.x;
+  }
+  vdst[y * cols + x] = ox;
+  float onx = qnan();
+  const float nx = nsrc[y * cols + x];
+  if (!isnan(nx)) {
+    const f3 ns{nx, nsrc[(y + rows) * cols + x], nsrc[(y + 2 * rows) * cols + x]};
+    const f3 nd = mul(R, ns);
+    ndst[(y + rows) * cols + x] = nd.y;
+    ndst[(y + 2 * rows) * cols + x] = nd.z;
+    onx = nd.x;
+  }
+  ndst[y * cols + x] = onx;
+}
+
+// copyMapsKernelTex, cudafuncs.cu:295-350
+__global__ void k_copy_maps(const float4* __restrict__ vtex, const float4* __restrict__ ntex, int cols, int rows,
+                            float4* __restrict__ vmaps_tmp, float* __restrict__ vmap, float* __restrict__ nmap) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  const float4 vs = vtex[y * cols + x];
+  const float4 ns = ntex[y * cols + x];
+  vmaps_tmp[y * cols + x] = vs;
+  f3 vd{qnan(), qnan(), qnan()}, nd{qnan(), qnan(), qnan()};
+  if (!(vs.z == 0)) {
+    vd = {vs.x, vs.y, vs.z};
+    nd = {ns.x, ns.y, ns.z};
+  }
+  vmap[y * cols + x] = vd.x;
+  vmap[(y + rows) * cols + x] = vd.y;
+  vmap[(y + 2 * rows) * cols + x] = vd.z;
+  nmap[y * cols + x] = nd.x;
+  nmap[(y + rows) * cols + x] = nd.y;
+  nmap[(y + 2 * rows) * cols + x] = nd.z;
+}
+
+// resizeMapKernel<normalize>, cudafuncs.cu:413-465
+template <bool NORMALIZE>
+__global__ void k_resize_map(const float* __restrict__ in, int scols, int srows, float* __restrict__ out) {
+  const int dcols = scols / 2, drows = srows / 2;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dcols || y >= drows) return;
+  const int xs = x * 2, ys = y * 2;
+  const float x00 = in[ys * scols + xs], x01 = in[ys * scols + xs + 1], x10 = in[(ys + 1) * scols + xs], x11 = in[(ys + 1) * scols + xs + 1];
+  if (isnan(x00) || isnan(x01) || isnan(x10) || isnan(x11)) { out[y * dcols + x] = qnan(); return; }
+  f3 n;
+  n.x = (x00 + x01 + x10 + x11) / 4;
+  const float* py = in + (size_t)srows * scols;
+  const float* pz = in + (size_t)2 * srows * scols;
+  n.y = (py[ys * scols + xs] + py[ys * scols + xs + 1] + py[(ys + 1) * scols + xs] + py[(ys + 1) * scols + xs + 1]) / 4;
+  n.z = (pz[ys * scols + xs] + pz[ys * scols + xs + 1] + pz[(ys + 1) * scols + xs] + pz[(ys + 1) * scols + xs + 1]) / 4;
+  if (NORMALIZE) n = normalized(n);
+  out[y * dcols + x] = n.x;
+  out[(y + drows) * dcols + x] = n.y;
+  out[(y + 2 * drows) * dcols + x] = n.z;
+}
+
+__device__ __forceinline__ float gauss25(int idx) {  // {1 4 6 4 1} (x) {1 4 6 4 1}, cudafuncs.cu:498-499
+  const int r = idx / 5, c = idx - r * 5;
+  const float wr = r == 2 ? 6.f : ((r == 1 || r == 3) ? 4.f : 1.f);
+  const float wc = c == 2 ? 6.f : ((c == 1 || c == 3) ? 4.f : 1.f);
+  return wr * wc;
+}
+
+// pyrDownKernelGaussF, cudafuncs.cu:383-411 (quirk Q7 kept)
+__global__ void k_pyr_down_gauss_f(const float* __restrict__ src, int scols, int srows, float* __restrict__ dst) {
+  const int dcols = scols / 2, drows = srows / 2, D = 5;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dcols || y >= drows) return;
+  const int tx = min(2 * x - D / 2 + D, scols - 1), ty = min(2 * y - D / 2 + D, srows - 1);
+  float sum = 0;
+  int count = 0;
+  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+      const float s = src[cy * scols + cx];
+      if (!isnan(s)) {
+        const float g = gauss25((ty - cy - 1) * 5 + (tx - cx - 1));
+        sum += s * g;
+        count = (int)((float)count + g);
+      }
+    }
+  dst[y * dcols + x] = (float)(sum / (float)count);
+}
+
+// pyrDownKernelIntensityGauss, cudafuncs.cu:512-542
+__global__ void k_pyr_down_uchar_gauss(const uint8_t* __restrict__ src, int scols, int srows, uint8_t* __restrict__ dst) {
+  const int dcols = scols / 2, drows = srows / 2, D = 5;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dcols || y >= drows) return;
+  const int tx = min(2 * x - D / 2 + D, scols - 1), ty = min(2 * y - D / 2 + D, srows - 1);
+  float sum = 0;
+  int count = 0;
+  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
+    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
+      const int s = src[cy * scols + cx];
+      if (s > 0) {
+        const float g = gauss25((ty - cy - 1) * 5 + (tx - cx - 1));
+        sum += (float)s * g;
+        count = (int)((float)count + g);
+      }
+    }
+  const float q = sum / (float)count;
+  const int iv = (q != q) ? 0 : (int)fminf(fmaxf(q, 0.0f), 255.0f);
+  dst[y * dcols + x] = (uint8_t)iv;
+}
+
+// verticesToDepthKernel, cudafuncs.cu:564-574
+__global__ void k_vertices_to_depth(const float4* __restrict__ vmaps_tmp, int cols, int rows, float cutOff, float* __restrict__ dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  const float z = vmaps_tmp[y * cols + x].z;
+  dst[y * cols + x] = (z > cutOff || z <= 0) ? qnan() : z;
+}
+
+__device__ __forceinline__ uint8_t intensity_of(float c0, float c1, float c2) {  // cudafuncs.cu:593 (Q5)
+  const int value = (int)(c0 * 0.114f + c1 * 0.299f + c2 * 0.587f);
+  return (uint8_t)value;
+}
+// bgr2IntensityKernel, cudafuncs.cu:584-596; CH = 4 (RGBA8 texel) or 3 (packed RGB as uploaded)
+template <int CH>
+__global__ void k_bgr_to_intensity(const uint8_t* __restrict__ src, int n, uint8_t* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* s = src + (size_t)i * CH;
+  dst[i] = intensity_of((float)s[0], (float)s[1], (float)s[2]);
+}
+
+// applyKernel, cudafuncs.cu:612-637 (quirk Q6 kept)
+__device__ __forceinline__ void sobel_px(const uint8_t* __restrict__ src, int cols, int rows, int x, int y, int16_t* dx, int16_t* dy) {
+  const float gsx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
+  const float gsy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
+  float dxVal = 0, dyVal = 0;
+  int k = 8;
+  for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); ++j)
+    for (int i = max(x - 1, 0); i <= min(x + 1, cols - 1); ++i) {
+      const float s = (float)src[j * cols + i];
+      dxVal += s * gsx[k];
+      dyVal += s * gsy[k];
+      --k;
+    }
+  dx[y * cols + x] = (int16_t)(int)dxVal;
+  dy[y * cols + x] = (int16_t)(int)dyVal;
+}
+__global__ void k_sobel(const uint8_t* __restrict__ src, int cols, int rows, int16_t* __restrict__ dx, int16_t* __restrict__ dy) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  sobel_px(src, cols, rows, x, y, dx, dy);
+}
+struct SobelLevels {
+  const uint8_t* src[NUM_PYRS];
+  int16_t* dx[NUM_PYRS];
+  int16_t* dy[NUM_PYRS];
+  int cols[NUM_PYRS], rows[NUM_PYRS];
+};
+__global__ void k_sobel_levels(const SobelLevels L) {
+  const int l = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= L.cols[l] || y >= L.rows[l]) return;
+  sobel_px(L.src[l], L.cols[l], L.rows[l], x, y, L.dx[l], L.dy[l]);
+}
+
+// projectPointsKernel, cudafuncs.cu:670-688
+__device__ __forceinline__ f3 project_point(int x, int y, float z, float invFx, float invFy, float cx, float cy) {
+  return {(float)((x - cx) * z * invFx), (float)((y - cy) * z * invFy), z};
+}
+__global__ void k_project_points(const float* __restrict__ depth, int cols, int rows, float invFx, float invFy, float cx,
+                                 float cy, float* __restrict__ cloud) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= cols || y >= rows) return;
+  const f3 p = project_point(x, y, depth[y * cols + x], invFx, invFy, cx, cy);
+  float* c = cloud + (size_t)(y * cols + x) * 3;
+  c[0] = p.x; c[1] = p.y; c[2] = p.z;
+}
+
+// ------------------------------------------------------------------------------------------
+// Model-side pyramids in one launch.  Each thread owns a 4x4 block of level-0 pixels and emits
+// level 0 (16 px), level 1 (2x2) and level 2 (1 px): copyMaps -> resizeVMap/NMap x2 -> tranformMaps x3
+// (RGBDOdometry.cpp:171-210) plus verticesToDepth for level 0 (:217).  Resizing happens on the
+// camera-frame values and the rigid transform is applied per level afterwards, exactly the
+// reference's order, so every output equals the multi-kernel path bit for bit; the intermediate
+// camera-frame pyramids never touch HBM.
+// ------------------------------------------------------------------------------------------
+struct ModelMapsArgs {
+  const float4* pred_vertex;
+  const float4* pred_normal;
+  const float4* fill_vertex;
+  const float4* fill_normal;
+  float* vmap[NUM_PYRS];
+  float* nmap[NUM_PYRS];
+  float* depth0;
+  int cols, rows;
+  float maxDepthRGB;
+};
+// ALL_PLANES: level 0 (copyMaps NaNs x, y and z of an empty texel); the resized levels only get the
+// x-plane NaN that resizeMapKernel / tranformMapsKernel write (quirk Q3: y/z planes keep stale data).
+template <bool ALL_PLANES>
+__device__ __forceinline__ void store_planar(float* m, int cols, int rows, int x, int y, bool valid, f3 v) {
+  if (valid) {
+    m[(y + rows) * cols + x] = v.y;
+    m[(y + 2 * rows) * cols + x] = v.z;
+    m[y * cols + x] = v.x;
+  } else {
+    m[y * cols + x] = qnan();
+    if (ALL_PLANES) {
+      m[(y + rows) * cols + x] = qnan();
+      m[(y + 2 * rows) * cols + x] = qnan();
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const TrackState* __restrict__ st) {
+  const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
+  const int cols = A.cols, rows = A.rows;
+  if (bx * 4 >= cols || by * 4 >= rows) return;
+  const bool fill = st->should_fill_in != 0;
+  const float4* __restrict__ vsrc = fill ? A.fill_vertex : A.pred_vertex;
+  const float4* __restrict__ nsrc = fill ? A.fill_normal : A.pred_normal;
+  const m33 R = m33_load(st->R_wc_f);
+  const f3 t{st->t_wc_f[0], st->t_wc_f[1], st->t_wc_f[2]};
+  const int c1 = cols / 2, r1 = rows / 2, c2 = cols / 4, r2 = rows / 4;
+  f3 v1[2][2], n1[2][2];
+  bool v1ok[2][2], n1ok[2][2];
+#pragma unroll
+  for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+    for (int qx = 0; qx < 2; ++qx) {
+      f3 v0[2][2], n0[2][2];
+      bool ok0[2][2];
+#pragma unroll
+      for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          const int x = bx * 4 + qx * 2 + sx, y = by * 4 + qy * 2 + sy;
+          const float4 vs = vsrc[y * cols + x];
+          const float4 ns = nsrc[y * cols + x];
+          const bool ok = !(vs.z == 0);
+          ok0[sy][sx] = ok;
+          v0[sy][sx] = {vs.x, vs.y, vs.z};
+          n0[sy][sx] = {ns.x, ns.y, ns.z};
+          A.depth0[y * cols + x] = (vs.z > A.maxDepthRGB || vs.z <= 0) ? qnan() : vs.z;
+          // level 0: copyMaps NaNs all planes where z == 0, transform propagates NaN via the x-plane
+          const bool nok = ok && !isnan(ns.x);
+          store_planar<true>(A.vmap[0], cols, rows, x, y, ok && !isnan(vs.x), mul(R, v0[sy][sx]) + t);
+          store_planar<true>(A.nmap[0], cols, rows, x, y, nok, mul(R, n0[sy][sx]));
+        }
+      // level 1: 2x2 box of the camera-frame level-0 maps (x-plane NaN test only)
+      const bool vok = ok0[0][0] && ok0[0][1] && ok0[1][0] && ok0[1][1] && !isnan(v0[0][0].x) && !isnan(v0[0][1].x) &&
+                       !isnan(v0[1][0].x) && !isnan(v0[1][1].x);
+      const bool nok = ok0[0][0] && ok0[0][1] && ok0[1][0] && ok0[1][1] && !isnan(n0[0][0].x) && !isnan(n0[0][1].x) &&
+                       !isnan(n0[1][0].x) && !isnan(n0[1][1].x);
+      f3 va{(v0[0][0].x + v0[0][1].x + v0[1][0].x + v0[1][1].x) / 4, (v0[0][0].y + v0[0][1].y + v0[1][0].y + v0[1][1].y) / 4,
+            (v0[0][0].z + v0[0][1].z + v0[1][0].z + v0[1][1].z) / 4};
+      f3 na{(n0[0][0].x + n0[0][1].x + n0[1][0].x + n0[1][1].x) / 4, (n0[0][0].y + n0[0][1].y + n0[1][0].y + n0[1][1].y) / 4,
+            (n0[0][0].z + n0[0][1].z + n0[1][0].z + n0[1][1].z) / 4};
+      na = normalized(na);
+      v1[qy][qx] = va; n1[qy][qx] = na;
+      // a valid-flagged average can still be NaN in x (NaN y/z never matter: only x is tested downstream)
+      v1ok[qy][qx] = vok; n1ok[qy][qx] = nok;
+      const int x1 = bx * 2 + qx, y1 = by * 2 + qy;
+      store_planar<false>(A.vmap[1], c1, r1, x1, y1, vok && !isnan(va.x), mul(R, va) + t);
+      store_planar<false>(A.nmap[1], c1, r1, x1, y1, nok && !isnan(na.x), mul(R, na));
+    }
+  // level 2
+  const bool vok2 = v1ok[0][0] && v1ok[0][1] && v1ok[1][0] && v1ok[1][1] && !isnan(v1[0][0].x) && !isnan(v1[0][1].x) &&
+                    !isnan(v1[1][0].x) && !isnan(v1[1][1].x);
+  const bool nok2 = n1ok[0][0] && n1ok[0][1] && n1ok[1][0] && n1ok[1][1] && !isnan(n1[0][0].x) && !isnan(n1[0][1].x) &&
+                    !isnan(n1[1][0].x) && !isnan(n1[1][1].x);
+  f3 va{(v1[0][0].x + v1[0][1].x + v1[1][0].x + v1[1][1].x) / 4, (v1[0][0].y + v1[0][1].y + v1[1][0].y + v1[1][1].y) / 4,
+        (v1[0][0].z + v1[0][1].z + v1[1][0].z + v1[1][1].z) / 4};
+  f3 na{(n1[0][0].x + n1[0][1].x + n1[1][0].x + n1[1][1].x) / 4, (n1[0][0].y + n1[0][1].y + n1[1][0].y + n1[1][1].y) / 4,
+        (n1[0][0].z + n1[0][1].z + n1[1][0].z + n1[1][1].z) / 4};
+  na = normalized(na);
+  store_planar<false>(A.vmap[2], c2, r2, bx, by, vok2 && !isnan(va.x), mul(R, va) + t);
+  store_planar<false>(A.nmap[2], c2, r2, bx, by, nok2 && !isnan(na.x), mul(R, na));
+}
+
+// ------------------------------------------------------------------------------------------
+// per-pixel Jacobian rows
+// ------------------------------------------------------------------------------------------
+struct IcpView {
+  const float* vmap_curr;
+  const float* nmap_curr;
+  const float* vmap_g_prev;
+  const float* nmap_g_prev;
+  int cols, rows;
+  Intr k;
+  float distThres, angleThres;
+};
+struct IcpPose { m33 Rcurr; f3 tcurr; m33 Rprev_inv; f3 tprev; };
+
+// search() + getProducts(), reduce.cu:228-309: fills row[7]; returns found
+__device__ __forceinline__ bool icp_row(const IcpView& V, const IcpPose& P, int x, int y, float (&row)[7]) {
+  const int cols = V.cols, rows = V.rows;
+  const int plane = cols * rows, idx = y * cols + x;
+  const f3 vcurr{V.vmap_curr[idx], V.vmap_curr[idx + plane], V.vmap_curr[idx + 2 * plane]};
+  const f3 vcurr_g = mul(P.Rcurr, vcurr) + P.tcurr;
+  const f3 vcurr_cp = mul(P.Rprev_inv, vcurr_g - P.tprev);
+  const int ux = f2i_rn(vcurr_cp.x * V.k.fx / vcurr_cp.z + V.k.cx);
+  const int uy = f2i_rn(vcurr_cp.y * V.k.fy / vcurr_cp.z + V.k.cy);
+  if (ux < 0 || uy < 0 || ux >= cols || uy >= rows || vcurr_cp.z < 0) return false;
+  const int pidx = uy * cols + ux;
+  const f3 vprev_g{V.vmap_g_prev[pidx], V.vmap_g_prev[pidx + plane], V.vmap_g_prev[pidx + 2 * plane]};
+  const f3 ncurr{V.nmap_curr[idx], V.nmap_curr[idx + plane], V.nmap_curr[idx + 2 * plane]};
+  const f3 ncurr_g = mul(P.Rcurr, ncurr);
+  const f3 nprev_g{V.nmap_g_prev[pidx], V.nmap_g_prev[pidx + plane], V.nmap_g_prev[pidx + 2 * plane]};
+  const float dist = norm(vprev_g - vcurr_g);
+  const float sine = norm(cross(ncurr_g, nprev_g));
+  if (!(sine < V.angleThres && dist <= V.distThres && !isnan(ncurr.x) && !isnan(nprev_g.x))) return false;
+  const f3 s_cp = mul(P.Rprev_inv, vcurr_g - P.tprev);
+  const f3 d_cp = mul(P.Rprev_inv, vprev_g - P.tprev);
+  const f3 n_cp = mul(P.Rprev_inv, nprev_g);
+  const f3 c = cross(s_cp, n_cp);
+  row[0] = n_cp.x; row[1] = n_cp.y; row[2] = n_cp.z;
+  row[3] = c.x; row[4] = c.y; row[5] = c.z;
+  row[6] = dot(n_cp, s_cp - d_cp);
+  return true;
+}
+
+struct RgbView {
+  const DataTerm* corres;
+  const float* lastDepth;     // level depth of the model image; the cloud is evaluated on the fly
+  const float* cloud;         // or an explicit float3 cloud (operator tier); one of the two is null
+  const int16_t* dIdx;
+  const int16_t* dIdy;
+  int cols, rows;
+  Intr k;
+  float sobelScale;
+};
+// RGBReduction::getProducts, reduce.cu:420-476
+__device__ __forceinline__ bool rgb_row(const RgbView& V, float sigma, int i, float (&row)[7]) {
+  const DataTerm c = V.corres[i];
+  if (!c.valid) return false;
+  float w = sigma + fabsf(c.diff);
+  w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
+  if (sigma == -1) w = 1;
+  row[6] = -w * c.diff;
+  f3 p;
+  const int zi = c.zero_y * V.cols + c.zero_x;
+  if (V.cloud) {
+    p = {V.cloud[(size_t)zi * 3], V.cloud[(size_t)zi * 3 + 1], V.cloud[(size_t)zi * 3 + 2]};
+  } else {  // projectPointsKernel folded in: same operations, same bits, no 12 B/px cloud in HBM
+    p = project_point(c.zero_x, c.zero_y, V.lastDepth[zi], 1.0f / V.k.fx, 1.0f / V.k.fy, V.k.cx, V.k.cy);
+  }
+  const float invz = (float)(1.0 / (double)p.z);
+  const int oi = c.one_y * V.cols + c.one_x;
+  const float dI_dx_val = w * V.sobelScale * V.dIdx[oi];
+  const float dI_dy_val = w * V.sobelScale * V.dIdy[oi];
+  const float v0 = dI_dx_val * V.k.fx * invz;
+  const float v1 = dI_dy_val * V.k.fy * invz;
+  const float v2 = -(v0 * p.x + v1 * p.y) * invz;
+  row[0] = v0; row[1] = v1; row[2] = v2;
+  row[3] = -p.z * v1 + p.y * v2;
+  row[4] = p.z * v0 - p.x * v2;
+  row[5] = -p.y * v0 + p.x * v1;
+  return true;
+}
+
+// the 27 upper-triangular products of [J r]^T [J r] + r^2 + count, JtJJtrSE3 order (types.cuh:98-143)
+__device__ __forceinline__ void accumulate29(const float (&row)[7], float (&acc)[29]) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 7; ++j) { acc[s] = fmaf(row[i], row[j], acc[s]); ++s; }
+  acc[27] = fmaf(row[6], row[6], acc[27]);
+  acc[28] += 1.0f;
+}
+
+struct ResidualView {
+  const int16_t* dIdx;
+  const int16_t* dIdy;
+  const float* lastDepth;
+  const float* nextDepth;
+  const uint8_t* lastImage;
+  const uint8_t* nextImage;
+  DataTerm* corres;
+  int cols, rows;
+  float minScale, maxDepthDelta;
+};
+// RGBResidual::getProducts, reduce.cu:631-701; returns {valid, diff^2 as int}
+__device__ __forceinline__ void residual_px(const ResidualView& V, const m33& K, const f3& kt, int k, int& cnt, int& sq) {
+  const int cols = V.cols, rows = V.rows;
+  const int i = k / cols, j0 = k - i * cols;
+  DataTerm corres;
+  corres.zero_x = corres.zero_y = corres.one_x = corres.one_y = 0;
+  corres.diff = 0.f;
+  corres.valid = 0;
+  corres.pad[0] = corres.pad[1] = corres.pad[2] = 0;
+  if (j0 < cols - 5 && i < rows - 1) {
+    bool valid = true;
+    for (int u = max(i - 2, 0); u < min(i + 2, rows); ++u)
+      for (int v = max(j0 - 2, 0); v < min(j0 + 2, cols); ++v) valid = valid && (V.nextImage[u * cols + v] > 0);
+    if (valid) {
+      const int valx = V.dIdx[k], valy = V.dIdy[k];
+      const float mTwo = (float)((valx * valx) + (valy * valy));
+      if (mTwo >= V.minScale) {
+        const int y = i, x = j0;
+        const float d1 = V.nextDepth[k];
+        if (!isnan(d1)) {
+          const float transformed_d1 = (float)(d1 * (K.r[2].x * x + K.r[2].y * y + K.r[2].z) + kt.z);
+          const int u0 = f2i_rn((d1 * (K.r[0].x * x + K.r[0].y * y + K.r[0].z) + kt.x) / transformed_d1);
+          const int v0 = f2i_rn((d1 * (K.r[1].x * x + K.r[1].y * y + K.r[1].z) + kt.y) / transformed_d1);
+          if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+            const float d0 = V.lastDepth[v0 * cols + u0];
+            const uint8_t li = V.lastImage[v0 * cols + u0];
+            if (d0 > 0 && fabsf(transformed_d1 - d0) <= V.maxDepthDelta && li != 0) {
+              corres.zero_x = (short)u0; corres.zero_y = (short)v0;
+              corres.one_x = (short)x; corres.one_y = (short)y;
+              corres.diff = (float)V.nextImage[k] - (float)li;
+              corres.valid = 1;
+              cnt += 1;
+              sq += (int)(corres.diff * corres.diff);
+            }
+          }
+        }
+      }
+    }
+  }
+  V.corres[k] = corres;
+}
+
+// SO3Reduction::getProducts, reduce.cu:820-897
+__device__ __forceinline__ void so3_gradient(const uint8_t* __restrict__ img, int cols, int x, int y, float& gx, float& gy) {
+  const float actu = (float)img[y * cols + x];
+  float back = (float)img[y * cols + x - 1], fore = (float)img[y * cols + x + 1];
+  gx = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+  back = (float)img[(y - 1) * cols + x];
+  fore = (float)img[(y + 1) * cols + x];
+  gy = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
+}
+__device__ __forceinline__ void so3_px(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, int cols,
+                                       int rows, const m33& IB, const m33& KI, const m33& KR, int k, float (&acc)[11]) {
+  const int y = k / cols, x = k - y * cols;
+  const f3 unwarped{(float)x, (float)y, 1.0f};
+  const f3 warped = mul(IB, unwarped);
+  const int wx = f2i_rn(warped.x / warped.z), wy = f2i_rn(warped.y / warped.z);
+  const bool found = (wx >= 1 && wx < cols - 1 && wy >= 1 && wy < rows - 1 && x >= 1 && x < cols - 1 && y >= 1 && y < rows - 1);
+  if (!found) return;  // zero row: contributes nothing
+  float gnx, gny, glx, gly;
+  so3_gradient(nextImage, cols, wx, wy, gnx, gny);
+  so3_gradient(lastImage, cols, x, y, glx, gly);
+  const float gx = (gnx + glx) / 2.0f, gy = (gny + gly) / 2.0f;
+  const f3 point = mul(KI, unwarped);
+  const float z2 = point.z * point.z;
+  const float a = KR.r[0].x, b = KR.r[0].y, c = KR.r[0].z;
+  const float d = KR.r[1].x, e = KR.r[1].y, f = KR.r[1].z;
+  const float g = KR.r[2].x, h = KR.r[2].y, ii = KR.r[2].z;
+  const f3 left{((point.z * (d * gy + a * gx)) - (gy * g * y) - (gx * g * x)) / z2,
+                ((point.z * (e * gy + b * gx)) - (gy * h * y) - (gx * h * x)) / z2,
+                ((point.z * (f * gy + c * gx)) - (gy * ii * y) - (gx * ii * x)) / z2};
+  const f3 jr = cross(left, point);
+  const float row[4] = {jr.x, jr.y, jr.z, -((float)nextImage[wy * cols + wx] - (float)lastImage[y * cols + x])};
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i; j < 4; ++j) { acc[s] = fmaf(row[i], row[j], acc[s]); ++s; }
+  acc[9] = fmaf(row[3], row[3], acc[9]);
+  acc[10] += 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// reduction kernels
+// ------------------------------------------------------------------------------------------
+
+// K6a: photometric correspondence search.  Integer sums go straight to two device-scope atomics
+// (exact, order-free), replacing reduceSum(int2) + cudaMalloc/cudaFree per call (reduce.cu:774-783).
+template <int PPT>
+__global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_residual(const ResidualView V, const float* __restrict__ krkinv,
+                                                                const float* __restrict__ ktp, int* sums,
+                                                                const int* __restrict__ skip_flag) {
+  __shared__ int lds[2 * REDUCE_BLOCK / 64];
+  if (skip_flag && *skip_flag) return;
+  const m33 K = m33_load(krkinv);
+  const f3 kt{ktp[0], ktp[1], ktp[2]};
+  const int N = V.cols * V.rows;
+  int cnt = 0, sq = 0;
+  const int base = blockIdx.x * REDUCE_BLOCK * PPT + threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int k = base + j * REDUCE_BLOCK;
+    if (k < N) residual_px(V, K, kt, k, cnt, sq);
+  }
+  block_reduce_atomic_int2<REDUCE_BLOCK>(cnt, sq, lds, sums);
+}
+
+// K6b: ICP + RGB normal-equation accumulation in one pass over the level.
+// partial row layout: [0..28] ICP, [32..60] RGB.  sigma follows RGBDOdometry.cpp:442 (quirk Q2).
+__device__ __forceinline__ float sigma_from_sums(int sigma, int rgbSize, bool rgbOnly) {
+  if (rgbOnly) return -1.0f;
+  const int arg = ((float)sigma / rgbSize == 0) ? 1 : rgbSize;
+  return (float)sqrt((double)arg);
+}
+template <int PPT, bool HAS_ICP, bool HAS_RGB>
+__global__ void __launch_bounds__(REDUCE_BLOCK) k_icp_rgb_accum(const IcpView IV, const RgbView RV, const TrackState* __restrict__ st,
+                                                                 bool rgbOnly, float* __restrict__ partials) {
+  __shared__ float lds[block_reduce_lds_floats<29, REDUCE_BLOCK>()];
+  float* out = partials + (size_t)blockIdx.x * PARTIAL_STRIDE;
+  if (st->rgb_broken) {
+    if (threadIdx.x < PARTIAL_STRIDE) out[threadIdx.x] = 0.f;
+    return;
+  }
+  const int N = IV.cols * IV.rows;
+  const int base = blockIdx.x * REDUCE_BLOCK * PPT + threadIdx.x;
+  if (HAS_ICP) {
+    IcpPose P;
+    P.Rcurr = m33_load(st->Rcurr);
+    P.tcurr = {st->tcurr[0], st->tcurr[1], st->tcurr[2]};
+    P.Rprev_inv = m33_load(st->Rprev_inv);
+    P.tprev = {st->tprev[0], st->tprev[1], st->tprev[2]};
+    float acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int i = base + j * REDUCE_BLOCK;
+      if (i < N) {
+        float row[7];
+        const int y = i / IV.cols, x = i - y * IV.cols;
+        if (icp_row(IV, P, x, y, row)) accumulate29(row, acc);
+      }
+    }
+    block_reduce_store<29, REDUCE_BLOCK>(acc, lds, out);
+    if (HAS_RGB) __syncthreads();
+  }
+  if (HAS_RGB) {
+    const float sigma = sigma_from_sums(st->rgb_sum[1], st->rgb_sum[0], rgbOnly);
+    float acc[29];
+#pragma unroll
+    for (int k = 0; k < 29; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int i = base + j * REDUCE_BLOCK;
+      if (i < N) {
+        float row[7];
+        if (rgb_row(RV, sigma, i, row)) accumulate29(row, acc);
+      }
+    }
+    block_reduce_store<29, REDUCE_BLOCK>(acc, lds, out + 32);
+  }
+}
+
+// fixed-order sum of nblocks partial rows, 256 threads: 4 row-groups x 64 columns
+__device__ __forceinline__ void sum_partials(const float* __restrict__ partials, int nblocks, float* lds /*4*64*/, float* out64) {
+  const int t = threadIdx.x, c = t & 63, g = t >> 6;
+  float s = 0.f;
+  for (int r = g; r < nblocks; r += 4) s += partials[(size_t)r * PARTIAL_STRIDE + c];
+  lds[g * 64 + c] = s;
+  __syncthreads();
+  if (t < 64) out64[t] = ((lds[t] + lds[64 + t]) + lds[128 + t]) + lds[192 + t];
+  __syncthreads();
+}
+
+// unpack 29 floats -> symmetric A[36], b[6] (reduce.cu:385-400)
+template <typename T>
+__host__ __device__ inline void unpack29(const float* h, T* A, T* b) {
+  int shift = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 7; ++j) {
+      const float value = h[shift++];
+      if (j == 6) b[i] = (T)value;
+      else A[j * 6 + i] = A[i * 6 + j] = (T)value;
+    }
+}
+
+// K R K^-1 and K t for the coming iteration (RGBDOdometry.cpp:395-417)
+__device__ inline void compute_krk(const double* resultRt, Intr k, float* krkinv, float* kt) {
+  double Rt[16];
+  efl::m4_affine_inverse(resultRt, Rt);
+  double R[9], K[9] = {k.fx, 0, k.cx, 0, k.fy, k.cy, 0, 0, 1}, Kinv[9], KR[9], KRK[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) R[r * 3 + c] = Rt[r * 4 + c];
+  efl::m3_inverse<double>(K, Kinv);
+  efl::m3_mul(K, R, KR);
+  efl::m3_mul(KR, Kinv, KRK);
+  for (int i = 0; i < 9; ++i) krkinv[i] = (float)KRK[i];
+  const double tv[3] = {Rt[3], Rt[7], Rt[11]};
+  double Kt[3];
+  efl::m3_mulv(K, tv, Kt);
+  for (int i = 0; i < 3; ++i) kt[i] = (float)Kt[i];
+}
+
+// first kernel of getIncrementalTransformation: Rprev/tprev/Rcurr/tcurr (RGBDOdometry.cpp:266-273,375-377)
+__global__ void k_track_begin(TrackState* st) {
+  if (threadIdx.x != 0) return;
+  double R[9];
+  efl::quat_to_mat<double>(st->q, R);
+  for (int i = 0; i < 9; ++i) st->Rprev[i] = st->Rcurr[i] = (float)R[i];
+  for (int i = 0; i < 3; ++i) st->tprev[i] = st->tcurr[i] = (float)st->t[i];
+  efl::m3_inverse<float>(st->Rprev, st->Rprev_inv);
+  for (int i = 0; i < 4; ++i) st->q_prev[i] = st->q[i];
+  for (int i = 0; i < 3; ++i) st->t_prev[i] = st->t[i];
+  efl::m4_identity(st->resultRt);
+  st->rgb_sum[0] = st->rgb_sum[1] = 0;
+  st->rgb_broken = 0;
+  st->so3_iterations = 0;
+}
+
+// after the SO(3) stage: seed resultRt and the first level's K R K^-1 (RGBDOdometry.cpp:379-388)
+__global__ void k_track_level_begin(TrackState* st, Intr klevel) {
+  if (threadIdx.x != 0) return;
+  compute_krk(st->resultRt, klevel, st->krkinv, st->kt);
+  st->lastRGBErrorLevel = 3.402823466e+38f;
+  st->rgb_broken = 0;
+}
+
+// K6c: sum the partial rows, build A,b in double, LDL^T solve, SE(3) update, next K R K^-1
+// (RGBDOdometry.cpp:440-551 + OdometryProvider.h:73-96).  One workgroup; the solve runs on lane 0.
+__global__ void __launch_bounds__(256) k_solve_update(TrackState* st, const float* __restrict__ partials, int nblocks, bool icp,
+                                                       bool rgb, bool rgbOnly, float icpWeight, Intr knext, bool level_changes) {
+  __shared__ float lds[4 * 64];
+  __shared__ float sums[64];
+  sum_partials(partials, nblocks, lds, sums);
+  if (threadIdx.x != 0) return;
+  const int sigma = st->rgb_sum[1], rgbSize = st->rgb_sum[0];
+  st->rgb_sum[0] = st->rgb_sum[1] = 0;
+  if (st->rgb_broken) {
+    if (level_changes) { st->rgb_broken = 0; st->lastRGBErrorLevel = 3.402823466e+38f; compute_krk(st->resultRt, knext, st->krkinv, st->kt); }
+    return;
+  }
+  const float rgbError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
+  if (rgbOnly && rgbError > st->lastRGBErrorLevel) {  // "break": skip the rest of this level
+    st->rgb_broken = level_changes ? 0 : 1;
+    if (level_changes) { st->lastRGBErrorLevel = 3.402823466e+38f; compute_krk(st->resultRt, knext, st->krkinv, st->kt); }
+    return;
+  }
+  st->lastRGBErrorLevel = rgbError;
+  st->lastRGBError = rgbError;
+  st->lastRGBCount = (float)rgbSize;
+  if (icp) {
+    st->lastICPError = sqrtf(sums[27]) / sums[28];
+    st->lastICPCount = sums[28];
+  }
+  double A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
+  unpack29<double>(sums, A_icp, b_icp);
+  unpack29<double>(sums + 32, A_rgb, b_rgb);
+  double A[36], b[6], result[6];
+  if (icp && rgb) {
+    const double w = icpWeight;
+    for (int k = 0; k < 36; ++k) A[k] = A_rgb[k] + w * w * A_icp[k];
+    for (int k = 0; k < 6; ++k) b[k] = b_rgb[k] + w * b_icp[k];
+  } else if (icp) {
+    for (int k = 0; k < 36; ++k) A[k] = A_icp[k];
+    for (int k = 0; k < 6; ++k) b[k] = b_icp[k];
+  } else {
+    for (int k = 0; k < 36; ++k) A[k] = A_rgb[k];
+    for (int k = 0; k < 6; ++k) b[k] = b_rgb[k];
+  }
+  for (int k = 0; k < 36; ++k) st->lastA[k] = A[k];
+  for (int k = 0; k < 6; ++k) st->lastb[k] = b[k];
+  efl::ldlt_solve<double, 6>(A, b, result);
+  // computeUpdateSE3
+  double upd[16], Rr[9];
+  efl::m4_identity(upd);
+  const double rvec[3] = {result[3], result[4], result[5]};
+  efl::rodrigues(rvec, Rr);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) upd[r * 4 + c] = Rr[r * 3 + c];
+    upd[r * 4 + 3] = result[r];
+  }
+  double nr[16];
+  efl::m4_mul(upd, st->resultRt, nr);
+  for (int k = 0; k < 16; ++k) st->resultRt[k] = nr[k];
+  // currentT = [Rprev|tprev] * rgbOdom^-1 in float (quirk Q13)
+  float oR[9], ot[3], iR[9], it[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) oR[r * 3 + c] = (float)nr[r * 4 + c];
+    ot[r] = (float)nr[r * 4 + 3];
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) iR[r * 3 + c] = oR[c * 3 + r];
+  for (int r = 0; r < 3; ++r) it[r] = -(iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1] + iR[r * 3 + 2] * ot[2]);
+  const float* Rp = st->Rprev;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) st->Rcurr[r * 3 + c] = Rp[r * 3] * iR[c] + Rp[r * 3 + 1] * iR[3 + c] + Rp[r * 3 + 2] * iR[6 + c];
+    st->tcurr[r] = (Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2]) + st->tprev[r];
+  }
+  if (level_changes) st->lastRGBErrorLevel = 3.402823466e+38f;
+  compute_krk(st->resultRt, knext, st->krkinv, st->kt);
+}
+
+// tail of getIncrementalTransformation (RGBDOdometry.cpp:555-570) + velocity weighting
+// (ElasticFusion.cpp:369-383) + the float matrices the map kernels consume.
+__device__ inline void publish_pose(TrackState* st) {
+  efl::SE3 T;
+  for (int i = 0; i < 4; ++i) T.q[i] = st->q[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = st->t[i];
+  efl::se3_inverse_matrix_f(T, st->T_cw);
+  efl::se3_castf_matrix(T, st->pose_f);
+  double R[9];
+  efl::quat_to_mat<double>(T.q, R);
+  for (int i = 0; i < 9; ++i) st->R_wc_f[i] = (float)R[i];
+  for (int i = 0; i < 3; ++i) st->t_wc_f[i] = (float)T.t[i];
+}
+__device__ inline void compute_weighting(TrackState* st, float weightMultiplier) {
+  efl::SE3 T, Tp;
+  for (int i = 0; i < 4; ++i) { T.q[i] = st->q[i]; Tp.q[i] = st->q_prev[i]; }
+  for (int i = 0; i < 3; ++i) { T.t[i] = st->t[i]; Tp.t[i] = st->t_prev[i]; }
+  const efl::SE3 Tcp = efl::se3_mul(efl::se3_inverse(T), Tp);
+  const double tn = sqrt(Tcp.t[0] * Tcp.t[0] + Tcp.t[1] * Tcp.t[1] + Tcp.t[2] * Tcp.t[2]);
+  const double ln = efl::se3_log_norm(Tcp);
+  float weighting = (float)(tn > ln ? tn : ln);
+  const float largest = 0.01f, minWeight = 0.5f;
+  if (weighting > largest) weighting = largest;
+  const float w = 1.0f - (weighting / largest);
+  st->weighting = (w > minWeight ? w : minWeight) * weightMultiplier;
+}
+__global__ void k_track_end(TrackState* st, bool rgb, float weightMultiplier) {
+  if (threadIdx.x != 0) return;
+  if (rgb) {
+    const float d0 = st->tcurr[0] - st->tprev[0], d1 = st->tcurr[1] - st->tprev[1], d2 = st->tcurr[2] - st->tprev[2];
+    if ((double)sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
+      for (int i = 0; i < 9; ++i) st->Rcurr[i] = st->Rprev[i];
+      for (int i = 0; i < 3; ++i) st->tcurr[i] = st->tprev[i];
+    }
+  }
+  double Rc[9], Rp[9];
+  for (int i = 0; i < 9; ++i) Rc[i] = (double)st->Rcurr[i];
+  efl::polar3(Rc, Rp);
+  efl::SE3 T;
+  efl::se3_set_rotation(T, Rp);
+  for (int i = 0; i < 4; ++i) st->q[i] = T.q[i];
+  for (int i = 0; i < 3; ++i) st->t[i] = (double)st->tcurr[i];
+  publish_pose(st);
+  compute_weighting(st, weightMultiplier);
+}
+// pose injected by the caller (in_T_wc != 0, ElasticFusion.cpp:367-369): q/t already uploaded
+__global__ void k_pose_injected(TrackState* st, float weightMultiplier, bool with_weighting) {
+  if (threadIdx.x != 0) return;
+  publish_pose(st);
+  if (with_weighting) compute_weighting(st, weightMultiplier);
+}
+__global__ void k_save_prev_pose(TrackState* st) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 4; ++i) st->q_prev[i] = st->q[i];
+  for (int i = 0; i < 3; ++i) st->t_prev[i] = st->t[i];
+}
+
+// SO(3) pre-alignment, RGBDOdometry.cpp:284-369, as ONE single-workgroup kernel: level 2 is only
+// 160x120, so all <= 10 iterations (kernel + reduce + 3x3 solve + convergence test) run inside one
+// 1024-thread workgroup, synchronised by s_barrier instead of ten host round trips.
+constexpr int SO3_BLOCK = 1024;
+__global__ void __launch_bounds__(SO3_BLOCK) k_so3_loop(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
+                                                         int cols, int rows, Intr k, TrackState* st) {
+  __shared__ float lds[block_reduce_lds_floats<11, SO3_BLOCK>()];
+  __shared__ float mats[27];
+  __shared__ float red[11];
+  __shared__ int done;
+  __shared__ double resultR[9], lastResultR[9];
+  __shared__ float R_lr[9];
+  __shared__ float lastError, lastCount;
+  const int t = threadIdx.x;
+  const int N = cols * rows;
+  if (t == 0) {
+    efl::m3_identity(resultR);
+    efl::m3_identity(lastResultR);
+    for (int i = 0; i < 9; ++i) R_lr[i] = (i % 4 == 0) ? 1.f : 0.f;
+    lastError = 3.402823466e+38f / 2;
+    lastCount = 3.402823466e+38f / 2;
+    done = 0;
+  }
+  __syncthreads();
+  for (int it = 0; it < 10; ++it) {
+    if (t == 0) {
+      double K[9] = {k.fx, 0, k.cx, 0, k.fy, k.cy, 0, 0, 1}, Kinv[9], KR[9], H[9];
+      efl::m3_inverse<double>(K, Kinv);
+      efl::m3_mul(K, resultR, KR);
+      efl::m3_mul(KR, Kinv, H);
+      for (int i = 0; i < 9; ++i) { mats[i] = (float)H[i]; mats[9 + i] = (float)Kinv[i]; mats[18 + i] = (float)KR[i]; }
+    }
+    __syncthreads();
+    const m33 IB = m33_load(mats), KI = m33_load(mats + 9), KR = m33_load(mats + 18);
+    float acc[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) acc[i] = 0.f;
+    for (int p = t; p < N; p += SO3_BLOCK) so3_px(lastImage, nextImage, cols, rows, IB, KI, KR, p, acc);
+    block_reduce_store<11, SO3_BLOCK>(acc, lds, red);
+    __syncthreads();
+    if (t == 0) {
+      st->so3_iterations = it + 1;
+      float jtj[9], jtr[3];
+      int shift = 0;
+      for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 4; ++j) {
+          const float value = red[shift++];
+          if (j == 3) jtr[i] = value;
+          else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
+        }
+      float err = sqrtf(red[9]) / red[10];
+      float cnt = red[10];
+      if (err < lastError && lastCount == cnt) {
+        done = 1;
+      } else if ((double)err > (double)lastError + 0.001) {
+        err = lastError; cnt = lastCount;
+        for (int i = 0; i < 9; ++i) resultR[i] = lastResultR[i];
+        done = 1;
+      } else {
+        lastError = err; lastCount = cnt;
+        for (int i = 0; i < 9; ++i) lastResultR[i] = resultR[i];
+        float delta[3];
+        efl::ldlt_solve<float, 3>(jtj, jtr, delta);
+        const double dv[3] = {(double)delta[0], (double)delta[1], (double)delta[2]};
+        double ru[9];
+        efl::rodrigues(dv, ru);
+        float ruf[9], nR[9];
+        for (int i = 0; i < 9; ++i) ruf[i] = (float)ru[i];
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) {
+            float s = 0;
+            for (int kk = 0; kk < 3; ++kk) s += ruf[r * 3 + kk] * R_lr[kk * 3 + c];
+            nR[r * 3 + c] = s;
+          }
+        for (int i = 0; i < 9; ++i) { R_lr[i] = nR[i]; resultR[i] = (double)nR[i]; }
+      }
+      st->lastSO3Error = err;
+      st->lastSO3Count = cnt;
+    }
+    __syncthreads();
+    if (done) break;
+  }
+  if (t == 0)
+    for (int x = 0; x < 3; ++x)
+      for (int y = 0; y < 3; ++y) st->resultRt[x * 4 + y] = resultR[x * 3 + y];
+}
+
+// ---- operator-tier single-shot reductions ----
+__global__ void __launch_bounds__(REDUCE_BLOCK) k_icp_op(const IcpView IV, const IcpArgs a, float* __restrict__ partials) {
+  __shared__ float lds[block_reduce_lds_floats<29, REDUCE_BLOCK>()];
+  IcpPose P;
+  P.Rcurr = m33_load(a.Rcurr); P.tcurr = {a.tcurr[0], a.tcurr[1], a.tcurr[2]};
+  P.Rprev_inv = m33_load(a.Rprev_inv); P.tprev = {a.tprev[0], a.tprev[1], a.tprev[2]};
+  const int N = IV.cols * IV.rows;
+  float acc[29];
+#pragma unroll
+  for (int k = 0; k < 29; ++k) acc[k] = 0.f;
+  const int i = blockIdx.x * REDUCE_BLOCK + threadIdx.x;
+  if (i < N) {
+    float row[7];
+    const int y = i / IV.cols, x = i - y * IV.cols;
+    if (icp_row(IV, P, x, y, row)) accumulate29(row, acc);
+  }
+  block_reduce_store<29, REDUCE_BLOCK>(acc, lds, partials + (size_t)blockIdx.x * PARTIAL_STRIDE);
+}
+__global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_op(const RgbView RV, float sigma, float* __restrict__ partials) {
+  __shared__ float lds[block_reduce_lds_floats<29, REDUCE_BLOCK>()];
+  const int N = RV.cols * RV.rows;
+  float acc[29];
+#pragma unroll
+  for (int k = 0; k < 29; ++k) acc[k] = 0.f;
+  const int i = blockIdx.x * REDUCE_BLOCK + threadIdx.x;
+  if (i < N) {
+    float row[7];
+    if (rgb_row(RV, sigma, i, row)) accumulate29(row, acc);
+  }
+  block_reduce_store<29, REDUCE_BLOCK>(acc, lds, partials + (size_t)blockIdx.x * PARTIAL_STRIDE);
+}
+__global__ void __launch_bounds__(256) k_sum_partials_op(const float* __restrict__ partials, int nblocks, int n, float* out) {
+  __shared__ float lds[4 * 64];
+  __shared__ float sums[64];
+  sum_partials(partials, nblocks, lds, sums);
+  if (threadIdx.x < n) out[threadIdx.x] = sums[threadIdx.x];
+}
+__global__ void __launch_bounds__(SO3_BLOCK) k_so3_op(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
+                                                       int cols, int rows, const So3Args a, float* out11) {
+  __shared__ float lds[block_reduce_lds_floats<11, SO3_BLOCK>()];
+  const m33 IB = m33_load(a.imageBasis), KI = m33_load(a.kinv), KR = m33_load(a.krlr);
+  float acc[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) acc[i] = 0.f;
+  for (int p = threadIdx.x; p < cols * rows; p += SO3_BLOCK) so3_px(lastImage, nextImage, cols, rows, IB, KI, KR, p, acc);
+  block_reduce_store<11, SO3_BLOCK>(acc, lds, out11);
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+void pyr_down_u16(const uint16_t* src, int scols, int srows, uint16_t* dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_pyr_down_u16, tile_grid(scols / 2, srows / 2), tile_block(), 0, s, src, scols, srows, dst);
+}
+void create_vmap(const uint16_t* depth, int cols, int rows, Intr k, float cutoff, float* vmap, hipStream_t s) {
+  hipLaunchKernelGGL(k_create_vmap, tile_grid(cols, rows), tile_block(), 0, s, depth, cols, rows, 1.f / k.fx, 1.f / k.fy, k.cx, k.cy, cutoff, vmap);
+}
+void create_nmap(const float* vmap, int cols, int rows, float* nmap, hipStream_t s) {
+  hipLaunchKernelGGL(k_create_nmap, tile_grid(cols, rows), tile_block(), 0, s, vmap, cols, rows, nmap);
+}
+void transform_maps(const float* vsrc, const float* nsrc, int cols, int rows, const float* R9_dev, const float* t3_dev, float* vdst,
+                    float* ndst, hipStream_t s) {
+  hipLaunchKernelGGL(k_transform_maps, tile_grid(cols, rows), tile_block(), 0, s, vsrc, nsrc, cols, rows, R9_dev, t3_dev, vdst, ndst);
+}
+void copy_maps(const float* vtex, const float* ntex, int cols, int rows, float* vmaps_tmp, float* vmap, float* nmap, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy_maps, tile_grid(cols, rows), tile_block(), 0, s, (const float4*)vtex, (const float4*)ntex, cols, rows,
+                     (float4*)vmaps_tmp, vmap, nmap);
+}
+void resize_map(const float* in, int scols, int srows, float* out, bool normalize, hipStream_t s) {
+  if (normalize) hipLaunchKernelGGL(k_resize_map<true>, tile_grid(scols / 2, srows / 2), tile_block(), 0, s, in, scols, srows, out);
+  else hipLaunchKernelGGL(k_resize_map<false>, tile_grid(scols / 2, srows / 2), tile_block(), 0, s, in, scols, srows, out);
+}
+void pyr_down_gauss_f(const float* src, int scols, int srows, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_pyr_down_gauss_f, tile_grid(scols / 2, srows / 2), tile_block(), 0, s, src, scols, srows, dst);
+}
+void pyr_down_uchar_gauss(const uint8_t* src, int scols, int srows, uint8_t* dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_pyr_down_uchar_gauss, tile_grid(scols / 2, srows / 2), tile_block(), 0, s, src, scols, srows, dst);
+}
+void vertices_to_depth(const float* vmaps_tmp, int cols, int rows, float cutoff, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_vertices_to_depth, tile_grid(cols, rows), tile_block(), 0, s, (const float4*)vmaps_tmp, cols, rows, cutoff, dst);
+}
+void bgr_to_intensity(const uint8_t* src, int channels, int cols, int rows, uint8_t* dst, hipStream_t s) {
+  const int n = cols * rows;
+  if (channels == 4) hipLaunchKernelGGL(k_bgr_to_intensity<4>, dim3(ceil_div(n, 256)), dim3(256), 0, s, src, n, dst);
+  else hipLaunchKernelGGL(k_bgr_to_intensity<3>, dim3(ceil_div(n, 256)), dim3(256), 0, s, src, n, dst);
+}
+void derivative_images(const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy, hipStream_t s) {
+  hipLaunchKernelGGL(k_sobel, tile_grid(cols, rows), tile_block(), 0, s, src, cols, rows, dx, dy);
+}
+void project_to_point_cloud(const float* depth, int cols, int rows, Intr k, float* cloud, hipStream_t s) {
+  hipLaunchKernelGGL(k_project_points, tile_grid(cols, rows), tile_block(), 0, s, depth, cols, rows, 1.0f / k.fx, 1.0f / k.fy, k.cx, k.cy, cloud);
+}
+
+void icp_step_op(const IcpArgs& a, const float* vmap_curr, const float* nmap_curr, const float* vmap_g_prev,
+                 const float* nmap_g_prev, int cols, int rows, float* partials, float* out29_dev, hipStream_t s) {
+  IcpView V{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, cols, rows, a.k, a.distThres, a.angleThres};
+  const int nb = ceil_div(cols * rows, REDUCE_BLOCK);
+  hipLaunchKernelGGL(k_icp_op, dim3(nb), dim3(REDUCE_BLOCK), 0, s, V, a, partials);
+  hipLaunchKernelGGL(k_sum_partials_op, dim3(1), dim3(256), 0, s, (const float*)partials, nb, 29, out29_dev);
+}
+void rgb_residual_op(const RgbResidualArgs& a, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
+                     const float* nextDepth, const uint8_t* lastImage, const uint8_t* nextImage, void* corres, int cols,
+                     int rows, int* out2_dev, hipStream_t s) {
+  ResidualView V{dIdx, dIdy, lastDepth, nextDepth, lastImage, nextImage, (DataTerm*)corres, cols, rows, a.minScale, a.maxDepthDelta};
+  float* params;
+  (void)hipMalloc((void**)&params, 12 * sizeof(float));
+  float h[12];
+  for (int i = 0; i < 9; ++i) h[i] = a.krkinv[i];
+  for (int i = 0; i < 3; ++i) h[9 + i] = a.kt[i];
+  (void)hipMemcpyAsync(params, h, sizeof(h), hipMemcpyHostToDevice, s);
+  (void)hipMemsetAsync(out2_dev, 0, 2 * sizeof(int), s);
+  hipLaunchKernelGGL(k_rgb_residual<1>, dim3(ceil_div(cols * rows, REDUCE_BLOCK)), dim3(REDUCE_BLOCK), 0, s, V, (const float*)params,
+                     (const float*)(params + 9), out2_dev, (const int*)nullptr);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(params);
+}
+void rgb_step_op(const void* corres, float sigma, const float* cloud, float fx, float fy, const int16_t* dIdx, const int16_t* dIdy,
+                 float sobelScale, int cols, int rows, float* partials, float* out29_dev, hipStream_t s) {
+  RgbView V{(const DataTerm*)corres, nullptr, cloud, dIdx, dIdy, cols, rows, Intr{fx, fy, 0, 0}, sobelScale};
+  const int nb = ceil_div(cols * rows, REDUCE_BLOCK);
+  hipLaunchKernelGGL(k_rgb_op, dim3(nb), dim3(REDUCE_BLOCK), 0, s, V, sigma, partials);
+  hipLaunchKernelGGL(k_sum_partials_op, dim3(1), dim3(256), 0, s, (const float*)partials, nb, 29, out29_dev);
+}
+void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* nextImage, int cols, int rows, float* out11_dev, hipStream_t s) {
+  hipLaunchKernelGGL(k_so3_op, dim3(1), dim3(SO3_BLOCK), 0, s, lastImage, nextImage, cols, rows, a, out11_dev);
+}
+
+// ---- frame tier ----
+void init_icp(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, hipStream_t s) {
+  // level 0 of depth_tmp is the filtered depth image itself (no copy: cudaMemcpy2DFromArray of
+  // RGBDOdometry.cpp:126-134 existed only to cross the GL/CUDA boundary)
+  for (int i = 1; i < NUM_PYRS; ++i)
+    pyr_down_u16(i == 1 ? depth_filtered : p.depth_tmp[i - 1], p.W(i - 1), p.H(i - 1), p.depth_tmp[i], s);
+  VNLevels L;
+  for (int i = 0; i < NUM_PYRS; ++i) {
+    L.depth[i] = i == 0 ? depth_filtered : p.depth_tmp[i];
+    L.vmap[i] = p.vmap_curr[i];
+    L.nmap[i] = p.nmap_curr[i];
+    L.cols[i] = p.W(i);
+    L.rows[i] = p.H(i);
+    L.k[i] = intr_level(k, i);
+  }
+  L.cutoff = cutoff;
+  dim3 g = tile_grid(p.W(0), p.H(0));
+  g.z = NUM_PYRS;
+  hipLaunchKernelGGL(k_vmap_nmap_levels, g, tile_block(), 0, s, L);
+}
+
+void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
+                    const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s) {
+  ModelMapsArgs A;
+  A.pred_vertex = (const float4*)pred_vertex; A.pred_normal = (const float4*)pred_normal;
+  A.fill_vertex = (const float4*)fill_vertex; A.fill_normal = (const float4*)fill_normal;
+  for (int i = 0; i < NUM_PYRS; ++i) { A.vmap[i] = p.vmap_g_prev[i]; A.nmap[i] = p.nmap_g_prev[i]; }
+  A.depth0 = p.lastDepth[0];
+  A.cols = p.W(0); A.rows = p.H(0);
+  A.maxDepthRGB = maxDepthRGB;
+  dim3 block(64, 4);
+  dim3 grid(ceil_div(p.W(0) / 4, 64), ceil_div(p.H(0) / 4, 4));
+  hipLaunchKernelGGL(k_model_maps, grid, block, 0, s, A, st);
+}
+
+namespace {
+// model intensity L0 comes from the predicted image unless the device-side flag says fill-in
+__global__ void k_model_intensity(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ fill, bool force_fill,
+                                  const TrackState* __restrict__ st, int n, uint8_t* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* src = (force_fill || st->should_fill_in) ? fill : pred;
+  const uchar4 c = ((const uchar4*)src)[i];
+  dst[i] = intensity_of((float)c.x, (float)c.y, (float)c.z);
+}
+}  // namespace
+
+void init_rgb(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* fill_image_rgba, bool frameToFrameRGB,
+              const uint8_t* rgb3, const TrackState* st, bool with_sobel, hipStream_t s) {
+  const int n = p.W(0) * p.H(0);
+  // populateRGBDData(model): depth L0 already written by init_icp_model
+  for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_gauss_f(p.lastDepth[i], p.W(i), p.H(i), p.lastDepth[i + 1], s);
+  hipLaunchKernelGGL(k_model_intensity, dim3(ceil_div(n, 256)), dim3(256), 0, s, pred_image_rgba, fill_image_rgba, frameToFrameRGB, st, n,
+                     p.lastImage[0]);
+  for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_uchar_gauss(p.lastImage[i], p.W(i), p.H(i), p.lastImage[i + 1], s);
+  // populateRGBDData(frame): nextDepth == lastDepth (Q1), only the intensity pyramid is new
+  bgr_to_intensity(rgb3, 3, p.W(0), p.H(0), p.nextImage[0], s);
+  for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_uchar_gauss(p.nextImage[i], p.W(i), p.H(i), p.nextImage[i + 1], s);
+  if (with_sobel) {
+    SobelLevels L;
+    for (int i = 0; i < NUM_PYRS; ++i) {
+      L.src[i] = p.nextImage[i]; L.dx[i] = p.dIdx[i]; L.dy[i] = p.dIdy[i];
+      L.cols[i] = p.W(i); L.rows[i] = p.H(i);
+    }
+    dim3 g = tile_grid(p.W(0), p.H(0));
+    g.z = NUM_PYRS;
+    hipLaunchKernelGGL(k_sobel_levels, g, tile_block(), 0, s, L);
+  }
+}
+
+void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s) {
+  bgr_to_intensity(rgb3, 3, p.W(0), p.H(0), p.lastNextImage[0], s);
+  for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_uchar_gauss(p.lastNextImage[i], p.W(i), p.H(i), p.lastNextImage[i + 1], s);
+}
+
+namespace {
+template <int PPT>
+void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const TrackParams& tp, bool icp, bool rgb, float minScale,
+                      Intr knext, bool level_changes, hipStream_t s) {
+  const int cols = p.W(level), rows = p.H(level), N = cols * rows;
+  const int nb = ceil_div(N, REDUCE_BLOCK * PPT);
+  if (rgb) {
+    ResidualView RV{p.dIdx[level], p.dIdy[level], p.lastDepth[level], p.lastDepth[level], p.lastImage[level], p.nextImage[level],
+                    (DataTerm*)p.corresImg[level], cols, rows, minScale, 0.07f /* maxDepthDeltaRGB, RGBDOdometry.cpp:41 */};
+    hipLaunchKernelGGL(k_rgb_residual<PPT>, dim3(nb), dim3(REDUCE_BLOCK), 0, s, RV, (const float*)st->krkinv, (const float*)st->kt,
+                       st->rgb_sum, (const int*)&st->rgb_broken);
+  }
+  IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres};
+  RgbView GV{(const DataTerm*)p.corresImg[level], p.lastDepth[level], nullptr, p.dIdx[level], p.dIdy[level], cols, rows, kl, 1.0f / 8.0f};
+  if (icp && rgb) hipLaunchKernelGGL((k_icp_rgb_accum<PPT, true, true>), dim3(nb), dim3(REDUCE_BLOCK), 0, s, IV, GV, (const TrackState*)st, tp.rgbOnly, p.partials);
+  else if (icp) hipLaunchKernelGGL((k_icp_rgb_accum<PPT, true, false>), dim3(nb), dim3(REDUCE_BLOCK), 0, s, IV, GV, (const TrackState*)st, tp.rgbOnly, p.partials);
+  else hipLaunchKernelGGL((k_icp_rgb_accum<PPT, false, true>), dim3(nb), dim3(REDUCE_BLOCK), 0, s, IV, GV, (const TrackState*)st, tp.rgbOnly, p.partials);
+  hipLaunchKernelGGL(k_solve_update, dim3(1), dim3(256), 0, s, st, (const float*)p.partials, nb, icp, rgb, tp.rgbOnly, tp.icpWeight, knext,
+                     level_changes);
+}
+}  // namespace
+
+void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s) {
+  const bool icp = !tp.rgbOnly && tp.icpWeight > 0;       // RGBDOdometry.cpp:266-267
+  const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
+  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st);
+  if (tp.so3) {
+    const int l = 2;
+    hipLaunchKernelGGL(k_so3_loop, dim3(1), dim3(SO3_BLOCK), 0, s, (const uint8_t*)p.lastNextImage[l], (const uint8_t*)p.nextImage[l], p.W(l),
+                       p.H(l), intr_level(k, l), st);
+  }
+  int iterations[NUM_PYRS];
+  iterations[0] = tp.fastOdom ? 3 : 10;  // RGBDOdometry.cpp:371-373
+  iterations[1] = tp.pyramid ? 5 : 0;
+  iterations[2] = tp.pyramid ? 4 : 0;
+  const float minGrad[NUM_PYRS] = {5, 3, 1};  // RGBDOdometry.cpp:112-114
+  int first_level = -1;
+  for (int i = NUM_PYRS - 1; i >= 0; --i)
+    if (iterations[i] > 0) { first_level = i; break; }
+  if (first_level >= 0) hipLaunchKernelGGL(k_track_level_begin, dim3(1), dim3(64), 0, s, st, intr_level(k, first_level));
+  for (int i = NUM_PYRS - 1; i >= 0; --i) {
+    const Intr kl = intr_level(k, i);
+    const float sobelScale = 1.0f / 8.0f;
+    const float minScale = (float)(pow((double)minGrad[i], 2.0) / pow((double)sobelScale, 2.0));  // RGBDOdometry.cpp:425
+    for (int j = 0; j < iterations[i]; ++j) {
+      const bool last_of_level = (j == iterations[i] - 1);
+      int next_level = i;
+      if (last_of_level) {
+        next_level = i;
+        for (int n = i - 1; n >= 0; --n)
+          if (iterations[n] > 0) { next_level = n; break; }
+      }
+      const Intr knext = intr_level(k, next_level);
+      const bool level_changes = last_of_level;
+      const int N = p.W(i) * p.H(i);
+      if (N >= 256 * 1024) launch_iteration<4>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s);
+      else if (N >= 128 * 1024) launch_iteration<2>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s);
+      else launch_iteration<1>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s);
+    }
+  }
+  if (tp.so3)
+    for (int i = 0; i < NUM_PYRS; ++i) { uint8_t* tmp = p.lastNextImage[i]; p.lastNextImage[i] = p.nextImage[i]; p.nextImage[i] = tmp; }
+}
+
+// exported for the context: finishing kernels
+void track_end(TrackState* st, bool rgb, float weightMultiplier, hipStream_t s) {
+  hipLaunchKernelGGL(k_track_end, dim3(1), dim3(64), 0, s, st, rgb, weightMultiplier);
+}
+void pose_injected(TrackState* st, float weightMultiplier, bool with_weighting, hipStream_t s) {
+  hipLaunchKernelGGL(k_pose_injected, dim3(1), dim3(64), 0, s, st, weightMultiplier, with_weighting);
+}
+void save_prev_pose(TrackState* st, hipStream_t s) { hipLaunchKernelGGL(k_save_prev_pose, dim3(1), dim3(64), 0, s, st); }
+
+}  // namespace eft

@@ -1,0 +1,212 @@
+/* libefusion_hip.so — C ABI of the MI355X-native ElasticFusion per-frame engine.
+ *
+ * Plain C, opaque context, raw pointers and sizes only; every call returns 0 on success or a negative
+ * EF_E* code (ef_last_error() gives the message).  Nothing exits the process, nothing is global: the
+ * reference's process-wide Resolution/Intrinsics singletons (Core/Utils/Resolution.h:25-58,
+ * Intrinsics.h:25-51) become fields of ef_config.  A context is single-owner and externally
+ * synchronised, the same contract as the reference's ElasticFusion object.
+ *
+ * Three tiers, mirroring the reference's own layering:
+ *   1. frame tier      ef_create / ef_process_frame / getters      <-> class ElasticFusion
+ *                                                                       (Core/ElasticFusion.h:40-255)
+ *   2. subsystem tier  ef_preprocess / ef_track / ef_predict / ...  <-> RGBDOdometry, IndexMap,
+ *                                                                       GlobalModel, FillIn, ComputePack
+ *   3. operator tier   ef_op_*  on raw DEVICE pointers               <-> the 17 free functions of
+ *                                                                       Core/Cuda/cudafuncs.cuh:61-169
+ *                                                                       and the GLSL passes (one each)
+ * All image layouts are the reference's (planar float[3*rows][cols] maps, 16-byte DataTerm,
+ * 48-byte surfels = 3 x vec4).  "dev" pointers are HIP device pointers.
+ */
+#ifndef EF_HIP_H_
+#define EF_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EF_OK 0
+#define EF_EINVAL (-1)   /* bad argument */
+#define EF_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
+#define EF_ENOMEM (-3)
+#define EF_ESTATE (-4)   /* call not valid in the current state */
+#define EF_ECAPACITY (-5) /* surfel capacity exceeded */
+
+typedef struct ef_ctx ef_ctx;
+
+/* ---- configuration: ElasticFusion ctor arguments (Core/ElasticFusion.h:42-58) + the two singletons */
+typedef struct ef_config {
+  int width, height;          /* Resolution::getInstance(w,h)                       */
+  float fx, fy, cx, cy;       /* Intrinsics::getInstance(fx,fy,cx,cy)               */
+  int time_delta;             /* timeDelta       (200; INT_MAX/2 in open loop)      */
+  float confidence;           /* confidence      (10)                               */
+  float depth_cut;            /* depthCut        (3 m)                              */
+  float icp_weight;           /* icpThresh       (10)                               */
+  int fast_odom;              /* fastOdom        (0)                                */
+  int so3;                    /* so3             (1)                                */
+  int frame_to_frame_rgb;     /* frameToFrameRGB (0)                                */
+  int pyramid;                /* setPyramid      (1)                                */
+  int rgb_only;               /* setRgbOnly      (0)                                */
+  int close_loops;            /* must be 0: loop closure is out of scope */
+  uint32_t max_surfels;       /* surfel capacity; reference: 3072*3072 (GlobalModel.cpp:22-24) */
+  int device;                 /* HIP device ordinal                                 */
+  void* stream;               /* hipStream_t to run on, or NULL to create a private one */
+} ef_config;
+
+void ef_default_config(ef_config* cfg);   /* front-end defaults, MainController.cpp:37-43,69-104, -o */
+
+/* ---- lifecycle ---- */
+int ef_create(const ef_config* cfg, ef_ctx** out);
+void ef_destroy(ef_ctx* ctx);
+const char* ef_last_error(const ef_ctx* ctx);   /* ctx may be NULL: last error of a failed ef_create */
+void* ef_stream(ef_ctx* ctx);                   /* the hipStream_t all work is enqueued on */
+int ef_synchronize(ef_ctx* ctx);
+
+/* ---- frame tier ----
+ * ef_process_frame == ElasticFusion::processFrame(rgb, depth, timestamp, weightMultiplier, in_T_wc)
+ * (Core/ElasticFusion.h:70-75).  rgb: W*H*3 bytes row-major; depth: W*H uint16 millimetres, 0 invalid.
+ * Host pointers are borrowed for the duration of the call (staged synchronously, like the reference's
+ * glTexture upload, ElasticFusion.cpp:278-280); all device work is only ENQUEUED: the call does not
+ * wait for the GPU.  in_T_wc: 16 doubles row-major or NULL.
+ * ef_process_frame_dev takes DEVICE pointers (frames already resident in HBM; the bench path). */
+int ef_process_frame(ef_ctx* ctx, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp,
+                     float weight_multiplier, const double* in_T_wc16);
+int ef_process_frame_dev(ef_ctx* ctx, const uint8_t* rgb_dev, const uint16_t* depth_dev, int64_t timestamp,
+                         float weight_multiplier, const double* in_T_wc16);
+int ef_predict(ef_ctx* ctx);                                  /* ElasticFusion::predict() */
+int ef_get_pose(ef_ctx* ctx, double* T_wc16);                 /* get_T_wc(); synchronises */
+int ef_get_tick(ef_ctx* ctx, int* tick);                      /* getTick() */
+int ef_set_tick(ef_ctx* ctx, int tick);                       /* setTick() */
+/* lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count (RGBDOdometry.h:74-79) */
+int ef_get_tracking_stats(ef_ctx* ctx, float* out6, double* lastA36_or_null, double* lastb6_or_null);
+int ef_get_trajectory(ef_ctx* ctx, double* T_wc16_array, int64_t* timestamps, int max_frames, int* n_frames);
+int ef_map_count(ef_ctx* ctx, uint32_t* count);               /* GlobalModel::lastCount(); synchronises */
+int ef_map_download(ef_ctx* ctx, float* surfels, uint32_t max_surfels, uint32_t* count); /* downloadMap(), 12 floats each */
+int ef_map_upload(ef_ctx* ctx, const float* surfels, uint32_t count);  /* test/bench seeding */
+int ef_save_freiburg(ef_ctx* ctx, const char* path);          /* trajectory dump of ~ElasticFusion, :112-139 */
+int ef_save_ply(ef_ctx* ctx, const char* path);               /* ElasticFusion::savePly, :684-781 */
+/* setters (Core/ElasticFusion.h:135-183) */
+int ef_set_rgb_only(ef_ctx*, int v);
+int ef_set_icp_weight(ef_ctx*, float v);
+int ef_set_pyramid(ef_ctx*, int v);
+int ef_set_fast_odom(ef_ctx*, int v);
+int ef_set_so3(ef_ctx*, int v);
+int ef_set_frame_to_frame_rgb(ef_ctx*, int v);
+int ef_set_confidence_threshold(ef_ctx*, float v);
+int ef_set_depth_cutoff(ef_ctx*, float v);
+
+/* named internal images, copied to HOST (synchronises); for tests and for a front-end's drawing code */
+enum ef_image {
+  EF_IMG_DEPTH_FILTERED = 0,      /* u16  */
+  EF_IMG_DEPTH_METRIC,            /* f32  */
+  EF_IMG_DEPTH_METRIC_FILTERED,   /* f32  */
+  EF_IMG_PREDICT_IMAGE,           /* u8x4 IndexMap::imageTex   */
+  EF_IMG_PREDICT_VERTEX,          /* f32x4 IndexMap::vertexTex */
+  EF_IMG_PREDICT_NORMAL,          /* f32x4 IndexMap::normalTex */
+  EF_IMG_PREDICT_TIME,            /* u16  IndexMap::timeTex    */
+  EF_IMG_FILL_IMAGE,              /* u8x4 FillIn::imageTexture */
+  EF_IMG_FILL_VERTEX,             /* f32x4 */
+  EF_IMG_FILL_NORMAL,             /* f32x4 */
+  EF_IMG_INDEX,                   /* u32  IndexMap::indexTex   */
+  EF_IMG_VERT_CONF,               /* f32x4 */
+  EF_IMG_COLOR_TIME,              /* f32x4 */
+  EF_IMG_NORM_RAD                 /* f32x4 */
+};
+int ef_get_image(ef_ctx* ctx, int which, void* host_dst, size_t bytes);
+/* tracker pyramids (RGBDOdometry private state) for kernel-level parity tests:
+ * which: 0 vmap_curr 1 nmap_curr 2 vmap_g_prev 3 nmap_g_prev 4 lastDepth 5 nextDepth 6 lastImage
+ *        7 nextImage 8 lastNextImage 9 dIdx 10 dIdy 11 depth_tmp */
+int ef_get_tracker_buffer(ef_ctx* ctx, int which, int level, void* host_dst, size_t bytes);
+
+/* per-stage GPU time of the last ef_process_frame (hipEvent pairs; names follow the reference's
+ * TICK/TOCK sites, Core/Utils/Stopwatch.h): fills up to max entries, returns count in *n */
+typedef struct ef_timing { const char* name; float ms; } ef_timing;
+int ef_enable_timing(ef_ctx* ctx, int on);
+int ef_get_timings(ef_ctx* ctx, ef_timing* out, int max, int* n);
+
+/* ---- device memory helpers (so that a non-HIP host can drive the operator tier) ---- */
+int ef_dev_alloc(void** dev, size_t bytes);
+int ef_dev_free(void* dev);
+int ef_dev_upload(void* dev, const void* host, size_t bytes);
+int ef_dev_download(void* host, const void* dev, size_t bytes);
+int ef_dev_memset(void* dev, int value, size_t bytes);
+int ef_dev_sync(void);
+int ef_device_count(int* n);
+int ef_set_device(int device);
+
+/* ---- operator tier: tracking (Core/Cuda/cudafuncs.cuh:61-169). All pointers are DEVICE pointers,
+ * work runs on `stream` (hipStream_t, NULL = default stream) and is synchronous only where the
+ * reference returns host results (icp/rgb/so3 steps, rgb residual). ---- */
+typedef struct ef_intr { float fx, fy, cx, cy; } ef_intr;   /* CameraModel, types.cuh:88-96 */
+
+int ef_op_pyr_down(const uint16_t* src, int src_cols, int src_rows, uint16_t* dst, void* stream);             /* pyrDown */
+int ef_op_create_vmap(const ef_intr* intr, const uint16_t* depth, int cols, int rows, float depth_cutoff,
+                      float* vmap, void* stream);                                                              /* createVMap */
+int ef_op_create_nmap(const float* vmap, int cols, int rows, float* nmap, void* stream);                       /* createNMap */
+int ef_op_transform_maps(const float* vmap_src, const float* nmap_src, int cols, int rows, const float* R9,
+                         const float* t3, float* vmap_dst, float* nmap_dst, void* stream);                      /* tranformMaps */
+int ef_op_copy_maps(const float* vmap_src_f4, const float* nmap_src_f4, int cols, int rows, float* vmaps_tmp,
+                    float* vmap_dst, float* nmap_dst, void* stream);                                            /* copyMaps */
+int ef_op_resize_vmap(const float* in, int src_cols, int src_rows, float* out, void* stream);                  /* resizeVMap */
+int ef_op_resize_nmap(const float* in, int src_cols, int src_rows, float* out, void* stream);                  /* resizeNMap */
+int ef_op_pyr_down_gauss_f(const float* src, int src_cols, int src_rows, float* dst, void* stream);            /* pyrDownGaussF */
+int ef_op_pyr_down_uchar_gauss(const uint8_t* src, int src_cols, int src_rows, uint8_t* dst, void* stream);    /* pyrDownUcharGauss */
+int ef_op_vertices_to_depth(const float* vmaps_tmp, int cols, int rows, float cutoff, float* dst, void* stream); /* verticesToDepth */
+int ef_op_image_bgr_to_intensity(const uint8_t* rgba, int cols, int rows, uint8_t* dst, void* stream);         /* imageBGRToIntensity */
+int ef_op_compute_derivative_images(const uint8_t* src, int cols, int rows, int16_t* dx, int16_t* dy, void* stream); /* computeDerivativeImages */
+int ef_op_project_to_point_cloud(const float* depth, int cols, int rows, const ef_intr* intr_level0, int level,
+                                 float* cloud_f3, void* stream);                                                /* projectToPointCloud */
+/* icpStep: host outputs A[36] row-major symmetric, b[6], residual[2] = {sum r^2, inliers} */
+int ef_op_icp_step(const float* Rcurr9, const float* tcurr3, const float* vmap_curr, const float* nmap_curr,
+                   const float* Rprev_inv9, const float* tprev3, const ef_intr* intr, const float* vmap_g_prev,
+                   const float* nmap_g_prev, float dist_thres, float angle_thres, int cols, int rows,
+                   float* A_host36, float* b_host6, float* residual_host2, void* stream);
+/* computeRgbResidual: corres_img is W*H 16-byte DataTerm records (types.cuh:81-86) */
+int ef_op_compute_rgb_residual(float min_scale, const int16_t* dIdx, const int16_t* dIdy, const float* last_depth,
+                               const float* next_depth, const uint8_t* last_image, const uint8_t* next_image,
+                               void* corres_img, float max_depth_delta, const float* kt3, const float* krkinv9,
+                               int cols, int rows, int* sigma_sum_host, int* count_host, void* stream);
+int ef_op_rgb_step(const void* corres_img, float sigma, const float* cloud_f3, float fx, float fy,
+                   const int16_t* dIdx, const int16_t* dIdy, float sobel_scale, int cols, int rows,
+                   float* A_host36, float* b_host6, void* stream);
+int ef_op_so3_step(const uint8_t* last_image, const uint8_t* next_image, const float* image_basis9,
+                   const float* kinv9, const float* krlr9, int cols, int rows, float* A_host9, float* b_host3,
+                   float* residual_host2, void* stream);
+
+/* ---- operator tier: pre-processing and surfel map (the reference's GLSL passes) ---- */
+typedef struct ef_cam { int cols, rows; float fx, fy, cx, cy; } ef_cam;
+
+int ef_op_filter_depth(const uint16_t* raw, int cols, int rows, float max_d, uint16_t* filtered, void* stream);   /* depth_bilateral.frag */
+int ef_op_metricise_depth(const uint16_t* in, int cols, int rows, float max_d, float* out, void* stream);         /* depth_metric.frag */
+/* vertex_feedback x2 + init_unstable: returns the number of seeded surfels in *count_host */
+int ef_op_seed_map(const ef_cam* cam, const uint8_t* rgb, const float* depth_metric, const float* depth_metric_filtered,
+                   int time, float max_depth, float* surfels_aos, uint32_t* count_host, void* stream);
+/* IndexMap::predictIndices: surfels_aos = count x 12 floats */
+int ef_op_predict_indices(const ef_cam* cam, const double* T_wc16, int time, const float* surfels_aos, uint32_t count,
+                          float max_depth, int time_delta, uint32_t* index_map, float* vert_conf, float* color_time,
+                          float* norm_rad, void* stream);
+/* IndexMap::combinedPredict (ACTIVE) */
+int ef_op_combined_predict(const ef_cam* cam, const double* T_wc16, const float* surfels_aos, uint32_t count,
+                           float max_depth, float conf_threshold, int time, int max_time, int time_delta,
+                           uint8_t* image_rgba, float* vertex, float* normal, uint16_t* time_map, void* stream);
+/* FillIn::{vertex,normal,image} */
+int ef_op_fill_in(const ef_cam* cam, const uint8_t* image_rgba, const float* vertex, const float* normal,
+                  const uint16_t* depth_filtered, const uint8_t* rgb, int passthrough, int passthrough_image,
+                  uint8_t* fill_image, float* fill_vertex, float* fill_normal, void* stream);
+/* Resize::image + denseEnough -> *dense_host in {0,1} */
+int ef_op_dense_enough(const ef_cam* cam, const uint8_t* image_rgba, int* dense_host, void* stream);
+/* GlobalModel::fuse: surfels updated in place; new_unstable gets the tagged candidates in draw order */
+int ef_op_fuse(const ef_cam* cam, const double* T_wc16, int time, const uint8_t* rgb, const float* depth_metric,
+               const float* depth_metric_filtered, const uint32_t* index_map, const float* vert_conf,
+               const float* color_time, const float* norm_rad, float max_depth, float weighting, float* surfels_aos,
+               uint32_t count, float* new_unstable_aos, uint32_t* new_count_host, void* stream);
+/* GlobalModel::clean (no deformation graph) */
+int ef_op_clean(const ef_cam* cam, const double* T_wc16, int time, const uint32_t* index_map, const float* vert_conf,
+                const float* color_time, const float* norm_rad, float conf_threshold, int time_delta, float max_depth,
+                const float* surfels_aos, uint32_t count, const float* new_unstable_aos, uint32_t new_count,
+                float* surfels_out_aos, uint32_t* out_count_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EF_HIP_H_ */

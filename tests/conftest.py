@@ -1,0 +1,65 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available() -> bool:
+    try:
+        from elasticfusion_amd import api
+        return os.path.exists("/dev/kfd") and api.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must FAIL loudly (the native path is the product), not skip:
+    # only plain runs (no -m) get the auto-skip.
+    if config.getoption("-m"):
+        return
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU here; run with -m gpu on the MI355X box")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def seq():
+    from elasticfusion_amd import synth
+    return synth.Sequence(0xEF0001)
+
+
+@pytest.fixture(scope="session")
+def frames(seq):
+    """First few frames of synthetic sequence 1 (rgb, depth, T_wc)."""
+    return [seq.frame(k) for k in range(4)]
+
+
+@pytest.fixture(scope="session")
+def oracle_state(frames):
+    """Oracle run over the first frames; exposes the oracle Fusion object positioned after frame 2."""
+    import efo
+    f = efo.Fusion()
+    for k in range(3):
+        rgb, depth, _ = frames[k]
+        f.process_frame(rgb, depth, k)
+    return f
+
+
+def rgba_of(rgb):
+    h, w, _ = rgb.shape
+    out = np.full((h, w, 4), 255, np.uint8)
+    out[..., :3] = rgb
+    return out

@@ -1,0 +1,113 @@
+"""GPU parity, frame tier: ef_process_frame (== ElasticFusion::processFrame) against the CPU oracle on the same
+synthetic frames.  Bars from BASELINE.json's north_star: pose within 1e-4 m / 1e-4 rad, fused surfel
+positions / normals / radii within 1e-5 relative.
+"""
+import numpy as np
+import pytest
+
+import efo
+
+pytestmark = pytest.mark.gpu
+
+
+def pose_err(T, Tr):
+    dt = float(np.linalg.norm(T[:3, 3] - Tr[:3, 3]))
+    dR = T[:3, :3].T @ Tr[:3, :3]
+    ang = float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))
+    return dt, ang
+
+
+def compare_maps(m, mr, rel=1e-5):
+    """surfel lists in stable order; returns the fraction of surfels within `rel` (positions/normals/radii/conf)."""
+    assert m.shape == mr.shape, (m.shape, mr.shape)
+    scale = np.maximum(np.abs(mr), 1e-3)
+    cols = [0, 1, 2, 3, 8, 9, 10, 11]
+    ok = (np.abs(m[:, cols] - mr[:, cols]) <= rel * np.maximum(scale[:, cols], np.linalg.norm(mr[:, :3], axis=1, keepdims=True))).all(axis=1)
+    ok &= (m[:, 4] == mr[:, 4]) & (m[:, 6] == mr[:, 6]) & (m[:, 7] == mr[:, 7])
+    return float(ok.mean())
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from elasticfusion_amd import api
+    return api
+
+
+def test_first_frame_matches_oracle(hip, frames):
+    rgb, depth, _ = frames[0]
+    ef = hip.ElasticFusion()
+    ef.processFrame(rgb, depth, 0)
+    o = efo.Fusion()
+    o.process_frame(rgb, depth, 0)
+    assert ef.lastCount() == o.map_count()
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    assert np.array_equal(ef.image("depth_filtered"), o.buffer("depthFiltered"))
+    for a, b in (("fill_vertex", "fill_vertex"), ("fill_normal", "fill_normal"), ("vertex", "vertex")):
+        x, y = ef.image(a), o.buffer(b)
+        assert np.array_equal(np.isnan(x), np.isnan(y))
+        assert np.array_equal(x[~np.isnan(x)], y[~np.isnan(y)])
+    assert np.array_equal(ef.image("fill_image"), o.buffer("fill_image"))
+    assert ef.getTick() == o.tick() == 2
+    ef.close()
+
+
+def test_tracking_and_fusion_sequence(hip, seq):
+    """12 frames, free-running tracking on both sides."""
+    n = 12
+    ef = hip.ElasticFusion()
+    o = efo.Fusion()
+    worst_t = worst_a = 0.0
+    for k in range(n):
+        rgb, depth, Tgt = seq.frame(k)
+        ef.processFrame(rgb, depth, k * 33333)
+        o.process_frame(rgb, depth, k * 33333)
+        dt, da = pose_err(ef.get_T_wc(), o.pose())
+        worst_t, worst_a = max(worst_t, dt), max(worst_a, da)
+        # tracker internals after each frame
+        st, _, _ = ef.trackingStats()
+        so = o.stats()
+        if k > 0:
+            assert st[1] == pytest.approx(so[1], rel=2e-3), (k, st, so)   # ICP inlier count
+    assert worst_t <= 1e-4 and worst_a <= 1e-4, (worst_t, worst_a)
+    # and both stay close to the generating trajectory (known-answer guard on the oracle itself)
+    dt, da = pose_err(ef.get_T_wc(), seq.pose(n - 1))
+    assert dt < 0.01 and da < 0.01, (dt, da)
+    m, mr = ef.downloadMap(), o.map()
+    assert abs(len(m) - len(mr)) <= max(4, int(2e-4 * len(mr))), (len(m), len(mr))
+    if len(m) == len(mr):
+        assert compare_maps(m, mr) > 0.995
+    traj, ts = ef.trajectory()
+    assert len(traj) == n and ts[3] == 3 * 33333
+    ef.close()
+
+
+def test_fusion_with_injected_poses(hip, seq):
+    """Ground-truth poses injected (in_T_wc), the reference's own way of decoupling fusion from tracking
+    (ElasticFusion.cpp:302,367-369): identical poses => the map must match surfel for surfel."""
+    n = 10
+    ef = hip.ElasticFusion(confidence=1.0)
+    o = efo.Fusion(confidence=1.0)
+    for k in range(n):
+        rgb, depth, Tgt = seq.frame(k)
+        T = None if k == 0 else Tgt
+        ef.processFrame(rgb, depth, k, in_T_wc=T)
+        o.process_frame(rgb, depth, k, T_wc=T)
+        assert ef.lastCount() == o.map_count(), k
+    m, mr = ef.downloadMap(), o.map()
+    assert m.shape == mr.shape
+    frac = compare_maps(m, mr, rel=1e-5)
+    assert frac == 1.0, frac
+    exact = float((m.view(np.uint32) == mr.view(np.uint32)).all(axis=1).mean())
+    assert exact > 0.999, exact
+    for name in ("image", "time", "fill_image"):
+        assert np.array_equal(ef.image(name), o.buffer(name)), name
+    ef.close()
+
+
+def test_api_errors(hip):
+    with pytest.raises(hip.EFError):
+        hip.ElasticFusion(closeLoops=True)
+    with pytest.raises(hip.EFError):
+        hip.ElasticFusion(width=642)
+    with pytest.raises(hip.EFError):
+        hip.ElasticFusion(maxSurfels=1000)
