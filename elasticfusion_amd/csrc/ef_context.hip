@@ -69,6 +69,10 @@ struct ef_ctx {
   // timing
   bool timing = false;
   std::vector<StageTimer> timers;
+  // HIP-event sampling of the dominant kernel (ef_kernel_timing)
+  int ktime_every = 0;
+  std::vector<hipEvent_t> kt_start, kt_stop;
+  eft::KernelProbe probe{nullptr, nullptr, 0, 0};
 };
 
 namespace {
@@ -192,7 +196,8 @@ int process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_d
       eft::init_rgb(c->pyr, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, c->rgb, c->st, rgb, s);
       timer_end(c, "odomInit");
       timer_begin(c, "odom");
-      eft::track(c->pyr, c->st, c->intr, tp, s);
+      const bool sample = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0;
+      eft::track(c->pyr, c->st, c->intr, tp, s, sample ? &c->probe : nullptr);
       eft::track_end(c->st, rgb, weightMultiplier, s);
       timer_end(c, "odom");
     } else {
@@ -318,6 +323,8 @@ void ctx_free(ef_ctx* c) {
   if (c->h_rgb) (void)hipHostFree(c->h_rgb);
   if (c->h_depth) (void)hipHostFree(c->h_depth);
   for (auto& t : c->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (auto e : c->kt_start) (void)hipEventDestroy(e);
+  for (auto e : c->kt_stop) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -617,6 +624,43 @@ int ef_get_timings(ef_ctx* c, ef_timing* out, int max, int* n) {
 }
 
 // ---- device helpers ----
+int ef_kernel_timing(ef_ctx* c, int every_n_frames) {
+  if (!c || every_n_frames < 0) return EF_EINVAL;
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  c->ktime_every = every_n_frames;
+  c->probe.used = 0;
+  if (every_n_frames > 0 && c->kt_start.empty()) {
+    const int cap = 4096;
+    c->kt_start.resize(cap);
+    c->kt_stop.resize(cap);
+    for (int i = 0; i < cap; ++i) {
+      EF_HIP(c, hipEventCreate(&c->kt_start[i]));
+      EF_HIP(c, hipEventCreate(&c->kt_stop[i]));
+    }
+    c->probe.start = c->kt_start.data();
+    c->probe.stop = c->kt_stop.data();
+    c->probe.capacity = cap;
+  }
+  return EF_OK;
+}
+int ef_get_kernel_timing(ef_ctx* c, ef_kernel_time* out) {
+  if (!c || !out) return EF_EINVAL;
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  double total_ms = 0;
+  for (int i = 0; i < c->probe.used; ++i) {
+    float ms = 0;
+    EF_HIP(c, hipEventElapsedTime(&ms, c->kt_start[i], c->kt_stop[i]));
+    total_ms += ms;
+  }
+  const bool icp = !c->cfg.rgb_only && c->cfg.icp_weight > 0, rgb = c->cfg.rgb_only || c->cfg.icp_weight < 100;
+  out->name = "k_icp_rgb_accum (level 0: icpStep + rgbStep normal equations)";
+  out->launches = c->probe.used;
+  out->avg_us = c->probe.used ? (float)(1e3 * total_ms / c->probe.used) : 0.f;
+  // icpStep 48 B per pixel-visit (4 planar float3 maps), rgbStep 32 B per pixel-visit
+  out->bytes_per_launch = (double)c->cam.cols * c->cam.rows * ((icp ? 48.0 : 0.0) + (rgb ? 32.0 : 0.0));
+  return EF_OK;
+}
+
 int ef_dev_alloc(void** dev, size_t bytes) { return hipMalloc(dev, bytes ? bytes : 1) == hipSuccess ? EF_OK : EF_ENOMEM; }
 int ef_dev_free(void* dev) { return hipFree(dev) == hipSuccess ? EF_OK : EF_EHIP; }
 int ef_dev_upload(void* dev, const void* host, size_t bytes) { return hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) == hipSuccess ? EF_OK : EF_EHIP; }

@@ -11,19 +11,23 @@
 
 namespace efl {
 
-#define EFL_HD __host__ __device__ inline
+#define EFL_HD __host__ __device__ __forceinline__
 
 EFL_HD void m3_identity(double* r) { for (int i = 0; i < 9; ++i) r[i] = (i % 4 == 0) ? 1.0 : 0.0; }
 EFL_HD void m4_identity(double* r) { for (int i = 0; i < 16; ++i) r[i] = (i % 5 == 0) ? 1.0 : 0.0; }
 
 EFL_HD void m3_mul(const double* a, const double* b, double* r) {
   double o[9];
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       double s = 0;
+#pragma unroll
       for (int k = 0; k < 3; ++k) s += a[i * 3 + k] * b[k * 3 + j];
       o[i * 3 + j] = s;
     }
+#pragma unroll
   for (int i = 0; i < 9; ++i) r[i] = o[i];
 }
 EFL_HD void m3_mulv(const double* a, const double* x, double* r) {
@@ -33,12 +37,16 @@ EFL_HD void m3_mulv(const double* a, const double* x, double* r) {
 }
 EFL_HD void m4_mul(const double* a, const double* b, double* r) {
   double o[16];
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
       double s = 0;
+#pragma unroll
       for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
       o[i * 4 + j] = s;
     }
+#pragma unroll
   for (int i = 0; i < 16; ++i) r[i] = o[i];
 }
 
@@ -79,50 +87,90 @@ EFL_HD void m4_affine_inverse(const double* a, double* r) {
 }
 
 // LDL^T with symmetric (diagonal) pivoting, as Eigen::LDLT does; A is N x N row-major symmetric.
+// Written so that every array index is a compile-time constant after unrolling (the data-dependent pivot
+// row/column swap is a chain of predicated swaps): the whole factorisation lives in registers — the
+// dynamically indexed version spilled to scratch and cost ~20 us per solve on gfx950.
+template <typename T>
+EFL_HD void cswap(bool c, T& a, T& b) { const T x = a, y = b; a = c ? y : x; b = c ? x : y; }
+
 template <typename T, int N>
 EFL_HD void ldlt_solve(const T* A_in, const T* b_in, T* x) {
-  T A[N * N];
+  T A[N][N];
   int perm[N];
-  for (int i = 0; i < N * N; ++i) A[i] = A_in[i];
-  for (int i = 0; i < N; ++i) perm[i] = i;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    perm[i] = i;
+#pragma unroll
+    for (int j = 0; j < N; ++j) A[i][j] = A_in[i * N + j];
+  }
+#pragma unroll
   for (int k = 0; k < N; ++k) {
     int p = k;
-    T best = fabs(A[k * N + k]);
+    T best = fabs(A[k][k]);
+#pragma unroll
     for (int i = k + 1; i < N; ++i) {
-      T v = fabs(A[i * N + i]);
-      if (v > best) { best = v; p = i; }
+      const T v = fabs(A[i][i]);
+      const bool g = v > best;
+      best = g ? v : best;
+      p = g ? i : p;
     }
-    if (p != k) {
-      for (int j = 0; j < N; ++j) { T s = A[k * N + j]; A[k * N + j] = A[p * N + j]; A[p * N + j] = s; }
-      for (int i = 0; i < N; ++i) { T s = A[i * N + k]; A[i * N + k] = A[i * N + p]; A[i * N + p] = s; }
-      int s = perm[k]; perm[k] = perm[p]; perm[p] = s;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const bool sw = (p == i);
+#pragma unroll
+      for (int j = 0; j < N; ++j) cswap(sw, A[k][j], A[i][j]);
+#pragma unroll
+      for (int r = 0; r < N; ++r) cswap(sw, A[r][k], A[r][i]);
+      cswap(sw, perm[k], perm[i]);
     }
-    const T d = A[k * N + k];
-    if (d == T(0)) continue;
+    const T d = A[k][k];
+    const bool live = !(d == T(0));
     T colk[N];
-    for (int i = k + 1; i < N; ++i) colk[i] = A[i * N + k];
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) colk[i] = A[i][k];
+#pragma unroll
     for (int i = k + 1; i < N; ++i) {
       const T l = colk[i] / d;
+#pragma unroll
       for (int j = k + 1; j <= i; ++j) {
-        A[i * N + j] -= l * colk[j];
-        A[j * N + i] = A[i * N + j];
+        const T v = A[i][j] - l * colk[j];
+        A[i][j] = live ? v : A[i][j];
+        A[j][i] = A[i][j];
       }
-      A[i * N + k] = l;
+      A[i][k] = live ? l : A[i][k];
     }
-    for (int j = k + 1; j < N; ++j) A[k * N + j] = T(0);
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) A[k][j] = live ? T(0) : A[k][j];
   }
   T y[N];
-  for (int i = 0; i < N; ++i) y[i] = b_in[perm[i]];
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < i; ++j) y[i] -= A[i * N + j] * y[j];
-  const T tiny = sizeof(T) == 8 ? (T)DBL_MIN : (T)FLT_MIN;
+#pragma unroll
   for (int i = 0; i < N; ++i) {
-    const T d = A[i * N + i];
+    T v = T(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) v = (perm[i] == j) ? b_in[j] : v;
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < i; ++j) y[i] -= A[i][j] * y[j];
+  const T tiny = sizeof(T) == 8 ? (T)DBL_MIN : (T)FLT_MIN;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const T d = A[i][i];
     y[i] = (fabs(d) > tiny) ? y[i] / d : T(0);
   }
+#pragma unroll
   for (int i = N - 1; i >= 0; --i)
-    for (int j = i + 1; j < N; ++j) y[i] -= A[j * N + i] * y[j];
-  for (int i = 0; i < N; ++i) x[perm[i]] = y[i];
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) y[i] -= A[j][i] * y[j];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    T v = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v = (perm[i] == j) ? y[i] : v;
+    x[j] = v;
+  }
 }
 
 // OdometryProvider::rodrigues

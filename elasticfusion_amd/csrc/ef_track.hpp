@@ -69,6 +69,15 @@ struct Pyramid {               // one RGBDOdometry instance's device buffers (RG
   int H(int l) const { return height >> l; }
 };
 
+// Optional HIP-event sampling of the level-0 normal-equation kernel (bench.py roofline leg): events are
+// recorded on the stream the kernel runs on, immediately before and after the launch.
+struct KernelProbe {
+  hipEvent_t* start;
+  hipEvent_t* stop;
+  int capacity;
+  int used;
+};
+
 struct TrackParams {           // host-side knobs of getIncrementalTransformation
   bool rgbOnly, pyramid, fastOdom, so3;
   float icpWeight;
@@ -125,7 +134,7 @@ void init_rgb(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* f
 // initFirstRGB, RGBDOdometry.cpp:246-257
 void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
 // getIncrementalTransformation, RGBDOdometry.cpp:259-571, entirely enqueued
-void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s);
+void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe = nullptr);
 // tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +
 // velocity weighting (ElasticFusion.cpp:369-383) + the float matrices of the map passes
 void track_end(TrackState* st, bool rgb, float weightMultiplier, hipStream_t s);

@@ -1179,8 +1179,9 @@ void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s) {
 namespace {
 template <int PPT>
 void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const TrackParams& tp, bool icp, bool rgb, float minScale,
-                      Intr knext, bool level_changes, hipStream_t s) {
+                      Intr knext, bool level_changes, hipStream_t s, KernelProbe* probe) {
   const int cols = p.W(level), rows = p.H(level), N = cols * rows;
+  const bool sample = probe && level == 0 && probe->used < probe->capacity;
   const int nb = ceil_div(N, REDUCE_BLOCK * PPT);
   if (rgb) {
     ResidualView RV{p.dIdx[level], p.dIdy[level], p.lastDepth[level], p.lastDepth[level], p.lastImage[level], p.nextImage[level],
@@ -1190,15 +1191,17 @@ void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, cons
   }
   IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres};
   RgbView GV{(const DataTerm*)p.corresImg[level], p.lastDepth[level], nullptr, p.dIdx[level], p.dIdy[level], cols, rows, kl, 1.0f / 8.0f};
+  if (sample) (void)hipEventRecord(probe->start[probe->used], s);
   if (icp && rgb) hipLaunchKernelGGL((k_icp_rgb_accum<PPT, true, true>), dim3(nb), dim3(REDUCE_BLOCK), 0, s, IV, GV, (const TrackState*)st, tp.rgbOnly, p.partials);
   else if (icp) hipLaunchKernelGGL((k_icp_rgb_accum<PPT, true, false>), dim3(nb), dim3(REDUCE_BLOCK), 0, s, IV, GV, (const TrackState*)st, tp.rgbOnly, p.partials);
   else hipLaunchKernelGGL((k_icp_rgb_accum<PPT, false, true>), dim3(nb), dim3(REDUCE_BLOCK), 0, s, IV, GV, (const TrackState*)st, tp.rgbOnly, p.partials);
+  if (sample) (void)hipEventRecord(probe->stop[probe->used++], s);
   hipLaunchKernelGGL(k_solve_update, dim3(1), dim3(256), 0, s, st, (const float*)p.partials, nb, icp, rgb, tp.rgbOnly, tp.icpWeight, knext,
                      level_changes);
 }
 }  // namespace
 
-void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s) {
+void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe) {
   const bool icp = !tp.rgbOnly && tp.icpWeight > 0;       // RGBDOdometry.cpp:266-267
   const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
   hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st);
@@ -1231,9 +1234,9 @@ void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_
       const Intr knext = intr_level(k, next_level);
       const bool level_changes = last_of_level;
       const int N = p.W(i) * p.H(i);
-      if (N >= 256 * 1024) launch_iteration<4>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s);
-      else if (N >= 128 * 1024) launch_iteration<2>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s);
-      else launch_iteration<1>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s);
+      if (N >= 256 * 1024) launch_iteration<4>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s, probe);
+      else if (N >= 128 * 1024) launch_iteration<2>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s, probe);
+      else launch_iteration<1>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s, probe);
     }
   }
   if (tp.so3)

@@ -124,6 +124,14 @@ typedef struct ef_timing { const char* name; float ms; } ef_timing;
 int ef_enable_timing(ef_ctx* ctx, int on);
 int ef_get_timings(ef_ctx* ctx, ef_timing* out, int max, int* n);
 
+/* HIP-event sampling of the dominant kernel (the level-0 icpStep+rgbStep normal-equation kernel) on the
+ * context's stream, every `every_n_frames`-th frame (0 = off; resets the samples).  ef_get_kernel_timing
+ * synchronises and returns the average launch duration, the number of sampled launches and the
+ * algorithmic bytes one launch must move -- bench.py's roofline leg. */
+typedef struct ef_kernel_time { const char* name; float avg_us; int launches; double bytes_per_launch; } ef_kernel_time;
+int ef_kernel_timing(ef_ctx* ctx, int every_n_frames);
+int ef_get_kernel_timing(ef_ctx* ctx, ef_kernel_time* out);
+
 /* ---- device memory helpers (so that a non-HIP host can drive the operator tier) ---- */
 int ef_dev_alloc(void** dev, size_t bytes);
 int ef_dev_free(void* dev);

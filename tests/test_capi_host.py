@@ -1,0 +1,67 @@
+"""CPU-only checks of the drop-in boundary: libefusion_hip.so loads, exports every symbol that include/ef_hip.h
+declares, refuses to run without a GPU (no silent fallback), and the host-side mirror never routes through oracle/."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def so():
+    from elasticfusion_amd import api, build
+    if not os.path.exists(api.LIB_PATH):
+        build.build()
+    return C.CDLL(api.LIB_PATH)
+
+
+def test_header_symbols_are_exported(so):
+    hdr = open(os.path.join(ROOT, "include", "ef_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(ef_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) > 60
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, missing
+
+
+def test_default_config_matches_front_end_defaults(so):
+    from elasticfusion_amd import api
+    cfg = api.ef_config()
+    so.ef_default_config(C.byref(cfg))
+    assert (cfg.width, cfg.height) == (640, 480)                      # MainController.cpp:37
+    assert (cfg.fx, cfg.fy, cfg.cx, cfg.cy) == (528.0, 528.0, 320.0, 240.0)  # MainController.cpp:42
+    assert cfg.confidence == 10.0 and cfg.depth_cut == 3.0 and cfg.icp_weight == 10.0
+    assert cfg.time_delta == 2147483647 // 2 and cfg.so3 == 1 and cfg.pyramid == 1 and cfg.close_loops == 0
+
+
+def test_create_fails_loudly_without_gpu_or_with_bad_config(so):
+    from elasticfusion_amd import api
+    so.ef_last_error.restype = C.c_char_p
+    so.ef_last_error.argtypes = [C.c_void_p]
+    cfg = api.default_config(close_loops=1)
+    h = C.c_void_p()
+    assert so.ef_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"loop closure" in so.ef_last_error(None)
+    cfg = api.default_config(width=641)
+    assert so.ef_create(C.byref(cfg), C.byref(h)) == -1
+    if not os.path.exists("/dev/kfd"):
+        cfg = api.default_config()
+        rc = so.ef_create(C.byref(cfg), C.byref(h))
+        assert rc == -2 and b"HIP" in so.ef_last_error(None)  # EF_EHIP: no device => error, never a CPU path
+        with pytest.raises(api.EFError):
+            api.ElasticFusion()
+
+
+def test_product_sources_never_reference_the_oracle():
+    bad = []
+    for base in ("elasticfusion_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"oracle/|libefo_oracle|import efo|efo_[a-z]+\(", txt) and f not in ("__init__.py",):
+                        if "oracle/" in txt and "does not touch oracle/" in txt and len(re.findall(r"oracle/", txt)) == 1:
+                            continue
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
