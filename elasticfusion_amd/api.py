@@ -412,6 +412,16 @@ class ops:
                                   _ptr(ops._f32(krlr).reshape(9)), c_i(w), c_i(h), _ptr(A), _ptr(b), _ptr(res), None))
         return A, b, res
 
+    LINALG = dict(ldlt6=0, ldlt3f=1, polar3=2, rodrigues=3, se3_inverse=4, se3_log_norm=5, scalar=6)
+
+    @staticmethod
+    def linalg(which, vec, n_out):
+        """The driver's Eigen/Sophus arithmetic as the device evaluates it (ef_op_linalg)."""
+        v = np.ascontiguousarray(np.asarray(vec, np.float64).reshape(-1))
+        out = np.zeros(n_out, np.float64)
+        _chk(lib().ef_op_linalg(c_i(ops.LINALG[which]), _ptr(v), c_i(v.size), _ptr(out), c_i(n_out)))
+        return out
+
     @staticmethod
     def filter_depth(raw, maxD):
         h, w = raw.shape

@@ -267,11 +267,10 @@ int ctx_init(ef_ctx* c) {
     EF_ALLOC(c, c->pyr.lastNextImage[i], n);
     EF_ALLOC(c, c->pyr.dIdx[i], n);
     EF_ALLOC(c, c->pyr.dIdy[i], n);
-    uint8_t* corr;
-    EF_ALLOC(c, corr, n * 16);
-    c->pyr.corresImg[i] = corr;
+    EF_ALLOC(c, c->pyr.corres[i], n);
+    EF_ALLOC(c, c->pyr.rgbMask[i], n);
   }
-  EF_ALLOC(c, c->pyr.partials, (size_t)eft::MAX_PARTIAL_BLOCKS * eft::PARTIAL_STRIDE);
+  EF_ALLOC(c, c->pyr.partials, (size_t)eft::PARTIAL_FLOATS);
   EF_ALLOC(c, c->st, 1);
   // prediction images
   EF_ALLOC(c, c->im.index, P);
@@ -722,7 +721,7 @@ int ef_op_project_to_point_cloud(const float* depth, int cols, int rows, const e
 }
 
 static int op_scratch(float** partials, float** out, int nfloats_out) {
-  if (hipMalloc((void**)partials, (size_t)eft::MAX_PARTIAL_BLOCKS * 8 * eft::PARTIAL_STRIDE * sizeof(float)) != hipSuccess) return EF_ENOMEM;
+  if (hipMalloc((void**)partials, (size_t)eft::OP_SCRATCH_FLOATS * sizeof(float)) != hipSuccess) return EF_ENOMEM;
   if (hipMalloc((void**)out, nfloats_out * sizeof(float)) != hipSuccess) { (void)hipFree(*partials); return EF_ENOMEM; }
   return EF_OK;
 }
@@ -737,7 +736,7 @@ static void unpack29_host(const float* h, float* A, float* b) {
 }
 int ef_op_icp_step(const float* Rc, const float* tc, const float* vc, const float* nc, const float* Rpi, const float* tp, const ef_intr* k,
                    const float* vg, const float* ng, float dist, float ang, int cols, int rows, float* A, float* b, float* res, void* s) {
-  if ((cols * rows + eft::REDUCE_BLOCK - 1) / eft::REDUCE_BLOCK > eft::MAX_PARTIAL_BLOCKS * 8) return EF_EINVAL;
+  if (cols <= 0 || rows <= 0 || cols > 2048 || rows > 2048) return EF_EINVAL;
   eft::IcpArgs a;
   memcpy(a.Rcurr, Rc, 36); memcpy(a.tcurr, tc, 12); memcpy(a.Rprev_inv, Rpi, 36); memcpy(a.tprev, tp, 12);
   a.k = eft::Intr{k->fx, k->fy, k->cx, k->cy};
@@ -790,13 +789,14 @@ int ef_op_so3_step(const uint8_t* lastImage, const uint8_t* nextImage, const flo
                    int rows, float* A, float* b, float* res, void* s) {
   eft::So3Args a;
   memcpy(a.imageBasis, ib, 36); memcpy(a.kinv, kinv, 36); memcpy(a.krlr, krlr, 36);
-  float* out;
-  if (hipMalloc((void**)&out, 16 * sizeof(float)) != hipSuccess) return EF_ENOMEM;
-  eft::so3_step_op(a, lastImage, nextImage, cols, rows, out, (hipStream_t)s);
+  float *partials, *out;
+  int r = op_scratch(&partials, &out, 16);
+  if (r != EF_OK) return r;
+  eft::so3_step_op(a, lastImage, nextImage, cols, rows, partials, out, (hipStream_t)s);
   float h[11];
   (void)hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)s);
   hipError_t e = hipStreamSynchronize((hipStream_t)s);
-  (void)hipFree(out);
+  (void)hipFree(partials); (void)hipFree(out);
   if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return EF_EHIP; }
   int shift = 0;
   for (int i = 0; i < 3; ++i)
@@ -806,6 +806,46 @@ int ef_op_so3_step(const uint8_t* lastImage, const uint8_t* nextImage, const flo
       else A[j * 3 + i] = A[i * 3 + j] = v;
     }
   res[0] = h[9]; res[1] = h[10];
+  return EF_OK;
+}
+
+// ---- operator tier: the driver's small linear algebra, evaluated on the device ----
+}  // extern "C"
+namespace {
+__global__ void k_linalg_probe(int which, const double* __restrict__ in, double* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  switch (which) {
+    case EF_LINALG_LDLT6: efl::ldlt_solve<double, 6>(in, in + 36, out); break;
+    case EF_LINALG_LDLT3F: {
+      float A[9], b[3], x[3];
+      for (int i = 0; i < 9; ++i) A[i] = (float)in[i];
+      for (int i = 0; i < 3; ++i) b[i] = (float)in[9 + i];
+      efl::ldlt_solve<float, 3>(A, b, x);
+      for (int i = 0; i < 3; ++i) out[i] = (double)x[i];
+      break;
+    }
+    case EF_LINALG_POLAR3: efl::polar3(in, out); break;
+    case EF_LINALG_RODRIGUES: efl::rodrigues(in, out); break;
+    case EF_LINALG_SE3_INVERSE: efl::se3_matrix(efl::se3_inverse(efl::se3_from_matrix(in)), out); break;
+    case EF_LINALG_SE3_LOG_NORM: out[0] = efl::se3_log_norm(efl::se3_from_matrix(in)); break;
+    case EF_LINALG_SCALAR:
+      out[0] = sqrt(in[0]); out[1] = in[0] / in[1]; out[2] = sin(in[0]); out[3] = cos(in[0]); out[4] = atan2(in[0], in[1]);
+      break;
+    default: break;
+  }
+}
+}  // namespace
+extern "C" {
+int ef_op_linalg(int which, const double* in, int n_in, double* out, int n_out) {
+  if (!in || !out || n_in <= 0 || n_out <= 0 || n_in > 64 || n_out > 64 || which < 0 || which > EF_LINALG_SCALAR) return EF_EINVAL;
+  double* d;
+  if (hipMalloc((void**)&d, 128 * sizeof(double)) != hipSuccess) return EF_ENOMEM;
+  (void)hipMemset(d, 0, 128 * sizeof(double));
+  (void)hipMemcpy(d, in, n_in * sizeof(double), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k_linalg_probe, dim3(1), dim3(64), 0, 0, which, (const double*)d, d + 64);
+  hipError_t e = hipMemcpy(out, d + 64, n_out * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return EF_EHIP; }
   return EF_OK;
 }
 

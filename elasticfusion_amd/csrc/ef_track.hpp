@@ -7,9 +7,17 @@
 namespace eft {
 
 constexpr int NUM_PYRS = 3;          // RGBDOdometry.h:114
-constexpr int REDUCE_BLOCK = 256;    // threads per reduction workgroup (4 waves)
-constexpr int PARTIAL_STRIDE = 64;   // floats per block partial: [0..28] ICP, [32..60] RGB
-constexpr int MAX_PARTIAL_BLOCKS = 2048;
+constexpr int REDUCE_BLOCK = 256;    // threads per workgroup of the integer (order-free) residual reduction
+// The fp32 normal-equation sums reproduce the reference's summation ORDER exactly (reduce.cu:313-317, :97-140):
+// a <<<64,256>>> grid-stride launch = 16384 "virtual threads", each summing pixels g, g+16384, ... in order, then a
+// warp32 shuffle tree, an 8-warp tree per block and a tree over the 64 block partials.  The kernels here run one
+// workgroup per virtual WARP (512 of them) and leave one partial vector per virtual warp, acc-major:
+// partials[acc * VWARPS + warp].
+constexpr int VTHREADS = 16384;      // 64 x 256, types.cuh:62-63
+constexpr int VWARPS = VTHREADS / 32;
+constexpr int SE3_ACCS = 29;         // JtJJtrSE3, types.cuh:98-143
+constexpr int SO3_ACCS = 11;         // JtJJtrSO3, types.cuh:145-168
+constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * VWARPS;  // ICP block then RGB block
 
 struct Intr { float fx, fy, cx, cy; };
 __host__ __device__ inline Intr intr_level(const Intr& k, int level) {  // CameraModel::operator()(level), types.cuh:92-95
@@ -38,6 +46,13 @@ struct TrackState {
   float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
   double lastA[36], lastb[6];
   int so3_iterations;
+  // SO(3) pre-alignment loop state (RGBDOdometry.cpp:284-369); the loop runs as <= 10 multi-workgroup launches
+  double so3_resultR[9], so3_lastResultR[9];
+  float so3_R_lr[9];
+  float so3_mats[27];         // imageBasis (K R K^-1), K^-1, K R of the coming iteration, float (RGBDOdometry.cpp:309-316)
+  float so3_lastError, so3_lastCount;
+  int so3_done;
+  unsigned so3_ticket;        // last-workgroup-done counter
   // per-frame scalars produced on the device
   float weighting;            // fusion weight (ElasticFusion.cpp:371-383)
   int should_fill_in;         // !denseEnough (ElasticFusion.cpp:304-305)
@@ -63,8 +78,11 @@ struct Pyramid {               // one RGBDOdometry instance's device buffers (RG
   uint8_t* lastNextImage[NUM_PYRS];
   int16_t* dIdx[NUM_PYRS];
   int16_t* dIdy[NUM_PYRS];
-  void* corresImg[NUM_PYRS];       // DataTerm[rows][cols]
-  float* partials;                 // MAX_PARTIAL_BLOCKS x PARTIAL_STRIDE
+  // photometric correspondences of the current iteration, 4 bytes per pixel instead of the reference's 16-byte
+  // DataTerm (types.cuh:81-86): bit31 valid | (diff+255) << 22 | v0 << 11 | u0 ("one" is the pixel itself)
+  uint32_t* corres[NUM_PYRS];
+  uint8_t* rgbMask[NUM_PYRS];      // iteration-invariant part of residualKernel's gates, built once per frame
+  float* partials;                 // PARTIAL_FLOATS
   int W(int l) const { return width >> l; }
   int H(int l) const { return height >> l; }
 };
@@ -105,8 +123,10 @@ struct IcpArgs {
   Intr k;
   float distThres, angleThres;
 };
+// scratch: >= OP_SCRATCH_FLOATS device floats; out*_dev receive the final sums in the reference's member order
+constexpr int OP_SCRATCH_FLOATS = SE3_ACCS * VWARPS + 64;
 void icp_step_op(const IcpArgs& a, const float* vmap_curr, const float* nmap_curr, const float* vmap_g_prev,
-                 const float* nmap_g_prev, int cols, int rows, float* partials, float* out29_dev, hipStream_t s);
+                 const float* nmap_g_prev, int cols, int rows, float* scratch, float* out29_dev, hipStream_t s);
 struct RgbResidualArgs {
   float minScale, maxDepthDelta;
   float kt[3], krkinv[9];
@@ -115,10 +135,10 @@ void rgb_residual_op(const RgbResidualArgs& a, const int16_t* dIdx, const int16_
                      const float* nextDepth, const uint8_t* lastImage, const uint8_t* nextImage, void* corres, int cols,
                      int rows, int* out2_dev, hipStream_t s);
 void rgb_step_op(const void* corres, float sigma, const float* cloud, float fx, float fy, const int16_t* dIdx,
-                 const int16_t* dIdy, float sobelScale, int cols, int rows, float* partials, float* out29_dev, hipStream_t s);
+                 const int16_t* dIdy, float sobelScale, int cols, int rows, float* scratch, float* out29_dev, hipStream_t s);
 struct So3Args { float imageBasis[9], kinv[9], krlr[9]; };
-void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* nextImage, int cols, int rows, float* out11_dev,
-                 hipStream_t s);
+void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* nextImage, int cols, int rows, float* scratch,
+                 float* out11_dev, hipStream_t s);
 
 // ---- frame-tier launchers (device-resident state; nothing here synchronises) ----
 // RGBDOdometry::initICP(filteredDepth, cutoff): u16 pyramid + vertex/normal maps, RGBDOdometry.cpp:121-147

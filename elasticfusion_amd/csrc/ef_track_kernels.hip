@@ -1,10 +1,11 @@
 // HIP kernels (gfx950, wave64) for the tracking pyramid and the Gauss-Newton reductions.
 // Reference behaviour: Core/Cuda/cudafuncs.cu (image operators), Core/Cuda/reduce.cu (icpStep,
 // computeRgbResidual, rgbStep, so3Step), Core/Utils/RGBDOdometry.cpp (driver).  The CUDA versions are
-// warp32 / 64x256-thread grid-stride / host-in-the-loop; here every reduction is a 256-thread
-// (4-wave) workgroup with LDS-staged column sums, one partial row per workgroup summed in fixed
-// order, and the 6x6 solve + SE(3) update run in a single-lane double-precision kernel so the
-// 19 iterations are enqueued back to back with no host round trip.
+// warp32 / 64x256-thread grid-stride / host-in-the-loop.  Here the fp32 sums keep the reference's summation
+// ORDER (so results are bit-identical to the reference's tree, see "Reference-order fp32 reductions" below) but
+// not its schedule: one workgroup per virtual warp, Jacobian rows staged in LDS, wave64 shuffles for the trees;
+// the 6x6 solve + SE(3) update run in a device kernel so the 19 iterations are enqueued back to back with no
+// host round trip.
 #include "ef_device.hpp"
 #include "ef_linalg_dev.hpp"
 #include "ef_track.hpp"
@@ -294,17 +295,46 @@ __global__ void k_sobel(const uint8_t* __restrict__ src, int cols, int rows, int
   if (x >= cols || y >= rows) return;
   sobel_px(src, cols, rows, x, y, dx, dy);
 }
+// 4-byte photometric correspondence (frame tier): bit31 valid | (diff + 255) << 22 | v0 << 11 | u0.
+// DataTerm.one is the pixel itself, DataTerm.diff an integer in [-255, 255] (difference of two u8 intensities).
+__device__ __forceinline__ uint32_t pack_corres(int u0, int v0, int idiff) {
+  return 0x80000000u | ((uint32_t)(idiff + 255) << 22) | ((uint32_t)v0 << 11) | (uint32_t)u0;
+}
+// Sobel for all three levels in one launch + the iteration-invariant half of the photometric gate.
+// residualKernel (reduce.cu:631-667) re-tests, on every one of the 19 iterations, conditions that only depend on
+// the frame: image-border limits, the 4x4 "no zero pixel" window on nextImage (quirk Q10), the gradient-magnitude
+// threshold and !isnan(nextDepth).  They are evaluated here once per frame into a 1-byte mask; the packed
+// correspondence of every pixel is reset to "invalid" and only masked-in pixels are revisited by the iterations.
 struct SobelLevels {
   const uint8_t* src[NUM_PYRS];
   int16_t* dx[NUM_PYRS];
   int16_t* dy[NUM_PYRS];
+  const float* nextDepth[NUM_PYRS];
+  uint8_t* mask[NUM_PYRS];
+  uint32_t* corres[NUM_PYRS];
+  float minScale[NUM_PYRS];
   int cols[NUM_PYRS], rows[NUM_PYRS];
 };
 __global__ void k_sobel_levels(const SobelLevels L) {
   const int l = blockIdx.z;
+  const int cols = L.cols[l], rows = L.rows[l];
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= L.cols[l] || y >= L.rows[l]) return;
-  sobel_px(L.src[l], L.cols[l], L.rows[l], x, y, L.dx[l], L.dy[l]);
+  if (x >= cols || y >= rows) return;
+  const uint8_t* __restrict__ img = L.src[l];
+  sobel_px(img, cols, rows, x, y, L.dx[l], L.dy[l]);
+  const int k = y * cols + x;
+  bool ok = (x < cols - 5 && y < rows - 1);
+  if (ok) {
+    for (int u = max(y - 2, 0); u < min(y + 2, rows); ++u)
+      for (int v = max(x - 2, 0); v < min(x + 2, cols); ++v) ok = ok && (img[u * cols + v] > 0);
+  }
+  if (ok) {
+    const int valx = L.dx[l][k], valy = L.dy[l][k];
+    const float mTwo = (float)((valx * valx) + (valy * valy));
+    ok = mTwo >= L.minScale[l] && !isnan(L.nextDepth[l][k]);
+  }
+  L.mask[l][k] = ok ? 1 : 0;
+  L.corres[l][k] = 0u;
 }
 
 // projectPointsKernel, cudafuncs.cu:670-688
@@ -464,7 +494,7 @@ __device__ __forceinline__ bool icp_row(const IcpView& V, const IcpPose& P, int 
 }
 
 struct RgbView {
-  const DataTerm* corres;
+  const void* corres;         // PACKED: uint32 per pixel (frame tier); else DataTerm (operator tier, types.cuh:81-86)
   const float* lastDepth;     // level depth of the model image; the cloud is evaluated on the fly
   const float* cloud;         // or an explicit float3 cloud (operator tier); one of the two is null
   const int16_t* dIdx;
@@ -474,22 +504,35 @@ struct RgbView {
   float sobelScale;
 };
 // RGBReduction::getProducts, reduce.cu:420-476
+template <bool PACKED>
 __device__ __forceinline__ bool rgb_row(const RgbView& V, float sigma, int i, float (&row)[7]) {
-  const DataTerm c = V.corres[i];
-  if (!c.valid) return false;
-  float w = sigma + fabsf(c.diff);
+  int zx, zy, oi;
+  float diff;
+  if (PACKED) {
+    const uint32_t c = ((const uint32_t*)V.corres)[i];
+    if (!(c & 0x80000000u)) return false;
+    zx = (int)(c & 0x7FFu); zy = (int)((c >> 11) & 0x7FFu);
+    diff = (float)((int)((c >> 22) & 0x1FFu) - 255);
+    oi = i;
+  } else {
+    const DataTerm c = ((const DataTerm*)V.corres)[i];
+    if (!c.valid) return false;
+    zx = c.zero_x; zy = c.zero_y;
+    diff = c.diff;
+    oi = c.one_y * V.cols + c.one_x;
+  }
+  float w = sigma + fabsf(diff);
   w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
   if (sigma == -1) w = 1;
-  row[6] = -w * c.diff;
+  row[6] = -w * diff;
   f3 p;
-  const int zi = c.zero_y * V.cols + c.zero_x;
+  const int zi = zy * V.cols + zx;
   if (V.cloud) {
     p = {V.cloud[(size_t)zi * 3], V.cloud[(size_t)zi * 3 + 1], V.cloud[(size_t)zi * 3 + 2]};
   } else {  // projectPointsKernel folded in: same operations, same bits, no 12 B/px cloud in HBM
-    p = project_point(c.zero_x, c.zero_y, V.lastDepth[zi], 1.0f / V.k.fx, 1.0f / V.k.fy, V.k.cx, V.k.cy);
+    p = project_point(zx, zy, V.lastDepth[zi], 1.0f / V.k.fx, 1.0f / V.k.fy, V.k.cx, V.k.cy);
   }
   const float invz = (float)(1.0 / (double)p.z);
-  const int oi = c.one_y * V.cols + c.one_x;
   const float dI_dx_val = w * V.sobelScale * V.dIdx[oi];
   const float dI_dy_val = w * V.sobelScale * V.dIdy[oi];
   const float v0 = dI_dx_val * V.k.fx * invz;
@@ -500,17 +543,6 @@ __device__ __forceinline__ bool rgb_row(const RgbView& V, float sigma, int i, fl
   row[4] = p.z * v0 - p.x * v2;
   row[5] = -p.y * v0 + p.x * v1;
   return true;
-}
-
-// the 27 upper-triangular products of [J r]^T [J r] + r^2 + count, JtJJtrSE3 order (types.cuh:98-143)
-__device__ __forceinline__ void accumulate29(const float (&row)[7], float (&acc)[29]) {
-  int s = 0;
-#pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = i; j < 7; ++j) { acc[s] = fmaf(row[i], row[j], acc[s]); ++s; }
-  acc[27] = fmaf(row[6], row[6], acc[27]);
-  acc[28] += 1.0f;
 }
 
 struct ResidualView {
@@ -575,14 +607,14 @@ __device__ __forceinline__ void so3_gradient(const uint8_t* __restrict__ img, in
   fore = (float)img[(y + 1) * cols + x];
   gy = ((back + actu) / 2.0f) - ((fore + actu) / 2.0f);
 }
-__device__ __forceinline__ void so3_px(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, int cols,
-                                       int rows, const m33& IB, const m33& KI, const m33& KR, int k, float (&acc)[11]) {
+__device__ __forceinline__ bool so3_row(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, int cols,
+                                        int rows, const m33& IB, const m33& KI, const m33& KR, int k, float (&row)[4]) {
   const int y = k / cols, x = k - y * cols;
   const f3 unwarped{(float)x, (float)y, 1.0f};
   const f3 warped = mul(IB, unwarped);
   const int wx = f2i_rn(warped.x / warped.z), wy = f2i_rn(warped.y / warped.z);
   const bool found = (wx >= 1 && wx < cols - 1 && wy >= 1 && wy < rows - 1 && x >= 1 && x < cols - 1 && y >= 1 && y < rows - 1);
-  if (!found) return;  // zero row: contributes nothing
+  if (!found) return false;  // zero row
   float gnx, gny, glx, gly;
   so3_gradient(nextImage, cols, wx, wy, gnx, gny);
   so3_gradient(lastImage, cols, x, y, glx, gly);
@@ -596,14 +628,9 @@ __device__ __forceinline__ void so3_px(const uint8_t* __restrict__ lastImage, co
                 ((point.z * (e * gy + b * gx)) - (gy * h * y) - (gx * h * x)) / z2,
                 ((point.z * (f * gy + c * gx)) - (gy * ii * y) - (gx * ii * x)) / z2};
   const f3 jr = cross(left, point);
-  const float row[4] = {jr.x, jr.y, jr.z, -((float)nextImage[wy * cols + wx] - (float)lastImage[y * cols + x])};
-  int s = 0;
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = i; j < 4; ++j) { acc[s] = fmaf(row[i], row[j], acc[s]); ++s; }
-  acc[9] = fmaf(row[3], row[3], acc[9]);
-  acc[10] += 1.0f;
+  row[0] = jr.x; row[1] = jr.y; row[2] = jr.z;
+  row[3] = -((float)nextImage[wy * cols + wx] - (float)lastImage[y * cols + x]);
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -612,89 +639,255 @@ __device__ __forceinline__ void so3_px(const uint8_t* __restrict__ lastImage, co
 
 // K6a: photometric correspondence search.  Integer sums go straight to two device-scope atomics
 // (exact, order-free), replacing reduceSum(int2) + cudaMalloc/cudaFree per call (reduce.cu:774-783).
-template <int PPT>
-__global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_residual(const ResidualView V, const float* __restrict__ krkinv,
-                                                                const float* __restrict__ ktp, int* sums,
-                                                                const int* __restrict__ skip_flag) {
+// Operator tier: every gate of residualKernel evaluated per call, 16-byte DataTerm out (the reference's layout).
+__global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_residual_op(const ResidualView V, const float* __restrict__ krkinv,
+                                                                   const float* __restrict__ ktp, int* sums) {
   __shared__ int lds[2 * REDUCE_BLOCK / 64];
-  if (skip_flag && *skip_flag) return;
   const m33 K = m33_load(krkinv);
   const f3 kt{ktp[0], ktp[1], ktp[2]};
   const int N = V.cols * V.rows;
   int cnt = 0, sq = 0;
+  const int k = blockIdx.x * REDUCE_BLOCK + threadIdx.x;
+  if (k < N) residual_px(V, K, kt, k, cnt, sq);
+  block_reduce_atomic_int2<REDUCE_BLOCK>(cnt, sq, lds, sums);
+}
+// Frame tier: the iteration-invariant gates come from the per-frame mask (k_sobel_levels); only masked-in pixels
+// do the warp + gathers and rewrite their 4-byte packed correspondence.
+struct ResidualPackedView {
+  const uint8_t* mask;
+  const float* lastDepth;     // == nextDepth (quirk Q1)
+  const uint8_t* lastImage;
+  const uint8_t* nextImage;
+  uint32_t* corres;
+  int cols, rows;
+  float maxDepthDelta;
+};
+template <int PPT>
+__global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_residual(const ResidualPackedView V, const float* __restrict__ krkinv,
+                                                                const float* __restrict__ ktp, int* sums,
+                                                                const int* __restrict__ skip_flag) {
+  __shared__ int lds[2 * REDUCE_BLOCK / 64];
+  if (*skip_flag) return;
+  const m33 K = m33_load(krkinv);
+  const f3 kt{ktp[0], ktp[1], ktp[2]};
+  const int N = V.cols * V.rows, cols = V.cols, rows = V.rows;
+  int cnt = 0, sq = 0;
   const int base = blockIdx.x * REDUCE_BLOCK * PPT + threadIdx.x;
+  uint8_t m[PPT];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     const int k = base + j * REDUCE_BLOCK;
-    if (k < N) residual_px(V, K, kt, k, cnt, sq);
+    m[j] = k < N ? V.mask[k] : (uint8_t)0;
+  }
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    if (!m[j]) continue;
+    const int k = base + j * REDUCE_BLOCK;
+    const int y = k / cols, x = k - y * cols;
+    uint32_t packed = 0u;
+    const float d1 = V.lastDepth[k];  // mask guarantees !isnan(d1)
+    const float transformed_d1 = (float)(d1 * (K.r[2].x * x + K.r[2].y * y + K.r[2].z) + kt.z);
+    const int u0 = f2i_rn((d1 * (K.r[0].x * x + K.r[0].y * y + K.r[0].z) + kt.x) / transformed_d1);
+    const int v0 = f2i_rn((d1 * (K.r[1].x * x + K.r[1].y * y + K.r[1].z) + kt.y) / transformed_d1);
+    if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
+      const float d0 = V.lastDepth[v0 * cols + u0];
+      const int li = V.lastImage[v0 * cols + u0];
+      if (d0 > 0 && fabsf(transformed_d1 - d0) <= V.maxDepthDelta && li != 0) {
+        const int idiff = (int)V.nextImage[k] - li;   // exact: float(next) - float(last) of two u8
+        packed = pack_corres(u0, v0, idiff);
+        cnt += 1;
+        sq += idiff * idiff;                          // (int)(diff*diff), exact for |diff| <= 255
+      }
+    }
+    V.corres[k] = packed;
   }
   block_reduce_atomic_int2<REDUCE_BLOCK>(cnt, sq, lds, sums);
 }
 
-// K6b: ICP + RGB normal-equation accumulation in one pass over the level.
-// partial row layout: [0..28] ICP, [32..60] RGB.  sigma follows RGBDOdometry.cpp:442 (quirk Q2).
+// sigma follows RGBDOdometry.cpp:442 (quirk Q2)
 __device__ __forceinline__ float sigma_from_sums(int sigma, int rgbSize, bool rgbOnly) {
   if (rgbOnly) return -1.0f;
   const int arg = ((float)sigma / rgbSize == 0) ? 1 : rgbSize;
   return (float)sqrt((double)arg);
 }
-template <int PPT, bool HAS_ICP, bool HAS_RGB>
-__global__ void __launch_bounds__(REDUCE_BLOCK) k_icp_rgb_accum(const IcpView IV, const RgbView RV, const TrackState* __restrict__ st,
-                                                                 bool rgbOnly, float* __restrict__ partials) {
-  __shared__ float lds[block_reduce_lds_floats<29, REDUCE_BLOCK>()];
-  float* out = partials + (size_t)blockIdx.x * PARTIAL_STRIDE;
-  if (st->rgb_broken) {
-    if (threadIdx.x < PARTIAL_STRIDE) out[threadIdx.x] = 0.f;
-    return;
+
+// ------------------------------------------------------------------------------------------
+// Reference-order fp32 reductions.
+//
+// The reference sums with a fixed tree: <<<64,256>>> grid-stride threads (virtual thread g owns pixels g, g+16384,
+// ... summed in that order with one FMA per product), warp32 shuffle tree, shared[32] + warp-0 tree per block,
+// reduceSum<<<1,1024>>> over the 64 block partials (reduce.cu:313-317, :57-140).  fp32 addition is not associative,
+// and the tracker is a chaotic feedback loop (pose -> association -> map -> next pose), so any other order drifts
+// away from the reference frame by frame.  These kernels keep the reference's order but not its schedule:
+//   phase A  one workgroup per virtual WARP (512 of them): every pixel-visit of that warp's 32 virtual threads is an
+//            independent task spread over the whole workgroup (the per-pixel Jacobian rows — all the memory traffic
+//            and nearly all the arithmetic); rows are staged in LDS as [pass][component][lane];
+//   phase B  256 threads walk the rows in pass order: (lane, term, part) owns <= 8 of the 29 accumulators of one
+//            virtual thread and applies the same FMA chain the reference thread would, then the warp32 tree runs as
+//            five width-32 shuffles.  One partial vector per virtual warp, acc-major, goes to HBM;
+//   final    the 8-warp and 64-block trees are shuffles of width 8 and 32 in the consumer (solve) kernel.
+// Adding an exact 0.0f (zero rows of rejected pixels, zero-padded lanes of the reference's shared[32]) never changes
+// a sum, so only the non-trivial additions are performed.
+// ------------------------------------------------------------------------------------------
+constexpr int ROW_STRIDE = 8 * 32;   // floats per pass in LDS: 8 components (7 row entries + found) x 32 lanes
+
+__device__ __forceinline__ void store_row(float* rows, int k, int l, const float (&row)[7], float found) {
+  float* r = rows + k * ROW_STRIDE + l;
+#pragma unroll
+  for (int c = 0; c < 7; ++c) r[c * 32] = row[c];
+  r[7 * 32] = found;
+}
+
+// the FMA chains of one (virtual thread, part) over passes [0, kend): JtJJtrSE3 member order (types.cuh:98-143) is
+// s = 0..26 over i = 0..5, j = i..6; 27 = row[6]^2 (residual), 28 = inliers.
+//   part 0: s 0..6   (i=0)            part 1: s 7..12 (i=1), 25,26 (i=5)
+//   part 2: s 13..17 (i=2), 22..24 (i=4)   part 3: s 18..21 (i=3), 27, 28
+__device__ __forceinline__ void se3_chains(const float* __restrict__ R, int l, int part, int kend, float (&acc)[8]) {
+  if (part == 0) {
+    for (int k = 0; k < kend; ++k) {
+      const float* r = R + k * ROW_STRIDE + l;
+      const float r0 = r[0], r1 = r[32], r2 = r[64], r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192];
+      acc[0] = fmaf(r0, r0, acc[0]); acc[1] = fmaf(r0, r1, acc[1]); acc[2] = fmaf(r0, r2, acc[2]); acc[3] = fmaf(r0, r3, acc[3]);
+      acc[4] = fmaf(r0, r4, acc[4]); acc[5] = fmaf(r0, r5, acc[5]); acc[6] = fmaf(r0, r6, acc[6]);
+    }
+  } else if (part == 1) {
+    for (int k = 0; k < kend; ++k) {
+      const float* r = R + k * ROW_STRIDE + l;
+      const float r1 = r[32], r2 = r[64], r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192];
+      acc[0] = fmaf(r1, r1, acc[0]); acc[1] = fmaf(r1, r2, acc[1]); acc[2] = fmaf(r1, r3, acc[2]); acc[3] = fmaf(r1, r4, acc[3]);
+      acc[4] = fmaf(r1, r5, acc[4]); acc[5] = fmaf(r1, r6, acc[5]);
+      acc[6] = fmaf(r5, r5, acc[6]); acc[7] = fmaf(r5, r6, acc[7]);
+    }
+  } else if (part == 2) {
+    for (int k = 0; k < kend; ++k) {
+      const float* r = R + k * ROW_STRIDE + l;
+      const float r2 = r[64], r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192];
+      acc[0] = fmaf(r2, r2, acc[0]); acc[1] = fmaf(r2, r3, acc[1]); acc[2] = fmaf(r2, r4, acc[2]); acc[3] = fmaf(r2, r5, acc[3]);
+      acc[4] = fmaf(r2, r6, acc[4]);
+      acc[5] = fmaf(r4, r4, acc[5]); acc[6] = fmaf(r4, r5, acc[6]); acc[7] = fmaf(r4, r6, acc[7]);
+    }
+  } else {
+    for (int k = 0; k < kend; ++k) {
+      const float* r = R + k * ROW_STRIDE + l;
+      const float r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192], f = r[224];
+      acc[0] = fmaf(r3, r3, acc[0]); acc[1] = fmaf(r3, r4, acc[1]); acc[2] = fmaf(r3, r5, acc[2]); acc[3] = fmaf(r3, r6, acc[3]);
+      acc[4] = fmaf(r6, r6, acc[4]);
+      acc[5] += f;
+    }
   }
-  const int N = IV.cols * IV.rows;
-  const int base = blockIdx.x * REDUCE_BLOCK * PPT + threadIdx.x;
+}
+__device__ __forceinline__ int se3_member(int part, int i) {  // accumulator slot -> JtJJtrSE3 member index (-1: unused)
+  if (part == 0) return i < 7 ? i : -1;
+  if (part == 1) return i < 6 ? 7 + i : 25 + (i - 6);
+  if (part == 2) return i < 5 ? 13 + i : 22 + (i - 5);
+  return i < 4 ? 18 + i : (i < 6 ? 27 + (i - 4) : -1);
+}
+
+struct Se3Inputs {            // device pointers: the Gauss-Newton state the accumulation reads
+  const float* Rcurr;         // 9
+  const float* tcurr;         // 3
+  const float* Rprev_inv;     // 9
+  const float* tprev;         // 3
+  const int* rgb_sum;         // {count, sum diff^2} of this iteration's residual pass, or null => sigma_fixed
+  const int* broken;          // rgbOnly early-exit flag, or null
+  float sigma_fixed;
+  bool rgbOnly;
+};
+
+template <int BLOCK, int KC, bool HAS_ICP, bool HAS_RGB, bool PACKED>
+__global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, float* __restrict__ partials_icp,
+                                                     float* __restrict__ partials_rgb) {
+  static_assert(BLOCK >= 256 && BLOCK % 64 == 0, "phase B needs 256 threads");
+  __shared__ float rows[2][KC * ROW_STRIDE];
+  if (in.broken && *in.broken) return;
+  const int t = threadIdx.x, W = blockIdx.x;
+  const int cols = HAS_ICP ? IV.cols : RV.cols, nrows = HAS_ICP ? IV.rows : RV.rows;
+  const int N = cols * nrows;
+  const int K = (N + VTHREADS - 1) / VTHREADS;
+  IcpPose P;
   if (HAS_ICP) {
-    IcpPose P;
-    P.Rcurr = m33_load(st->Rcurr);
-    P.tcurr = {st->tcurr[0], st->tcurr[1], st->tcurr[2]};
-    P.Rprev_inv = m33_load(st->Rprev_inv);
-    P.tprev = {st->tprev[0], st->tprev[1], st->tprev[2]};
-    float acc[29];
-#pragma unroll
-    for (int k = 0; k < 29; ++k) acc[k] = 0.f;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int i = base + j * REDUCE_BLOCK;
-      if (i < N) {
-        float row[7];
-        const int y = i / IV.cols, x = i - y * IV.cols;
-        if (icp_row(IV, P, x, y, row)) accumulate29(row, acc);
-      }
-    }
-    block_reduce_store<29, REDUCE_BLOCK>(acc, lds, out);
-    if (HAS_RGB) __syncthreads();
+    P.Rcurr = m33_load(in.Rcurr);
+    P.tcurr = {in.tcurr[0], in.tcurr[1], in.tcurr[2]};
+    P.Rprev_inv = m33_load(in.Rprev_inv);
+    P.tprev = {in.tprev[0], in.tprev[1], in.tprev[2]};
   }
-  if (HAS_RGB) {
-    const float sigma = sigma_from_sums(st->rgb_sum[1], st->rgb_sum[0], rgbOnly);
-    float acc[29];
+  float sigma = in.sigma_fixed;
+  if (HAS_RGB && in.rgb_sum) sigma = sigma_from_sums(in.rgb_sum[1], in.rgb_sum[0], in.rgbOnly);
+  // phase-B identity of this thread
+  const int l = t & 31, term = (t >> 5) & 1, part = t >> 6;
+  const bool chain_thread = t < 256 && (term == 0 ? HAS_ICP : HAS_RGB);
+  const int g = W * 32 + l;
+  const int nk = g < N ? (N - g + VTHREADS - 1) / VTHREADS : 0;   // passes virtual thread g really makes
+  float acc[8];
 #pragma unroll
-    for (int k = 0; k < 29; ++k) acc[k] = 0.f;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-      const int i = base + j * REDUCE_BLOCK;
-      if (i < N) {
-        float row[7];
-        if (rgb_row(RV, sigma, i, row)) accumulate29(row, acc);
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    const int kc = min(KC, K - k0);
+    for (int s = t; s < kc * 32; s += BLOCK) {
+      const int k = s >> 5, sl = s & 31;
+      const int p = (k0 + k) * VTHREADS + W * 32 + sl;
+      if (HAS_ICP) {
+        float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float found = 0.f;
+        if (p < N) {
+          const int y = p / cols, x = p - y * cols;
+          if (icp_row(IV, P, x, y, row)) found = 1.f;
+        }
+        store_row(rows[0], k, sl, row, found);
+      }
+      if (HAS_RGB) {
+        float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float found = 0.f;
+        if (p < N && rgb_row<PACKED>(RV, sigma, p, row)) found = 1.f;
+        store_row(rows[1], k, sl, row, found);
       }
     }
-    block_reduce_store<29, REDUCE_BLOCK>(acc, lds, out + 32);
+    __syncthreads();
+    if (chain_thread) se3_chains(rows[term], l, part, min(kc, nk - k0), acc);
+    __syncthreads();
+  }
+  if (chain_thread) {
+    // warpReduceSum, reduce.cu:57-95: val += shfl_down(val, offset) for offset = 16..1 (lane 0 of each virtual warp)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 32);
+    if (l == 0) {
+      float* out = (term == 0 ? partials_icp : partials_rgb) + W;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int a = se3_member(part, i);
+        if (a >= 0) out[(size_t)a * VWARPS] = acc[i];
+      }
+    }
   }
 }
 
-// fixed-order sum of nblocks partial rows, 256 threads: 4 row-groups x 64 columns
-__device__ __forceinline__ void sum_partials(const float* __restrict__ partials, int nblocks, float* lds /*4*64*/, float* out64) {
-  const int t = threadIdx.x, c = t & 63, g = t >> 6;
-  float s = 0.f;
-  for (int r = g; r < nblocks; r += 4) s += partials[(size_t)r * PARTIAL_STRIDE + c];
-  lds[g * 64 + c] = s;
+// The rest of the reference tree over the 512 virtual-warp partials of `na` accumulators (acc-major):
+//   blockReduceSum's second stage: lanes 0..7 of warp 0 hold the 8 warp sums, the other 24 lanes hold 0.0f
+//     => shfl_down tree of width 8 (offsets 4, 2, 1);
+//   reduceSum<<<1,1024>>>: threads 0..63 hold the 64 block partials => two warp32 trees, then shared[0] + shared[1].
+// bs: na*64 floats of LDS, out: na floats of LDS.  COHERENT: read the partials with agent-scope atomic loads (used
+// by the last-workgroup-done pattern, where the partials were written by other workgroups of the same launch).
+template <int BLOCK, bool COHERENT>
+__device__ __forceinline__ void final_tree(const float* partials, int na, float* bs, float* out) {
+  const int t = threadIdx.x;
+  for (int idx = t; idx < na * VWARPS; idx += BLOCK) {
+    float v = COHERENT ? __hip_atomic_load(partials + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials[idx];
+    v += __shfl_down(v, 4, 8);
+    v += __shfl_down(v, 2, 8);
+    v += __shfl_down(v, 1, 8);
+    if ((idx & 7) == 0) bs[idx >> 3] = v;   // [acc][block]
+  }
   __syncthreads();
-  if (t < 64) out64[t] = ((lds[t] + lds[64 + t]) + lds[128 + t]) + lds[192 + t];
+  for (int idx = t; idx < na * 64; idx += BLOCK) {
+    float v = bs[idx];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
+    const float w1 = __shfl(v, 32, 64);
+    if ((idx & 63) == 0) out[idx >> 6] = v + w1;
+  }
   __syncthreads();
 }
 
@@ -727,8 +920,20 @@ __device__ inline void compute_krk(const double* resultRt, Intr k, float* krkinv
   for (int i = 0; i < 3; ++i) kt[i] = (float)Kt[i];
 }
 
-// first kernel of getIncrementalTransformation: Rprev/tprev/Rcurr/tcurr (RGBDOdometry.cpp:266-273,375-377)
-__global__ void k_track_begin(TrackState* st) {
+// float matrices of one SO(3) iteration: homography K R K^-1, K^-1, K R (RGBDOdometry.cpp:309-316)
+__device__ inline void so3_matrices(const double* resultR, Intr k, float* mats27) {
+  double K[9] = {k.fx, 0, k.cx, 0, k.fy, k.cy, 0, 0, 1}, Kinv[9], KR[9], H[9];
+  efl::m3_inverse<double>(K, Kinv);
+  efl::m3_mul(K, resultR, KR);
+  efl::m3_mul(KR, Kinv, H);
+  for (int i = 0; i < 9; ++i) { mats27[i] = (float)H[i]; mats27[9 + i] = (float)Kinv[i]; mats27[18 + i] = (float)KR[i]; }
+}
+
+// first kernel of getIncrementalTransformation: Rprev/tprev/Rcurr/tcurr (RGBDOdometry.cpp:266-273,375-377),
+// the !denseEnough() decision of this frame's model prediction (ElasticFusion.cpp:256-268,304-305) is taken by
+// k_frame_begin before the pyramids are built; here also the SO(3) loop state, or — without SO(3) — the first
+// level's K R K^-1.
+__global__ void k_track_begin(TrackState* st, bool so3, Intr kso3, Intr kfirst) {
   if (threadIdx.x != 0) return;
   double R[9];
   efl::quat_to_mat<double>(st->q, R);
@@ -740,28 +945,40 @@ __global__ void k_track_begin(TrackState* st) {
   efl::m4_identity(st->resultRt);
   st->rgb_sum[0] = st->rgb_sum[1] = 0;
   st->rgb_broken = 0;
-  st->so3_iterations = 0;
-}
-
-// after the SO(3) stage: seed resultRt and the first level's K R K^-1 (RGBDOdometry.cpp:379-388)
-__global__ void k_track_level_begin(TrackState* st, Intr klevel) {
-  if (threadIdx.x != 0) return;
-  compute_krk(st->resultRt, klevel, st->krkinv, st->kt);
   st->lastRGBErrorLevel = 3.402823466e+38f;
-  st->rgb_broken = 0;
+  st->so3_iterations = 0;
+  st->so3_ticket = 0;
+  if (so3) {
+    efl::m3_identity(st->so3_resultR);
+    efl::m3_identity(st->so3_lastResultR);
+    for (int i = 0; i < 9; ++i) st->so3_R_lr[i] = (i % 4 == 0) ? 1.f : 0.f;
+    st->so3_lastError = 3.402823466e+38f / 2;
+    st->so3_lastCount = 3.402823466e+38f / 2;
+    st->so3_done = 0;
+    so3_matrices(st->so3_resultR, kso3, st->so3_mats);
+  } else {
+    st->so3_done = 1;
+    compute_krk(st->resultRt, kfirst, st->krkinv, st->kt);
+  }
 }
 
-// K6c: sum the partial rows, build A,b in double, LDL^T solve, SE(3) update, next K R K^-1
-// (RGBDOdometry.cpp:440-551 + OdometryProvider.h:73-96).  One workgroup; the solve runs on lane 0.
-__global__ void __launch_bounds__(256) k_solve_update(TrackState* st, const float* __restrict__ partials, int nblocks, bool icp,
-                                                       bool rgb, bool rgbOnly, float icpWeight, Intr knext, bool level_changes) {
-  __shared__ float lds[4 * 64];
-  __shared__ float sums[64];
-  sum_partials(partials, nblocks, lds, sums);
+// K6c: finish the reference tree over the virtual-warp partials, build A,b in double, LDL^T solve, SE(3) update,
+// next K R K^-1 (RGBDOdometry.cpp:440-551 + OdometryProvider.h:73-96).  One workgroup; the solve runs on lane 0.
+constexpr int SOLVE_BLOCK = 512;
+__global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_update(TrackState* st, const float* __restrict__ partials, bool icp, bool rgb,
+                                                               bool rgbOnly, float icpWeight, Intr knext, bool level_changes) {
+  __shared__ float bs[2 * SE3_ACCS * 64];
+  __shared__ float sums[2 * SE3_ACCS];
+  const bool broken = st->rgb_broken != 0;
+  if (!broken) {
+    if (icp && rgb) final_tree<SOLVE_BLOCK, false>(partials, 2 * SE3_ACCS, bs, sums);
+    else if (icp) final_tree<SOLVE_BLOCK, false>(partials, SE3_ACCS, bs, sums);
+    else final_tree<SOLVE_BLOCK, false>(partials + SE3_ACCS * VWARPS, SE3_ACCS, bs, sums + SE3_ACCS);
+  }
   if (threadIdx.x != 0) return;
   const int sigma = st->rgb_sum[1], rgbSize = st->rgb_sum[0];
   st->rgb_sum[0] = st->rgb_sum[1] = 0;
-  if (st->rgb_broken) {
+  if (broken) {
     if (level_changes) { st->rgb_broken = 0; st->lastRGBErrorLevel = 3.402823466e+38f; compute_krk(st->resultRt, knext, st->krkinv, st->kt); }
     return;
   }
@@ -778,20 +995,18 @@ __global__ void __launch_bounds__(256) k_solve_update(TrackState* st, const floa
     st->lastICPError = sqrtf(sums[27]) / sums[28];
     st->lastICPCount = sums[28];
   }
-  double A_icp[36], b_icp[6], A_rgb[36], b_rgb[6];
-  unpack29<double>(sums, A_icp, b_icp);
-  unpack29<double>(sums + 32, A_rgb, b_rgb);
   double A[36], b[6], result[6];
   if (icp && rgb) {
+    float Ai[36], bi[6], Ar[36], br[6];
+    unpack29<float>(sums, Ai, bi);
+    unpack29<float>(sums + SE3_ACCS, Ar, br);
     const double w = icpWeight;
-    for (int k = 0; k < 36; ++k) A[k] = A_rgb[k] + w * w * A_icp[k];
-    for (int k = 0; k < 6; ++k) b[k] = b_rgb[k] + w * b_icp[k];
+    for (int k = 0; k < 36; ++k) A[k] = (double)Ar[k] + w * w * (double)Ai[k];
+    for (int k = 0; k < 6; ++k) b[k] = (double)br[k] + w * (double)bi[k];
   } else if (icp) {
-    for (int k = 0; k < 36; ++k) A[k] = A_icp[k];
-    for (int k = 0; k < 6; ++k) b[k] = b_icp[k];
+    unpack29<double>(sums, A, b);
   } else {
-    for (int k = 0; k < 36; ++k) A[k] = A_rgb[k];
-    for (int k = 0; k < 6; ++k) b[k] = b_rgb[k];
+    unpack29<double>(sums + SE3_ACCS, A, b);
   }
   for (int k = 0; k < 36; ++k) st->lastA[k] = A[k];
   for (int k = 0; k < 6; ++k) st->lastb[k] = b[k];
@@ -883,139 +1098,150 @@ __global__ void k_save_prev_pose(TrackState* st) {
   for (int i = 0; i < 3; ++i) st->t_prev[i] = st->t[i];
 }
 
-// SO(3) pre-alignment, RGBDOdometry.cpp:284-369, as ONE single-workgroup kernel: level 2 is only
-// 160x120, so all <= 10 iterations (kernel + reduce + 3x3 solve + convergence test) run inside one
-// 1024-thread workgroup, synchronised by s_barrier instead of ten host round trips.
-constexpr int SO3_BLOCK = 1024;
-__global__ void __launch_bounds__(SO3_BLOCK) k_so3_loop(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
-                                                         int cols, int rows, Intr k, TrackState* st) {
-  __shared__ float lds[block_reduce_lds_floats<11, SO3_BLOCK>()];
-  __shared__ float mats[27];
-  __shared__ float red[11];
-  __shared__ int done;
-  __shared__ double resultR[9], lastResultR[9];
-  __shared__ float R_lr[9];
-  __shared__ float lastError, lastCount;
+// ------------------------------------------------------------------------------------------
+// SO(3) pre-alignment, RGBDOdometry.cpp:284-369.  One launch per iteration, SO3_WPB virtual warps per workgroup
+// (level 2 is small: 160x120 = 1.2 passes of the 16384 virtual threads), reference-order sums as above; the LAST
+// workgroup to finish runs the rest of the tree, the 3x3 float LDL^T, Rodrigues, the convergence / divergence tests
+// and the next iteration's matrices, so an iteration is a single kernel with no host round trip.  Launches after
+// convergence return immediately.
+// ------------------------------------------------------------------------------------------
+constexpr int SO3_WPB = 4, SO3_BLOCK = 256, SO3_KC = 8;
+__device__ __forceinline__ void so3_chains(const float* __restrict__ R, int l, int kend, float (&acc)[SO3_ACCS]) {
+  for (int k = 0; k < kend; ++k) {
+    const float* r = R + k * ROW_STRIDE + l;
+    const float r0 = r[0], r1 = r[32], r2 = r[64], r3 = r[96], f = r[128];
+    acc[0] = fmaf(r0, r0, acc[0]); acc[1] = fmaf(r0, r1, acc[1]); acc[2] = fmaf(r0, r2, acc[2]); acc[3] = fmaf(r0, r3, acc[3]);
+    acc[4] = fmaf(r1, r1, acc[4]); acc[5] = fmaf(r1, r2, acc[5]); acc[6] = fmaf(r1, r3, acc[6]);
+    acc[7] = fmaf(r2, r2, acc[7]); acc[8] = fmaf(r2, r3, acc[8]);
+    acc[9] = fmaf(r3, r3, acc[9]);
+    acc[10] += f;
+  }
+}
+// phase A + B of so3Step for the virtual warps of this workgroup; leaves partials[acc * VWARPS + warp]
+__device__ __forceinline__ void so3_accumulate(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, int cols,
+                                               int rows, const m33& IB, const m33& KI, const m33& KR, float* lds_rows,
+                                               float* __restrict__ partials) {
+  const int t = threadIdx.x, N = cols * rows;
+  const int K = (N + VTHREADS - 1) / VTHREADS;
+  const int l = t & 31, w = t >> 5;   // phase-B identity (t < 32 * SO3_WPB)
+  const int W = blockIdx.x * SO3_WPB + w;
+  const int g = W * 32 + l;
+  const int nk = g < N ? (N - g + VTHREADS - 1) / VTHREADS : 0;
+  float acc[SO3_ACCS];
+#pragma unroll
+  for (int i = 0; i < SO3_ACCS; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += SO3_KC) {
+    const int kc = min(SO3_KC, K - k0);
+    for (int s = t; s < SO3_WPB * kc * 32; s += SO3_BLOCK) {
+      const int sl = s & 31, q = s >> 5, k = q % kc, sw = q / kc;
+      const int p = (k0 + k) * VTHREADS + (blockIdx.x * SO3_WPB + sw) * 32 + sl;
+      float row[4] = {0.f, 0.f, 0.f, 0.f};
+      float found = 0.f;
+      if (p < N && so3_row(lastImage, nextImage, cols, rows, IB, KI, KR, p, row)) found = 1.f;
+      float* r = lds_rows + (sw * SO3_KC + k) * ROW_STRIDE + sl;
+      r[0] = row[0]; r[32] = row[1]; r[64] = row[2]; r[96] = row[3]; r[128] = found;
+    }
+    __syncthreads();
+    if (t < 32 * SO3_WPB) so3_chains(lds_rows + w * SO3_KC * ROW_STRIDE, l, min(kc, nk - k0), acc);
+    __syncthreads();
+  }
+  if (t < 32 * SO3_WPB) {
+#pragma unroll
+    for (int i = 0; i < SO3_ACCS; ++i)
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 32);
+    if (l == 0)
+#pragma unroll
+      for (int i = 0; i < SO3_ACCS; ++i) partials[(size_t)i * VWARPS + W] = acc[i];
+  }
+}
+
+__global__ void __launch_bounds__(SO3_BLOCK) k_so3_iteration(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
+                                                              int cols, int rows, Intr k, Intr kfirst, int it, TrackState* st,
+                                                              float* __restrict__ partials) {
+  __shared__ float lds_rows[SO3_WPB * SO3_KC * ROW_STRIDE];
+  __shared__ float red[SO3_ACCS];
+  __shared__ int is_last;
+  if (st->so3_done) return;
   const int t = threadIdx.x;
-  const int N = cols * rows;
+  {
+    const m33 IB = m33_load(st->so3_mats), KI = m33_load(st->so3_mats + 9), KR = m33_load(st->so3_mats + 18);
+    so3_accumulate(lastImage, nextImage, cols, rows, IB, KI, KR, lds_rows, partials);
+  }
+  // last-workgroup-done: release our partials, take a ticket, the last one acquires everybody's
+  __threadfence();
+  __syncthreads();
   if (t == 0) {
-    efl::m3_identity(resultR);
-    efl::m3_identity(lastResultR);
-    for (int i = 0; i < 9; ++i) R_lr[i] = (i % 4 == 0) ? 1.f : 0.f;
-    lastError = 3.402823466e+38f / 2;
-    lastCount = 3.402823466e+38f / 2;
-    done = 0;
+    const unsigned ticket = __hip_atomic_fetch_add(&st->so3_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (ticket == gridDim.x - 1);
   }
   __syncthreads();
-  for (int it = 0; it < 10; ++it) {
-    if (t == 0) {
-      double K[9] = {k.fx, 0, k.cx, 0, k.fy, k.cy, 0, 0, 1}, Kinv[9], KR[9], H[9];
-      efl::m3_inverse<double>(K, Kinv);
-      efl::m3_mul(K, resultR, KR);
-      efl::m3_mul(KR, Kinv, H);
-      for (int i = 0; i < 9; ++i) { mats[i] = (float)H[i]; mats[9 + i] = (float)Kinv[i]; mats[18 + i] = (float)KR[i]; }
+  if (!is_last) return;
+  __threadfence();
+  final_tree<SO3_BLOCK, true>(partials, SO3_ACCS, lds_rows /* reused: 11*64 floats */, red);
+  if (t != 0) return;
+  st->so3_ticket = 0;
+  st->so3_iterations = it + 1;
+  float jtj[9], jtr[3];
+  int shift = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = i; j < 4; ++j) {
+      const float value = red[shift++];
+      if (j == 3) jtr[i] = value;
+      else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
     }
-    __syncthreads();
-    const m33 IB = m33_load(mats), KI = m33_load(mats + 9), KR = m33_load(mats + 18);
-    float acc[11];
-#pragma unroll
-    for (int i = 0; i < 11; ++i) acc[i] = 0.f;
-    for (int p = t; p < N; p += SO3_BLOCK) so3_px(lastImage, nextImage, cols, rows, IB, KI, KR, p, acc);
-    block_reduce_store<11, SO3_BLOCK>(acc, lds, red);
-    __syncthreads();
-    if (t == 0) {
-      st->so3_iterations = it + 1;
-      float jtj[9], jtr[3];
-      int shift = 0;
-      for (int i = 0; i < 3; ++i)
-        for (int j = i; j < 4; ++j) {
-          const float value = red[shift++];
-          if (j == 3) jtr[i] = value;
-          else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
-        }
-      float err = sqrtf(red[9]) / red[10];
-      float cnt = red[10];
-      if (err < lastError && lastCount == cnt) {
-        done = 1;
-      } else if ((double)err > (double)lastError + 0.001) {
-        err = lastError; cnt = lastCount;
-        for (int i = 0; i < 9; ++i) resultR[i] = lastResultR[i];
-        done = 1;
-      } else {
-        lastError = err; lastCount = cnt;
-        for (int i = 0; i < 9; ++i) lastResultR[i] = resultR[i];
-        float delta[3];
-        efl::ldlt_solve<float, 3>(jtj, jtr, delta);
-        const double dv[3] = {(double)delta[0], (double)delta[1], (double)delta[2]};
-        double ru[9];
-        efl::rodrigues(dv, ru);
-        float ruf[9], nR[9];
-        for (int i = 0; i < 9; ++i) ruf[i] = (float)ru[i];
-        for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c) {
-            float s = 0;
-            for (int kk = 0; kk < 3; ++kk) s += ruf[r * 3 + kk] * R_lr[kk * 3 + c];
-            nR[r * 3 + c] = s;
-          }
-        for (int i = 0; i < 9; ++i) { R_lr[i] = nR[i]; resultR[i] = (double)nR[i]; }
+  float err = sqrtf(red[9]) / red[10];
+  float cnt = red[10];
+  bool done = false;
+  if (err < st->so3_lastError && st->so3_lastCount == cnt) {
+    done = true;
+  } else if ((double)err > (double)st->so3_lastError + 0.001) {
+    err = st->so3_lastError; cnt = st->so3_lastCount;
+    for (int i = 0; i < 9; ++i) st->so3_resultR[i] = st->so3_lastResultR[i];
+    done = true;
+  } else {
+    st->so3_lastError = err; st->so3_lastCount = cnt;
+    for (int i = 0; i < 9; ++i) st->so3_lastResultR[i] = st->so3_resultR[i];
+    float delta[3];
+    efl::ldlt_solve<float, 3>(jtj, jtr, delta);
+    const double dv[3] = {(double)delta[0], (double)delta[1], (double)delta[2]};
+    double ru[9];
+    efl::rodrigues(dv, ru);
+    float ruf[9], nR[9];
+    for (int i = 0; i < 9; ++i) ruf[i] = (float)ru[i];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        float s = 0;
+        for (int kk = 0; kk < 3; ++kk) s += ruf[r * 3 + kk] * st->so3_R_lr[kk * 3 + c];
+        nR[r * 3 + c] = s;
       }
-      st->lastSO3Error = err;
-      st->lastSO3Count = cnt;
-    }
-    __syncthreads();
-    if (done) break;
+    for (int i = 0; i < 9; ++i) { st->so3_R_lr[i] = nR[i]; st->so3_resultR[i] = (double)nR[i]; }
   }
-  if (t == 0)
+  st->lastSO3Error = err;
+  st->lastSO3Count = cnt;
+  if (done || it == 9) {
+    // resultRt.topLeftCorner(3,3) = resultR (RGBDOdometry.cpp:381-388) and the first level's K R K^-1, K t
     for (int x = 0; x < 3; ++x)
-      for (int y = 0; y < 3; ++y) st->resultRt[x * 4 + y] = resultR[x * 3 + y];
+      for (int y = 0; y < 3; ++y) st->resultRt[x * 4 + y] = st->so3_resultR[x * 3 + y];
+    compute_krk(st->resultRt, kfirst, st->krkinv, st->kt);
+    st->so3_done = 1;
+  } else {
+    so3_matrices(st->so3_resultR, k, st->so3_mats);
+  }
 }
 
 // ---- operator-tier single-shot reductions ----
-__global__ void __launch_bounds__(REDUCE_BLOCK) k_icp_op(const IcpView IV, const IcpArgs a, float* __restrict__ partials) {
-  __shared__ float lds[block_reduce_lds_floats<29, REDUCE_BLOCK>()];
-  IcpPose P;
-  P.Rcurr = m33_load(a.Rcurr); P.tcurr = {a.tcurr[0], a.tcurr[1], a.tcurr[2]};
-  P.Rprev_inv = m33_load(a.Rprev_inv); P.tprev = {a.tprev[0], a.tprev[1], a.tprev[2]};
-  const int N = IV.cols * IV.rows;
-  float acc[29];
-#pragma unroll
-  for (int k = 0; k < 29; ++k) acc[k] = 0.f;
-  const int i = blockIdx.x * REDUCE_BLOCK + threadIdx.x;
-  if (i < N) {
-    float row[7];
-    const int y = i / IV.cols, x = i - y * IV.cols;
-    if (icp_row(IV, P, x, y, row)) accumulate29(row, acc);
-  }
-  block_reduce_store<29, REDUCE_BLOCK>(acc, lds, partials + (size_t)blockIdx.x * PARTIAL_STRIDE);
-}
-__global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_op(const RgbView RV, float sigma, float* __restrict__ partials) {
-  __shared__ float lds[block_reduce_lds_floats<29, REDUCE_BLOCK>()];
-  const int N = RV.cols * RV.rows;
-  float acc[29];
-#pragma unroll
-  for (int k = 0; k < 29; ++k) acc[k] = 0.f;
-  const int i = blockIdx.x * REDUCE_BLOCK + threadIdx.x;
-  if (i < N) {
-    float row[7];
-    if (rgb_row(RV, sigma, i, row)) accumulate29(row, acc);
-  }
-  block_reduce_store<29, REDUCE_BLOCK>(acc, lds, partials + (size_t)blockIdx.x * PARTIAL_STRIDE);
-}
-__global__ void __launch_bounds__(256) k_sum_partials_op(const float* __restrict__ partials, int nblocks, int n, float* out) {
-  __shared__ float lds[4 * 64];
-  __shared__ float sums[64];
-  sum_partials(partials, nblocks, lds, sums);
-  if (threadIdx.x < n) out[threadIdx.x] = sums[threadIdx.x];
-}
 __global__ void __launch_bounds__(SO3_BLOCK) k_so3_op(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
-                                                       int cols, int rows, const So3Args a, float* out11) {
-  __shared__ float lds[block_reduce_lds_floats<11, SO3_BLOCK>()];
+                                                       int cols, int rows, const So3Args a, float* __restrict__ partials) {
+  __shared__ float lds_rows[SO3_WPB * SO3_KC * ROW_STRIDE];
   const m33 IB = m33_load(a.imageBasis), KI = m33_load(a.kinv), KR = m33_load(a.krlr);
-  float acc[11];
-#pragma unroll
-  for (int i = 0; i < 11; ++i) acc[i] = 0.f;
-  for (int p = threadIdx.x; p < cols * rows; p += SO3_BLOCK) so3_px(lastImage, nextImage, cols, rows, IB, KI, KR, p, acc);
-  block_reduce_store<11, SO3_BLOCK>(acc, lds, out11);
+  so3_accumulate(lastImage, nextImage, cols, rows, IB, KI, KR, lds_rows, partials);
+}
+__global__ void __launch_bounds__(SOLVE_BLOCK) k_final_tree_op(const float* __restrict__ partials, int na, float* __restrict__ out) {
+  __shared__ float bs[SE3_ACCS * 64];
+  __shared__ float sums[SE3_ACCS];
+  final_tree<SOLVE_BLOCK, false>(partials, na, bs, sums);
+  if ((int)threadIdx.x < na) out[threadIdx.x] = sums[threadIdx.x];
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -1067,12 +1293,33 @@ void project_to_point_cloud(const float* depth, int cols, int rows, Intr k, floa
   hipLaunchKernelGGL(k_project_points, tile_grid(cols, rows), tile_block(), 0, s, depth, cols, rows, 1.0f / k.fx, 1.0f / k.fy, k.cx, k.cy, cloud);
 }
 
+namespace {
+constexpr int ACC_BLOCK_BIG = 640, ACC_BLOCK_SMALL = 256, ACC_KC = 19;
+// one normal-equation accumulation launch (either tier)
+template <bool HAS_ICP, bool HAS_RGB, bool PACKED>
+void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int N, float* partials_icp, float* partials_rgb, hipStream_t s) {
+  if (N > 8 * VTHREADS)
+    hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_BIG, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(ACC_BLOCK_BIG), 0, s, IV, RV, in,
+                       partials_icp, partials_rgb);
+  else
+    hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_SMALL, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(ACC_BLOCK_SMALL), 0, s, IV, RV, in,
+                       partials_icp, partials_rgb);
+}
+}  // namespace
+
 void icp_step_op(const IcpArgs& a, const float* vmap_curr, const float* nmap_curr, const float* vmap_g_prev,
-                 const float* nmap_g_prev, int cols, int rows, float* partials, float* out29_dev, hipStream_t s) {
+                 const float* nmap_g_prev, int cols, int rows, float* scratch, float* out29_dev, hipStream_t s) {
   IcpView V{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, cols, rows, a.k, a.distThres, a.angleThres};
-  const int nb = ceil_div(cols * rows, REDUCE_BLOCK);
-  hipLaunchKernelGGL(k_icp_op, dim3(nb), dim3(REDUCE_BLOCK), 0, s, V, a, partials);
-  hipLaunchKernelGGL(k_sum_partials_op, dim3(1), dim3(256), 0, s, (const float*)partials, nb, 29, out29_dev);
+  RgbView RV{};
+  float* pose = scratch + SE3_ACCS * VWARPS;   // 24 floats of parameters behind the partials
+  float h[24];
+  for (int i = 0; i < 9; ++i) { h[i] = a.Rcurr[i]; h[12 + i] = a.Rprev_inv[i]; }
+  for (int i = 0; i < 3; ++i) { h[9 + i] = a.tcurr[i]; h[21 + i] = a.tprev[i]; }
+  (void)hipMemcpyAsync(pose, h, sizeof(h), hipMemcpyHostToDevice, s);
+  (void)hipStreamSynchronize(s);  // h is a stack buffer
+  Se3Inputs in{pose, pose + 9, pose + 12, pose + 21, nullptr, nullptr, 0.f, false};
+  launch_accum<true, false, false>(V, RV, in, cols * rows, scratch, scratch, s);
+  hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SE3_ACCS, out29_dev);
 }
 void rgb_residual_op(const RgbResidualArgs& a, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
                      const float* nextDepth, const uint8_t* lastImage, const uint8_t* nextImage, void* corres, int cols,
@@ -1085,20 +1332,23 @@ void rgb_residual_op(const RgbResidualArgs& a, const int16_t* dIdx, const int16_
   for (int i = 0; i < 3; ++i) h[9 + i] = a.kt[i];
   (void)hipMemcpyAsync(params, h, sizeof(h), hipMemcpyHostToDevice, s);
   (void)hipMemsetAsync(out2_dev, 0, 2 * sizeof(int), s);
-  hipLaunchKernelGGL(k_rgb_residual<1>, dim3(ceil_div(cols * rows, REDUCE_BLOCK)), dim3(REDUCE_BLOCK), 0, s, V, (const float*)params,
-                     (const float*)(params + 9), out2_dev, (const int*)nullptr);
+  hipLaunchKernelGGL(k_rgb_residual_op, dim3(ceil_div(cols * rows, REDUCE_BLOCK)), dim3(REDUCE_BLOCK), 0, s, V, (const float*)params,
+                     (const float*)(params + 9), out2_dev);
   (void)hipStreamSynchronize(s);
   (void)hipFree(params);
 }
 void rgb_step_op(const void* corres, float sigma, const float* cloud, float fx, float fy, const int16_t* dIdx, const int16_t* dIdy,
-                 float sobelScale, int cols, int rows, float* partials, float* out29_dev, hipStream_t s) {
-  RgbView V{(const DataTerm*)corres, nullptr, cloud, dIdx, dIdy, cols, rows, Intr{fx, fy, 0, 0}, sobelScale};
-  const int nb = ceil_div(cols * rows, REDUCE_BLOCK);
-  hipLaunchKernelGGL(k_rgb_op, dim3(nb), dim3(REDUCE_BLOCK), 0, s, V, sigma, partials);
-  hipLaunchKernelGGL(k_sum_partials_op, dim3(1), dim3(256), 0, s, (const float*)partials, nb, 29, out29_dev);
+                 float sobelScale, int cols, int rows, float* scratch, float* out29_dev, hipStream_t s) {
+  IcpView IV{};
+  RgbView V{corres, nullptr, cloud, dIdx, dIdy, cols, rows, Intr{fx, fy, 0, 0}, sobelScale};
+  Se3Inputs in{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sigma, false};
+  launch_accum<false, true, false>(IV, V, in, cols * rows, scratch, scratch, s);
+  hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SE3_ACCS, out29_dev);
 }
-void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* nextImage, int cols, int rows, float* out11_dev, hipStream_t s) {
-  hipLaunchKernelGGL(k_so3_op, dim3(1), dim3(SO3_BLOCK), 0, s, lastImage, nextImage, cols, rows, a, out11_dev);
+void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* nextImage, int cols, int rows, float* scratch, float* out11_dev,
+                 hipStream_t s) {
+  hipLaunchKernelGGL(k_so3_op, dim3(VWARPS / SO3_WPB), dim3(SO3_BLOCK), 0, s, lastImage, nextImage, cols, rows, a, scratch);
+  hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SO3_ACCS, out11_dev);
 }
 
 // ---- frame tier ----
@@ -1161,8 +1411,12 @@ void init_rgb(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* f
   for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_uchar_gauss(p.nextImage[i], p.W(i), p.H(i), p.nextImage[i + 1], s);
   if (with_sobel) {
     SobelLevels L;
+    const float minGrad[NUM_PYRS] = {5, 3, 1};  // RGBDOdometry.cpp:112-114
+    const float sobelScale = 1.0f / 8.0f;       // RGBDOdometry.cpp:39-40
     for (int i = 0; i < NUM_PYRS; ++i) {
       L.src[i] = p.nextImage[i]; L.dx[i] = p.dIdx[i]; L.dy[i] = p.dIdy[i];
+      L.nextDepth[i] = p.lastDepth[i]; L.mask[i] = p.rgbMask[i]; L.corres[i] = p.corres[i];
+      L.minScale[i] = (float)(pow((double)minGrad[i], 2.0) / pow((double)sobelScale, 2.0));  // RGBDOdometry.cpp:425
       L.cols[i] = p.W(i); L.rows[i] = p.H(i);
     }
     dim3 g = tile_grid(p.W(0), p.H(0));
@@ -1178,25 +1432,30 @@ void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s) {
 
 namespace {
 template <int PPT>
-void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const TrackParams& tp, bool icp, bool rgb, float minScale,
-                      Intr knext, bool level_changes, hipStream_t s, KernelProbe* probe) {
+void launch_residual(const Pyramid& p, TrackState* st, int level, hipStream_t s) {
+  const int cols = p.W(level), rows = p.H(level), N = cols * rows;
+  ResidualPackedView RV{p.rgbMask[level], p.lastDepth[level], p.lastImage[level], p.nextImage[level], p.corres[level], cols, rows,
+                        0.07f /* maxDepthDeltaRGB, RGBDOdometry.cpp:41 */};
+  hipLaunchKernelGGL(k_rgb_residual<PPT>, dim3(ceil_div(N, REDUCE_BLOCK * PPT)), dim3(REDUCE_BLOCK), 0, s, RV, (const float*)st->krkinv,
+                     (const float*)st->kt, st->rgb_sum, (const int*)&st->rgb_broken);
+}
+void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const TrackParams& tp, bool icp, bool rgb, Intr knext,
+                      bool level_changes, hipStream_t s, KernelProbe* probe) {
   const int cols = p.W(level), rows = p.H(level), N = cols * rows;
   const bool sample = probe && level == 0 && probe->used < probe->capacity;
-  const int nb = ceil_div(N, REDUCE_BLOCK * PPT);
   if (rgb) {
-    ResidualView RV{p.dIdx[level], p.dIdy[level], p.lastDepth[level], p.lastDepth[level], p.lastImage[level], p.nextImage[level],
-                    (DataTerm*)p.corresImg[level], cols, rows, minScale, 0.07f /* maxDepthDeltaRGB, RGBDOdometry.cpp:41 */};
-    hipLaunchKernelGGL(k_rgb_residual<PPT>, dim3(nb), dim3(REDUCE_BLOCK), 0, s, RV, (const float*)st->krkinv, (const float*)st->kt,
-                       st->rgb_sum, (const int*)&st->rgb_broken);
+    if (N >= 256 * 1024) launch_residual<2>(p, st, level, s);
+    else launch_residual<1>(p, st, level, s);
   }
   IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres};
-  RgbView GV{(const DataTerm*)p.corresImg[level], p.lastDepth[level], nullptr, p.dIdx[level], p.dIdy[level], cols, rows, kl, 1.0f / 8.0f};
+  RgbView GV{p.corres[level], p.lastDepth[level], nullptr, p.dIdx[level], p.dIdy[level], cols, rows, kl, 1.0f / 8.0f};
+  Se3Inputs in{st->Rcurr, st->tcurr, st->Rprev_inv, st->tprev, st->rgb_sum, &st->rgb_broken, 0.f, tp.rgbOnly};
   if (sample) (void)hipEventRecord(probe->start[probe->used], s);
-  if (icp && rgb) hipLaunchKernelGGL((k_icp_rgb_accum<PPT, true, true>), dim3(nb), dim3(REDUCE_BLOCK), 0, s, IV, GV, (const TrackState*)st, tp.rgbOnly, p.partials);
-  else if (icp) hipLaunchKernelGGL((k_icp_rgb_accum<PPT, true, false>), dim3(nb), dim3(REDUCE_BLOCK), 0, s, IV, GV, (const TrackState*)st, tp.rgbOnly, p.partials);
-  else hipLaunchKernelGGL((k_icp_rgb_accum<PPT, false, true>), dim3(nb), dim3(REDUCE_BLOCK), 0, s, IV, GV, (const TrackState*)st, tp.rgbOnly, p.partials);
+  if (icp && rgb) launch_accum<true, true, true>(IV, GV, in, N, p.partials, p.partials + SE3_ACCS * VWARPS, s);
+  else if (icp) launch_accum<true, false, true>(IV, GV, in, N, p.partials, p.partials + SE3_ACCS * VWARPS, s);
+  else launch_accum<false, true, true>(IV, GV, in, N, p.partials, p.partials + SE3_ACCS * VWARPS, s);
   if (sample) (void)hipEventRecord(probe->stop[probe->used++], s);
-  hipLaunchKernelGGL(k_solve_update, dim3(1), dim3(256), 0, s, st, (const float*)p.partials, nb, icp, rgb, tp.rgbOnly, tp.icpWeight, knext,
+  hipLaunchKernelGGL(k_solve_update, dim3(1), dim3(SOLVE_BLOCK), 0, s, st, (const float*)p.partials, icp, rgb, tp.rgbOnly, tp.icpWeight, knext,
                      level_changes);
 }
 }  // namespace
@@ -1204,39 +1463,30 @@ void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, cons
 void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe) {
   const bool icp = !tp.rgbOnly && tp.icpWeight > 0;       // RGBDOdometry.cpp:266-267
   const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
-  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st);
-  if (tp.so3) {
-    const int l = 2;
-    hipLaunchKernelGGL(k_so3_loop, dim3(1), dim3(SO3_BLOCK), 0, s, (const uint8_t*)p.lastNextImage[l], (const uint8_t*)p.nextImage[l], p.W(l),
-                       p.H(l), intr_level(k, l), st);
-  }
   int iterations[NUM_PYRS];
   iterations[0] = tp.fastOdom ? 3 : 10;  // RGBDOdometry.cpp:371-373
   iterations[1] = tp.pyramid ? 5 : 0;
   iterations[2] = tp.pyramid ? 4 : 0;
-  const float minGrad[NUM_PYRS] = {5, 3, 1};  // RGBDOdometry.cpp:112-114
-  int first_level = -1;
+  int first_level = 0;
   for (int i = NUM_PYRS - 1; i >= 0; --i)
     if (iterations[i] > 0) { first_level = i; break; }
-  if (first_level >= 0) hipLaunchKernelGGL(k_track_level_begin, dim3(1), dim3(64), 0, s, st, intr_level(k, first_level));
+  const int so3_level = 2;
+  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st, tp.so3, intr_level(k, so3_level), intr_level(k, first_level));
+  if (tp.so3) {
+    for (int it = 0; it < 10; ++it)
+      hipLaunchKernelGGL(k_so3_iteration, dim3(VWARPS / SO3_WPB), dim3(SO3_BLOCK), 0, s, (const uint8_t*)p.lastNextImage[so3_level],
+                         (const uint8_t*)p.nextImage[so3_level], p.W(so3_level), p.H(so3_level), intr_level(k, so3_level),
+                         intr_level(k, first_level), it, st, p.partials);
+  }
   for (int i = NUM_PYRS - 1; i >= 0; --i) {
     const Intr kl = intr_level(k, i);
-    const float sobelScale = 1.0f / 8.0f;
-    const float minScale = (float)(pow((double)minGrad[i], 2.0) / pow((double)sobelScale, 2.0));  // RGBDOdometry.cpp:425
     for (int j = 0; j < iterations[i]; ++j) {
       const bool last_of_level = (j == iterations[i] - 1);
       int next_level = i;
-      if (last_of_level) {
-        next_level = i;
+      if (last_of_level)
         for (int n = i - 1; n >= 0; --n)
           if (iterations[n] > 0) { next_level = n; break; }
-      }
-      const Intr knext = intr_level(k, next_level);
-      const bool level_changes = last_of_level;
-      const int N = p.W(i) * p.H(i);
-      if (N >= 256 * 1024) launch_iteration<4>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s, probe);
-      else if (N >= 128 * 1024) launch_iteration<2>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s, probe);
-      else launch_iteration<1>(p, st, i, kl, tp, icp, rgb, minScale, knext, level_changes, s, probe);
+      launch_iteration(p, st, i, kl, tp, icp, rgb, intr_level(k, next_level), last_of_level, s, probe);
     }
   }
   if (tp.so3)

@@ -181,6 +181,20 @@ int ef_op_so3_step(const uint8_t* last_image, const uint8_t* next_image, const f
                    const float* kinv9, const float* krlr9, int cols, int rows, float* A_host9, float* b_host3,
                    float* residual_host2, void* stream);
 
+/* The tracking driver's small linear algebra (Eigen / Sophus arithmetic of RGBDOdometry.cpp:356,526-534,566-570,
+ * OdometryProvider.h:34-96, ElasticFusion.cpp:371-374) as the DEVICE evaluates it, host vectors in and out
+ * (<= 64 doubles each) -- for parity tests against the oracle's efo_ldlt6 / efo_polar3 / ... */
+enum ef_linalg_op {
+  EF_LINALG_LDLT6 = 0,        /* in A[36] b[6]              -> x[6]   Eigen::LDLT solve, double            */
+  EF_LINALG_LDLT3F,           /* in A[9] b[3] (as doubles)  -> x[3]   Eigen::LDLT solve, float             */
+  EF_LINALG_POLAR3,           /* in A[9]                    -> R[9]   JacobiSVD U V^T                      */
+  EF_LINALG_RODRIGUES,        /* in v[3]                    -> R[9]   OdometryProvider::rodrigues          */
+  EF_LINALG_SE3_INVERSE,      /* in T[16]                   -> T^-1[16] Sophus::SE3d::inverse().matrix()    */
+  EF_LINALG_SE3_LOG_NORM,     /* in T[16]                   -> |log(T)| Sophus::SE3d::log().norm()          */
+  EF_LINALG_SCALAR            /* in a, b -> sqrt(a), a/b, sin(a), cos(a), atan2(a,b) (fp64 device math)     */
+};
+int ef_op_linalg(int which, const double* in_host, int n_in, double* out_host, int n_out);
+
 /* ---- operator tier: pre-processing and surfel map (the reference's GLSL passes) ---- */
 typedef struct ef_cam { int cols, rows; float fx, fy, cx, cy; } ef_cam;
 

@@ -52,30 +52,34 @@ def test_first_frame_matches_oracle(hip, frames):
 
 
 def test_tracking_and_fusion_sequence(hip, seq):
-    """12 frames, free-running tracking on both sides."""
-    n = 12
+    """Free-running tracking + fusion on both sides.  The HIP reductions reproduce the reference's fp32 summation
+    tree, so nothing is left to drift: the tracker statistics, the pose and every surfel must be IDENTICAL to the
+    oracle's frame after frame (the north_star bars — 1e-4 m / 1e-4 rad, 1e-5 relative — are met with zero error)."""
+    n = 16
     ef = hip.ElasticFusion()
     o = efo.Fusion()
-    worst_t = worst_a = 0.0
     for k in range(n):
         rgb, depth, Tgt = seq.frame(k)
         ef.processFrame(rgb, depth, k * 33333)
         o.process_frame(rgb, depth, k * 33333)
-        dt, da = pose_err(ef.get_T_wc(), o.pose())
-        worst_t, worst_a = max(worst_t, dt), max(worst_a, da)
-        # tracker internals after each frame
-        st, _, _ = ef.trackingStats()
+        st, A, b = ef.trackingStats()
         so = o.stats()
         if k > 0:
-            assert st[1] == pytest.approx(so[1], rel=1e-2), (k, st, so)   # ICP inlier count (free-running: fp32 sum order differs)
-    assert worst_t <= 1e-4 and worst_a <= 1e-4, (worst_t, worst_a)
+            assert np.array_equal(np.asarray(st, np.float32).view(np.uint32), np.asarray(so, np.float32).view(np.uint32)), (k, st, so)
+        dt, da = pose_err(ef.get_T_wc(), o.pose())
+        assert dt <= 1e-4 and da <= 1e-4, (k, dt, da)
+        # the double-precision pose may differ in its last bits (libm sin/cos/atan2, test_gpu_ops_linalg.py); what the
+        # float pipeline consumes from it does not
+        assert np.abs(ef.get_T_wc() - o.pose()).max() <= 1e-15, (k, np.abs(ef.get_T_wc() - o.pose()).max())
+        assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32)), k
+        assert ef.lastCount() == o.map_count(), k
     # and both stay close to the generating trajectory (known-answer guard on the oracle itself)
     dt, da = pose_err(ef.get_T_wc(), seq.pose(n - 1))
     assert dt < 0.01 and da < 0.01, (dt, da)
     m, mr = ef.downloadMap(), o.map()
-    assert abs(len(m) - len(mr)) <= max(4, int(2e-4 * len(mr))), (len(m), len(mr))
-    if len(m) == len(mr):
-        assert compare_maps(m, mr) > 0.995
+    assert m.shape == mr.shape
+    assert compare_maps(m, mr) == 1.0
+    assert np.array_equal(m.view(np.uint32), mr.view(np.uint32))
     traj, ts = ef.trajectory()
     assert len(traj) == n and ts[3] == 3 * 33333
     ef.close()

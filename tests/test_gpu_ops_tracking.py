@@ -166,11 +166,9 @@ def test_icp_step(ops, odo, oracle_state):
                 odo.buffer("vmap_g_prev", level), odo.buffer("nmap_g_prev", level), 0.10, float(np.sin(20 * 3.14159254 / 180)))
         A_r, b_r, res_r = efo.icp_step(*args)
         A, b, res = ops.icp_step(*args)
-        assert res[1] == res_r[1] and res_r[1] > 1000, (res, res_r)   # inlier count exact
-        scaleA = np.abs(A_r).max()
-        assert np.abs(A - A_r).max() <= 1e-5 * scaleA, (level, np.abs(A - A_r).max(), scaleA)
-        assert np.abs(b - b_r).max() <= 1e-5 * max(np.abs(b_r).max(), 1e-3 * scaleA)
-        assert abs(res[0] - res_r[0]) <= 1e-5 * res_r[0]
+        assert res_r[1] > 1000, (res, res_r)
+        # the HIP reduction reproduces the reference's fp32 summation tree (reduce.cu:57-140,313-317): bit-exact
+        assert bits_equal(A, A_r) and bits_equal(b, b_r) and bits_equal(res, res_r), (level, np.abs(A - A_r).max(), res, res_r)
         assert np.array_equal(A, A.T)
 
 
@@ -196,9 +194,7 @@ def test_rgb_residual_and_step(ops, odo):
         sigma = float(np.sqrt(cnt_r))
         A_r, b_r = efo.rgb_step(c_r, sigma, cloud, fx, fy, odo.buffer("dIdx", level), odo.buffer("dIdy", level), 0.125)
         A, b = ops.rgb_step(c, sigma, cloud, fx, fy, odo.buffer("dIdx", level), odo.buffer("dIdy", level), 0.125)
-        scaleA = np.abs(A_r).max()
-        assert np.abs(A - A_r).max() <= 1e-5 * scaleA
-        assert np.abs(b - b_r).max() <= 1e-5 * max(np.abs(b_r).max(), 1e-3 * scaleA)
+        assert bits_equal(A, A_r) and bits_equal(b, b_r), (level, np.abs(A - A_r).max())
 
 
 def test_so3_step(ops, odo):
@@ -210,7 +206,5 @@ def test_so3_step(ops, odo):
             np.linalg.inv(K).astype(np.float32), (K @ R).astype(np.float32))
     A_r, b_r, res_r = efo.so3_step(*args)
     A, b, res = ops.so3_step(*args)
-    assert res[1] == res_r[1] and res_r[1] > 1000
-    assert np.abs(A - A_r).max() <= 1e-5 * np.abs(A_r).max()
-    assert np.abs(b - b_r).max() <= 1e-5 * max(np.abs(b_r).max(), 1e-3 * np.abs(A_r).max())
-    assert abs(res[0] - res_r[0]) <= 1e-5 * res_r[0]
+    assert res_r[1] > 1000
+    assert bits_equal(A, A_r) and bits_equal(b, b_r) and bits_equal(res, res_r), (np.abs(A - A_r).max(), res, res_r)
