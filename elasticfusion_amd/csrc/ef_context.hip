@@ -51,7 +51,6 @@ struct ef_ctx {
   efm::PredictMaps pm{};
   efm::FillMaps fm{};
   unsigned long long* zbuf = nullptr;
-  unsigned* dense_counter = nullptr;
   // global model
   efm::SurfelSoA maps[2]{};
   int cur = 0;
@@ -110,24 +109,11 @@ int dev_alloc(ef_ctx* c, T** p, size_t n, int fill = 0) {
   } while (0)
 
 // scalar per-frame bookkeeping kernels -----------------------------------------------------------
-// !denseEnough(): float(sum)/float(rows*cols) > 0.75f over the (W/20)x(H/20) samples (ElasticFusion.cpp:256-268)
-__global__ void k_frame_begin(eft::TrackState* st, unsigned* dense_counter, int samples) {
+__global__ void k_init_state(eft::TrackState* st, int dense_samples) {
   if (threadIdx.x != 0) return;
-  const unsigned sum = *dense_counter;
-  *dense_counter = 0;
-  st->should_fill_in = !((float)sum / (float)samples > 0.75f);
-}
-__global__ void k_set_pose(eft::TrackState* st, efl::SE3 T) {
-  if (threadIdx.x != 0) return;
-  for (int i = 0; i < 4; ++i) st->q[i] = T.q[i];
-  for (int i = 0; i < 3; ++i) st->t[i] = T.t[i];
-}
-__global__ void k_log_pose(const eft::TrackState* st, double* traj, int slot) {
-  if (threadIdx.x != 0) return;
-  efl::SE3 T;
-  for (int i = 0; i < 4; ++i) T.q[i] = st->q[i];
-  for (int i = 0; i < 3; ++i) T.t[i] = st->t[i];
-  efl::se3_matrix(T, traj + (size_t)slot * 16);
+  st->dense_count = 0;
+  st->dense_samples = dense_samples;
+  st->map_counts[0] = st->map_counts[1] = 0;
 }
 __global__ void k_set_count(unsigned* count_dev, unsigned v) {
   if (threadIdx.x == 0) *count_dev = v;
@@ -151,9 +137,9 @@ void timer_end(ef_ctx* c, const char* name) {
 
 int do_predict(ef_ctx* c) {
   // ElasticFusion::predict(), ElasticFusion.cpp:621-653: combinedPredict(ACTIVE) + FillIn (fused into the resolve)
-  efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_count, c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick,
+  efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick,
                         c->cfg.time_delta, c->zbuf, c->pm, c->fm, c->depth_filtered, c->rgb, c->cfg.frame_to_frame_rgb != 0,
-                        c->dense_counter, c->stream);
+                        &c->st->dense_count, c->stream);
   return EF_OK;
 }
 
@@ -169,14 +155,17 @@ int process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_d
   timer_begin(c, "Preprocess");
   efm::preprocess_depth(c->depth_raw, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, s);
   timer_end(c, "Preprocess");
-  hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, s, c->st, c->dense_counter, (W / 20) * (H / 20));
 
   const bool rgbOnly = c->cfg.rgb_only != 0;
+  // t_T_wc.push_back / poseLogTimes.push_back, ElasticFusion.cpp:588-589: the pose is logged by the kernel that produces it
+  const int log_slot = (int)c->stamps.size() < c->traj_cap ? (int)c->stamps.size() : -1;
+  if (log_slot >= 0) c->stamps.push_back(timestamp);
   if (c->tick == 1) {  // ElasticFusion.cpp:290-296
     timer_begin(c, "feedbackBuffers");
     efm::seed_map(c->cam, c->rgb, c->depth_metric, c->depth_metric_filtered, c->tick, c->maxDepthProcessed, c->maps[c->cur],
-                  &c->st->map_count, c->cs, s);
+                  &c->st->map_counts[c->cur], c->cs, s);
     eft::init_first_rgb(c->pyr, c->rgb, s);
+    if (log_slot >= 0) eft::log_pose(c->st, c->traj, log_slot, s);
     timer_end(c, "feedbackBuffers");
   } else {
     if (!in_T_wc) {
@@ -198,38 +187,31 @@ int process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_d
       timer_begin(c, "odom");
       const bool sample = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0;
       eft::track(c->pyr, c->st, c->intr, tp, s, sample ? &c->probe : nullptr);
-      eft::track_end(c->st, rgb, weightMultiplier, s);
+      eft::track_end(c->st, rgb, weightMultiplier, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
       timer_end(c, "odom");
     } else {
-      eft::save_prev_pose(c->st, s);
-      hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->st, efl::se3_from_matrix(in_T_wc));
-      eft::pose_injected(c->st, weightMultiplier, true, s);
+      eft::pose_injected(c->st, in_T_wc, true, weightMultiplier, true, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
     }
     // mid-frame predict() of ElasticFusion.cpp:387 is dead work without loop closure: skipped
     if (!rgbOnly) {  // ElasticFusion.cpp:536-585
       timer_begin(c, "indexMap");
-      efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_count, c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
+      efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
                            c->im, s);
       timer_end(c, "indexMap");
       timer_begin(c, "Fuse::Data+Update");
       efm::fuse(c->cam, c->st->pose_f, c->tick, c->rgb, c->depth_metric, c->depth_metric_filtered, c->im, c->maxDepthProcessed,
-                &c->st->weighting, c->maps[c->cur], &c->st->map_count, c->cand, c->winner, s);
+                &c->st->weighting, c->maps[c->cur], &c->st->map_counts[c->cur], c->cand, c->winner, s);
       timer_end(c, "Fuse::Data+Update");
       timer_begin(c, "indexMap2");
-      efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_count, c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
+      efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
                            c->im, s);
       timer_end(c, "indexMap2");
       timer_begin(c, "Fuse::Copy");
-      efm::clean(c->cam, c->st->T_cw, c->tick, c->im, c->cfg.confidence, c->cfg.time_delta, c->maps[c->cur], &c->st->map_count, c->cand,
-                 c->winner, c->maps[c->cur ^ 1], c->capacity, c->cs, c->overflow, s);
+      efm::clean(c->cam, c->st->T_cw, c->tick, c->im, c->cfg.confidence, c->cfg.time_delta, c->maps[c->cur], &c->st->map_counts[c->cur], c->cand,
+                 c->winner, c->maps[c->cur ^ 1], &c->st->map_counts[c->cur ^ 1], c->capacity, c->cs, c->overflow, s);
       c->cur ^= 1;
       timer_end(c, "Fuse::Copy");
     }
-  }
-  // t_T_wc.push_back / poseLogTimes.push_back, ElasticFusion.cpp:588-589
-  if ((int)c->stamps.size() < c->traj_cap) {
-    hipLaunchKernelGGL(k_log_pose, dim3(1), dim3(64), 0, s, (const eft::TrackState*)c->st, c->traj, (int)c->stamps.size());
-    c->stamps.push_back(timestamp);
   }
   timer_begin(c, "IndexMap::ACTIVE");
   do_predict(c);  // ElasticFusion.cpp:599
@@ -285,7 +267,6 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->fm.vertex, P);
   EF_ALLOC(c, c->fm.normal, P);
   EF_ALLOC(c, c->zbuf, P, 0xFF);
-  EF_ALLOC(c, c->dense_counter, 1);
   EF_ALLOC(c, c->overflow, 1);
   // global model
   c->capacity = g.max_surfels;
@@ -308,10 +289,10 @@ int ctx_init(ef_ctx* c) {
   c->traj_cap = 1 << 16;
   EF_ALLOC(c, c->traj, (size_t)c->traj_cap * 16);
   // T_wc = identity (ElasticFusion.h: T_wc_curr default) -> publish the float matrices
-  efl::SE3 I{{0, 0, 0, 1}, {0, 0, 0}};
-  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, c->st, I);
-  eft::save_prev_pose(c->st, s);
-  eft::pose_injected(c->st, 1.0f, false, s);
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->st, (W / 20) * (H / 20));
+  const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  eft::pose_injected(c->st, I16, false, 1.0f, false, nullptr, 0, s);
+  eft::pose_injected(c->st, I16, true, 1.0f, false, nullptr, 0, s);   // previous pose = identity too
   EF_HIP(c, hipStreamSynchronize(s));
   return EF_OK;
 }
@@ -418,7 +399,7 @@ int ef_process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* dept
 }
 int ef_predict(ef_ctx* c) {
   if (!c) return EF_EINVAL;
-  EF_HIP(c, hipMemsetAsync(c->dense_counter, 0, sizeof(unsigned), c->stream));
+  EF_HIP(c, hipMemsetAsync(&c->st->dense_count, 0, sizeof(unsigned), c->stream));
   return do_predict(c);
 }
 int ef_get_pose(ef_ctx* c, double* T16) {
@@ -459,7 +440,7 @@ int ef_get_trajectory(ef_ctx* c, double* T16s, int64_t* stamps, int max_frames, 
 }
 int ef_map_count(ef_ctx* c, uint32_t* count) {
   if (!c || !count) return EF_EINVAL;
-  EF_HIP(c, hipMemcpyAsync(count, &c->st->map_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipMemcpyAsync(count, &c->st->map_counts[c->cur], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   EF_HIP(c, hipStreamSynchronize(c->stream));
   return EF_OK;
 }
@@ -495,7 +476,7 @@ int ef_map_upload(ef_ctx* c, const float* surfels, uint32_t count) {
     (void)hipFree(tmp);
     EF_HIP(c, e);
   }
-  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, c->stream, &c->st->map_count, count);
+  hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, c->stream, &c->st->map_counts[c->cur], count);
   return EF_OK;
 }
 int ef_save_freiburg(ef_ctx* c, const char* path) {
@@ -1055,9 +1036,10 @@ int ef_op_clean(const ef_cam* cam, const double* T16, int time, const uint32_t* 
   cs.chunk_offset = m.alloc<uint32_t>(cs.max_chunks);
   cs.totals = m.alloc<uint32_t>(8);
   efm::IndexMaps im{(uint32_t*)index, (float4*)vc, (float4*)ct, (float4*)nr};
-  efm::clean(to_cam(cam), mats, time, im, confThreshold, timeDelta, soa, cnt, cand, winner, out, cap, cs, nullptr, s);
+  unsigned* cnt_out = m.alloc<unsigned>(1);
+  efm::clean(to_cam(cam), mats, time, im, confThreshold, timeDelta, soa, cnt, cand, winner, out, cnt_out, cap, cs, nullptr, s);
   unsigned hn = 0;
-  (void)hipMemcpyAsync(&hn, cnt, sizeof(hn), hipMemcpyDeviceToHost, s);
+  (void)hipMemcpyAsync(&hn, cnt_out, sizeof(hn), hipMemcpyDeviceToHost, s);
   OP_SYNC(s);
   efm::soa_to_aos(out, hn, surfels_out, s);
   OP_SYNC(s);

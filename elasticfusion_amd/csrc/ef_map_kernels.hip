@@ -163,8 +163,10 @@ __global__ void k_soa_to_aos(SurfelSoA soa, uint32_t count, float4* __restrict__
 // n = *count_dev + extra (count_dev may be null => n = extra)
 __device__ __forceinline__ unsigned dyn_n(const unsigned* count_dev, unsigned extra) { return (count_dev ? *count_dev : 0u) + extra; }
 
+// count_out / capacity / overflow_flag: optional clamped copy of the total (the new surfel count of clean())
 __global__ void __launch_bounds__(1024) k_scan_chunks(const uint32_t* __restrict__ counts, const unsigned* count_dev, unsigned extra,
-                                                       uint32_t* __restrict__ offsets, uint32_t* total_out) {
+                                                       uint32_t* __restrict__ offsets, uint32_t* total_out, unsigned* count_out = nullptr,
+                                                       uint32_t capacity = 0, int* overflow_flag = nullptr) {
   __shared__ unsigned wsum[16];
   __shared__ unsigned carry_s;
   const unsigned n = dyn_n(count_dev, extra);
@@ -195,7 +197,14 @@ __global__ void __launch_bounds__(1024) k_scan_chunks(const uint32_t* __restrict
     if (t == 0) carry_s = carry + tot;
     __syncthreads();
   }
-  if (t == 0) *total_out = carry_s;
+  if (t == 0) {
+    *total_out = carry_s;
+    if (count_out) {
+      unsigned tot = carry_s;
+      if (tot > capacity) { tot = capacity; if (overflow_flag) *overflow_flag = 1; }
+      *count_out = tot;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -737,12 +746,6 @@ __global__ void __launch_bounds__(BLK) k_clean_scatter(SurfelSoA map, const unsi
     }
   }
 }
-__global__ void k_clean_finish(const uint32_t* total, unsigned* count_dev, uint32_t capacity, int* overflow_flag) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  unsigned t = *total;
-  if (t > capacity) { t = capacity; if (overflow_flag) *overflow_flag = 1; }
-  *count_dev = t;
-}
 
 // candidates (tag != 0) -> AoS list in draw order
 __global__ void __launch_bounds__(BLK) k_cand_flags(Candidates cand, uint8_t* __restrict__ flags, uint32_t* __restrict__ chunk_count) {
@@ -865,16 +868,15 @@ void fuse(const Cam& cam, const float* pose_f16_dev, int time, const uint8_t* rg
 }
 
 void clean(const Cam& cam, const float* T_cw16_dev, int time, IndexMaps im, float confThreshold, int timeDelta, SurfelSoA map,
-           unsigned* count_dev, Candidates cand, uint32_t* winner, SurfelSoA out, uint32_t capacity, const CompactScratch& cs,
-           int* overflow_flag, hipStream_t s) {
+           const unsigned* count_dev, Candidates cand, uint32_t* winner, SurfelSoA out, unsigned* count_out_dev, uint32_t capacity,
+           const CompactScratch& cs, int* overflow_flag, hipStream_t s) {
   CleanArgs A{cam, T_cw16_dev, time, im, confThreshold, timeDelta};
-  hipLaunchKernelGGL(k_clean_flags, dim3(SURFEL_GRID), dim3(BLK), 0, s, A, map, (const unsigned*)count_dev, cand, winner, cs.flags,
+  hipLaunchKernelGGL(k_clean_flags, dim3(SURFEL_GRID), dim3(BLK), 0, s, A, map, count_dev, cand, winner, cs.flags,
                      cs.chunk_count);
   hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, (const uint32_t*)cs.chunk_count, (const unsigned*)count_dev, (unsigned)cand.n,
-                     cs.chunk_offset, cs.totals);
-  hipLaunchKernelGGL(k_clean_scatter, dim3(SURFEL_GRID), dim3(BLK), 0, s, map, (const unsigned*)count_dev, cand, (const uint8_t*)cs.flags,
+                     cs.chunk_offset, cs.totals, count_out_dev, capacity, overflow_flag);
+  hipLaunchKernelGGL(k_clean_scatter, dim3(SURFEL_GRID), dim3(BLK), 0, s, map, count_dev, cand, (const uint8_t*)cs.flags,
                      (const uint32_t*)cs.chunk_offset, time, out, capacity);
-  hipLaunchKernelGGL(k_clean_finish, dim3(1), dim3(64), 0, s, (const uint32_t*)cs.totals, count_dev, capacity, overflow_flag);
 }
 
 void candidates_to_aos(Candidates cand, float* aos, unsigned* count_dev, const CompactScratch& cs, hipStream_t s) {

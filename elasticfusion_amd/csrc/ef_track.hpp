@@ -15,6 +15,7 @@ constexpr int REDUCE_BLOCK = 256;    // threads per workgroup of the integer (or
 // partials[acc * VWARPS + warp].
 constexpr int VTHREADS = 16384;      // 64 x 256, types.cuh:62-63
 constexpr int VWARPS = VTHREADS / 32;
+constexpr int RGB_SLOTS = 64;
 constexpr int SE3_ACCS = 29;         // JtJJtrSE3, types.cuh:98-143
 constexpr int SO3_ACCS = 11;         // JtJJtrSO3, types.cuh:145-168
 constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * VWARPS;  // ICP block then RGB block
@@ -39,7 +40,10 @@ struct TrackState {
   float Rcurr[9], tcurr[3];
   double resultRt[16];
   float krkinv[9], kt[3];     // K R K^-1 and K t of the coming iteration (RGBDOdometry.cpp:407-417)
-  int rgb_sum[2];             // {count, sum diff^2}: integer atomics => order independent (reduce.cu:687-709)
+  // {count, sum diff^2} of the residual pass, integer => order independent (reduce.cu:687-709).  Spread over
+  // RGB_SLOTS cache lines (workgroup b adds to slot b % RGB_SLOTS) so the device-scope atomics do not serialise
+  // on one address; consumers add the slots up.
+  int rgb_slots[RGB_SLOTS][16];
   float lastRGBErrorLevel;    // rgbOnly early-exit bookkeeping (RGBDOdometry.cpp:445-450)
   int rgb_broken;
   // outputs (RGBDOdometry.h:74-82)
@@ -55,10 +59,13 @@ struct TrackState {
   unsigned so3_ticket;        // last-workgroup-done counter
   // per-frame scalars produced on the device
   float weighting;            // fusion weight (ElasticFusion.cpp:371-383)
-  int should_fill_in;         // !denseEnough (ElasticFusion.cpp:304-305)
+  // denseEnough() tally of the last predict() (Resize::image samples with r,g,b > 0; ElasticFusion.cpp:256-268):
+  // surface_resolve adds to it, the next frame's tracker reads it (fill-in maps are used when
+  // !(dense_count / dense_samples > 0.75), :304-305) and k_track_begin / k_pose_injected re-arm it.
+  unsigned dense_count;
+  int dense_samples;
   int tick;
-  unsigned map_count;         // live surfels
-  unsigned new_count;         // fuse candidates this frame
+  unsigned map_counts[2];     // live surfels of the two ping-pong map buffers (clean reads one, writes the other)
   // float matrices consumed by the map kernels
   float T_cw[16];             // T_wc.inverse().matrix().cast<float>()  (IndexMap.cpp:208)
   float pose_f[16];           // T_wc.cast<float>().matrix()            (GlobalModel.cpp:403)
@@ -143,7 +150,7 @@ void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* next
 // ---- frame-tier launchers (device-resident state; nothing here synchronises) ----
 // RGBDOdometry::initICP(filteredDepth, cutoff): u16 pyramid + vertex/normal maps, RGBDOdometry.cpp:121-147
 void init_icp(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, hipStream_t s);
-// initICPModel + initRGBModel's depth half: predicted (or fill-in, chosen by st->should_fill_in) float4 maps ->
+// initICPModel + initRGBModel's depth half: predicted (or fill-in, chosen by the dense_count tally) float4 maps ->
 // world-frame planar pyramids + model depth L0.  RGBDOdometry.cpp:171-210, :217
 void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
                     const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s);
@@ -157,8 +164,12 @@ void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
 void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe = nullptr);
 // tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +
 // velocity weighting (ElasticFusion.cpp:369-383) + the float matrices of the map passes
-void track_end(TrackState* st, bool rgb, float weightMultiplier, hipStream_t s);
-void pose_injected(TrackState* st, float weightMultiplier, bool with_weighting, hipStream_t s);
-void save_prev_pose(TrackState* st, hipStream_t s);
+// traj / slot: device trajectory log (16 doubles per frame; t_T_wc of ElasticFusion.cpp:588) or null
+void track_end(TrackState* st, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s);
+// caller-supplied pose (in_T_wc, ElasticFusion.cpp:367-369): sets q/t from the row-major 4x4, optionally keeping the old
+// pose as "previous" for the velocity weighting, publishes the float matrices, re-arms the denseEnough() tally
+void pose_injected(TrackState* st, const double* T_wc16, bool save_prev, float weightMultiplier, bool with_weighting, double* traj,
+                   int slot, hipStream_t s);
+void log_pose(const TrackState* st, double* traj, int slot, hipStream_t s);
 
 }  // namespace eft

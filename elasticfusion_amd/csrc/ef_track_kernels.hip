@@ -358,6 +358,10 @@ __global__ void k_project_points(const float* __restrict__ depth, int cols, int 
 // reference's order, so every output equals the multi-kernel path bit for bit; the intermediate
 // camera-frame pyramids never touch HBM.
 // ------------------------------------------------------------------------------------------
+// !denseEnough(): float(sum) / float(rows * cols) > 0.75f over the (W/20)x(H/20) samples (ElasticFusion.cpp:256-268,304-305)
+__device__ __forceinline__ bool use_fill_in(const TrackState* __restrict__ st) {
+  return !((float)st->dense_count / (float)st->dense_samples > 0.75f);
+}
 struct ModelMapsArgs {
   const float4* pred_vertex;
   const float4* pred_normal;
@@ -389,7 +393,7 @@ __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const
   const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
   const int cols = A.cols, rows = A.rows;
   if (bx * 4 >= cols || by * 4 >= rows) return;
-  const bool fill = st->should_fill_in != 0;
+  const bool fill = use_fill_in(st);
   const float4* __restrict__ vsrc = fill ? A.fill_vertex : A.pred_vertex;
   const float4* __restrict__ nsrc = fill ? A.fill_normal : A.pred_normal;
   const m33 R = m33_load(st->R_wc_f);
@@ -701,9 +705,22 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_residual(const ResidualPac
     }
     V.corres[k] = packed;
   }
-  block_reduce_atomic_int2<REDUCE_BLOCK>(cnt, sq, lds, sums);
+  block_reduce_atomic_int2<REDUCE_BLOCK>(cnt, sq, lds, sums + (blockIdx.x % RGB_SLOTS) * 16);
 }
 
+// {count, sum diff^2} = sum over the RGB_SLOTS slots; call with the whole first wave (threadIdx.x < 64) converged
+__device__ __forceinline__ void sum_rgb_slots(const int* __restrict__ slots, int& cnt, int& sq) {
+  static_assert(RGB_SLOTS == 64, "one slot per lane");
+  const int lane = threadIdx.x & 63;
+  int a = slots[lane * 16], b = slots[lane * 16 + 1];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off, 64);
+    b += __shfl_down(b, off, 64);
+  }
+  cnt = __shfl(a, 0, 64);
+  sq = __shfl(b, 0, 64);
+}
 // sigma follows RGBDOdometry.cpp:442 (quirk Q2)
 __device__ __forceinline__ float sigma_from_sums(int sigma, int rgbSize, bool rgbOnly) {
   if (rgbOnly) return -1.0f;
@@ -788,7 +805,7 @@ struct Se3Inputs {            // device pointers: the Gauss-Newton state the acc
   const float* tcurr;         // 3
   const float* Rprev_inv;     // 9
   const float* tprev;         // 3
-  const int* rgb_sum;         // {count, sum diff^2} of this iteration's residual pass, or null => sigma_fixed
+  const int* rgb_slots;       // residual-pass sums (TrackState::rgb_slots), or null => sigma_fixed
   const int* broken;          // rgbOnly early-exit flag, or null
   float sigma_fixed;
   bool rgbOnly;
@@ -812,7 +829,16 @@ __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const Rgb
     P.tprev = {in.tprev[0], in.tprev[1], in.tprev[2]};
   }
   float sigma = in.sigma_fixed;
-  if (HAS_RGB && in.rgb_sum) sigma = sigma_from_sums(in.rgb_sum[1], in.rgb_sum[0], in.rgbOnly);
+  if (HAS_RGB && in.rgb_slots) {
+    __shared__ float sigma_s;
+    if (t < 64) {
+      int cnt, sq;
+      sum_rgb_slots(in.rgb_slots, cnt, sq);
+      if (t == 0) sigma_s = sigma_from_sums(sq, cnt, in.rgbOnly);
+    }
+    __syncthreads();
+    sigma = sigma_s;
+  }
   // phase-B identity of this thread
   const int l = t & 31, term = (t >> 5) & 1, part = t >> 6;
   const bool chain_thread = t < 256 && (term == 0 ? HAS_ICP : HAS_RGB);
@@ -870,23 +896,34 @@ __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const Rgb
 //   reduceSum<<<1,1024>>>: threads 0..63 hold the 64 block partials => two warp32 trees, then shared[0] + shared[1].
 // bs: na*64 floats of LDS, out: na floats of LDS.  COHERENT: read the partials with agent-scope atomic loads (used
 // by the last-workgroup-done pattern, where the partials were written by other workgroups of the same launch).
-template <int BLOCK, bool COHERENT>
-__device__ __forceinline__ void final_tree(const float* partials, int na, float* bs, float* out) {
+// All loads of a thread are issued before the first shuffle (NA is a compile-time count): one memory round trip, not NA.
+template <int BLOCK, int NA, bool COHERENT>
+__device__ __forceinline__ void final_tree(const float* partials, float* bs, float* out) {
+  static_assert((NA * VWARPS) % BLOCK == 0 && BLOCK % 64 == 0, "whole waves, whole passes");
+  constexpr int PASSES = NA * VWARPS / BLOCK;
   const int t = threadIdx.x;
-  for (int idx = t; idx < na * VWARPS; idx += BLOCK) {
-    float v = COHERENT ? __hip_atomic_load(partials + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials[idx];
-    v += __shfl_down(v, 4, 8);
-    v += __shfl_down(v, 2, 8);
-    v += __shfl_down(v, 1, 8);
-    if ((idx & 7) == 0) bs[idx >> 3] = v;   // [acc][block]
+  float v[PASSES];
+#pragma unroll
+  for (int j = 0; j < PASSES; ++j) {
+    const int idx = t + j * BLOCK;
+    v[j] = COHERENT ? __hip_atomic_load(partials + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials[idx];
+  }
+#pragma unroll
+  for (int j = 0; j < PASSES; ++j) {
+    const int idx = t + j * BLOCK;
+    float x = v[j];
+    x += __shfl_down(x, 4, 8);
+    x += __shfl_down(x, 2, 8);
+    x += __shfl_down(x, 1, 8);
+    if ((idx & 7) == 0) bs[idx >> 3] = x;   // [acc][block]
   }
   __syncthreads();
-  for (int idx = t; idx < na * 64; idx += BLOCK) {
-    float v = bs[idx];
+  for (int idx = t; idx < NA * 64; idx += BLOCK) {
+    float x = bs[idx];
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_down(v, off, 32);
-    const float w1 = __shfl(v, 32, 64);
-    if ((idx & 63) == 0) out[idx >> 6] = v + w1;
+    for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, 32);
+    const float w1 = __shfl(x, 32, 64);
+    if ((idx & 63) == 0) out[idx >> 6] = x + w1;
   }
   __syncthreads();
 }
@@ -929,10 +966,9 @@ __device__ inline void so3_matrices(const double* resultR, Intr k, float* mats27
   for (int i = 0; i < 9; ++i) { mats27[i] = (float)H[i]; mats27[9 + i] = (float)Kinv[i]; mats27[18 + i] = (float)KR[i]; }
 }
 
-// first kernel of getIncrementalTransformation: Rprev/tprev/Rcurr/tcurr (RGBDOdometry.cpp:266-273,375-377),
-// the !denseEnough() decision of this frame's model prediction (ElasticFusion.cpp:256-268,304-305) is taken by
-// k_frame_begin before the pyramids are built; here also the SO(3) loop state, or — without SO(3) — the first
-// level's K R K^-1.
+// first kernel of getIncrementalTransformation: Rprev/tprev/Rcurr/tcurr (RGBDOdometry.cpp:266-273,375-377), the
+// SO(3) loop state or — without SO(3) — the first level's K R K^-1; re-arms the denseEnough() tally (its consumers,
+// the model-side pyramids, have run by now).
 __global__ void k_track_begin(TrackState* st, bool so3, Intr kso3, Intr kfirst) {
   if (threadIdx.x != 0) return;
   double R[9];
@@ -943,11 +979,12 @@ __global__ void k_track_begin(TrackState* st, bool so3, Intr kso3, Intr kfirst) 
   for (int i = 0; i < 4; ++i) st->q_prev[i] = st->q[i];
   for (int i = 0; i < 3; ++i) st->t_prev[i] = st->t[i];
   efl::m4_identity(st->resultRt);
-  st->rgb_sum[0] = st->rgb_sum[1] = 0;
+  for (int i = 0; i < RGB_SLOTS; ++i) st->rgb_slots[i][0] = st->rgb_slots[i][1] = 0;
   st->rgb_broken = 0;
   st->lastRGBErrorLevel = 3.402823466e+38f;
   st->so3_iterations = 0;
   st->so3_ticket = 0;
+  st->dense_count = 0;
   if (so3) {
     efl::m3_identity(st->so3_resultR);
     efl::m3_identity(st->so3_lastResultR);
@@ -971,13 +1008,17 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_update(TrackState* st, co
   __shared__ float sums[2 * SE3_ACCS];
   const bool broken = st->rgb_broken != 0;
   if (!broken) {
-    if (icp && rgb) final_tree<SOLVE_BLOCK, false>(partials, 2 * SE3_ACCS, bs, sums);
-    else if (icp) final_tree<SOLVE_BLOCK, false>(partials, SE3_ACCS, bs, sums);
-    else final_tree<SOLVE_BLOCK, false>(partials + SE3_ACCS * VWARPS, SE3_ACCS, bs, sums + SE3_ACCS);
+    if (icp && rgb) final_tree<SOLVE_BLOCK, 2 * SE3_ACCS, false>(partials, bs, sums);
+    else if (icp) final_tree<SOLVE_BLOCK, SE3_ACCS, false>(partials, bs, sums);
+    else final_tree<SOLVE_BLOCK, SE3_ACCS, false>(partials + SE3_ACCS * VWARPS, bs, sums + SE3_ACCS);
+  }
+  int sigma = 0, rgbSize = 0;
+  if (threadIdx.x < 64) {
+    sum_rgb_slots(&st->rgb_slots[0][0], rgbSize, sigma);
+    st->rgb_slots[threadIdx.x][0] = 0;
+    st->rgb_slots[threadIdx.x][1] = 0;
   }
   if (threadIdx.x != 0) return;
-  const int sigma = st->rgb_sum[1], rgbSize = st->rgb_sum[0];
-  st->rgb_sum[0] = st->rgb_sum[1] = 0;
   if (broken) {
     if (level_changes) { st->rgb_broken = 0; st->lastRGBErrorLevel = 3.402823466e+38f; compute_krk(st->resultRt, knext, st->krkinv, st->kt); }
     return;
@@ -1067,7 +1108,15 @@ __device__ inline void compute_weighting(TrackState* st, float weightMultiplier)
   const float w = 1.0f - (weighting / largest);
   st->weighting = (w > minWeight ? w : minWeight) * weightMultiplier;
 }
-__global__ void k_track_end(TrackState* st, bool rgb, float weightMultiplier) {
+// t_T_wc.push_back(T_wc), ElasticFusion.cpp:588: one 4x4 double matrix per frame in a device-resident log
+__device__ inline void log_pose(const TrackState* st, double* traj, int slot) {
+  if (!traj) return;
+  efl::SE3 T;
+  for (int i = 0; i < 4; ++i) T.q[i] = st->q[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = st->t[i];
+  efl::se3_matrix(T, traj + (size_t)slot * 16);
+}
+__global__ void k_track_end(TrackState* st, bool rgb, float weightMultiplier, double* traj, int slot) {
   if (threadIdx.x != 0) return;
   if (rgb) {
     const float d0 = st->tcurr[0] - st->tprev[0], d1 = st->tcurr[1] - st->tprev[1], d2 = st->tcurr[2] - st->tprev[2];
@@ -1085,17 +1134,25 @@ __global__ void k_track_end(TrackState* st, bool rgb, float weightMultiplier) {
   for (int i = 0; i < 3; ++i) st->t[i] = (double)st->tcurr[i];
   publish_pose(st);
   compute_weighting(st, weightMultiplier);
+  log_pose(st, traj, slot);
 }
-// pose injected by the caller (in_T_wc != 0, ElasticFusion.cpp:367-369): q/t already uploaded
-__global__ void k_pose_injected(TrackState* st, float weightMultiplier, bool with_weighting) {
+// pose injected by the caller (in_T_wc != 0, ElasticFusion.cpp:367-369)
+__global__ void k_pose_injected(TrackState* st, efl::SE3 T, bool save_prev, float weightMultiplier, bool with_weighting, double* traj,
+                                int slot) {
   if (threadIdx.x != 0) return;
+  if (save_prev) {
+    for (int i = 0; i < 4; ++i) st->q_prev[i] = st->q[i];
+    for (int i = 0; i < 3; ++i) st->t_prev[i] = st->t[i];
+  }
+  for (int i = 0; i < 4; ++i) st->q[i] = T.q[i];
+  for (int i = 0; i < 3; ++i) st->t[i] = T.t[i];
   publish_pose(st);
   if (with_weighting) compute_weighting(st, weightMultiplier);
+  st->dense_count = 0;
+  log_pose(st, traj, slot);
 }
-__global__ void k_save_prev_pose(TrackState* st) {
-  if (threadIdx.x != 0) return;
-  for (int i = 0; i < 4; ++i) st->q_prev[i] = st->q[i];
-  for (int i = 0; i < 3; ++i) st->t_prev[i] = st->t[i];
+__global__ void k_log_pose(const TrackState* st, double* traj, int slot) {
+  if (threadIdx.x == 0) log_pose(st, traj, slot);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1178,7 +1235,7 @@ __global__ void __launch_bounds__(SO3_BLOCK) k_so3_iteration(const uint8_t* __re
   __syncthreads();
   if (!is_last) return;
   __threadfence();
-  final_tree<SO3_BLOCK, true>(partials, SO3_ACCS, lds_rows /* reused: 11*64 floats */, red);
+  final_tree<SO3_BLOCK, SO3_ACCS, true>(partials, lds_rows /* reused: 11*64 floats */, red);
   if (t != 0) return;
   st->so3_ticket = 0;
   st->so3_iterations = it + 1;
@@ -1240,7 +1297,8 @@ __global__ void __launch_bounds__(SO3_BLOCK) k_so3_op(const uint8_t* __restrict_
 __global__ void __launch_bounds__(SOLVE_BLOCK) k_final_tree_op(const float* __restrict__ partials, int na, float* __restrict__ out) {
   __shared__ float bs[SE3_ACCS * 64];
   __shared__ float sums[SE3_ACCS];
-  final_tree<SOLVE_BLOCK, false>(partials, na, bs, sums);
+  if (na == SE3_ACCS) final_tree<SOLVE_BLOCK, SE3_ACCS, false>(partials, bs, sums);
+  else final_tree<SOLVE_BLOCK, SO3_ACCS, false>(partials, bs, sums);
   if ((int)threadIdx.x < na) out[threadIdx.x] = sums[threadIdx.x];
 }
 
@@ -1392,7 +1450,7 @@ __global__ void k_model_intensity(const uint8_t* __restrict__ pred, const uint8_
                                   const TrackState* __restrict__ st, int n, uint8_t* __restrict__ dst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint8_t* src = (force_fill || st->should_fill_in) ? fill : pred;
+  const uint8_t* src = (force_fill || use_fill_in(st)) ? fill : pred;
   const uchar4 c = ((const uchar4*)src)[i];
   dst[i] = intensity_of((float)c.x, (float)c.y, (float)c.z);
 }
@@ -1437,7 +1495,7 @@ void launch_residual(const Pyramid& p, TrackState* st, int level, hipStream_t s)
   ResidualPackedView RV{p.rgbMask[level], p.lastDepth[level], p.lastImage[level], p.nextImage[level], p.corres[level], cols, rows,
                         0.07f /* maxDepthDeltaRGB, RGBDOdometry.cpp:41 */};
   hipLaunchKernelGGL(k_rgb_residual<PPT>, dim3(ceil_div(N, REDUCE_BLOCK * PPT)), dim3(REDUCE_BLOCK), 0, s, RV, (const float*)st->krkinv,
-                     (const float*)st->kt, st->rgb_sum, (const int*)&st->rgb_broken);
+                     (const float*)st->kt, &st->rgb_slots[0][0], (const int*)&st->rgb_broken);
 }
 void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const TrackParams& tp, bool icp, bool rgb, Intr knext,
                       bool level_changes, hipStream_t s, KernelProbe* probe) {
@@ -1449,7 +1507,7 @@ void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, cons
   }
   IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres};
   RgbView GV{p.corres[level], p.lastDepth[level], nullptr, p.dIdx[level], p.dIdy[level], cols, rows, kl, 1.0f / 8.0f};
-  Se3Inputs in{st->Rcurr, st->tcurr, st->Rprev_inv, st->tprev, st->rgb_sum, &st->rgb_broken, 0.f, tp.rgbOnly};
+  Se3Inputs in{st->Rcurr, st->tcurr, st->Rprev_inv, st->tprev, &st->rgb_slots[0][0], &st->rgb_broken, 0.f, tp.rgbOnly};
   if (sample) (void)hipEventRecord(probe->start[probe->used], s);
   if (icp && rgb) launch_accum<true, true, true>(IV, GV, in, N, p.partials, p.partials + SE3_ACCS * VWARPS, s);
   else if (icp) launch_accum<true, false, true>(IV, GV, in, N, p.partials, p.partials + SE3_ACCS * VWARPS, s);
@@ -1494,12 +1552,14 @@ void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_
 }
 
 // exported for the context: finishing kernels
-void track_end(TrackState* st, bool rgb, float weightMultiplier, hipStream_t s) {
-  hipLaunchKernelGGL(k_track_end, dim3(1), dim3(64), 0, s, st, rgb, weightMultiplier);
+void track_end(TrackState* st, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_track_end, dim3(1), dim3(64), 0, s, st, rgb, weightMultiplier, traj, slot);
 }
-void pose_injected(TrackState* st, float weightMultiplier, bool with_weighting, hipStream_t s) {
-  hipLaunchKernelGGL(k_pose_injected, dim3(1), dim3(64), 0, s, st, weightMultiplier, with_weighting);
+void pose_injected(TrackState* st, const double* T_wc16, bool save_prev, float weightMultiplier, bool with_weighting, double* traj, int slot,
+                   hipStream_t s) {
+  hipLaunchKernelGGL(k_pose_injected, dim3(1), dim3(64), 0, s, st, efl::se3_from_matrix(T_wc16), save_prev, weightMultiplier, with_weighting,
+                     traj, slot);
 }
-void save_prev_pose(TrackState* st, hipStream_t s) { hipLaunchKernelGGL(k_save_prev_pose, dim3(1), dim3(64), 0, s, st); }
+void log_pose(const TrackState* st, double* traj, int slot, hipStream_t s) { hipLaunchKernelGGL(k_log_pose, dim3(1), dim3(64), 0, s, st, traj, slot); }
 
 }  // namespace eft
