@@ -412,7 +412,7 @@ class ops:
                                   _ptr(ops._f32(krlr).reshape(9)), c_i(w), c_i(h), _ptr(A), _ptr(b), _ptr(res), None))
         return A, b, res
 
-    LINALG = dict(ldlt6=0, ldlt3f=1, polar3=2, rodrigues=3, se3_inverse=4, se3_log_norm=5, scalar=6)
+    LINALG = dict(ldlt6=0, ldlt3f=1, polar3=2, rodrigues=3, se3_inverse=4, se3_log_norm=5, scalar=6, ldlt6_wave=7)
 
     @staticmethod
     def linalg(which, vec, n_out):

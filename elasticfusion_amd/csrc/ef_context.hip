@@ -12,6 +12,7 @@
 
 #include "../../include/ef_hip.h"
 #include "ef_linalg_dev.hpp"
+#include "ef_solve_dev.hpp"
 #include "ef_map.hpp"
 #include "ef_track.hpp"
 
@@ -426,6 +427,14 @@ int ef_get_tracking_stats(ef_ctx* c, float* out6, double* A36, double* b6) {
   if (b6) memcpy(b6, h.lastb, sizeof(h.lastb));
   return EF_OK;
 }
+int ef_debug_clocks(ef_ctx* c, unsigned long long* out16) {
+  if (!c || !out16) return EF_EINVAL;
+  eft::TrackState h;
+  EF_HIP(c, hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  memcpy(out16, h.dbg_clock, sizeof(h.dbg_clock));
+  return EF_OK;
+}
 int ef_get_trajectory(ef_ctx* c, double* T16s, int64_t* stamps, int max_frames, int* n_frames) {
   if (!c || !n_frames) return EF_EINVAL;
   int n = (int)c->stamps.size();
@@ -794,6 +803,15 @@ int ef_op_so3_step(const uint8_t* lastImage, const uint8_t* nextImage, const flo
 }  // extern "C"
 namespace {
 __global__ void k_linalg_probe(int which, const double* __restrict__ in, double* __restrict__ out) {
+  if (which == EF_LINALG_LDLT6_WAVE) {  // the one-element-per-lane factorisation the tracker uses (ef_solve_dev.hpp)
+    __shared__ efs::SolveScratch S;
+    const int lane = threadIdx.x;
+    if (lane < 6) S.b[lane] = in[36 + lane];
+    efs::wave_sync();
+    efs::ldlt6_wave(in[lane < 36 ? lane : 0], S);
+    if (lane < 6) out[lane] = S.x[lane];
+    return;
+  }
   if (threadIdx.x != 0) return;
   switch (which) {
     case EF_LINALG_LDLT6: efl::ldlt_solve<double, 6>(in, in + 36, out); break;
@@ -818,7 +836,7 @@ __global__ void k_linalg_probe(int which, const double* __restrict__ in, double*
 }  // namespace
 extern "C" {
 int ef_op_linalg(int which, const double* in, int n_in, double* out, int n_out) {
-  if (!in || !out || n_in <= 0 || n_out <= 0 || n_in > 64 || n_out > 64 || which < 0 || which > EF_LINALG_SCALAR) return EF_EINVAL;
+  if (!in || !out || n_in <= 0 || n_out <= 0 || n_in > 64 || n_out > 64 || which < 0 || which > EF_LINALG_LDLT6_WAVE) return EF_EINVAL;
   double* d;
   if (hipMalloc((void**)&d, 128 * sizeof(double)) != hipSuccess) return EF_ENOMEM;
   (void)hipMemset(d, 0, 128 * sizeof(double));

@@ -18,7 +18,8 @@ constexpr int VWARPS = VTHREADS / 32;
 constexpr int RGB_SLOTS = 64;
 constexpr int SE3_ACCS = 29;         // JtJJtrSE3, types.cuh:98-143
 constexpr int SO3_ACCS = 11;         // JtJJtrSO3, types.cuh:145-168
-constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * VWARPS;  // ICP block then RGB block
+// ICP block then RGB block of virtual-warp partials, then the 64 reference-block partials of both terms
+constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * VWARPS + 2 * SE3_ACCS * 64;
 
 struct Intr { float fx, fy, cx, cy; };
 __host__ __device__ inline Intr intr_level(const Intr& k, int level) {  // CameraModel::operator()(level), types.cuh:92-95
@@ -57,6 +58,9 @@ struct TrackState {
   float so3_lastError, so3_lastCount;
   int so3_done;
   unsigned so3_ticket;        // last-workgroup-done counter
+  // normal-equation kernel: arrival counters of the 64 reference blocks (8 virtual warps each) and of the blocks
+  unsigned acc_tickets[64];
+  unsigned acc_ticket_final;
   // per-frame scalars produced on the device
   float weighting;            // fusion weight (ElasticFusion.cpp:371-383)
   // denseEnough() tally of the last predict() (Resize::image samples with r,g,b > 0; ElasticFusion.cpp:256-268):
@@ -65,6 +69,7 @@ struct TrackState {
   unsigned dense_count;
   int dense_samples;
   int tick;
+  unsigned long long dbg_clock[16];   // developer instrumentation (EF_STAGE_CLOCKS builds only)
   unsigned map_counts[2];     // live surfels of the two ping-pong map buffers (clean reads one, writes the other)
   // float matrices consumed by the map kernels
   float T_cw[16];             // T_wc.inverse().matrix().cast<float>()  (IndexMap.cpp:208)

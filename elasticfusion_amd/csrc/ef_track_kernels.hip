@@ -8,6 +8,7 @@
 // host round trip.
 #include "ef_device.hpp"
 #include "ef_linalg_dev.hpp"
+#include "ef_solve_dev.hpp"
 #include "ef_track.hpp"
 
 using namespace ef;
@@ -810,14 +811,25 @@ struct Se3Inputs {            // device pointers: the Gauss-Newton state the acc
   float sigma_fixed;
   bool rgbOnly;
 };
+__device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sums, bool broken, bool icp, bool rgb, bool rgbOnly,
+                                                float icpWeight, Intr knext, bool level_changes, efs::SolveScratch& S);
+// In-launch hand-off of partial sums between workgroups (which may sit on different XCDs, each with its own L2):
+// payload goes out with agent-scope (write-through) stores, the writer drains them (s_waitcnt vmcnt(0)) before its
+// workgroup takes a ticket with a relaxed atomic, and the last arriver reads with agent-scope loads.  No
+// __threadfence(): on this part a release fence writes back the whole L2 and ~2000 of them per launch cost 200+ us
+// (MI355X_MICROARCH.md, "handoff-flag": sc1 payload -> vmcnt(0) -> flag).
+__device__ __forceinline__ float coherent_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned take_ticket(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int BLOCK, int KC, bool HAS_ICP, bool HAS_RGB, bool PACKED>
 __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, float* __restrict__ partials_icp,
                                                      float* __restrict__ partials_rgb) {
   static_assert(BLOCK >= 256 && BLOCK % 64 == 0, "phase B needs 256 threads");
   __shared__ float rows[2][KC * ROW_STRIDE];
-  if (in.broken && *in.broken) return;
   const int t = threadIdx.x, W = blockIdx.x;
+  if (in.broken && *in.broken) return;  // rgbOnly "break": the level is over (k_se3_finish does the bookkeeping)
   const int cols = HAS_ICP ? IV.cols : RV.cols, nrows = HAS_ICP ? IV.rows : RV.rows;
   const int N = cols * nrows;
   const int K = (N + VTHREADS - 1) / VTHREADS;
@@ -983,7 +995,10 @@ __global__ void k_track_begin(TrackState* st, bool so3, Intr kso3, Intr kfirst) 
   st->rgb_broken = 0;
   st->lastRGBErrorLevel = 3.402823466e+38f;
   st->so3_iterations = 0;
+  st->dbg_clock[11] = ~0ull; st->dbg_clock[12] = 0;
   st->so3_ticket = 0;
+  st->acc_ticket_final = 0;
+  for (int i = 0; i < 64; ++i) st->acc_tickets[i] = 0;
   st->dense_count = 0;
   if (so3) {
     efl::m3_identity(st->so3_resultR);
@@ -999,87 +1014,99 @@ __global__ void k_track_begin(TrackState* st, bool so3, Intr kso3, Intr kfirst) 
   }
 }
 
-// K6c: finish the reference tree over the virtual-warp partials, build A,b in double, LDL^T solve, SE(3) update,
-// next K R K^-1 (RGBDOdometry.cpp:440-551 + OdometryProvider.h:73-96).  One workgroup; the solve runs on lane 0.
+// K6c: the Gauss-Newton update (RGBDOdometry.cpp:440-551 + OdometryProvider.h:73-96) on one wavefront, one matrix
+// element per lane (ef_solve_dev.hpp); called by the last workgroup of k_se3_accum.
 constexpr int SOLVE_BLOCK = 512;
-__global__ void __launch_bounds__(SOLVE_BLOCK) k_solve_update(TrackState* st, const float* __restrict__ partials, bool icp, bool rgb,
-                                                               bool rgbOnly, float icpWeight, Intr knext, bool level_changes) {
-  __shared__ float bs[2 * SE3_ACCS * 64];
-  __shared__ float sums[2 * SE3_ACCS];
-  const bool broken = st->rgb_broken != 0;
-  if (!broken) {
-    if (icp && rgb) final_tree<SOLVE_BLOCK, 2 * SE3_ACCS, false>(partials, bs, sums);
-    else if (icp) final_tree<SOLVE_BLOCK, SE3_ACCS, false>(partials, bs, sums);
-    else final_tree<SOLVE_BLOCK, SE3_ACCS, false>(partials + SE3_ACCS * VWARPS, bs, sums + SE3_ACCS);
-  }
+// bookkeeping around the update (rgbOnly early exit, statistics); all lanes of wave 0 take the same path
+__device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sums, bool broken, bool icp, bool rgb, bool rgbOnly,
+                                                float icpWeight, Intr knext, bool level_changes, efs::SolveScratch& S) {
+  const int lane = threadIdx.x & 63;
   int sigma = 0, rgbSize = 0;
-  if (threadIdx.x < 64) {
-    sum_rgb_slots(&st->rgb_slots[0][0], rgbSize, sigma);
-    st->rgb_slots[threadIdx.x][0] = 0;
-    st->rgb_slots[threadIdx.x][1] = 0;
-  }
-  if (threadIdx.x != 0) return;
-  if (broken) {
-    if (level_changes) { st->rgb_broken = 0; st->lastRGBErrorLevel = 3.402823466e+38f; compute_krk(st->resultRt, knext, st->krkinv, st->kt); }
-    return;
-  }
+  sum_rgb_slots((const int*)&st->rgb_slots[0][0], rgbSize, sigma);
+  st->rgb_slots[lane][0] = 0;
+  st->rgb_slots[lane][1] = 0;
+  const float lastLevelErr = st->lastRGBErrorLevel;
   const float rgbError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
-  if (rgbOnly && rgbError > st->lastRGBErrorLevel) {  // "break": skip the rest of this level
-    st->rgb_broken = level_changes ? 0 : 1;
-    if (level_changes) { st->lastRGBErrorLevel = 3.402823466e+38f; compute_krk(st->resultRt, knext, st->krkinv, st->kt); }
+  const bool brk = !broken && rgbOnly && rgbError > lastLevelErr;   // "break": skip the rest of this level
+  if (broken || brk) {
+    if (lane == 0) {
+      st->rgb_broken = level_changes ? 0 : 1;
+      if (level_changes) { st->lastRGBErrorLevel = 3.402823466e+38f; compute_krk(st->resultRt, knext, st->krkinv, st->kt); }
+    }
     return;
   }
-  st->lastRGBErrorLevel = rgbError;
-  st->lastRGBError = rgbError;
-  st->lastRGBCount = (float)rgbSize;
-  if (icp) {
-    st->lastICPError = sqrtf(sums[27]) / sums[28];
-    st->lastICPCount = sums[28];
+  if (lane == 0) {
+    st->lastRGBErrorLevel = level_changes ? 3.402823466e+38f : rgbError;
+    st->lastRGBError = rgbError;
+    st->lastRGBCount = (float)rgbSize;
+    if (icp) {
+      st->lastICPError = sqrtf(sums[27]) / sums[28];
+      st->lastICPCount = sums[28];
+    }
   }
-  double A[36], b[6], result[6];
-  if (icp && rgb) {
-    float Ai[36], bi[6], Ar[36], br[6];
-    unpack29<float>(sums, Ai, bi);
-    unpack29<float>(sums + SE3_ACCS, Ar, br);
-    const double w = icpWeight;
-    for (int k = 0; k < 36; ++k) A[k] = (double)Ar[k] + w * w * (double)Ai[k];
-    for (int k = 0; k < 6; ++k) b[k] = (double)br[k] + w * (double)bi[k];
-  } else if (icp) {
-    unpack29<double>(sums, A, b);
-  } else {
-    unpack29<double>(sums + SE3_ACCS, A, b);
+  EF_STAMP(st, 3);
+  efs::SolveInputs in{icp, rgb, rgbOnly, icpWeight, knext, level_changes};
+  efs::gauss_newton_update_wave(st, sums, in, S);
+}
+// K6c': the rest of the reference tree + the update, as ONE small launch of 64 workgroups (one per reference block):
+//   each reduces the 8 virtual-warp partials of its block (blockReduceSum's second stage: lanes 0..7 hold the warp
+//   sums, the other 24 lanes of the reference hold 0.0f => shuffle tree of width 8) and hands the block partial over
+//   with write-through stores + a ticket; the LAST workgroup runs reduceSum<<<1,1024>>> (two warp32 trees + one add)
+//   over the 64 block partials and then the Gauss-Newton step on its first wavefront.
+// A single workgroup reading all 512 x 58 warp partials would be bound by one CU's memory pipe (~9 us for 118 KB).
+constexpr int FINISH_BLOCK = 512;
+struct FinishArgs {
+  bool icp, rgb, rgbOnly;
+  float icpWeight;
+  Intr knext;
+  bool level_changes;
+};
+__global__ void __launch_bounds__(FINISH_BLOCK) k_se3_finish(TrackState* st, const float* __restrict__ partials_icp,
+                                                             const float* __restrict__ partials_rgb, float* block_partials,
+                                                             const FinishArgs A) {
+  __shared__ efs::SolveScratch S;
+  __shared__ float sums_s[2 * SE3_ACCS];
+  __shared__ int last_s;
+  const int t = threadIdx.x, b = blockIdx.x;
+  if (st->rgb_broken) {  // rgbOnly "break": only the bookkeeping of the update step runs
+    if (b == 0 && t < 64) solve_step_wave(st, nullptr, true, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S);
+    return;
   }
-  for (int k = 0; k < 36; ++k) st->lastA[k] = A[k];
-  for (int k = 0; k < 6; ++k) st->lastb[k] = b[k];
-  efl::ldlt_solve<double, 6>(A, b, result);
-  // computeUpdateSE3
-  double upd[16], Rr[9];
-  efl::m4_identity(upd);
-  const double rvec[3] = {result[3], result[4], result[5]};
-  efl::rodrigues(rvec, Rr);
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) upd[r * 4 + c] = Rr[r * 3 + c];
-    upd[r * 4 + 3] = result[r];
+  const int na = (A.icp ? SE3_ACCS : 0) + (A.rgb ? SE3_ACCS : 0);
+  if (t < na * 8) {   // na * 8 <= 464: whole 8-lane groups
+    const int a = t >> 3, w = t & 7;
+    const float* src = (A.icp && a < SE3_ACCS) ? partials_icp + (size_t)a * VWARPS : partials_rgb + (size_t)(a - (A.icp ? SE3_ACCS : 0)) * VWARPS;
+    float v = src[b * 8 + w];
+    v += __shfl_down(v, 4, 8);
+    v += __shfl_down(v, 2, 8);
+    v += __shfl_down(v, 1, 8);
+    if (w == 0) { coherent_store(block_partials + a * 64 + b, v); drain_stores(); }
   }
-  double nr[16];
-  efl::m4_mul(upd, st->resultRt, nr);
-  for (int k = 0; k < 16; ++k) st->resultRt[k] = nr[k];
-  // currentT = [Rprev|tprev] * rgbOdom^-1 in float (quirk Q13)
-  float oR[9], ot[3], iR[9], it[3];
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) oR[r * 3 + c] = (float)nr[r * 4 + c];
-    ot[r] = (float)nr[r * 4 + 3];
+  __syncthreads();
+  if (t == 0) last_s = (take_ticket(&st->acc_ticket_final) == 63u);
+  __syncthreads();
+  if (!last_s) return;
+  {
+    constexpr int PASSES = (2 * SE3_ACCS * 64 + FINISH_BLOCK - 1) / FINISH_BLOCK;
+    float v[PASSES];
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q) {
+      const int idx = t + q * FINISH_BLOCK;
+      v[q] = idx < na * 64 ? coherent_load(block_partials + idx) : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q) {
+      const int idx = t + q * FINISH_BLOCK;
+      float x = v[q];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, 32);
+      const float w1 = __shfl(x, 32, 64);
+      if (idx < na * 64 && (idx & 63) == 0) sums_s[(A.icp ? 0 : SE3_ACCS) + (idx >> 6)] = x + w1;
+    }
   }
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) iR[r * 3 + c] = oR[c * 3 + r];
-  for (int r = 0; r < 3; ++r) it[r] = -(iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1] + iR[r * 3 + 2] * ot[2]);
-  const float* Rp = st->Rprev;
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) st->Rcurr[r * 3 + c] = Rp[r * 3] * iR[c] + Rp[r * 3 + 1] * iR[3 + c] + Rp[r * 3 + 2] * iR[6 + c];
-    st->tcurr[r] = (Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2]) + st->tprev[r];
-  }
-  if (level_changes) st->lastRGBErrorLevel = 3.402823466e+38f;
-  compute_krk(st->resultRt, knext, st->krkinv, st->kt);
+  if (t == 0) st->acc_ticket_final = 0;
+  __syncthreads();
+  if (t < 64) solve_step_wave(st, sums_s, false, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S);
 }
 
 // tail of getIncrementalTransformation (RGBDOdometry.cpp:555-570) + velocity weighting
@@ -1207,9 +1234,11 @@ __device__ __forceinline__ void so3_accumulate(const uint8_t* __restrict__ lastI
     for (int i = 0; i < SO3_ACCS; ++i)
 #pragma unroll
       for (int off = 16; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 32);
-    if (l == 0)
+    if (l == 0) {
 #pragma unroll
-      for (int i = 0; i < SO3_ACCS; ++i) partials[(size_t)i * VWARPS + W] = acc[i];
+      for (int i = 0; i < SO3_ACCS; ++i) coherent_store(partials + (size_t)i * VWARPS + W, acc[i]);
+      drain_stores();
+    }
   }
 }
 
@@ -1225,16 +1254,11 @@ __global__ void __launch_bounds__(SO3_BLOCK) k_so3_iteration(const uint8_t* __re
     const m33 IB = m33_load(st->so3_mats), KI = m33_load(st->so3_mats + 9), KR = m33_load(st->so3_mats + 18);
     so3_accumulate(lastImage, nextImage, cols, rows, IB, KI, KR, lds_rows, partials);
   }
-  // last-workgroup-done: release our partials, take a ticket, the last one acquires everybody's
-  __threadfence();
+  // last-workgroup-done: our partials are drained to the coherence point, take a ticket
   __syncthreads();
-  if (t == 0) {
-    const unsigned ticket = __hip_atomic_fetch_add(&st->so3_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (ticket == gridDim.x - 1);
-  }
+  if (t == 0) is_last = (take_ticket(&st->so3_ticket) == gridDim.x - 1);
   __syncthreads();
   if (!is_last) return;
-  __threadfence();
   final_tree<SO3_BLOCK, SO3_ACCS, true>(partials, lds_rows /* reused: 11*64 floats */, red);
   if (t != 0) return;
   st->so3_ticket = 0;
@@ -1508,13 +1532,15 @@ void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, cons
   IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres};
   RgbView GV{p.corres[level], p.lastDepth[level], nullptr, p.dIdx[level], p.dIdy[level], cols, rows, kl, 1.0f / 8.0f};
   Se3Inputs in{st->Rcurr, st->tcurr, st->Rprev_inv, st->tprev, &st->rgb_slots[0][0], &st->rgb_broken, 0.f, tp.rgbOnly};
+  float* prgb = p.partials + SE3_ACCS * VWARPS;
+  float* pblk = p.partials + 2 * SE3_ACCS * VWARPS;
   if (sample) (void)hipEventRecord(probe->start[probe->used], s);
-  if (icp && rgb) launch_accum<true, true, true>(IV, GV, in, N, p.partials, p.partials + SE3_ACCS * VWARPS, s);
-  else if (icp) launch_accum<true, false, true>(IV, GV, in, N, p.partials, p.partials + SE3_ACCS * VWARPS, s);
-  else launch_accum<false, true, true>(IV, GV, in, N, p.partials, p.partials + SE3_ACCS * VWARPS, s);
+  if (icp && rgb) launch_accum<true, true, true>(IV, GV, in, N, p.partials, prgb, s);
+  else if (icp) launch_accum<true, false, true>(IV, GV, in, N, p.partials, prgb, s);
+  else launch_accum<false, true, true>(IV, GV, in, N, p.partials, prgb, s);
   if (sample) (void)hipEventRecord(probe->stop[probe->used++], s);
-  hipLaunchKernelGGL(k_solve_update, dim3(1), dim3(SOLVE_BLOCK), 0, s, st, (const float*)p.partials, icp, rgb, tp.rgbOnly, tp.icpWeight, knext,
-                     level_changes);
+  const FinishArgs fa{icp, rgb, tp.rgbOnly, tp.icpWeight, knext, level_changes};
+  hipLaunchKernelGGL(k_se3_finish, dim3(64), dim3(FINISH_BLOCK), 0, s, st, (const float*)p.partials, (const float*)prgb, pblk, fa);
 }
 }  // namespace
 

@@ -132,6 +132,10 @@ typedef struct ef_kernel_time { const char* name; float avg_us; int launches; do
 int ef_kernel_timing(ef_ctx* ctx, int every_n_frames);
 int ef_get_kernel_timing(ef_ctx* ctx, ef_kernel_time* out);
 
+/* developer instrumentation: the 16 wall_clock64() (100 MHz) stamps the last tracking solve left in the device state;
+ * all zero unless the library was built with -DEF_STAGE_CLOCKS (EF_HIPCC_FLAGS=-DEF_STAGE_CLOCKS python -m elasticfusion_amd.build) */
+int ef_debug_clocks(ef_ctx* ctx, unsigned long long* out16);
+
 /* ---- device memory helpers (so that a non-HIP host can drive the operator tier) ---- */
 int ef_dev_alloc(void** dev, size_t bytes);
 int ef_dev_free(void* dev);
@@ -191,7 +195,8 @@ enum ef_linalg_op {
   EF_LINALG_RODRIGUES,        /* in v[3]                    -> R[9]   OdometryProvider::rodrigues          */
   EF_LINALG_SE3_INVERSE,      /* in T[16]                   -> T^-1[16] Sophus::SE3d::inverse().matrix()    */
   EF_LINALG_SE3_LOG_NORM,     /* in T[16]                   -> |log(T)| Sophus::SE3d::log().norm()          */
-  EF_LINALG_SCALAR            /* in a, b -> sqrt(a), a/b, sin(a), cos(a), atan2(a,b) (fp64 device math)     */
+  EF_LINALG_SCALAR,           /* in a, b -> sqrt(a), a/b, sin(a), cos(a), atan2(a,b) (fp64 device math)     */
+  EF_LINALG_LDLT6_WAVE        /* as EF_LINALG_LDLT6, through the one-element-per-lane wavefront version      */
 };
 int ef_op_linalg(int which, const double* in_host, int n_in, double* out_host, int n_out);
 

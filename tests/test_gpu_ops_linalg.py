@@ -48,8 +48,9 @@ def test_ldlt6_bit_exact(ops):
         b = rng.randn(6)
         x_r = np.zeros(6)
         efo.lib().efo_ldlt6(_p(A), _p(b), _p(x_r))
-        x = ops.linalg("ldlt6", np.concatenate([A.reshape(-1), b]), 6)
-        assert np.array_equal(x.view(np.uint64), x_r.view(np.uint64)), (t, x, x_r)
+        for which in ("ldlt6", "ldlt6_wave"):   # scalar restatement and the wave-parallel version the tracker runs
+            x = ops.linalg(which, np.concatenate([A.reshape(-1), b]), 6)
+            assert np.array_equal(x.view(np.uint64), x_r.view(np.uint64)), (which, t, x, x_r)
 
 
 def test_ldlt3f_bit_exact(ops):
