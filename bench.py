@@ -73,9 +73,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from elasticfusion_amd import multi
+    rank, local_rank, world = multi.rank_info()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
@@ -85,13 +84,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        multi.init_process_group("nccl", local_rank)
 
     from elasticfusion_amd import api
 
     n_frames = a.warmup + a.steps + 1  # frame 0 seeds the map (tick 1) and is never timed
-    frames = generate_frames(0xEF0001 + rank, n_frames)
+    frames = generate_frames(multi.sequence_seed(rank), n_frames)
 
     stream = torch.cuda.current_stream().cuda_stream
     ef = api.ElasticFusion(width=W, height=H, device=local_rank, stream=stream)
@@ -127,31 +125,27 @@ def main():
     err_t = float(np.linalg.norm(T[:3, 3] - Tgt[:3, 3]))
     count = ef.lastCount()
 
-    stats = torch.tensor([dt, float(a.steps), err_t, float(count)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        gathered = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)   # the only collective: <=32 B per rank over xGMI
-        allstats = torch.stack(gathered).cpu().numpy()
-    else:
-        allstats = stats.cpu().numpy()[None]
+    # the only collective: 32 B per rank over xGMI (RCCL all_gather)
+    allstats = multi.gather_stats([dt, float(a.steps), err_t, float(count)], device="cuda")
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-    t_max = float(allstats[:, 0].max())
-    total_frames = float(allstats[:, 1].sum())
-    value = total_frames / t_max
+    agg = multi.aggregate(allstats)
+    t_max, value = agg["t_max"], agg["value"]
 
     roofline = None
     if have_ktime:
         class KT(C.Structure):
-            _fields_ = [("name", C.c_char_p), ("avg_us", C.c_float), ("launches", C.c_int), ("bytes_per_launch", C.c_double)]
+            _fields_ = [("name", C.c_char_p), ("avg_us", C.c_float), ("launches", C.c_int), ("bytes_per_launch", C.c_double),
+                        ("raw_avg_us", C.c_float), ("empty_pair_us", C.c_float)]
         kt = KT()
         if lib.ef_get_kernel_timing(ef.h, C.byref(kt)) == 0 and kt.launches > 0:
             achieved = kt.bytes_per_launch / (kt.avg_us * 1e-6) / 1e9
             roofline = {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                        "avg_us": round(float(kt.avg_us), 3), "launches_sampled": int(kt.launches),
+                        "avg_us": round(float(kt.avg_us), 3), "event_pair_raw_us": round(float(kt.raw_avg_us), 3),
+                        "event_pair_empty_us": round(float(kt.empty_pair_us), 3), "launches_sampled": int(kt.launches),
                         "algorithmic_bytes_per_launch": int(kt.bytes_per_launch)}
     out = {
         "metric": "frames/s per GPU, 640x480 3-level ICP+fuse",
@@ -171,7 +165,7 @@ def main():
                                "stand-in for configs[1] (dyson_lab.klg is not available offline)",
                    "resolution": [W, H], "sequences": world, "surfels_end": int(count),
                    "pose_err_vs_generating_traj_m": round(err_t, 5),
-                   "per_rank_fps": [round(float(s[1] / s[0]), 2) for s in allstats]},
+                   "per_rank_fps": [round(x, 2) for x in agg["per_rank_fps"]]},
         "roofline": roofline,
     }
     if not a.no_cpu_baseline:

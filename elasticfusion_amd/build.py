@@ -15,6 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libefusion_hip.so")
+SHIM_LIB = os.path.join(HERE, "libefusion.so")          # class ElasticFusion (include/ElasticFusion.h) over the C ABI
 SOURCES = ["ef_track_kernels.hip", "ef_map_kernels.hip", "ef_context.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
@@ -28,7 +29,7 @@ def _hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(SHIM_LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "ef_hip.h"), __file__]
@@ -57,6 +58,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    # libefusion.so: host-only C++ (compiled by hipcc for the shared __host__ __device__ linear-algebra header)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", SHIM_LIB,
+           os.path.join(CSRC, "efusion_shim.hip"), "-L" + HERE, "-lefusion_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"libefusion.so build failed:\n{r.stdout}")
+    # headless replay front-end (plain g++: it only sees include/ElasticFusion.h)
+    replay = os.path.join(HERE, "efusion_replay")
+    cmd = ["g++", "-O2", "-std=c++17", os.path.join(os.path.dirname(HERE), "tools", "efusion_replay.cpp"), "-o", replay, "-L" + HERE,
+           "-lefusion", "-lefusion_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link," + HERE]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"efusion_replay build failed:\n{r.stdout}")
     return LIB
 
 

@@ -6,7 +6,7 @@
 // issues an fp64 op every 8 cycles no matter how many lanes are live — and it sits between every pair of reduction
 // kernels, 19 times a frame.  Spread over lanes (36 lanes hold the 6x6 matrix, 16 a 4x4, 9 a 3x3 ...) the same
 // arithmetic is ~700 instructions.  Every element still sees exactly the scalar sequence of IEEE operations of
-// ef_linalg_dev.hpp (= oracle/efo_linalg.h, the Eigen/Sophus restatement), so results are bit-identical; lanes
+// ef_linalg_dev.hpp (the Eigen/Sophus restatement), so results are bit-identical to the single-lane version; lanes
 // exchange values through ds_bpermute shuffles and a small LDS scratch, ordered by wave_sync().
 #pragma once
 #include <hip/hip_runtime.h>

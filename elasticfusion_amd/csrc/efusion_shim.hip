@@ -1,0 +1,190 @@
+// libefusion.so: class ElasticFusion (include/ElasticFusion.h) over the C ABI of libefusion_hip.so.
+// Host code only; the per-frame script, kernels and device state are behind ef_process_frame (ef_context.hip).
+#include "../../include/ElasticFusion.h"
+
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+#include "../../include/ef_hip.h"
+#include "ef_linalg_dev.hpp"
+
+// ---- singletons (Core/Utils/Resolution.h, Intrinsics.h): first call fixes the values for the process ----
+Resolution::Resolution(int width, int height) : imgWidth(width), imgHeight(height), imgNumPixels(width * height) {
+  if (!(width > 0 && height > 0)) throw std::runtime_error("You haven't initialised the Resolution class!");
+}
+const Resolution& Resolution::getInstance(int width, int height) {
+  static const Resolution instance(width, height);
+  return instance;
+}
+Intrinsics::Intrinsics(float fx, float fy, float cx, float cy) : fx_(fx), fy_(fy), cx_(cx), cy_(cy) {
+  if (!(fx != 0 && fy != 0)) throw std::runtime_error("You haven't initialised the Intrinsics class!");
+}
+const Intrinsics& Intrinsics::getInstance(float fx, float fy, float cx, float cy) {
+  static const Intrinsics instance(fx, fy, cx, cy);
+  return instance;
+}
+
+namespace efusion {
+
+namespace {
+ef_ctx* C(void* p) { return static_cast<ef_ctx*>(p); }
+void chk(int rc, void* ctx, const char* what) {
+  if (rc != EF_OK) {
+    const char* m = ef_last_error(C(ctx));
+    throw std::runtime_error(std::string(what) + ": libefusion_hip error " + std::to_string(rc) + (m ? std::string(": ") + m : ""));
+  }
+}
+}  // namespace
+
+void ef_ctx_deleter::operator()(void* p) const { if (p) ef_destroy(C(p)); }
+
+SE3d SE3d::fromMatrix(const double* M) {
+  const efl::SE3 T = efl::se3_from_matrix(M);   // Sophus::SE3d(Matrix4d): quaternion from the rotation block, normalised
+  SE3d r;
+  std::memcpy(r.q, T.q, sizeof(r.q));
+  std::memcpy(r.t, T.t, sizeof(r.t));
+  return r;
+}
+void SE3d::matrix(double* out16) const {
+  efl::SE3 T;
+  std::memcpy(T.q, q, sizeof(q));
+  std::memcpy(T.t, t, sizeof(t));
+  efl::se3_matrix(T, out16);
+}
+
+ElasticFusion::ElasticFusion(const int timeDelta_, const int /*countThresh*/, const float /*errThresh*/, const float /*covThresh*/,
+                             const bool closeLoops, const bool /*iclnuim*/, const bool /*reloc*/, const float /*photoThresh*/,
+                             const float confidence, const float depthCut, const float icpThresh, const bool fastOdom,
+                             const float /*fernThresh*/, const bool so3, const bool frameToFrameRGB, const std::string fileName,
+                             const int device)
+    : saveFilename(fileName), timeDelta(timeDelta_), confidenceThreshold(confidence) {
+  ef_config cfg;
+  ef_default_config(&cfg);
+  cfg.width = Resolution::getInstance().width();
+  cfg.height = Resolution::getInstance().height();
+  cfg.fx = Intrinsics::getInstance().fx();
+  cfg.fy = Intrinsics::getInstance().fy();
+  cfg.cx = Intrinsics::getInstance().cx();
+  cfg.cy = Intrinsics::getInstance().cy();
+  cfg.time_delta = timeDelta_;
+  cfg.confidence = confidence;
+  cfg.depth_cut = depthCut;
+  cfg.icp_weight = icpThresh;
+  cfg.fast_odom = fastOdom;
+  cfg.so3 = so3;
+  cfg.frame_to_frame_rgb = frameToFrameRGB;
+  cfg.close_loops = closeLoops;
+  cfg.device = device;
+  ef_ctx* c = nullptr;
+  chk(ef_create(&cfg, &c), nullptr, "ElasticFusion::ElasticFusion");
+  ctx.reset(c);
+  indexMap.ctx = globalModel.ctx = c;
+  indexMap.w = cfg.width;
+  indexMap.h = cfg.height;
+  if (!saveFilename.empty()) {  // the reference truncates <file>.freiburg in its constructor (ElasticFusion.cpp:97-102)
+    if (FILE* f = std::fopen((saveFilename + ".freiburg").c_str(), "w")) std::fclose(f);
+  }
+}
+
+ElasticFusion::~ElasticFusion() {
+  if (ctx && !saveFilename.empty()) (void)ef_save_freiburg(C(ctx.get()), (saveFilename + ".freiburg").c_str());
+}
+
+void ElasticFusion::processFrame(const uint8_t* rgb, const uint16_t* depth, const int64_t& timestamp, const float weightMultiplier,
+                                 const SE3d* in_T_wc) {
+  double M[16];
+  if (in_T_wc) in_T_wc->matrix(M);
+  chk(ef_process_frame(C(ctx.get()), rgb, depth, timestamp, weightMultiplier, in_T_wc ? M : nullptr), ctx.get(), "processFrame");
+}
+#ifdef EFUSION_USE_SOPHUS
+void ElasticFusion::processFrame(const uint8_t* rgb, const uint16_t* depth, const int64_t& timestamp, const float weightMultiplier,
+                                 const Sophus::SE3d* in_T_wc) {
+  if (!in_T_wc) return processFrame(rgb, depth, timestamp, weightMultiplier, (const SE3d*)nullptr);
+  SE3d T;
+  std::memcpy(T.q, in_T_wc->so3().unit_quaternion().coeffs().data(), sizeof(T.q));
+  std::memcpy(T.t, in_T_wc->translation().data(), sizeof(T.t));
+  processFrame(rgb, depth, timestamp, weightMultiplier, &T);
+}
+Sophus::SE3d ElasticFusion::get_T_wc_sophus() {
+  const SE3d& T = get_T_wc();
+  return Sophus::SE3d(Eigen::Quaterniond(T.q[3], T.q[0], T.q[1], T.q[2]), Eigen::Vector3d(T.t[0], T.t[1], T.t[2]));
+}
+#endif
+
+void ElasticFusion::predict() { chk(ef_predict(C(ctx.get())), ctx.get(), "predict"); }
+
+const OdometryStats& ElasticFusion::getModelToModel() {
+  float s[6];
+  chk(ef_get_tracking_stats(C(ctx.get()), s, stats.lastA, stats.lastb), ctx.get(), "getModelToModel");
+  stats.lastICPError = s[0]; stats.lastICPCount = s[1]; stats.lastRGBError = s[2];
+  stats.lastRGBCount = s[3]; stats.lastSO3Error = s[4]; stats.lastSO3Count = s[5];
+  return stats;
+}
+
+void ElasticFusion::setRgbOnly(const bool& v) { chk(ef_set_rgb_only(C(ctx.get()), v), ctx.get(), "setRgbOnly"); }
+void ElasticFusion::setIcpWeight(const float& v) { chk(ef_set_icp_weight(C(ctx.get()), v), ctx.get(), "setIcpWeight"); }
+void ElasticFusion::setPyramid(const bool& v) { chk(ef_set_pyramid(C(ctx.get()), v), ctx.get(), "setPyramid"); }
+void ElasticFusion::setFastOdom(const bool& v) { chk(ef_set_fast_odom(C(ctx.get()), v), ctx.get(), "setFastOdom"); }
+void ElasticFusion::setSo3(const bool& v) { chk(ef_set_so3(C(ctx.get()), v), ctx.get(), "setSo3"); }
+void ElasticFusion::setFrameToFrameRGB(const bool& v) { chk(ef_set_frame_to_frame_rgb(C(ctx.get()), v), ctx.get(), "setFrameToFrameRGB"); }
+void ElasticFusion::setConfidenceThreshold(const float& v) {
+  chk(ef_set_confidence_threshold(C(ctx.get()), v), ctx.get(), "setConfidenceThreshold");
+  confidenceThreshold = v;
+}
+void ElasticFusion::setFernThresh(const float&) {}
+void ElasticFusion::setDepthCutoff(const float& v) { chk(ef_set_depth_cutoff(C(ctx.get()), v), ctx.get(), "setDepthCutoff"); }
+
+const int& ElasticFusion::getTick() {
+  chk(ef_get_tick(C(ctx.get()), &tick), ctx.get(), "getTick");
+  return tick;
+}
+void ElasticFusion::setTick(const int& val) { chk(ef_set_tick(C(ctx.get()), val), ctx.get(), "setTick"); }
+
+const SE3d& ElasticFusion::get_T_wc() {
+  double M[16];
+  chk(ef_get_pose(C(ctx.get()), M), ctx.get(), "get_T_wc");
+  T_wc = SE3d::fromMatrix(M);
+  return T_wc;
+}
+
+void ElasticFusion::savePly() { chk(ef_save_ply(C(ctx.get()), (saveFilename + ".ply").c_str()), ctx.get(), "savePly"); }
+void ElasticFusion::synchronize() { chk(ef_synchronize(C(ctx.get())), ctx.get(), "synchronize"); }
+
+unsigned int GlobalModelView::lastCount() {
+  uint32_t n = 0;
+  chk(ef_map_count(C(ctx), &n), ctx, "lastCount");
+  return n;
+}
+std::vector<float> GlobalModelView::downloadMap() {
+  uint32_t n = 0;
+  chk(ef_map_count(C(ctx), &n), ctx, "downloadMap");
+  std::vector<float> m((size_t)n * 12);
+  if (n) chk(ef_map_download(C(ctx), m.data(), n, &n), ctx, "downloadMap");
+  m.resize((size_t)n * 12);
+  return m;
+}
+
+std::vector<uint8_t> IndexMapView::image() {
+  std::vector<uint8_t> v((size_t)w * h * 4);
+  chk(ef_get_image(C(ctx), EF_IMG_PREDICT_IMAGE, v.data(), v.size()), ctx, "imageTex");
+  return v;
+}
+std::vector<float> IndexMapView::vertex() {
+  std::vector<float> v((size_t)w * h * 4);
+  chk(ef_get_image(C(ctx), EF_IMG_PREDICT_VERTEX, v.data(), v.size() * 4), ctx, "vertexTex");
+  return v;
+}
+std::vector<float> IndexMapView::normal() {
+  std::vector<float> v((size_t)w * h * 4);
+  chk(ef_get_image(C(ctx), EF_IMG_PREDICT_NORMAL, v.data(), v.size() * 4), ctx, "normalTex");
+  return v;
+}
+std::vector<uint16_t> IndexMapView::time() {
+  std::vector<uint16_t> v((size_t)w * h);
+  chk(ef_get_image(C(ctx), EF_IMG_PREDICT_TIME, v.data(), v.size() * 2), ctx, "timeTex");
+  return v;
+}
+
+}  // namespace efusion

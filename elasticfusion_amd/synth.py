@@ -126,3 +126,22 @@ class Sequence:
         mm = np.rint(1000.0 * z)
         depth = np.where((mm >= 300) & (mm <= 3000), mm, 0).astype(np.uint16)
         return rgb, depth, self.pose(k)
+
+
+def write_klg(path: str, frames, timestamps=None, compress_depth: bool = False) -> None:
+    """Writes frames [(rgb HxWx3 u8, depth HxW u16, ...)] as a .klg log (layout of Tools/RawLogReader.cpp:29,63-109):
+    int32 numFrames, then per frame int64 timestamp, int32 depthSize, int32 imageSize, depth bytes (raw little-endian
+    u16, or one zlib stream when ``compress_depth``), image bytes (raw RGB8: imageSize == 3*W*H means "not JPEG")."""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", len(frames)))
+        for k, fr in enumerate(frames):
+            rgb, depth = np.ascontiguousarray(fr[0], np.uint8), np.ascontiguousarray(fr[1], "<u2")
+            d = depth.tobytes()
+            if compress_depth:
+                d = zlib.compress(d)
+            ts = int(timestamps[k]) if timestamps is not None else k * 33333
+            f.write(struct.pack("<qii", ts, len(d), rgb.nbytes))
+            f.write(d)
+            f.write(rgb.tobytes())

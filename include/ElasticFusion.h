@@ -1,0 +1,175 @@
+// libefusion.so — the reference's C++ API surface (class ElasticFusion, Core/ElasticFusion.h:40-255) re-implemented
+// over the C ABI of libefusion_hip.so (include/ef_hip.h).  Written from scratch for this repository; only the PUBLIC
+// names, argument meanings and defaults follow the reference so that its front-end (MainController.cpp:178-194,
+// 222-254,262-500,520) compiles against it with the GL/Pangolin-typed getters removed.
+//
+// What is different, and why:
+//  * Sophus::SE3d / Eigen are not vendored by the reference checkout (third-party/* empty) and are absent here, so
+//    poses cross this boundary as Sophus-layout PODs (unit quaternion x,y,z,w + translation) with a row-major
+//    matrix() accessor.  When <sophus/se3.hpp> is on the include path, define EFUSION_USE_SOPHUS and the same
+//    methods take / return real Sophus::SE3d (conversion is a memcpy of 7 doubles).
+//  * getIndexMap()/getGlobalModel()/getModelToModel() return small HBM-backed facades with the members the
+//    front-end actually reads (lastCount, lastICPError, lastICPCount, downloadMap, host copies of the predicted
+//    images); there is no GL texture or VBO behind them.
+//  * closeLoops must be false (open loop, -o): loop closure is out of scope for this build.
+//  * errors throw std::runtime_error instead of assert()/exit(0).
+#ifndef EFUSION_ELASTICFUSION_H_
+#define EFUSION_ELASTICFUSION_H_
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#ifdef EFUSION_USE_SOPHUS
+#include <sophus/se3.hpp>
+#endif
+
+// ---- process-wide singletons of the reference (Core/Utils/Resolution.h:25-58, Intrinsics.h:25-51) ----
+class Resolution {
+ public:
+  static const Resolution& getInstance(int width = 0, int height = 0);
+  const int& width() const { return imgWidth; }
+  const int& height() const { return imgHeight; }
+  const int& cols() const { return imgWidth; }
+  const int& rows() const { return imgHeight; }
+  const int& numPixels() const { return imgNumPixels; }
+
+ private:
+  Resolution(int width, int height);
+  const int imgWidth, imgHeight, imgNumPixels;
+};
+
+class Intrinsics {
+ public:
+  static const Intrinsics& getInstance(float fx = 0, float fy = 0, float cx = 0, float cy = 0);
+  const float& fx() const { return fx_; }
+  const float& fy() const { return fy_; }
+  const float& cx() const { return cx_; }
+  const float& cy() const { return cy_; }
+
+ private:
+  Intrinsics(float fx, float fy, float cx, float cy);
+  const float fx_, fy_, cx_, cy_;
+};
+
+namespace efusion {
+
+// Sophus::SE3d's data layout: Eigen::Quaterniond (x, y, z, w) followed by Eigen::Vector3d
+struct SE3d {
+  double q[4] = {0, 0, 0, 1};
+  double t[3] = {0, 0, 0};
+  SE3d() = default;
+  static SE3d fromMatrix(const double* T_wc16_rowmajor);
+  void matrix(double* out16_rowmajor) const;      // Sophus::SE3d::matrix()
+  const double* translation() const { return t; } // Sophus::SE3d::translation()
+};
+
+struct ef_ctx_deleter { void operator()(void* p) const; };
+
+// what MainController reads from getModelToModel() (RGBDOdometry.h:74-82)
+struct OdometryStats {
+  float lastICPError = 0, lastICPCount = 0, lastRGBError = 0, lastRGBCount = 0, lastSO3Error = 0, lastSO3Count = 0;
+  double lastA[36] = {0}, lastb[6] = {0};
+};
+
+class ElasticFusion;
+
+// GlobalModel facade (Core/GlobalModel.h:46-58): the surfel map lives in HBM inside the context
+class GlobalModelView {
+ public:
+  unsigned int lastCount();                 // GlobalModel::lastCount()
+  // GlobalModel::downloadMap(): count x 12 floats {x,y,z,conf} {colour,0,initTime,lastTime} {nx,ny,nz,radius}
+  std::vector<float> downloadMap();
+ private:
+  friend class ::efusion::ElasticFusion;
+  void* ctx = nullptr;
+};
+
+// IndexMap facade (Core/IndexMap.h): host copies of the predicted-surface images of the last predict()
+class IndexMapView {
+ public:
+  std::vector<uint8_t> image();             // imageTex:  W*H*4 u8
+  std::vector<float> vertex();              // vertexTex: W*H*4 f32
+  std::vector<float> normal();              // normalTex: W*H*4 f32
+  std::vector<uint16_t> time();             // timeTex:   W*H u16
+ private:
+  friend class ::efusion::ElasticFusion;
+  void* ctx = nullptr;
+  int w = 0, h = 0;
+};
+
+class ElasticFusion {
+ public:
+  // same parameters, order and defaults as Core/ElasticFusion.h:42-58; `device` selects the HIP device
+  ElasticFusion(const int timeDelta = 200, const int countThresh = 35000, const float errThresh = 5e-05,
+                const float covThresh = 1e-05, const bool closeLoops = true, const bool iclnuim = false,
+                const bool reloc = false, const float photoThresh = 115, const float confidence = 10,
+                const float depthCut = 3, const float icpThresh = 10, const bool fastOdom = false,
+                const float fernThresh = 0.3095, const bool so3 = true, const bool frameToFrameRGB = false,
+                const std::string fileName = "", const int device = 0);
+  virtual ~ElasticFusion();   // writes <fileName>.freiburg like the reference's destructor (ElasticFusion.cpp:107-139)
+
+  // rgb: W*H*3 u8 row major; depth: W*H u16 millimetres, 0 invalid; borrowed for the duration of the call.
+  // All GPU work is only enqueued; getters that return results synchronise.
+  void processFrame(const uint8_t* rgb, const uint16_t* depth, const int64_t& timestamp, const float weightMultiplier = 1.f,
+                    const SE3d* in_T_wc = 0);
+#ifdef EFUSION_USE_SOPHUS
+  void processFrame(const uint8_t* rgb, const uint16_t* depth, const int64_t& timestamp, const float weightMultiplier,
+                    const Sophus::SE3d* in_T_wc);
+  Sophus::SE3d get_T_wc_sophus();
+#endif
+  void predict();
+
+  IndexMapView& getIndexMap() { return indexMap; }
+  GlobalModelView& getGlobalModel() { return globalModel; }
+  const OdometryStats& getModelToModel();   // refreshed from the device on each call
+
+  const float& getConfidenceThreshold() { return confidenceThreshold; }
+  void setRgbOnly(const bool& val);
+  void setIcpWeight(const float& val);
+  void setPyramid(const bool& val);
+  void setFastOdom(const bool& val);
+  void setSo3(const bool& val);
+  void setFrameToFrameRGB(const bool& val);
+  void setConfidenceThreshold(const float& val);
+  void setFernThresh(const float& val);     // accepted and ignored (no fern database in open loop)
+  void setDepthCutoff(const float& val);
+
+  const bool& getLost() { return lost; }
+  const int& getTick();
+  const int& getTimeDelta() { return timeDelta; }
+  void setTick(const int& val);
+  const float& getMaxDepthProcessed() { return maxDepthProcessed; }
+  const SE3d& get_T_wc();
+  const int& getDeforms() { return deforms; }
+  const int& getFernDeforms() { return fernDeforms; }
+  void savePly();                            // <fileName>.ply, binary little endian (ElasticFusion.cpp:684-781)
+
+  void synchronize();                        // wait for everything enqueued so far
+  void* context() { return ctx.get(); }      // the ef_ctx* underneath (include/ef_hip.h)
+
+ private:
+  std::unique_ptr<void, ef_ctx_deleter> ctx;
+  IndexMapView indexMap;
+  GlobalModelView globalModel;
+  OdometryStats stats;
+  SE3d T_wc;
+  std::string saveFilename;
+  int tick = 1;
+  int timeDelta;
+  float confidenceThreshold;
+  float maxDepthProcessed = 20.0f;
+  bool lost = false;
+  int deforms = 0, fernDeforms = 0;
+};
+
+}  // namespace efusion
+
+// the reference's class lives in the global namespace
+using efusion::ElasticFusion;
+#ifndef EFUSION_USE_SOPHUS
+namespace Sophus { using SE3d = efusion::SE3d; }
+#endif
+
+#endif  // EFUSION_ELASTICFUSION_H_

@@ -128,7 +128,11 @@ int ef_get_timings(ef_ctx* ctx, ef_timing* out, int max, int* n);
  * context's stream, every `every_n_frames`-th frame (0 = off; resets the samples).  ef_get_kernel_timing
  * synchronises and returns the average launch duration, the number of sampled launches and the
  * algorithmic bytes one launch must move -- bench.py's roofline leg. */
-typedef struct ef_kernel_time { const char* name; float avg_us; int launches; double bytes_per_launch; } ef_kernel_time;
+/* avg_us = raw_avg_us - empty_pair_us: an event pair with nothing between the two records already spans
+ * empty_pair_us on the stream (measured when sampling is switched on); the difference is the kernel. */
+typedef struct ef_kernel_time {
+  const char* name; float avg_us; int launches; double bytes_per_launch; float raw_avg_us; float empty_pair_us;
+} ef_kernel_time;
 int ef_kernel_timing(ef_ctx* ctx, int every_n_frames);
 int ef_get_kernel_timing(ef_ctx* ctx, ef_kernel_time* out);
 

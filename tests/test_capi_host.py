@@ -65,3 +65,29 @@ def test_product_sources_never_reference_the_oracle():
                             continue
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_cpp_shim_library_and_replay_tool_exist_and_fail_loudly(tmp_path):
+    """libefusion.so (class ElasticFusion of include/ElasticFusion.h) and the headless replay front-end are built by
+    build(); without a GPU the front-end must exit with an error, not fall back."""
+    import subprocess
+    import numpy as np
+    from elasticfusion_amd import api, build, synth
+    build.build()
+    shim = os.path.join(os.path.dirname(api.LIB_PATH), "libefusion.so")
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "efusion_replay")
+    assert os.path.exists(shim) and os.path.exists(exe)
+    syms = subprocess.run(["nm", "-DC", shim], stdout=subprocess.PIPE, text=True).stdout
+    for name in ("efusion::ElasticFusion::processFrame(", "efusion::ElasticFusion::predict()", "efusion::ElasticFusion::get_T_wc()",
+                 "efusion::ElasticFusion::savePly()", "Resolution::getInstance(int, int)", "Intrinsics::getInstance(float, float, float, float)",
+                 "efusion::GlobalModelView::lastCount()"):
+        assert name in syms, name
+    assert subprocess.run([exe]).returncode == 2
+    rgb = np.full((480, 640, 3), 7, np.uint8)
+    depth = np.full((480, 640), 1000, np.uint16)
+    log = str(tmp_path / "two.klg")
+    synth.write_klg(log, [(rgb, depth), (rgb, depth)], compress_depth=True)
+    assert os.path.getsize(log) < 4 + 2 * (16 + 640 * 480 * 5)
+    if not os.path.exists("/dev/kfd"):
+        r = subprocess.run([exe, "-l", log, "-q"], stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 1 and "libefusion_hip error" in r.stderr

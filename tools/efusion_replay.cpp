@@ -1,0 +1,120 @@
+// Headless replay front-end: what MainController::run() does around ElasticFusion::processFrame
+// (MainController.cpp:201-254) with the GUI removed.  Reads a .klg log (format of Tools/RawLogReader.cpp:29,63-109:
+// int32 numFrames; per frame int64 timestamp, int32 depthSize, int32 imageSize, depth bytes (raw u16 or zlib),
+// image bytes (raw RGB8; JPEG frames are rejected — libjpeg is not available in this image)), replays it through
+// libefusion.so and writes <log>.freiburg (+ <log>.ply with -ply).
+//
+//   efusion_replay -l seq.klg [-w 640 -h 480] [-cal fx fy cx cy] [-d depthCut] [-c confidence] [-t timeDelta]
+//                  [-fo] [-nso] [-ftf] [-i icpWeight] [-e endFrame] [-ply] [-dev N] [-q]
+//
+// Always open loop (the reference's -o): loop closure is out of scope of this build.
+#include <zlib.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../include/ElasticFusion.h"
+
+namespace {
+struct KlgReader {
+  FILE* fp = nullptr;
+  int32_t numFrames = 0;
+  int numPixels;
+  std::vector<uint8_t> depthRead, imageRead, depth, rgb;
+  int64_t timestamp = 0;
+  int current = 0;
+  KlgReader(const std::string& file, int w, int h) : numPixels(w * h) {
+    fp = std::fopen(file.c_str(), "rb");
+    if (!fp) throw std::runtime_error("cannot open " + file);
+    if (std::fread(&numFrames, sizeof(int32_t), 1, fp) != 1) throw std::runtime_error("empty log");
+    depthRead.resize((size_t)numPixels * 2 + 65536);
+    imageRead.resize((size_t)numPixels * 3 + 65536);
+    depth.resize((size_t)numPixels * 2);
+    rgb.resize((size_t)numPixels * 3);
+  }
+  ~KlgReader() { if (fp) std::fclose(fp); }
+  bool hasMore() const { return current < numFrames; }
+  void getNext() {
+    int32_t depthSize = 0, imageSize = 0;
+    if (std::fread(&timestamp, sizeof(int64_t), 1, fp) != 1 || std::fread(&depthSize, sizeof(int32_t), 1, fp) != 1 ||
+        std::fread(&imageSize, sizeof(int32_t), 1, fp) != 1)
+      throw std::runtime_error("truncated log header");
+    if (depthSize < 0 || (size_t)depthSize > depthRead.size() || imageSize < 0 || (size_t)imageSize > imageRead.size())
+      throw std::runtime_error("frame larger than the configured resolution");
+    if (depthSize && std::fread(depthRead.data(), depthSize, 1, fp) != 1) throw std::runtime_error("truncated depth");
+    if (imageSize && std::fread(imageRead.data(), imageSize, 1, fp) != 1) throw std::runtime_error("truncated image");
+    if (depthSize == numPixels * 2) {
+      std::memcpy(depth.data(), depthRead.data(), depth.size());
+    } else {
+      unsigned long len = depth.size();
+      if (uncompress(depth.data(), &len, depthRead.data(), depthSize) != Z_OK) throw std::runtime_error("zlib depth frame corrupt");
+    }
+    if (imageSize == numPixels * 3) std::memcpy(rgb.data(), imageRead.data(), rgb.size());
+    else if (imageSize == 0) std::memset(rgb.data(), 0, rgb.size());
+    else throw std::runtime_error("JPEG-compressed colour frames are not supported in this build (no libjpeg)");
+    ++current;
+  }
+};
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string log;
+  int w = 640, h = 480, timeDelta = 200, end = -1, dev = 0;
+  float fx = 528, fy = 528, cx = 320, cy = 240, depthCut = 3, confidence = 10, icp = 10;
+  bool fastOdom = false, so3 = true, ftf = false, ply = false, quiet = false;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto next = [&](int n = 1) { if (i + n >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
+    if (a == "-l") log = next();
+    else if (a == "-w") w = std::atoi(next());
+    else if (a == "-h") h = std::atoi(next());
+    else if (a == "-cal") { fx = std::atof(next()); fy = std::atof(next()); cx = std::atof(next()); cy = std::atof(next()); }
+    else if (a == "-d") depthCut = std::atof(next());
+    else if (a == "-c") confidence = std::atof(next());
+    else if (a == "-t") timeDelta = std::atoi(next());
+    else if (a == "-i") icp = std::atof(next());
+    else if (a == "-e") end = std::atoi(next());
+    else if (a == "-dev") dev = std::atoi(next());
+    else if (a == "-fo") fastOdom = true;
+    else if (a == "-nso") so3 = false;
+    else if (a == "-ftf") ftf = true;
+    else if (a == "-ply") ply = true;
+    else if (a == "-q") quiet = true;
+    else if (a == "-o") {}
+    else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
+  }
+  if (log.empty()) { std::fprintf(stderr, "usage: efusion_replay -l file.klg [...]\n"); return 2; }
+  try {
+    Resolution::getInstance(w, h);
+    Intrinsics::getInstance(fx, fy, cx, cy);
+    KlgReader reader(log, w, h);
+    // open loop: timeDelta = INT_MAX / 2 exactly as MainController does for -o (MainController.cpp:179-183)
+    ElasticFusion eFusion(2147483647 / 2, 35000, 5e-05f, 1e-05f, false, false, false, 115, confidence, depthCut, icp, fastOdom, 0.3095f,
+                          so3, ftf, log, dev);
+    (void)timeDelta;
+    const auto t0 = std::chrono::steady_clock::now();
+    int n = 0;
+    while (reader.hasMore() && (end < 0 || n < end)) {
+      reader.getNext();
+      eFusion.processFrame(reader.rgb.data(), (const uint16_t*)reader.depth.data(), reader.timestamp, 1.0f);
+      ++n;
+    }
+    eFusion.synchronize();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    double M[16];
+    eFusion.get_T_wc().matrix(M);
+    if (!quiet)
+      std::printf("frames %d  %.1f fps  surfels %u  icp %g/%g  t_wc %.9g %.9g %.9g\n", n, n / dt, eFusion.getGlobalModel().lastCount(),
+                  (double)eFusion.getModelToModel().lastICPError, (double)eFusion.getModelToModel().lastICPCount, M[3], M[7], M[11]);
+    if (ply) eFusion.savePly();
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "efusion_replay: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
