@@ -142,8 +142,16 @@ def main():
         kt = KT()
         if lib.ef_get_kernel_timing(ef.h, C.byref(kt)) == 0 and kt.launches > 0:
             achieved = kt.bytes_per_launch / (kt.avg_us * 1e-6) / 1e9
+            # HBM-side bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the last
+            # measurement committed under profiles/ by tools/pmc_traffic.sh, for this same kernel and workload
+            traffic = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    traffic = int(json.load(f)["traffic_bytes_per_launch"])
+            except Exception:
+                pass
             roofline = {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "avg_us": round(float(kt.avg_us), 3), "event_pair_raw_us": round(float(kt.raw_avg_us), 3),
                         "event_pair_empty_us": round(float(kt.empty_pair_us), 3), "launches_sampled": int(kt.launches),
                         "algorithmic_bytes_per_launch": int(kt.bytes_per_launch)}

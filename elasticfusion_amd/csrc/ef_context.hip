@@ -662,8 +662,11 @@ int ef_get_kernel_timing(ef_ctx* c, ef_kernel_time* out) {
   out->raw_avg_us = c->probe.used ? (float)(1e3 * total_ms / c->probe.used) : 0.f;
   out->empty_pair_us = c->kt_empty_pair_us;
   out->avg_us = out->raw_avg_us > out->empty_pair_us ? out->raw_avg_us - out->empty_pair_us : out->raw_avg_us;
-  // icpStep 48 B per pixel-visit (4 planar float3 maps), rgbStep 32 B per pixel-visit
-  out->bytes_per_launch = (double)c->cam.cols * c->cam.rows * ((icp ? 48.0 : 0.0) + (rgb ? 32.0 : 0.0));
+  // algorithmic bytes of ONE launch of this kernel (DESIGN.md "Roofline accounting"): icpStep 48 B per pixel-visit
+  // (4 planar float3 maps); rgbStep reads the 4-byte packed correspondence of every pixel — the
+  // reference's 16-byte DataTerm + 12-byte cloud are gone, so they are not counted — the ~10 % valid pixels' gathers
+  // (depth + 2 gradients) are left out (data dependent): a lower bound, which can only understate `achieved`
+  out->bytes_per_launch = (double)c->cam.cols * c->cam.rows * ((icp ? 48.0 : 0.0) + (rgb ? 4.0 : 0.0));
   return EF_OK;
 }
 
