@@ -64,6 +64,14 @@ def lib():
     return _lib
 
 
+def use_library(path: str | None = None):
+    """Rebinds this module to another build of the same C ABI (tests only: libefusion_hip_nofma.so, the -DEF_NO_FMA
+    variant that is compared bit for bit with the compiled reference).  None = back to the product library."""
+    global _lib, LIB_PATH
+    _lib = None
+    LIB_PATH = path or os.path.join(_HERE, "libefusion_hip.so")
+
+
 def _chk(rc: int, ctx=None):
     if rc != 0:
         msg = lib().ef_last_error(ctx)
@@ -247,6 +255,7 @@ class ElasticFusion:
     def setFrameToFrameRGB(self, v): _chk(lib().ef_set_frame_to_frame_rgb(self.h, c_i(int(v))), self.h)
     def setConfidenceThreshold(self, v): _chk(lib().ef_set_confidence_threshold(self.h, c_f(v)), self.h)
     def setDepthCutoff(self, v): _chk(lib().ef_set_depth_cutoff(self.h, c_f(v)), self.h)
+    def setInputOverlap(self, on): _chk(lib().ef_set_input_overlap(self.h, c_i(int(on))), self.h)
 
     def image(self, name: str) -> np.ndarray:
         which, dt, ch = self.IMAGES[name]

@@ -15,6 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libefusion_hip.so")
+NOFMA_LIB = os.path.join(HERE, "libefusion_hip_nofma.so")   # TEST-ONLY variant (-DEF_NO_FMA, see csrc/ef_device.hpp): compared bit
+                                                              # for bit with the compiled reference in tests/test_gpu_vs_reference.py
 SHIM_LIB = os.path.join(HERE, "libefusion.so")          # class ElasticFusion (include/ElasticFusion.h) over the C ABI
 SOURCES = ["ef_track_kernels.hip", "ef_map_kernels.hip", "ef_context.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -29,7 +31,7 @@ def _hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB) or not os.path.exists(SHIM_LIB):
+    if not os.path.exists(LIB) or not os.path.exists(SHIM_LIB) or not os.path.exists(NOFMA_LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "ef_hip.h"), __file__]
@@ -39,25 +41,27 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    objs = []
+    objs = {"": [], "_nofma": []}
     procs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [_hipcc(), *FLAGS, *os.environ.get("EF_HIPCC_FLAGS", "").split(), "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
+    for variant, extra in (("", []), ("_nofma", ["-DEF_NO_FMA"])):
+        for src in SOURCES:
+            obj = os.path.join(CSRC, src.replace(".hip", variant + ".o"))
+            cmd = [_hipcc(), *FLAGS, *extra, *os.environ.get("EF_HIPCC_FLAGS", "").split(), "-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            objs[variant].append(obj)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-Wl,-rpath,/opt/rocm/lib"]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stdout}")
+    for variant, target in (("", LIB), ("_nofma", NOFMA_LIB)):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target, *objs[variant], "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}")
     # libefusion.so: host-only C++ (compiled by hipcc for the shared __host__ __device__ linear-algebra header)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", SHIM_LIB,
            os.path.join(CSRC, "efusion_shim.hip"), "-L" + HERE, "-lefusion_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]

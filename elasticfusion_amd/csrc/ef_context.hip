@@ -42,6 +42,17 @@ struct ef_ctx {
   uint16_t* depth_filtered = nullptr;
   float* depth_metric = nullptr;
   float* depth_metric_filtered = nullptr;
+  // second set of the five frame images: frame k+1's input stage (copy, bilateral filter, frame pyramids) runs on
+  // in_stream while frame k is still being fused on `stream`, so the two frames must not share these buffers
+  uint8_t* rgb_alt = nullptr;
+  uint16_t* depth_raw_alt = nullptr;
+  uint16_t* depth_filtered_alt = nullptr;
+  float* depth_metric_alt = nullptr;
+  float* depth_metric_filtered_alt = nullptr;
+  hipStream_t in_stream = nullptr;
+  hipEvent_t ev_input_done = nullptr, ev_track_done = nullptr, ev_staged = nullptr;
+  bool overlap = false;
+  bool staged_pending = false;
   uint8_t* h_rgb = nullptr;      // pinned staging
   uint16_t* h_depth = nullptr;
   // tracker
@@ -145,29 +156,49 @@ int do_predict(ef_ctx* c) {
   return EF_OK;
 }
 
-int process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_dev, int64_t timestamp, float weightMultiplier,
-                      const double* in_T_wc) {
+// rgb_src / depth_src: host (pinned staging) or device pointers, `kind` says which
+int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, hipMemcpyKind kind, int64_t timestamp,
+                  float weightMultiplier, const double* in_T_wc) {
   hipStream_t s = c->stream;
   const int W = c->cam.cols, H = c->cam.rows;
+  // Input stage: everything that needs nothing but the new frame.  With overlap on it is enqueued on in_stream and
+  // waits only for the previous frame's TRACKER (the last reader of the frame-side pyramids); it then runs concurrently
+  // with the previous frame's fusion + prediction on `stream`, which read the other set of frame images.
+  const bool overlap = c->overlap && !c->timing && c->in_stream != nullptr;
+  hipStream_t sb = overlap ? c->in_stream : s;
+  std::swap(c->rgb, c->rgb_alt);
+  std::swap(c->depth_raw, c->depth_raw_alt);
+  std::swap(c->depth_filtered, c->depth_filtered_alt);
+  std::swap(c->depth_metric, c->depth_metric_alt);
+  std::swap(c->depth_metric_filtered, c->depth_metric_filtered_alt);
+  const bool track_this = c->tick > 1 && !in_T_wc;
+  if (overlap) EF_HIP(c, hipStreamWaitEvent(sb, c->ev_track_done, 0));
   // the frame images are referenced by later stages of this frame and by the next frame's tracker
-  // (fill-in / predict read depth_filtered + rgb), so they are copied into context-owned buffers (D2D)
-  if (rgb_dev != c->rgb) EF_HIP(c, hipMemcpyAsync(c->rgb, rgb_dev, (size_t)W * H * 3, hipMemcpyDeviceToDevice, s));
-  if (depth_dev != c->depth_raw) EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_dev, (size_t)W * H * 2, hipMemcpyDeviceToDevice, s));
-
+  // (fill-in / predict read depth_filtered + rgb), so they are copied into context-owned buffers
+  EF_HIP(c, hipMemcpyAsync(c->rgb, rgb_src, (size_t)W * H * 3, kind, sb));
+  EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_src, (size_t)W * H * 2, kind, sb));
+  if (kind == hipMemcpyHostToDevice) { EF_HIP(c, hipEventRecord(c->ev_staged, sb)); c->staged_pending = true; }
   timer_begin(c, "Preprocess");
-  efm::preprocess_depth(c->depth_raw, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, s);
+  efm::preprocess_depth(c->depth_raw, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb);
   timer_end(c, "Preprocess");
+  if (track_this) {
+    eft::init_icp(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, sb);
+    eft::init_rgb_frame(c->pyr, c->rgb, sb);
+  }
+  if (overlap) EF_HIP(c, hipEventRecord(c->ev_input_done, sb));
 
   const bool rgbOnly = c->cfg.rgb_only != 0;
   // t_T_wc.push_back / poseLogTimes.push_back, ElasticFusion.cpp:588-589: the pose is logged by the kernel that produces it
   const int log_slot = (int)c->stamps.size() < c->traj_cap ? (int)c->stamps.size() : -1;
   if (log_slot >= 0) c->stamps.push_back(timestamp);
   if (c->tick == 1) {  // ElasticFusion.cpp:290-296
+    if (overlap) EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
     timer_begin(c, "feedbackBuffers");
     efm::seed_map(c->cam, c->rgb, c->depth_metric, c->depth_metric_filtered, c->tick, c->maxDepthProcessed, c->maps[c->cur],
                   &c->st->map_counts[c->cur], c->cs, s);
     eft::init_first_rgb(c->pyr, c->rgb, s);
     if (log_slot >= 0) eft::log_pose(c->st, c->traj, log_slot, s);
+    EF_HIP(c, hipEventRecord(c->ev_track_done, s));
     timer_end(c, "feedbackBuffers");
   } else {
     if (!in_T_wc) {
@@ -183,8 +214,9 @@ int process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_d
       timer_begin(c, "odomInit");
       eft::init_icp_model(c->pyr, (const float*)c->pm.vertex, (const float*)c->pm.normal, (const float*)c->fm.vertex,
                           (const float*)c->fm.normal, c->st, 6.0f /* maxDepthRGB, RGBDOdometry.cpp:42 */, s);
-      eft::init_icp(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, s);
-      eft::init_rgb(c->pyr, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, c->rgb, c->st, rgb, s);
+      eft::init_rgb_model(c->pyr, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, c->st, s);
+      if (overlap) EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
+      if (rgb) eft::init_rgb_sobel(c->pyr, s);
       timer_end(c, "odomInit");
       timer_begin(c, "odom");
       const bool sample = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0;
@@ -192,8 +224,11 @@ int process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_d
       eft::track_end(c->st, rgb, weightMultiplier, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
       timer_end(c, "odom");
     } else {
+      if (overlap) EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
       eft::pose_injected(c->st, in_T_wc, true, weightMultiplier, true, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
     }
+    // from here on nothing of this frame reads the frame-side pyramids: the next frame's input stage may start
+    EF_HIP(c, hipEventRecord(c->ev_track_done, s));
     // mid-frame predict() of ElasticFusion.cpp:387 is dead work without loop closure: skipped
     if (!rgbOnly) {  // ElasticFusion.cpp:536-585
       timer_begin(c, "indexMap");
@@ -233,6 +268,16 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->depth_filtered, P);
   EF_ALLOC(c, c->depth_metric, P);
   EF_ALLOC(c, c->depth_metric_filtered, P);
+  EF_ALLOC(c, c->rgb_alt, P * 3);
+  EF_ALLOC(c, c->depth_raw_alt, P);
+  EF_ALLOC(c, c->depth_filtered_alt, P);
+  EF_ALLOC(c, c->depth_metric_alt, P);
+  EF_ALLOC(c, c->depth_metric_filtered_alt, P);
+  EF_HIP(c, hipStreamCreateWithFlags(&c->in_stream, hipStreamNonBlocking));
+  EF_HIP(c, hipEventCreateWithFlags(&c->ev_input_done, hipEventDisableTiming));
+  EF_HIP(c, hipEventCreateWithFlags(&c->ev_track_done, hipEventDisableTiming));
+  EF_HIP(c, hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+  c->overlap = getenv("EF_OVERLAP") != nullptr && atoi(getenv("EF_OVERLAP")) != 0;   // measured: see DESIGN.md §6
   EF_HIP(c, hipHostMalloc((void**)&c->h_rgb, P * 3));
   EF_HIP(c, hipHostMalloc((void**)&c->h_depth, P * 2));
   // tracker pyramids (zero-filled: the stale y/z planes of quirk Q3 are then deterministic)
@@ -283,7 +328,7 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->cand.col_time, c->cand.n);
   EF_ALLOC(c, c->cand.nrm_rad, c->cand.n);
   EF_ALLOC(c, c->cand.best, c->cand.n);
-  c->cs.max_chunks = (int)((c->capacity + (size_t)c->cand.n + 2 * P) / efm::CHUNK + 8);
+  c->cs.max_chunks = (int)((c->capacity + (size_t)c->cand.n + 2 * P) / efm::CLEAN_ROW + 8);
   EF_ALLOC(c, c->cs.flags, (size_t)c->capacity + c->cand.n + 2 * P);
   EF_ALLOC(c, c->cs.chunk_count, c->cs.max_chunks);
   EF_ALLOC(c, c->cs.chunk_offset, c->cs.max_chunks);
@@ -300,7 +345,11 @@ int ctx_init(ef_ctx* c) {
 }
 
 void ctx_free(ef_ctx* c) {
+  if (c->in_stream) (void)hipStreamSynchronize(c->in_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->in_stream) (void)hipStreamDestroy(c->in_stream);
+  for (hipEvent_t e : {c->ev_input_done, c->ev_track_done, c->ev_staged})
+    if (e) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->h_rgb) (void)hipHostFree(c->h_rgb);
   if (c->h_depth) (void)hipHostFree(c->h_depth);
@@ -387,18 +436,17 @@ int ef_synchronize(ef_ctx* c) {
 int ef_process_frame(ef_ctx* c, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, float wm, const double* T) {
   if (!c || !rgb || !depth) return EF_EINVAL;
   const size_t P = (size_t)c->cam.cols * c->cam.rows;
-  // the staging buffers may still be in flight from the previous frame's async copy
-  EF_HIP(c, hipStreamSynchronize(c->stream));
+  // the pinned staging buffers may still be in flight from the previous frame's async copy: wait for that copy only
+  if (c->staged_pending) { EF_HIP(c, hipEventSynchronize(c->ev_staged)); c->staged_pending = false; }
   memcpy(c->h_rgb, rgb, P * 3);
   memcpy(c->h_depth, depth, P * 2);
-  EF_HIP(c, hipMemcpyAsync(c->rgb, c->h_rgb, P * 3, hipMemcpyHostToDevice, c->stream));
-  EF_HIP(c, hipMemcpyAsync(c->depth_raw, c->h_depth, P * 2, hipMemcpyHostToDevice, c->stream));
-  return process_frame_dev(c, c->rgb, c->depth_raw, timestamp, wm, T);
+  return process_frame(c, c->h_rgb, c->h_depth, hipMemcpyHostToDevice, timestamp, wm, T);
 }
 int ef_process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_dev, int64_t timestamp, float wm, const double* T) {
   if (!c || !rgb_dev || !depth_dev) return EF_EINVAL;
-  return process_frame_dev(c, rgb_dev, depth_dev, timestamp, wm, T);
+  return process_frame(c, rgb_dev, depth_dev, hipMemcpyDeviceToDevice, timestamp, wm, T);
 }
+int ef_set_input_overlap(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->overlap = on != 0; return EF_OK; }
 int ef_predict(ef_ctx* c) {
   if (!c) return EF_EINVAL;
   EF_HIP(c, hipMemsetAsync(&c->st->dense_count, 0, sizeof(unsigned), c->stream));
@@ -1068,7 +1116,7 @@ int ef_op_clean(const ef_cam* cam, const double* T16, int time, const uint32_t* 
   hipLaunchKernelGGL(k_aos_to_cand, dim3((cand.n + 255) / 256), dim3(256), 0, s, (const float4*)newUnstable, newCount, cand);
   uint32_t* winner = m.alloc<uint32_t>(count, 0xFF);
   efm::CompactScratch cs;
-  cs.max_chunks = (int)((cap + 1) / efm::CHUNK + 8);
+  cs.max_chunks = (int)((cap + 1) / efm::CLEAN_ROW + 8);
   cs.flags = m.alloc<uint8_t>((size_t)cap + 1);
   cs.chunk_count = m.alloc<uint32_t>(cs.max_chunks);
   cs.chunk_offset = m.alloc<uint32_t>(cs.max_chunks);

@@ -9,6 +9,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Fused multiply-adds of the tracking kernels appear only through EF_FMA.  The product build fuses them (the
+// numerics specification shared with the oracle); building with -DEF_NO_FMA (libefusion_hip_nofma.so, test-only) splits each
+// into an IEEE multiply and an IEEE add, which is what the reference's own CUDA sources compute when compiled without
+// contraction — that variant is compared bit for bit with the compiled reference / its golden vectors on the GPU
+// (tests/test_gpu_vs_reference.py).
+#ifdef EF_NO_FMA
+#define EF_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define EF_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
+
 namespace ef {
 
 struct f3 { float x, y, z; };
@@ -16,9 +27,9 @@ struct f3 { float x, y, z; };
 __device__ __forceinline__ float qnan() { return __int_as_float(0x7fffffff); }
 __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ float dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return EF_FMA(a.z, b.z, EF_FMA(a.y, b.y, a.x * b.x)); }
 __device__ __forceinline__ f3 cross(f3 a, f3 b) {
-  return {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+  return {EF_FMA(a.y, b.z, -(a.z * b.y)), EF_FMA(a.z, b.x, -(a.x * b.z)), EF_FMA(a.x, b.y, -(a.y * b.x))};
 }
 __device__ __forceinline__ float norm(f3 a) { return sqrtf(dot(a, a)); }
 __device__ __forceinline__ f3 normalized(f3 a) {

@@ -23,7 +23,8 @@ struct SurfelSoA {
 
 constexpr unsigned long long ZBUF_EMPTY = 0xFFFFFFFFFFFFFFFFull;
 constexpr unsigned WINNER_EMPTY = 0xFFFFFFFFu;
-constexpr int CHUNK = 1024;  // elements per compaction chunk (256 threads x 4)
+constexpr int CHUNK = 1024;  // elements per compaction chunk (256 threads x 4) of the seeding / candidate passes
+constexpr int CLEAN_ROW = 256; // elements per compaction chunk of clean(): one per thread
 
 // per-pixel model prediction products
 struct IndexMaps {   // IndexMap::predictIndices outputs (IndexMap.h:74-88)

@@ -16,6 +16,8 @@ namespace {
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 constexpr int SURFEL_GRID = 1024;   // grid-stride workgroups for per-surfel passes (count lives on the device)
 constexpr int BLK = 256;
+constexpr int CLEAN_GRID = 4096;     // grid-stride workgroups of the clean passes (one 256-element row each)
+static_assert(CLEAN_ROW == BLK, "clean kernels run one element per thread");
 
 __device__ __forceinline__ uint32_t depth_key(float z) {  // order-preserving float -> uint
   const uint32_t b = __float_as_uint(z);
@@ -166,11 +168,11 @@ __device__ __forceinline__ unsigned dyn_n(const unsigned* count_dev, unsigned ex
 // count_out / capacity / overflow_flag: optional clamped copy of the total (the new surfel count of clean())
 __global__ void __launch_bounds__(1024) k_scan_chunks(const uint32_t* __restrict__ counts, const unsigned* count_dev, unsigned extra,
                                                        uint32_t* __restrict__ offsets, uint32_t* total_out, unsigned* count_out = nullptr,
-                                                       uint32_t capacity = 0, int* overflow_flag = nullptr) {
+                                                       uint32_t capacity = 0, int* overflow_flag = nullptr, unsigned chunk = CHUNK) {
   __shared__ unsigned wsum[16];
   __shared__ unsigned carry_s;
   const unsigned n = dyn_n(count_dev, extra);
-  const unsigned nchunks = (n + CHUNK - 1) / CHUNK;
+  const unsigned nchunks = (n + chunk - 1) / chunk;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (t == 0) carry_s = 0;
   __syncthreads();
@@ -639,6 +641,24 @@ struct CleanArgs {
   float confThreshold;
   int timeDelta;
 };
+// The 4 taps of one axis (N4: pixel offsets {-1,-.5,0,+.5} -> texel floor(x+off), clamped) hit at most 3 distinct
+// texels (the offsets span 1.5, so the floors span <= 2, and clamping is monotone).  The keep-test only counts taps,
+// so each distinct texel is fetched once and counted with its multiplicity: 9 gathers instead of 16, all issued
+// before the first use.
+struct Taps3 { int u[3]; int m[3]; };
+__device__ __forceinline__ Taps3 dedupe_taps(float x, int hi) {
+  int t[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) t[a] = clampi((int)floorf(x + (-1.0f + 0.5f * a)), 0, hi);
+  Taps3 r;
+  r.u[0] = t[0];
+  r.u[2] = t[3];
+  r.u[1] = (t[1] != t[0] && t[1] != t[3]) ? t[1] : t[2];
+  r.m[0] = 1 + (t[1] == t[0]) + (t[2] == t[0]) + (t[3] == t[0]);
+  r.m[2] = (t[3] != t[0]) ? (1 + (t[0] == t[3]) + (t[1] == t[3]) + (t[2] == t[3])) : 0;
+  r.m[1] = (r.u[1] != t[0] && r.u[1] != t[3]) ? ((t[1] == r.u[1]) + (t[2] == r.u[1])) : 0;
+  return r;
+}
 // copy_unstable.vert:49-130 (nodes == 0); returns keep flag; ct.w tag -2 is rewritten to time by the caller
 __device__ __forceinline__ bool clean_test(const CleanArgs& A, const rt34& T, float4 pc, float4 ct, float4 nr) {
   const Cam& cam = A.cam;
@@ -650,25 +670,34 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& A, const rt34& T, fl
   const f3 localNorm = normalized(mul(T.R, f3{nr.x, nr.y, nr.z}));
   int cnt = 0, zCount = 0;
   if (ftime - ct.w < ftd && localPos.z > 0 && x > 0 && y > 0 && x < (float)cam.cols && y < (float)cam.rows) {
+    const Taps3 tx = dedupe_taps(x, cam.cols - 1), ty = dedupe_taps(y, cam.rows - 1);
+    uint32_t idx[9];
+    float4 vcs[9], c2s[9];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int tx = clampi((int)floorf(x + (-1.0f + 0.5f * a)), 0, cam.cols - 1);  // N4 offsets {-1,-.5,0,+.5}
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int ty = clampi((int)floorf(y + (-1.0f + 0.5f * b)), 0, cam.rows - 1);
-        const int ti = ty * cam.cols + tx;
-        if (A.im.index[ti] > 0U) {
-          const float4 vc = A.im.vert_conf[ti];
-          const float4 c2 = A.im.color_time[ti];
+      for (int b = 0; b < 3; ++b) {
+        const int ti = ty.u[b] * cam.cols + tx.u[a];
+        idx[a * 3 + b] = A.im.index[ti];
+        vcs[a * 3 + b] = A.im.vert_conf[ti];
+        c2s[a * 3 + b] = A.im.color_time[ti];
+      }
+    const bool steep = fabsf(localNorm.z) > 0.85f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int w = tx.m[a] * ty.m[b];   // how many of the 16 taps land on this texel
+        const float4 vc = vcs[a * 3 + b], c2 = c2s[a * 3 + b];
+        if (w > 0 && idx[a * 3 + b] > 0U) {
           const float dx = vc.x - localPos.x, dy = vc.y - localPos.y;
           if (c2.z < ct.z && vc.w > A.confThreshold && vc.z > localPos.z && vc.z - localPos.z < 0.01f &&
               sqrtf(dx * dx + dy * dy) < nr.w * 1.4f)
-            cnt++;
-          if (c2.w == ftime && vc.w > A.confThreshold && vc.z > localPos.z && vc.z - localPos.z > 0.01f && fabsf(localNorm.z) > 0.85f)
-            zCount++;
+            cnt += w;
+          if (c2.w == ftime && vc.w > A.confThreshold && vc.z > localPos.z && vc.z - localPos.z > 0.01f && steep)
+            zCount += w;
         }
       }
-    }
   }
   if (cnt > 8 || zCount > 4) test = 0;
   float lastTime = ct.w;
@@ -689,32 +718,34 @@ __device__ __forceinline__ bool load_element(const SurfelSoA& map, const Candida
   pc = cand.pos_conf[r]; nr = cand.nrm_rad[r];
   return true;
 }
+// one element per thread, one CLEAN_ROW-element compaction chunk per workgroup iteration: everything a row needs
+// is in flight at once (the element count is device-resident, hence the grid-stride over rows)
 __global__ void __launch_bounds__(BLK) k_clean_flags(const CleanArgs A, SurfelSoA map, const unsigned* __restrict__ count_dev,
                                                       Candidates cand, uint32_t* winner, uint8_t* __restrict__ flags,
                                                       uint32_t* __restrict__ chunk_count) {
   __shared__ unsigned lds[BLK / 64];
   const unsigned count = *count_dev;
   const unsigned n = count + (unsigned)cand.n;
-  const unsigned nchunks = (n + CHUNK - 1) / CHUNK;
+  const unsigned nrows = (n + CLEAN_ROW - 1) / CLEAN_ROW;
   const rt34 T = rt34_load16(A.T16);
-  for (unsigned c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    unsigned keep = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      // element order inside a chunk: k*256 + t keeps loads coalesced; ranks are recovered the same way in scatter
-      const unsigned e = c * CHUNK + k * BLK + threadIdx.x;
-      if (e < n) {
-        float4 pc, ct, nr;
-        uint8_t f = 0;
-        if (load_element(map, cand, count, e, pc, ct, nr)) f = clean_test(A, T, pc, ct, nr) ? 1 : 0;
-        if (e < count) winner[e] = WINNER_EMPTY;  // re-arm the association winners for the next frame
-        flags[e] = f;
-        keep += f;
-      }
+  for (unsigned r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const unsigned e = r * CLEAN_ROW + threadIdx.x;
+    bool f = false;
+    if (e < n) {
+      float4 pc, ct, nr;
+      if (load_element(map, cand, count, e, pc, ct, nr)) f = clean_test(A, T, pc, ct, nr);
+      if (e < count) winner[e] = WINNER_EMPTY;  // re-arm the association winners for the next frame
+      flags[e] = f ? 1 : 0;
     }
-    unsigned tot;
-    block_excl_scan(keep, lds, tot);
-    if (threadIdx.x == 0) chunk_count[c] = tot;
+    const unsigned wave_keep = (unsigned)__popcll(__ballot(f));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = wave_keep;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned tot = 0;
+#pragma unroll
+      for (int i = 0; i < BLK / 64; ++i) tot += lds[i];
+      chunk_count[r] = tot;
+    }
     __syncthreads();
   }
 }
@@ -724,26 +755,21 @@ __global__ void __launch_bounds__(BLK) k_clean_scatter(SurfelSoA map, const unsi
   __shared__ unsigned lds[BLK / 64];
   const unsigned count = *count_dev;
   const unsigned n = count + (unsigned)cand.n;
-  const unsigned nchunks = (n + CHUNK - 1) / CHUNK;
-  for (unsigned c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    unsigned base = chunk_offset[c];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {  // four 256-element rows per chunk, each scanned in element order
-      const unsigned e = c * CHUNK + k * BLK + threadIdx.x;
-      const unsigned f = (e < n) ? flags[e] : 0u;
-      unsigned tot;
-      const unsigned pos = base + block_excl_scan(f, lds, tot);
-      if (f && pos < capacity) {
-        float4 pc, ct, nr;
-        load_element(map, cand, count, e, pc, ct, nr);
-        if (ct.w == -2.0f) ct.w = (float)time;  // copy_unstable.vert:114-117
-        out.pos_conf[pos] = pc;
-        out.col_time[pos] = ct;
-        out.nrm_rad[pos] = nr;
-      }
-      base += tot;
-      __syncthreads();
+  const unsigned nrows = (n + CLEAN_ROW - 1) / CLEAN_ROW;
+  for (unsigned r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const unsigned e = r * CLEAN_ROW + threadIdx.x;
+    const unsigned f = (e < n) ? flags[e] : 0u;
+    float4 pc = make_float4(0, 0, 0, 0), ct = pc, nr = pc;
+    if (f) load_element(map, cand, count, e, pc, ct, nr);
+    unsigned tot;
+    const unsigned pos = chunk_offset[r] + block_excl_scan(f, lds, tot);
+    if (f && pos < capacity) {
+      if (ct.w == -2.0f) ct.w = (float)time;  // copy_unstable.vert:114-117
+      out.pos_conf[pos] = pc;
+      out.col_time[pos] = ct;
+      out.nrm_rad[pos] = nr;
     }
+    __syncthreads();
   }
 }
 
@@ -871,11 +897,11 @@ void clean(const Cam& cam, const float* T_cw16_dev, int time, IndexMaps im, floa
            const unsigned* count_dev, Candidates cand, uint32_t* winner, SurfelSoA out, unsigned* count_out_dev, uint32_t capacity,
            const CompactScratch& cs, int* overflow_flag, hipStream_t s) {
   CleanArgs A{cam, T_cw16_dev, time, im, confThreshold, timeDelta};
-  hipLaunchKernelGGL(k_clean_flags, dim3(SURFEL_GRID), dim3(BLK), 0, s, A, map, count_dev, cand, winner, cs.flags,
+  hipLaunchKernelGGL(k_clean_flags, dim3(CLEAN_GRID), dim3(BLK), 0, s, A, map, count_dev, cand, winner, cs.flags,
                      cs.chunk_count);
   hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, (const uint32_t*)cs.chunk_count, (const unsigned*)count_dev, (unsigned)cand.n,
-                     cs.chunk_offset, cs.totals, count_out_dev, capacity, overflow_flag);
-  hipLaunchKernelGGL(k_clean_scatter, dim3(SURFEL_GRID), dim3(BLK), 0, s, map, count_dev, cand, (const uint8_t*)cs.flags,
+                     cs.chunk_offset, cs.totals, count_out_dev, capacity, overflow_flag, (unsigned)CLEAN_ROW);
+  hipLaunchKernelGGL(k_clean_scatter, dim3(CLEAN_GRID), dim3(BLK), 0, s, map, count_dev, cand, (const uint8_t*)cs.flags,
                      (const uint32_t*)cs.chunk_offset, time, out, capacity);
 }
 

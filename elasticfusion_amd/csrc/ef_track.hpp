@@ -159,10 +159,15 @@ void init_icp(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cu
 // world-frame planar pyramids + model depth L0.  RGBDOdometry.cpp:171-210, :217
 void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
                     const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s);
-// the rest of populateRGBDData for both the model ("last") and the frame ("next"): Gaussian depth pyramid,
-// intensity pyramids; then Sobel on the "next" pyramid.  RGBDOdometry.cpp:212-244, :275-279
-void init_rgb(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* fill_image_rgba, bool frameToFrameRGB,
-              const uint8_t* rgb3, const TrackState* st, bool with_sobel, hipStream_t s);
+// the rest of populateRGBDData (RGBDOdometry.cpp:212-244, :275-279) in three independently enqueueable parts, so that
+// the part that only needs the new frame can run on the input stream while the previous frame is still being fused:
+//   model ("last"): Gaussian depth pyramid + intensity pyramid of the predicted (or fill-in) image
+//   frame ("next"): intensity pyramid of the camera image
+//   sobel: derivative images of the "next" pyramid + the iteration-invariant photometric gates (needs both)
+void init_rgb_model(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* fill_image_rgba, bool frameToFrameRGB,
+                    const TrackState* st, hipStream_t s);
+void init_rgb_frame(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
+void init_rgb_sobel(const Pyramid& p, hipStream_t s);
 // initFirstRGB, RGBDOdometry.cpp:246-257
 void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
 // getIncrementalTransformation, RGBDOdometry.cpp:259-571, entirely enqueued

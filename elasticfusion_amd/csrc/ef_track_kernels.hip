@@ -765,31 +765,31 @@ __device__ __forceinline__ void se3_chains(const float* __restrict__ R, int l, i
     for (int k = 0; k < kend; ++k) {
       const float* r = R + k * ROW_STRIDE + l;
       const float r0 = r[0], r1 = r[32], r2 = r[64], r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192];
-      acc[0] = fmaf(r0, r0, acc[0]); acc[1] = fmaf(r0, r1, acc[1]); acc[2] = fmaf(r0, r2, acc[2]); acc[3] = fmaf(r0, r3, acc[3]);
-      acc[4] = fmaf(r0, r4, acc[4]); acc[5] = fmaf(r0, r5, acc[5]); acc[6] = fmaf(r0, r6, acc[6]);
+      acc[0] = EF_FMA(r0, r0, acc[0]); acc[1] = EF_FMA(r0, r1, acc[1]); acc[2] = EF_FMA(r0, r2, acc[2]); acc[3] = EF_FMA(r0, r3, acc[3]);
+      acc[4] = EF_FMA(r0, r4, acc[4]); acc[5] = EF_FMA(r0, r5, acc[5]); acc[6] = EF_FMA(r0, r6, acc[6]);
     }
   } else if (part == 1) {
     for (int k = 0; k < kend; ++k) {
       const float* r = R + k * ROW_STRIDE + l;
       const float r1 = r[32], r2 = r[64], r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192];
-      acc[0] = fmaf(r1, r1, acc[0]); acc[1] = fmaf(r1, r2, acc[1]); acc[2] = fmaf(r1, r3, acc[2]); acc[3] = fmaf(r1, r4, acc[3]);
-      acc[4] = fmaf(r1, r5, acc[4]); acc[5] = fmaf(r1, r6, acc[5]);
-      acc[6] = fmaf(r5, r5, acc[6]); acc[7] = fmaf(r5, r6, acc[7]);
+      acc[0] = EF_FMA(r1, r1, acc[0]); acc[1] = EF_FMA(r1, r2, acc[1]); acc[2] = EF_FMA(r1, r3, acc[2]); acc[3] = EF_FMA(r1, r4, acc[3]);
+      acc[4] = EF_FMA(r1, r5, acc[4]); acc[5] = EF_FMA(r1, r6, acc[5]);
+      acc[6] = EF_FMA(r5, r5, acc[6]); acc[7] = EF_FMA(r5, r6, acc[7]);
     }
   } else if (part == 2) {
     for (int k = 0; k < kend; ++k) {
       const float* r = R + k * ROW_STRIDE + l;
       const float r2 = r[64], r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192];
-      acc[0] = fmaf(r2, r2, acc[0]); acc[1] = fmaf(r2, r3, acc[1]); acc[2] = fmaf(r2, r4, acc[2]); acc[3] = fmaf(r2, r5, acc[3]);
-      acc[4] = fmaf(r2, r6, acc[4]);
-      acc[5] = fmaf(r4, r4, acc[5]); acc[6] = fmaf(r4, r5, acc[6]); acc[7] = fmaf(r4, r6, acc[7]);
+      acc[0] = EF_FMA(r2, r2, acc[0]); acc[1] = EF_FMA(r2, r3, acc[1]); acc[2] = EF_FMA(r2, r4, acc[2]); acc[3] = EF_FMA(r2, r5, acc[3]);
+      acc[4] = EF_FMA(r2, r6, acc[4]);
+      acc[5] = EF_FMA(r4, r4, acc[5]); acc[6] = EF_FMA(r4, r5, acc[6]); acc[7] = EF_FMA(r4, r6, acc[7]);
     }
   } else {
     for (int k = 0; k < kend; ++k) {
       const float* r = R + k * ROW_STRIDE + l;
       const float r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192], f = r[224];
-      acc[0] = fmaf(r3, r3, acc[0]); acc[1] = fmaf(r3, r4, acc[1]); acc[2] = fmaf(r3, r5, acc[2]); acc[3] = fmaf(r3, r6, acc[3]);
-      acc[4] = fmaf(r6, r6, acc[4]);
+      acc[0] = EF_FMA(r3, r3, acc[0]); acc[1] = EF_FMA(r3, r4, acc[1]); acc[2] = EF_FMA(r3, r5, acc[2]); acc[3] = EF_FMA(r3, r6, acc[3]);
+      acc[4] = EF_FMA(r6, r6, acc[4]);
       acc[5] += f;
     }
   }
@@ -1194,10 +1194,10 @@ __device__ __forceinline__ void so3_chains(const float* __restrict__ R, int l, i
   for (int k = 0; k < kend; ++k) {
     const float* r = R + k * ROW_STRIDE + l;
     const float r0 = r[0], r1 = r[32], r2 = r[64], r3 = r[96], f = r[128];
-    acc[0] = fmaf(r0, r0, acc[0]); acc[1] = fmaf(r0, r1, acc[1]); acc[2] = fmaf(r0, r2, acc[2]); acc[3] = fmaf(r0, r3, acc[3]);
-    acc[4] = fmaf(r1, r1, acc[4]); acc[5] = fmaf(r1, r2, acc[5]); acc[6] = fmaf(r1, r3, acc[6]);
-    acc[7] = fmaf(r2, r2, acc[7]); acc[8] = fmaf(r2, r3, acc[8]);
-    acc[9] = fmaf(r3, r3, acc[9]);
+    acc[0] = EF_FMA(r0, r0, acc[0]); acc[1] = EF_FMA(r0, r1, acc[1]); acc[2] = EF_FMA(r0, r2, acc[2]); acc[3] = EF_FMA(r0, r3, acc[3]);
+    acc[4] = EF_FMA(r1, r1, acc[4]); acc[5] = EF_FMA(r1, r2, acc[5]); acc[6] = EF_FMA(r1, r3, acc[6]);
+    acc[7] = EF_FMA(r2, r2, acc[7]); acc[8] = EF_FMA(r2, r3, acc[8]);
+    acc[9] = EF_FMA(r3, r3, acc[9]);
     acc[10] += f;
   }
 }
@@ -1480,31 +1480,33 @@ __global__ void k_model_intensity(const uint8_t* __restrict__ pred, const uint8_
 }
 }  // namespace
 
-void init_rgb(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* fill_image_rgba, bool frameToFrameRGB,
-              const uint8_t* rgb3, const TrackState* st, bool with_sobel, hipStream_t s) {
+void init_rgb_model(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* fill_image_rgba, bool frameToFrameRGB,
+                    const TrackState* st, hipStream_t s) {
   const int n = p.W(0) * p.H(0);
   // populateRGBDData(model): depth L0 already written by init_icp_model
   for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_gauss_f(p.lastDepth[i], p.W(i), p.H(i), p.lastDepth[i + 1], s);
   hipLaunchKernelGGL(k_model_intensity, dim3(ceil_div(n, 256)), dim3(256), 0, s, pred_image_rgba, fill_image_rgba, frameToFrameRGB, st, n,
                      p.lastImage[0]);
   for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_uchar_gauss(p.lastImage[i], p.W(i), p.H(i), p.lastImage[i + 1], s);
+}
+void init_rgb_frame(const Pyramid& p, const uint8_t* rgb3, hipStream_t s) {
   // populateRGBDData(frame): nextDepth == lastDepth (Q1), only the intensity pyramid is new
   bgr_to_intensity(rgb3, 3, p.W(0), p.H(0), p.nextImage[0], s);
   for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_uchar_gauss(p.nextImage[i], p.W(i), p.H(i), p.nextImage[i + 1], s);
-  if (with_sobel) {
-    SobelLevels L;
-    const float minGrad[NUM_PYRS] = {5, 3, 1};  // RGBDOdometry.cpp:112-114
-    const float sobelScale = 1.0f / 8.0f;       // RGBDOdometry.cpp:39-40
-    for (int i = 0; i < NUM_PYRS; ++i) {
-      L.src[i] = p.nextImage[i]; L.dx[i] = p.dIdx[i]; L.dy[i] = p.dIdy[i];
-      L.nextDepth[i] = p.lastDepth[i]; L.mask[i] = p.rgbMask[i]; L.corres[i] = p.corres[i];
-      L.minScale[i] = (float)(pow((double)minGrad[i], 2.0) / pow((double)sobelScale, 2.0));  // RGBDOdometry.cpp:425
-      L.cols[i] = p.W(i); L.rows[i] = p.H(i);
-    }
-    dim3 g = tile_grid(p.W(0), p.H(0));
-    g.z = NUM_PYRS;
-    hipLaunchKernelGGL(k_sobel_levels, g, tile_block(), 0, s, L);
+}
+void init_rgb_sobel(const Pyramid& p, hipStream_t s) {
+  SobelLevels L;
+  const float minGrad[NUM_PYRS] = {5, 3, 1};  // RGBDOdometry.cpp:112-114
+  const float sobelScale = 1.0f / 8.0f;       // RGBDOdometry.cpp:39-40
+  for (int i = 0; i < NUM_PYRS; ++i) {
+    L.src[i] = p.nextImage[i]; L.dx[i] = p.dIdx[i]; L.dy[i] = p.dIdy[i];
+    L.nextDepth[i] = p.lastDepth[i]; L.mask[i] = p.rgbMask[i]; L.corres[i] = p.corres[i];
+    L.minScale[i] = (float)(pow((double)minGrad[i], 2.0) / pow((double)sobelScale, 2.0));  // RGBDOdometry.cpp:425
+    L.cols[i] = p.W(i); L.rows[i] = p.H(i);
   }
+  dim3 g = tile_grid(p.W(0), p.H(0));
+  g.z = NUM_PYRS;
+  hipLaunchKernelGGL(k_sobel_levels, g, tile_block(), 0, s, L);
 }
 
 void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s) {

@@ -73,6 +73,10 @@ int ef_process_frame(ef_ctx* ctx, const uint8_t* rgb, const uint16_t* depth, int
                      float weight_multiplier, const double* in_T_wc16);
 int ef_process_frame_dev(ef_ctx* ctx, const uint8_t* rgb_dev, const uint16_t* depth_dev, int64_t timestamp,
                          float weight_multiplier, const double* in_T_wc16);
+/* Input-stage overlap (default off; EF_OVERLAP=1 in the environment or this setter turns it on): the part of a frame that
+ * needs only the new images (copy-in, bilateral filter + metric depth, frame-side pyramids) is enqueued on a second
+ * internal stream and runs while the previous frame is still being fused.  Results are identical either way. */
+int ef_set_input_overlap(ef_ctx* ctx, int on);
 int ef_predict(ef_ctx* ctx);                                  /* ElasticFusion::predict() */
 int ef_get_pose(ef_ctx* ctx, double* T_wc16);                 /* get_T_wc(); synchronises */
 int ef_get_tick(ef_ctx* ctx, int* tick);                      /* getTick() */

@@ -17,6 +17,18 @@
 #include <cstring>
 #include <limits>
 
+// Fused multiply-adds of the tracking side appear only through EFO_FMA.  The default build fuses them (the
+// specification the HIP kernels restate).  -DEFO_NO_FMA builds the same restatement with every EFO_FMA split into an
+// IEEE multiply and an IEEE add: that variant must agree BIT FOR BIT with the reference's own sources compiled
+// without contraction (oracle/_ref, tests/test_oracle_vs_reference.py), which pins operation order, summation
+// tree and every gate of the restatement against the reference; the only thing left to specification is which
+// multiply-add pairs are fused.
+#ifdef EFO_NO_FMA
+#define EFO_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define EFO_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
+
 namespace efo {
 
 struct f3 { float x, y, z; };
@@ -30,9 +42,9 @@ inline float qnan() {
 }
 inline f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 inline f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-inline float dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }  // operators.cuh:71
+inline float dot(f3 a, f3 b) { return EFO_FMA(a.z, b.z, EFO_FMA(a.y, b.y, a.x * b.x)); }  // operators.cuh:71
 inline f3 cross(f3 a, f3 b) {                                                        // operators.cuh:67
-  return {fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
+  return {EFO_FMA(a.y, b.z, -(a.z * b.y)), EFO_FMA(a.z, b.x, -(a.x * b.z)), EFO_FMA(a.x, b.y, -(a.y * b.x))};
 }
 inline float norm(f3 a) { return sqrtf(dot(a, a)); }                                 // operators.cuh:75
 inline f3 normalized(f3 a) {                                                         // operators.cuh:79

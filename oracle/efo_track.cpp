@@ -334,8 +334,8 @@ Acc<T, K> two_stage_reduce(int N, F&& products) {
 inline void add_products7(const float row[7], float found, Acc<float, 29>& sum) {
   int s = 0;
   for (int i = 0; i < 6; ++i)
-    for (int j = i; j < 7; ++j) { sum.v[s] = fmaf(row[i], row[j], sum.v[s]); ++s; }
-  sum.v[27] = fmaf(row[6], row[6], sum.v[27]);
+    for (int j = i; j < 7; ++j) { sum.v[s] = EFO_FMA(row[i], row[j], sum.v[s]); ++s; }
+  sum.v[27] = EFO_FMA(row[6], row[6], sum.v[27]);
   sum.v[28] += found;
 }
 
@@ -520,8 +520,8 @@ void efo_so3_step(const uint8_t* lastImage, const uint8_t* nextImage, const floa
     }
     int s = 0;
     for (int i = 0; i < 3; ++i)
-      for (int j = i; j < 4; ++j) { sum.v[s] = fmaf(row[i], row[j], sum.v[s]); ++s; }
-    sum.v[9] = fmaf(row[3], row[3], sum.v[9]);
+      for (int j = i; j < 4; ++j) { sum.v[s] = EFO_FMA(row[i], row[j], sum.v[s]); ++s; }
+    sum.v[9] = EFO_FMA(row[3], row[3], sum.v[9]);
     sum.v[10] += found ? 1.0f : 0.0f;
   };
   Acc<float, 11> h = two_stage_reduce<float, 11>(cols * rows, products);

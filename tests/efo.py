@@ -27,8 +27,66 @@ def build(force: bool = False) -> str:
     return so
 
 
+_BACKEND = None   # set by `with efo.backend(...)`: operator wrappers below then call another library
+
+
+class _Proxy:
+    """Routes efo_<op> to <prefix><op> of another library with the same signatures (oracle/_ref, no-FMA oracle)."""
+
+    OPS = {"efo_" + n for n in ("pyr_down_u16", "create_vmap", "create_nmap", "transform_maps", "copy_maps", "resize_map",
+                                "pyr_down_gauss_f", "pyr_down_uchar_gauss", "vertices_to_depth", "bgr_to_intensity",
+                                "derivative_images", "project_to_point_cloud", "icp_step", "rgb_residual", "rgb_step", "so3_step")}
+
+    def __init__(self, so, prefix, default):
+        self._so, self._prefix, self._default = so, prefix, default
+
+    def __getattr__(self, name):
+        if name in self.OPS:   # the 16 tracking operators (cudafuncs.cuh:61-169); everything else stays on the oracle
+            return getattr(self._so, self._prefix + name[len("efo_"):])
+        return getattr(self._default, name)
+
+
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libefr_cuda.so")
+NOFMA_SO = os.path.join(ORACLE_DIR, "libefo_oracle_nofma.so")
+
+
+def have_reference() -> bool:
+    """oracle/_ref/libefr_cuda.so = the reference's own Core/Cuda sources compiled for the CPU (oracle/Makefile `ref`).
+    It can only be BUILT where /root/reference exists; the built file travels with the repo snapshot."""
+    if not os.path.exists(REF_SO) and os.path.isdir("/root/reference/Core/Cuda"):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
+    return os.path.exists(REF_SO)
+
+
+class backend:
+    """with efo.backend("reference") / efo.backend("nofma"): the tracking-operator wrappers of this module run on
+    the compiled reference / on the oracle built with -DEFO_NO_FMA instead of the default oracle."""
+
+    def __init__(self, which):
+        self.which = which
+
+    def __enter__(self):
+        global _BACKEND
+        default = lib()
+        if self.which == "reference":
+            assert have_reference(), "oracle/_ref/libefr_cuda.so is missing and cannot be built here"
+            _BACKEND = _Proxy(C.CDLL(REF_SO), "efr_", default)
+        elif self.which == "nofma":
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libefo_oracle_nofma.so"])
+            _BACKEND = _Proxy(C.CDLL(NOFMA_SO), "efo_", default)
+        else:
+            raise ValueError(self.which)
+        return self
+
+    def __exit__(self, *a):
+        global _BACKEND
+        _BACKEND = None
+
+
 def lib():
     global _LIB
+    if _BACKEND is not None:
+        return _BACKEND
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.efo_odom_create.restype = P

@@ -85,6 +85,33 @@ def test_tracking_and_fusion_sequence(hip, seq):
     ef.close()
 
 
+def test_pipelined_frames_match_oracle(hip, seq):
+    """Frames enqueued back to back with no getter in between: frame k+1's input stage (copy-in, bilateral filter,
+    frame pyramids) runs on the second stream while frame k is still being fused.  The whole trajectory and the
+    final map must still be the oracle's, bit for bit, and identical to a run with the overlap switched off."""
+    n = 12
+    o = efo.Fusion()
+    for k in range(n):
+        rgb, depth, _ = seq.frame(k)
+        o.process_frame(rgb, depth, k * 33333)
+    runs = []
+    for overlap in (True, False):
+        ef = hip.ElasticFusion()
+        ef.setInputOverlap(overlap)
+        for k in range(n):
+            rgb, depth, _ = seq.frame(k)
+            ef.processFrame(rgb, depth, k * 33333)
+        traj, _ = ef.trajectory()
+        runs.append((traj, ef.downloadMap(), ef.image("depth_filtered"), ef.image("fill_image")))
+        assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32))
+        assert ef.lastCount() == o.map_count()
+        assert np.array_equal(runs[-1][1].view(np.uint32), o.map().view(np.uint32))
+        assert np.array_equal(runs[-1][2], o.buffer("depthFiltered"))
+        ef.close()
+    for a, b in zip(runs[0], runs[1]):
+        assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+
+
 def test_fusion_with_injected_poses(hip, seq):
     """Ground-truth poses injected (in_T_wc), the reference's own way of decoupling fusion from tracking
     (ElasticFusion.cpp:302,367-369): identical poses => the map must match surfel for surfel."""

@@ -1,0 +1,54 @@
+"""GPU parity against the REFERENCE's own sources, operator tier.
+
+libefusion_hip_nofma.so is the product's HIP code built with -DEF_NO_FMA (every specified fused multiply-add split into
+an IEEE multiply and add — the one numerics choice that cannot be read off the reference, see csrc/ef_device.hpp).  In that
+build every one of the 16 tracking operators must reproduce, BIT FOR BIT, what the reference's Core/Cuda sources
+compute (compiled for the CPU, oracle/_ref): against the committed golden vectors always, and against the live compiled
+reference at full resolution when oracle/_ref/libefr_cuda.so travelled with the snapshot.  The product build itself is
+compared with the (FMA-specified) oracle in tests/test_gpu_ops_tracking.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import efo
+import trackops
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tracking_ops_reference.npz")
+
+
+@pytest.fixture(scope="module")
+def nofma_ops():
+    from elasticfusion_amd import api, build
+    assert os.path.exists(build.NOFMA_LIB), "libefusion_hip_nofma.so not built (python -m elasticfusion_amd.build)"
+    api.use_library(build.NOFMA_LIB)
+    yield trackops.HipOps(api.ops)
+    api.use_library(None)
+
+
+def test_hip_nofma_reproduces_reference_golden_bits(nofma_ops):
+    z = np.load(GOLDEN)
+    inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    ref = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+    got = trackops.run_ops(nofma_ops, inp)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert trackops.bits_differ(got[k], ref[k]) == 0, (k, trackops.max_rel(got[k], ref[k]) if ref[k].dtype.kind == "f" else None)
+
+
+@pytest.mark.parametrize("level", [1, 0])
+def test_hip_nofma_equals_live_compiled_reference(nofma_ops, seq, level):
+    if not efo.have_reference():
+        pytest.skip("oracle/_ref/libefr_cuda.so did not travel with the snapshot (the golden test above covers level 2)")
+    f = efo.Fusion()
+    for k in range(3):
+        rgb, depth, _ = seq.frame(k)
+        f.process_frame(rgb, depth, k)
+    inp = trackops.make_inputs(f, seq.frame(2)[0], level)
+    with efo.backend("reference"):
+        ref = trackops.run_ops(efo, inp)
+    got = trackops.run_ops(nofma_ops, inp)
+    for k in ref:
+        assert trackops.bits_differ(got[k], ref[k]) == 0, (level, k)

@@ -1,0 +1,84 @@
+"""Pins the oracle against the REFERENCE ITSELF, on the CPU.
+
+oracle/_ref/libefr_cuda.so is the reference's own Core/Cuda/{reduce,cudafuncs}.cu + containers/device_memory.cpp, compiled
+where they lie under /root/reference by g++ against the CUDA-on-CPU shim of oracle/cuda_on_cpu/ (threads of a block are
+coroutines; __syncthreads / __shfl_down_sync have their real semantics; warpSize 32; -ffp-contract=off).  Two claims:
+
+1. the oracle restatement built WITHOUT fused multiply-adds (-DEFO_NO_FMA) agrees with it BIT FOR BIT on all 16 tracking
+   operators — every gate, rounding, NaN convention and the complete fp32 summation tree of the four reductions;
+2. the oracle as specified (FMAs in dot / cross / product accumulation, what nvcc is free to do and the HIP kernels
+   restate) differs from it only by those roundings: integer-valued outputs identical, fp32 outputs within the
+   tolerances below.
+
+The same comparison against committed golden vectors (no /root/reference needed) is tests/test_oracle_golden.py.
+"""
+import numpy as np
+import pytest
+
+import efo
+import trackops
+
+pytestmark = pytest.mark.skipif(not efo.have_reference(), reason="oracle/_ref/libefr_cuda.so absent and /root/reference not present to build it")
+
+# max |a-b| / max|b| over one output array, FMA-specified oracle vs FMA-free reference
+TOL_ELEMENTWISE = 1e-5   # maps touched by dot/cross (the cross product of two nearly parallel differences amplifies one rounding)
+TOL_SUMS = 1e-5          # 27-product normal equations over up to 307200 pixels
+
+
+@pytest.fixture(scope="module")
+def state(seq):
+    f = efo.Fusion()
+    for k in range(3):
+        rgb, depth, _ = seq.frame(k)
+        f.process_frame(rgb, depth, k)
+    return f, seq.frame(2)[0]
+
+
+@pytest.mark.parametrize("level", [2, 1, 0])
+def test_oracle_against_compiled_reference(state, level):
+    f, rgb = state
+    inp = trackops.make_inputs(f, rgb, level)
+    with efo.backend("reference"):
+        ref = trackops.run_ops(efo, inp)
+    with efo.backend("nofma"):
+        nofma = trackops.run_ops(efo, inp)
+    spec = trackops.run_ops(efo, inp)
+    assert ref["icp_res"][1] > 1000 and ref["residual_sums"][1] > 100 and ref["so3_res"][1] > 1000   # the inputs exercise the paths
+    for k in ref:
+        assert trackops.bits_differ(nofma[k], ref[k]) == 0, (level, k)
+        if k in trackops.INTEGER_OUTPUTS:
+            assert trackops.bits_differ(spec[k], ref[k]) == 0, (level, k)
+        else:
+            tol = TOL_SUMS if k.split("_")[0] in ("icp", "rgb", "so3") else TOL_ELEMENTWISE
+            assert trackops.max_rel(spec[k], ref[k]) <= tol, (level, k, trackops.max_rel(spec[k], ref[k]))
+
+
+def test_edge_cases_against_compiled_reference():
+    """ragged / degenerate inputs: holes, all-invalid windows (0/0 in the Gaussian pyramids), tiny images"""
+    rng = np.random.RandomState(5)
+    f = rng.uniform(0.5, 3.0, size=(40, 56)).astype(np.float32)
+    f[rng.rand(*f.shape) < 0.3] = np.nan
+    f[:6, :8] = np.nan
+    u = rng.randint(0, 256, size=(40, 56)).astype(np.uint8)
+    u[rng.rand(*u.shape) < 0.3] = 0
+    u[:6, :8] = 0
+    d = rng.randint(0, 4000, size=(36, 52)).astype(np.uint16)
+    d[rng.rand(*d.shape) < 0.2] = 0
+    empty = np.zeros((24, 32), np.uint16)
+
+    def run():
+        v = efo.create_vmap(d, 100.0, 100.0, 26.0, 18.0, 3.0)
+        ve = efo.create_vmap(empty, 100.0, 100.0, 16.0, 12.0, 3.0)
+        return dict(gf=efo.pyr_down_gauss_f(f), gu=efo.pyr_down_uchar_gauss(u), pd=efo.pyr_down_u16(d), v=v, n=efo.create_nmap(v),
+                    ve=ve, ne=efo.create_nmap(ve), sx=efo.derivative_images(u)[0], sy=efo.derivative_images(u)[1])
+    with efo.backend("reference"):
+        ref = run()
+    with efo.backend("nofma"):
+        nofma = run()
+    spec = run()
+    for k in ref:
+        assert trackops.bits_differ(nofma[k], ref[k]) == 0, k
+        if k not in ("n", "ne"):
+            assert trackops.bits_differ(spec[k], ref[k]) == 0, k
+    # quirk Q3 in the compiled reference: an invalid pixel gets NaN in the x plane only, y/z keep what was there (zeros)
+    assert np.isnan(ref["ve"][:24]).all() and (ref["ve"][24:] == 0).all()
