@@ -124,16 +124,85 @@ __device__ __forceinline__ uint16_t bilateral_px(const uint16_t* __restrict__ ra
 __device__ __forceinline__ float metric_px(unsigned value, unsigned maxv) {
   return (value > maxv || value < 300U) ? 0.0f : (float)value / 1000.0f;
 }
+// Bilateral filter, the fast path.  The arithmetic of bilateral_px is kept operation for operation (the filtered depth must
+// be the oracle's, bit for bit); what changes is how it is fed and issued:
+//   * the 76 x 20 neighbourhood of a 64 x 8 pixel tile is staged once in LDS as float (169 global loads per pixel -> 1);
+//   * every lane filters TWO pixels (rows y and y + 4) with float2 arithmetic, which the compiler issues as packed
+//     v_pk_{mul,add,fma}_f32 — one instruction per pair; the chain per tap is ~18 packed + 12 scalar ops for two pixels;
+//   * taps outside the image are given the weight +0 instead of being skipped: x + 0 == x exactly, so the two sums see the
+//     same sequence of non-trivial additions in the same order as the clipped loops of depth_bilateral.frag:49-72.
+typedef float float2v __attribute__((ext_vector_type(2)));
+constexpr int PRE_TW = 64, PRE_TH = 8, PRE_R = 6, PRE_LW = PRE_TW + 2 * PRE_R, PRE_LH = PRE_TH + 2 * PRE_R;
+__device__ __forceinline__ float2v ef_expf2(float2v x) {   // ef_expf on both lanes of the pair
+  const float2v n = {rintf(x.x * 1.44269504088896341f), rintf(x.y * 1.44269504088896341f)};
+  float2v r = __builtin_elementwise_fma(n, (float2v)(-0.693359375f), x);
+  r = __builtin_elementwise_fma(n, (float2v)(2.12194440e-4f), r);
+  float2v p = (float2v)(1.9875691500e-4f);
+  p = __builtin_elementwise_fma(p, r, (float2v)(1.3981999507e-3f));
+  p = __builtin_elementwise_fma(p, r, (float2v)(8.3334519073e-3f));
+  p = __builtin_elementwise_fma(p, r, (float2v)(4.1665795894e-2f));
+  p = __builtin_elementwise_fma(p, r, (float2v)(1.6666665459e-1f));
+  p = __builtin_elementwise_fma(p, r, (float2v)(5.0000001201e-1f));
+  const float2v e = __builtin_elementwise_fma(p, r * r, r) + (float2v)(1.0f);
+  float2v o = {ldexpf(e.x, (int)n.x), ldexpf(e.y, (int)n.y)};
+  if (x.x < -87.0f) o.x = 0.0f;
+  if (x.y < -87.0f) o.y = 0.0f;
+  return o;
+}
 template <bool WITH_METRIC>
-__global__ void k_preprocess(const uint16_t* __restrict__ raw, int cols, int rows, unsigned maxv, uint16_t* __restrict__ filtered,
-                             float* __restrict__ metric, float* __restrict__ metric_filtered) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= cols || y >= rows) return;
-  const uint16_t f = bilateral_px(raw, cols, rows, x, y, maxv);
-  filtered[y * cols + x] = f;
-  if (WITH_METRIC) {
-    metric[y * cols + x] = metric_px(raw[y * cols + x], maxv);
-    metric_filtered[y * cols + x] = metric_px(f, maxv);
+__global__ void __launch_bounds__(256) k_preprocess(const uint16_t* __restrict__ raw, int cols, int rows, unsigned maxv,
+                                                     uint16_t* __restrict__ filtered, float* __restrict__ metric,
+                                                     float* __restrict__ metric_filtered) {
+  __shared__ float tile[PRE_LH][PRE_LW];
+  const int x0 = blockIdx.x * PRE_TW, y0 = blockIdx.y * PRE_TH;
+  const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
+  for (int i = t; i < PRE_LH * PRE_LW; i += 256) {
+    const int ly = i / PRE_LW, lx = i - ly * PRE_LW;
+    const int gx = x0 + lx - PRE_R, gy = y0 + ly - PRE_R;
+    tile[ly][lx] = (gx >= 0 && gx < cols && gy >= 0 && gy < rows) ? (float)raw[gy * cols + gx] : 0.0f;
+  }
+  __syncthreads();
+  const int x = x0 + tx, ya = y0 + ty, yb = ya + 4;
+  if (x >= cols) return;
+  const bool in_a = ya < rows, in_b = yb < rows;
+  const float2v value = {tile[ty + PRE_R][tx + PRE_R], tile[ty + 4 + PRE_R][tx + PRE_R]};
+  const unsigned va = (unsigned)value.x, vb = (unsigned)value.y;
+  const bool gate_a = in_a && !(va > maxv || va < 300U), gate_b = in_b && !(vb > maxv || vb < 300U);
+  const float sigma_space2_inv_half = 0.024691358f, sigma_color2_inv_half = 0.000555556f;
+  const bool interior = x0 >= PRE_R && y0 >= PRE_R && x0 + PRE_TW + PRE_R <= cols && y0 + PRE_TH + PRE_R <= rows;   // block-uniform
+  float2v sum1 = (float2v)(0.0f), sum2 = (float2v)(0.0f);
+  if (gate_a || gate_b) {
+    for (int dy = -PRE_R; dy <= PRE_R; ++dy) {
+      const float fdy2 = (float)(dy * dy);
+      const bool row_a = interior || (ya + dy >= 0 && ya + dy < rows), row_b = interior || (yb + dy >= 0 && yb + dy < rows);
+#pragma unroll
+      for (int dx = -PRE_R; dx <= PRE_R; ++dx) {
+        const float2v tmp = {tile[ty + PRE_R + dy][tx + PRE_R + dx], tile[ty + 4 + PRE_R + dy][tx + PRE_R + dx]};
+        const float space2 = (float)(dx * dx) + fdy2;            // (x-cx)^2 + (y-cy)^2: exact small integers, any order
+        const float S = space2 * sigma_space2_inv_half;
+        const float2v d = value - tmp;
+        const float2v color2 = d * d;
+        const float2v arg = (float2v)(S) + color2 * (float2v)(sigma_color2_inv_half);
+        float2v w = ef_expf2(-arg);
+        if (!interior) {
+          const bool col_ok = x + dx >= 0 && x + dx < cols;
+          if (!(col_ok && row_a)) w.x = 0.0f;
+          if (!(col_ok && row_b)) w.y = 0.0f;
+        }
+        sum1 = sum1 + tmp * w;
+        sum2 = sum2 + w;
+      }
+    }
+  }
+  if (in_a) {
+    const uint16_t f = gate_a ? (uint16_t)(unsigned)roundf(sum1.x / sum2.x) : (uint16_t)0;
+    filtered[ya * cols + x] = f;
+    if (WITH_METRIC) { metric[ya * cols + x] = metric_px(va, maxv); metric_filtered[ya * cols + x] = metric_px(f, maxv); }
+  }
+  if (in_b) {
+    const uint16_t f = gate_b ? (uint16_t)(unsigned)roundf(sum1.y / sum2.y) : (uint16_t)0;
+    filtered[yb * cols + x] = f;
+    if (WITH_METRIC) { metric[yb * cols + x] = metric_px(vb, maxv); metric_filtered[yb * cols + x] = metric_px(f, maxv); }
   }
 }
 __global__ void k_metricise(const uint16_t* __restrict__ in, int n, unsigned maxv, float* __restrict__ out) {
@@ -818,7 +887,7 @@ __global__ void __launch_bounds__(BLK) k_cand_scatter(Candidates cand, const uin
 static inline dim3 tgrid(int cols, int rows) { return dim3(ceil_div(cols, 64), ceil_div(rows, 4)); }
 
 void filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s) {
-  hipLaunchKernelGGL(k_preprocess<false>, tgrid(cols, rows), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered,
+  hipLaunchKernelGGL(k_preprocess<false>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered,
                      (float*)nullptr, (float*)nullptr);
 }
 void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, hipStream_t s) {
@@ -826,7 +895,7 @@ void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* 
 }
 void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric, float* metric_filtered,
                       hipStream_t s) {
-  hipLaunchKernelGGL(k_preprocess<true>, tgrid(cols, rows), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered, metric,
+  hipLaunchKernelGGL(k_preprocess<true>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered, metric,
                      metric_filtered);
 }
 void aos_to_soa(const float* aos, uint32_t count, SurfelSoA soa, hipStream_t s) {

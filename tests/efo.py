@@ -37,16 +37,21 @@ class _Proxy:
                                 "pyr_down_gauss_f", "pyr_down_uchar_gauss", "vertices_to_depth", "bgr_to_intensity",
                                 "derivative_images", "project_to_point_cloud", "icp_step", "rgb_residual", "rgb_step", "so3_step")}
 
-    def __init__(self, so, prefix, default):
+    MAP_OPS = {"efo_" + n for n in ("filter_depth", "metricise_depth", "seed_map", "predict_indices", "combined_predict", "fill_in", "fuse",
+                                    "clean")}
+
+    def __init__(self, so, prefix, default, ops=None):
         self._so, self._prefix, self._default = so, prefix, default
+        self.OPS = ops if ops is not None else _Proxy.OPS
 
     def __getattr__(self, name):
-        if name in self.OPS:   # the 16 tracking operators (cudafuncs.cuh:61-169); everything else stays on the oracle
+        if name in self.OPS:   # the routed operators; everything else (handles, drivers) stays on the oracle
             return getattr(self._so, self._prefix + name[len("efo_"):])
         return getattr(self._default, name)
 
 
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libefr_cuda.so")
+REF_GLSL_SO = os.path.join(ORACLE_DIR, "_ref", "libefr_glsl.so")
 NOFMA_SO = os.path.join(ORACLE_DIR, "libefo_oracle_nofma.so")
 
 
@@ -56,6 +61,20 @@ def have_reference() -> bool:
     if not os.path.exists(REF_SO) and os.path.isdir("/root/reference/Core/Cuda"):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "ref"])
     return os.path.exists(REF_SO)
+
+
+def have_reference_glsl() -> bool:
+    """oracle/_ref/libefr_glsl.so = the reference's own Core/Shaders sources compiled for the CPU (oracle/Makefile `refglsl`)."""
+    if not os.path.exists(REF_GLSL_SO) and os.path.isdir("/root/reference/Core/Shaders"):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "refglsl"])
+    return os.path.exists(REF_GLSL_SO)
+
+
+def reference_glsl_lib():
+    assert have_reference_glsl()
+    so = C.CDLL(REF_GLSL_SO)
+    so.efg_set_texel_snap.argtypes = [C.c_double]
+    return so
 
 
 class backend:
@@ -71,9 +90,11 @@ class backend:
         if self.which == "reference":
             assert have_reference(), "oracle/_ref/libefr_cuda.so is missing and cannot be built here"
             _BACKEND = _Proxy(C.CDLL(REF_SO), "efr_", default)
+        elif self.which == "reference_glsl":
+            _BACKEND = _Proxy(reference_glsl_lib(), "efg_", default, _Proxy.MAP_OPS)
         elif self.which == "nofma":
             subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libefo_oracle_nofma.so"])
-            _BACKEND = _Proxy(C.CDLL(NOFMA_SO), "efo_", default)
+            _BACKEND = _Proxy(C.CDLL(NOFMA_SO), "efo_", default, _Proxy.OPS | _Proxy.MAP_OPS)
         else:
             raise ValueError(self.which)
         return self

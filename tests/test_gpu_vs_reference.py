@@ -52,3 +52,49 @@ def test_hip_nofma_equals_live_compiled_reference(nofma_ops, seq, level):
     got = trackops.run_ops(nofma_ops, inp)
     for k in ref:
         assert trackops.bits_differ(got[k], ref[k]) == 0, (level, k)
+
+
+# ---- map side: the HIP map kernels (no-FMA build) against the reference's own shaders ----
+MAP_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "map_passes_reference.npz")
+
+
+@pytest.fixture(scope="module")
+def nofma_map_ops():
+    from elasticfusion_amd import api, build
+    import mapops
+    api.use_library(build.NOFMA_LIB)
+    yield mapops.HipMapOps(api)
+    api.use_library(None)
+
+
+def _check_map(got, ref):
+    import mapops
+    assert set(got) == set(ref)
+    for k in ref:
+        if k in mapops.INDEX_OUTPUTS:
+            continue
+        assert got[k].shape == ref[k].shape, (k, got[k].shape, ref[k].shape)
+        assert trackops.bits_differ(got[k], ref[k]) == 0, k
+    bad, n = mapops.index_pixels_differing(got, ref)
+    assert bad <= max(1, mapops.INDEX_PIXEL_TOLERANCE * n), (bad, n)
+
+
+def test_hip_nofma_map_passes_reproduce_shader_golden_bits(nofma_map_ops):
+    import mapops
+    z = np.load(MAP_GOLDEN)
+    inp = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    ref = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+    _check_map(mapops.run_passes(nofma_map_ops, inp), ref)
+
+
+def test_hip_nofma_map_passes_equal_live_compiled_shaders(nofma_map_ops):
+    import mapops
+    if not efo.have_reference_glsl():
+        pytest.skip("oracle/_ref/libefr_glsl.so did not travel with the snapshot (the golden test above covers 96x72)")
+    so = efo.reference_glsl_lib()
+    so.efg_use_specified_exp(1)
+    so.efg_set_depth_compare(1)
+    inp = mapops.make_inputs(640, 480)
+    with efo.backend("reference_glsl"):
+        ref = mapops.run_passes(efo, inp)
+    _check_map(mapops.run_passes(nofma_map_ops, inp), ref)

@@ -1,6 +1,10 @@
 #!/usr/bin/env python
-"""Generates tests/golden/tracking_ops_reference.npz: inputs + the outputs of the REFERENCE's own tracking operators
-(Core/Cuda/{reduce,cudafuncs}.cu compiled for the CPU by `make -C oracle ref`, see oracle/cuda_on_cpu/) on those inputs.
+"""Generates the golden vectors under tests/golden/ from the REFERENCE's own sources compiled for the CPU:
+
+tracking_ops_reference.npz: inputs + the outputs of the reference's 16 tracking operators (Core/Cuda/{reduce,cudafuncs}.cu,
+`make -C oracle ref`, see oracle/cuda_on_cpu/) on those inputs;
+map_passes_reference.npz: inputs + the outputs of the reference's 18 hot-path shaders (Core/Shaders/*, `make -C oracle
+refglsl`, see oracle/glsl_on_cpu/ and oracle/ref_glsl_bridge.cpp) run pass by pass at 96x72.
 
 Must be run where /root/reference exists (this container); the fixture then pins the oracle and the HIP kernels anywhere
 (tests/test_oracle_golden.py, tests/test_gpu_vs_reference.py).  Inputs: pyramid level 2 (160x120) of the tracking state
@@ -35,6 +39,18 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "tracking_ops_reference.npz")
     np.savez_compressed(path, **{"in_" + k: v for k, v in inp.items()}, **{"out_" + k: v for k, v in out.items()})
     print(path, os.path.getsize(path), "bytes;", len(inp), "inputs,", len(out), "outputs")
+
+    # map side: the reference's own shaders (make -C oracle refglsl), 96x72 so that the fixture stays small
+    import mapops
+    so = efo.reference_glsl_lib()
+    so.efg_use_specified_exp(1)
+    so.efg_set_depth_compare(1)
+    minp = mapops.make_inputs(96, 72)
+    with efo.backend("reference_glsl"):
+        mout = mapops.run_passes(efo, minp)
+    path = os.path.join(ROOT, "tests", "golden", "map_passes_reference.npz")
+    np.savez_compressed(path, **{"in_" + k: v for k, v in minp.items()}, **{"out_" + k: v for k, v in mout.items()})
+    print(path, os.path.getsize(path), "bytes;", len(minp), "inputs,", len(mout), "outputs;", len(minp["surf"]), "surfels")
 
 
 if __name__ == "__main__":
