@@ -27,31 +27,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-W, H = 640, 480
+W, H = 640, 480                # default workload = BASELINE.json configs[1] shape; --width/--height select configs[2] (1280x960)
 
 
 def _gen_frame(args):
-    seed, k = args
+    seed, k, w, h = args
     from elasticfusion_amd import synth
-    rgb, depth, T = _gen_frame.cache.setdefault(seed, synth.Sequence(seed)).frame(k)
+    rgb, depth, T = _gen_frame.cache.setdefault((seed, w, h), synth.Sequence(seed, width=w, height=h)).frame(k)
     return rgb, depth, T
 
 
 _gen_frame.cache = {}
 
 
-def generate_frames(seed: int, n: int):
+def generate_frames(seed: int, n: int, w: int = W, h: int = H):
     workers = max(1, min(16, (os.cpu_count() or 2) - 1))
     with ProcessPoolExecutor(max_workers=workers) as ex:
-        return list(ex.map(_gen_frame, [(seed, k) for k in range(n)], chunksize=4))
+        return list(ex.map(_gen_frame, [(seed, k, w, h) for k in range(n)], chunksize=4))
 
 
-def cpu_baseline(frames, budget_s: float = 20.0):
+def cpu_baseline(frames, budget_s: float = 20.0, w: int = W, h: int = H):
     """Times the CPU oracle (the reference restated; the reference itself has no CPU path and cannot be built here)
     on the same frames, single thread, bounded to ~budget_s of CPU work.  Checker code used as a *baseline leg* only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import efo
-    o = efo.Fusion()
+    o = efo.Fusion(width=w, height=h, fx=528.0 * w / 640, fy=528.0 * w / 640, cx=320.0 * w / 640, cy=240.0 * w / 640)
     t0 = time.perf_counter()
     n = 0
     for rgb, depth, _ in frames:
@@ -61,7 +61,7 @@ def cpu_baseline(frames, budget_s: float = 20.0):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} frames of the same 640x480 sequence through the oracle's full processFrame "
+            "sample": f"first {n} frames of the same {w}x{h} sequence through the oracle's full processFrame "
                       f"(tracking + fuse), single thread, {dt:.1f} s"}
 
 
@@ -71,7 +71,11 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--width", type=int, default=W, help="1280 (with --height 960) = BASELINE.json configs[2]: the first frame seeds "
+                    "~1.2 M surfels, i.e. the 1 M-surfel HBM-bound map; NOT the headline metric")
+    ap.add_argument("--height", type=int, default=H)
     a = ap.parse_args()
+    w, h = a.width, a.height
 
     from elasticfusion_amd import multi
     rank, local_rank, world = multi.rank_info()
@@ -89,10 +93,12 @@ def main():
     from elasticfusion_amd import api
 
     n_frames = a.warmup + a.steps + 1  # frame 0 seeds the map (tick 1) and is never timed
-    frames = generate_frames(multi.sequence_seed(rank), n_frames)
+    frames = generate_frames(multi.sequence_seed(rank), n_frames, w, h)
 
     stream = torch.cuda.current_stream().cuda_stream
-    ef = api.ElasticFusion(width=W, height=H, device=local_rank, stream=stream)
+    sc = w / 640.0
+    ef = api.ElasticFusion(width=w, height=h, fx=528.0 * sc, fy=528.0 * sc, cx=320.0 * sc, cy=240.0 * sc, device=local_rank, stream=stream,
+                           maxSurfels=max(4 * 1024 * 1024, 6 * w * h))
     dev = [(api.DevBuf.from_array(r), api.DevBuf.from_array(d)) for r, d, _ in frames]
 
     def step(k):
@@ -146,6 +152,8 @@ def main():
             # measurement committed under profiles/ by tools/pmc_traffic.sh, for this same kernel and workload
             traffic = None
             try:
+                if (w, h) != (W, H):
+                    raise KeyError("the committed PMC measurement is for the default workload")
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                     traffic = int(json.load(f)["traffic_bytes_per_launch"])
             except Exception:
@@ -156,7 +164,7 @@ def main():
                         "event_pair_empty_us": round(float(kt.empty_pair_us), 3), "launches_sampled": int(kt.launches),
                         "algorithmic_bytes_per_launch": int(kt.bytes_per_launch)}
     out = {
-        "metric": "frames/s per GPU, 640x480 3-level ICP+fuse",
+        "metric": f"frames/s per GPU, {w}x{h} 3-level ICP+fuse",
         "value": round(value, 2),
         "unit": "frames/s",
         "n_gpus": world,
@@ -168,16 +176,17 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "640x480 synthetic RGB-D replay (box+spheres, Lissajous trajectory), open loop, "
+        "config": {"workload": f"{w}x{h} synthetic RGB-D replay (box+spheres, Lissajous trajectory), open loop, "
                                "SO(3)+ICP+RGB 3-level tracking (10/5/4 its) + surfel fuse/clean/predict; "
-                               "stand-in for configs[1] (dyson_lab.klg is not available offline)",
-                   "resolution": [W, H], "sequences": world, "surfels_end": int(count),
+                               + ("stand-in for configs[1] (dyson_lab.klg is not available offline)" if (w, h) == (W, H) else
+                                  "configs[2]: 1280x960 stream, ~1.2 M-surfel map"),
+                   "resolution": [w, h], "sequences": world, "surfels_end": int(count),
                    "pose_err_vs_generating_traj_m": round(err_t, 5),
                    "per_rank_fps": [round(x, 2) for x in agg["per_rank_fps"]]},
         "roofline": roofline,
     }
     if not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(frames[: min(len(frames), 40)])
+        out["cpu_baseline"] = cpu_baseline(frames[: min(len(frames), 40)], w=w, h=h)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

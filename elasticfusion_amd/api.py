@@ -483,6 +483,15 @@ class ops:
                 tm.to_array(np.uint16, shp))
 
     @staticmethod
+    def synthesize_depth(cam, T_wc, surfels, maxDepth, confThreshold, time, maxTime, timeDelta):
+        s = ops._f32(surfels).reshape(-1, 12)
+        Pn = cam.cols * cam.rows
+        sb, d = DevBuf.from_array(s), DevBuf(Pn * 4)
+        _chk(lib().ef_op_synthesize_depth(C.byref(cam), _ptr(ops._T(T_wc)), sb.p, c_u32(len(s)), c_f(maxDepth), c_f(confThreshold),
+                                          c_i(time), c_i(maxTime), c_i(timeDelta), d.p, None))
+        return d.to_array(np.float32, (cam.rows, cam.cols))
+
+    @staticmethod
     def fill_in(cam, image, vertex, normal, depthFiltered, rgb, passthrough=0, passthroughImage=0):
         bufs = [DevBuf.from_array(a) for a in (image, ops._f32(vertex), ops._f32(normal), depthFiltered, rgb)]
         Pn = cam.cols * cam.rows

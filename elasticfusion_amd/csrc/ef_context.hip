@@ -51,6 +51,10 @@ struct ef_ctx {
   float* depth_metric_filtered_alt = nullptr;
   hipStream_t in_stream = nullptr;
   hipEvent_t ev_input_done = nullptr, ev_track_done = nullptr, ev_staged = nullptr;
+  hipEvent_t ev_frame_done[2] = {nullptr, nullptr};   // end of the frame that last used each set of frame images
+  int frame_parity = 0;
+  int overlap_mode = 1;          // 1: whole input stage after the previous tracker; 2: copy + bilateral filter already during it
+  unsigned pre_lds = 0;          // extra dynamic LDS of the bilateral kernel = an occupancy cap while it shares the GPU
   bool overlap = false;
   bool staged_pending = false;
   uint8_t* h_rgb = nullptr;      // pinned staging
@@ -172,15 +176,18 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   std::swap(c->depth_metric, c->depth_metric_alt);
   std::swap(c->depth_metric_filtered, c->depth_metric_filtered_alt);
   const bool track_this = c->tick > 1 && !in_T_wc;
-  if (overlap) EF_HIP(c, hipStreamWaitEvent(sb, c->ev_track_done, 0));
+  c->frame_parity ^= 1;
+  if (overlap) EF_HIP(c, hipStreamWaitEvent(sb, c->overlap_mode == 2 ? c->ev_frame_done[c->frame_parity] : c->ev_track_done, 0));
   // the frame images are referenced by later stages of this frame and by the next frame's tracker
   // (fill-in / predict read depth_filtered + rgb), so they are copied into context-owned buffers
   EF_HIP(c, hipMemcpyAsync(c->rgb, rgb_src, (size_t)W * H * 3, kind, sb));
   EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_src, (size_t)W * H * 2, kind, sb));
   if (kind == hipMemcpyHostToDevice) { EF_HIP(c, hipEventRecord(c->ev_staged, sb)); c->staged_pending = true; }
   timer_begin(c, "Preprocess");
-  efm::preprocess_depth(c->depth_raw, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb);
+  efm::preprocess_depth(c->depth_raw, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb,
+                        overlap ? c->pre_lds : 0u);
   timer_end(c, "Preprocess");
+  if (overlap && c->overlap_mode == 2) EF_HIP(c, hipStreamWaitEvent(sb, c->ev_track_done, 0));
   if (track_this) {
     eft::init_icp(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, sb);
     eft::init_rgb_frame(c->pyr, c->rgb, sb);
@@ -253,6 +260,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   timer_begin(c, "IndexMap::ACTIVE");
   do_predict(c);  // ElasticFusion.cpp:599
   timer_end(c, "IndexMap::ACTIVE");
+  EF_HIP(c, hipEventRecord(c->ev_frame_done[c->frame_parity], s));
   c->tick++;
   EF_HIP(c, hipGetLastError());
   return EF_OK;
@@ -273,7 +281,15 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->depth_filtered_alt, P);
   EF_ALLOC(c, c->depth_metric_alt, P);
   EF_ALLOC(c, c->depth_metric_filtered_alt, P);
-  EF_HIP(c, hipStreamCreateWithFlags(&c->in_stream, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0;   // numerically lower = higher priority; the input stream must never delay the tracker
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const bool low = getenv("EF_OVERLAP_PRIO") != nullptr && atoi(getenv("EF_OVERLAP_PRIO")) != 0;
+    EF_HIP(c, hipStreamCreateWithPriority(&c->in_stream, hipStreamNonBlocking, low ? lo : 0));
+  }
+  for (auto& e : c->ev_frame_done) EF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (getenv("EF_OVERLAP")) c->overlap_mode = atoi(getenv("EF_OVERLAP")) == 2 ? 2 : 1;
+  if (getenv("EF_PRE_LDS")) c->pre_lds = (unsigned)atoi(getenv("EF_PRE_LDS"));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_input_done, hipEventDisableTiming));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_track_done, hipEventDisableTiming));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
@@ -348,7 +364,7 @@ void ctx_free(ef_ctx* c) {
   if (c->in_stream) (void)hipStreamSynchronize(c->in_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->in_stream) (void)hipStreamDestroy(c->in_stream);
-  for (hipEvent_t e : {c->ev_input_done, c->ev_track_done, c->ev_staged})
+  for (hipEvent_t e : {c->ev_input_done, c->ev_track_done, c->ev_staged, c->ev_frame_done[0], c->ev_frame_done[1]})
     if (e) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->h_rgb) (void)hipHostFree(c->h_rgb);
@@ -1012,6 +1028,25 @@ int ef_op_combined_predict(const ef_cam* cam, const double* T16, const float* su
   efm::FillMaps none{nullptr, nullptr, nullptr};
   efm::combined_predict(to_cam(cam), mats, soa, cnt, maxDepth, confThreshold, time, maxTime, timeDelta, zbuf, pm, none, nullptr, nullptr, false,
                         nullptr, s);
+  OP_SYNC(s);
+  return EF_OK;
+}
+
+int ef_op_synthesize_depth(const ef_cam* cam, const double* T16, const float* surfels, uint32_t count, float maxDepth, float confThreshold,
+                           int time, int maxTime, int timeDelta, float* depth, void* s_) {
+  hipStream_t s = (hipStream_t)s_;
+  OpMap m;
+  const size_t P = (size_t)cam->cols * cam->rows;
+  efm::SurfelSoA soa = m.soa(count);
+  efm::aos_to_soa(surfels, count, soa, s);
+  float h[32];
+  pose_mats(T16, h, h + 16);
+  float* mats = m.alloc<float>(32);
+  (void)hipMemcpyAsync(mats, h, sizeof(h), hipMemcpyHostToDevice, s);
+  unsigned* cnt = m.alloc<unsigned>(1);
+  (void)hipMemcpyAsync(cnt, &count, sizeof(unsigned), hipMemcpyHostToDevice, s);
+  unsigned long long* zbuf = m.alloc<unsigned long long>(P, 0xFF);
+  efm::synthesize_depth(to_cam(cam), mats, soa, cnt, maxDepth, confThreshold, time, maxTime, timeDelta, zbuf, depth, s);
   OP_SYNC(s);
   return EF_OK;
 }

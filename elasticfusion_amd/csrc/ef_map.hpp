@@ -64,8 +64,9 @@ struct CompactScratch {
 void filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s);
 void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, hipStream_t s);
 // fused: bilateral + both metric conversions in one pass over the raw depth
+// extra_lds: unused dynamic LDS bytes added to the launch = an occupancy cap for when the kernel shares the GPU
 void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric,
-                      float* metric_filtered, hipStream_t s);
+                      float* metric_filtered, hipStream_t s, unsigned extra_lds = 0);
 
 // ---- layout conversion at the API boundary ----
 void aos_to_soa(const float* aos, uint32_t count, SurfelSoA soa, hipStream_t s);
@@ -84,6 +85,9 @@ void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, co
                       // optional fused fill-in + denseEnough sampling (null fill.image => skipped)
                       FillMaps fill, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthroughImage,
                       unsigned* dense_counter, hipStream_t s);
+// IndexMap::synthesizeDepth (splat.vert + depth_splat.frag): float depth of the nearest splat per pixel, 0 = none
+void synthesize_depth(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
+                      float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s);
 void fill_in(const Cam& cam, PredictMaps pred, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthrough,
              bool passthroughImage, FillMaps out, hipStream_t s);
 // counts the (W/20)x(H/20) sample texels with r,g,b > 0 into *counter (Resize::image + denseEnough)

@@ -560,6 +560,19 @@ __global__ void __launch_bounds__(BLK) k_surface_resolve(const Cam cam, const fl
     dense_sample(cam, px, py, im, dense_counter);
   }
 }
+// IndexMap::synthesizeDepth (G6): depth_splat.frag's only output is the intersection depth the z-buffer key already holds
+__device__ __forceinline__ float depth_of_key(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__global__ void __launch_bounds__(BLK) k_depth_resolve(int n, unsigned long long* zbuf, float* __restrict__ depth) {
+  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pi >= n) return;
+  const unsigned long long key = zbuf[pi];
+  float z = 0.f;   // glClearColor(0, 0, 0, 0)
+  if (key != ZBUF_EMPTY) {
+    zbuf[pi] = ZBUF_EMPTY;
+    z = depth_of_key((uint32_t)(key >> 32));
+  }
+  depth[pi] = z;
+}
 __global__ void __launch_bounds__(BLK) k_fill_in(const Cam cam, PredictMaps pred, const uint16_t* __restrict__ depth_filtered,
                                                   const uint8_t* __restrict__ rgb3, bool passthrough, bool passthroughImage, FillMaps out) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -894,8 +907,8 @@ void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* 
   hipLaunchKernelGGL(k_metricise, dim3(ceil_div(cols * rows, 256)), dim3(256), 0, s, in, cols * rows, (unsigned)(maxD * 1000.0f), out);
 }
 void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric, float* metric_filtered,
-                      hipStream_t s) {
-  hipLaunchKernelGGL(k_preprocess<true>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered, metric,
+                      hipStream_t s, unsigned extra_lds) {
+  hipLaunchKernelGGL(k_preprocess<true>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), extra_lds, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered, metric,
                      metric_filtered);
 }
 void aos_to_soa(const float* aos, uint32_t count, SurfelSoA soa, hipStream_t s) {
@@ -942,6 +955,13 @@ void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, co
   else
     hipLaunchKernelGGL(k_surface_resolve<false>, g, dim3(BLK), 0, s, cam, T_cw16_dev, map, maxDepth, confThreshold, time, maxTime, timeDelta,
                        zbuf, out, fill, depth_filtered, rgb3, passthroughImage, dense_counter);
+}
+void synthesize_depth(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth, float confThreshold,
+                      int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s) {
+  hipLaunchKernelGGL(k_surface_splat, dim3(SURFEL_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold, time,
+                     maxTime, timeDelta, zbuf);
+  const int n = cam.cols * cam.rows;
+  hipLaunchKernelGGL(k_depth_resolve, dim3(ceil_div(n, BLK)), dim3(BLK), 0, s, n, zbuf, depth);
 }
 void fill_in(const Cam& cam, PredictMaps pred, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthrough, bool passthroughImage,
              FillMaps out, hipStream_t s) {

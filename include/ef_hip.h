@@ -224,6 +224,10 @@ int ef_op_predict_indices(const ef_cam* cam, const double* T_wc16, int time, con
 int ef_op_combined_predict(const ef_cam* cam, const double* T_wc16, const float* surfels_aos, uint32_t count,
                            float max_depth, float conf_threshold, int time, int max_time, int time_delta,
                            uint8_t* image_rgba, float* vertex, float* normal, uint16_t* time_map, void* stream);
+/* IndexMap::synthesizeDepth (splat.vert + depth_splat.frag, IndexMap.cpp:395-476): float depth, 0 = nothing drawn */
+int ef_op_synthesize_depth(const ef_cam* cam, const double* T_wc16, const float* surfels_aos, uint32_t count,
+                           float max_depth, float conf_threshold, int time, int max_time, int time_delta,
+                           float* depth, void* stream);
 /* FillIn::{vertex,normal,image} */
 int ef_op_fill_in(const ef_cam* cam, const uint8_t* image_rgba, const float* vertex, const float* normal,
                   const uint16_t* depth_filtered, const uint8_t* rgb, int passthrough, int passthrough_image,

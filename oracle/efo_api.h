@@ -71,6 +71,9 @@ void efo_predict_indices(const efo_cam* cam, const double* T_wc16, int time, con
 void efo_combined_predict(const efo_cam* cam, const double* T_wc16, const float* surfels, int count, float maxDepth,
                           float confThreshold, int time, int maxTime, int timeDelta, uint8_t* image_rgba,
                           float* vertex, float* normal, uint16_t* timeMap);
+/* IndexMap::synthesizeDepth (G6): float depth image, 0 = nothing drawn */
+void efo_synthesize_depth(const efo_cam* cam, const double* T_wc16, const float* surfels, int count, float maxDepth,
+                          float confThreshold, int time, int maxTime, int timeDelta, float* depth);
 void efo_fill_in(const efo_cam* cam, const uint8_t* image_rgba, const float* vertex, const float* normal,
                  const uint16_t* depthFiltered, const uint8_t* rgb, int passthrough, int passthroughImage,
                  uint8_t* fill_image_rgba, float* fill_vertex, float* fill_normal);

@@ -3,7 +3,8 @@
 // Shared scalar conventions of the restatement.  The reference's device arithmetic lives in
 // nvcc- and NVIDIA-GLSL-compiled code whose contraction / approximate-intrinsic choices cannot be
 // observed here, so the oracle *specifies* them once, and the HIP kernels under
-// elasticfusion_amd/csrc restate the same specification independently:
+// elasticfusion_amd/csrc restate the same specification independently (everything else — operation order, gates,
+// summation trees — is pinned bit for bit against the reference's sources compiled for the CPU, oracle/README.md):
 //   * fp32 everywhere the reference uses float; no implicit contraction (-ffp-contract=off);
 //     dot / cross / accumulate use explicit fmaf in the order written below;
 //   * 1/sqrt is 1.0f / sqrtf(x) (both correctly rounded) where the reference uses rsqrtf /

@@ -16,7 +16,8 @@
 //   N4 NEAREST sampling, CLAMP_TO_EDGE; the 4 taps/axis of data.vert / copy_unstable.vert sit at
 //      pixel offsets {-1,-1/2,0,+1/2} -> texel floor(x+off)
 //   N5 update-map collisions: first pixel in draw (column-major) order wins
-// parity unpinned: no reference vectors exist and the GL/driver stack cannot run here.
+// parity PINNED: built with -DEFO_NO_FMA this file reproduces, bit for bit, the reference's own shaders compiled for the
+// CPU (oracle/_ref/libefr_glsl.so, oracle/glsl_on_cpu/) and the golden vectors made from them (tests/golden/); N1-N5 stay specified.
 #include "efo_common.h"
 #include "efo_linalg.h"
 #include "efo_pose.h"
@@ -263,6 +264,20 @@ void efo_combined_predict(const efo_cam* cam, const double* T_wc16, const float*
         timeMap[pi] = (uint16_t)(unsigned)s[6];
       }
   }
+}
+
+// IndexMap::synthesizeDepth + splat.vert + depth_splat.frag (G6), IndexMap.cpp:395-476.  depth_splat.frag:35-46 is
+// combo_splat.frag:37-48 with FragColor = corrected_pos.z as the only output, same sprite, same depth test: the synthesized
+// depth IS the z channel of combinedPredict's vertex map (0 where nothing was drawn: glClearColor(0,0,0,0)).
+void efo_synthesize_depth(const efo_cam* cam, const double* T_wc16, const float* surfels, int count, float maxDepth,
+                          float confThreshold, int time, int maxTime, int timeDelta, float* depth) {
+  const size_t P = (size_t)cam->cols * cam->rows;
+  std::vector<uint8_t> image(4 * P);
+  std::vector<float> vertex(4 * P), normal(4 * P);
+  std::vector<uint16_t> timeMap(P);
+  efo_combined_predict(cam, T_wc16, surfels, count, maxDepth, confThreshold, time, maxTime, timeDelta, image.data(), vertex.data(),
+                       normal.data(), timeMap.data());
+  for (size_t i = 0; i < P; ++i) depth[i] = vertex[4 * i + 2];
 }
 
 // FillIn::{vertex,normal,image} + fill_*.frag (G7).  cam = (cx, cy, 1/fx, 1/fy), FillIn.cpp:115-119

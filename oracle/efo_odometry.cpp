@@ -5,7 +5,8 @@
 //   vertex / normal image : float4 [rows][cols]       (GL_RGBA32F, IndexMap / FillIn outputs)
 //   colour image          : uchar4 [rows][cols]       (GL_RGBA8; .x .y .z as bgr2Intensity reads them)
 //   filtered depth        : u16    [rows][cols]
-// parity unpinned (no reference vectors exist; Eigen/Sophus un-vendored) — see efo_linalg.h.
+// parity of THIS file unpinned (host driver: Eigen/Sophus un-vendored, cannot be compiled; no reference vectors) — see
+// efo_linalg.h; the device operators it calls are pinned against the compiled reference (efo_track.cpp).
 #include "efo_common.h"
 #include "efo_linalg.h"
 #include "efo_api.h"

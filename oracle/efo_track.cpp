@@ -5,7 +5,8 @@
 //   Core/Cuda/reduce.cu     (icpStep, computeRgbResidual, rgbStep, so3Step + two-stage reductions)
 // Each function cites the lines it follows.  Image layouts are the reference's: planar maps are
 // float[3*rows][cols] (x rows, then y rows, then z rows); quirks Q1-Q14 of SURVEY.md §8a are kept.
-// parity unpinned: the reference ships no golden vectors and cannot be built here.
+// parity PINNED: built with -DEFO_NO_FMA this file reproduces, bit for bit, the reference's own Core/Cuda sources compiled
+// for the CPU (oracle/_ref/libefr_cuda.so, oracle/cuda_on_cpu/) and the golden vectors made from them (tests/golden/).
 #include "efo_common.h"
 #include "efo_api.h"
 #include <algorithm>

@@ -212,6 +212,48 @@ void efg_combined_predict(const efo_cam* cam, const double* T_wc16, const float*
   }
 }
 
+// IndexMap::synthesizeDepth: splat.vert + depth_splat.frag into an R32F attachment cleared to 0 (IndexMap.cpp:395-476)
+void efg_synthesize_depth(const efo_cam* cam, const double* T_wc16, const float* surfels, int count, float maxDepth, float confThreshold,
+                          int time, int maxTime, int timeDelta, float* depth) {
+  namespace V = glsl::sh_splat_vert;
+  namespace F = glsl::sh_depth_splat_frag;
+  const int cols = cam->cols, rows = cam->rows, P = cols * rows;
+  V::t_inv = to_mat4(efo::T_cw_float(T_wc16));
+  V::cam = vec4(cam->cx, cam->cy, cam->fx, cam->fy);
+  V::cols = (float)cols; V::rows = (float)rows; V::maxDepth = maxDepth; V::confThreshold = confThreshold;
+  V::time = time; V::maxTime = maxTime; V::timeDelta = timeDelta;
+  F::cam = V::cam; F::maxDepth = maxDepth;
+  std::vector<float> zbuf(P, std::numeric_limits<float>::infinity());
+  std::fill(depth, depth + P, 0.f);
+  for (int id = 0; id < count; ++id) {
+    const float* s = surfels + (size_t)id * 12;
+    V::vPosition = get4(s); V::vColor = get4(s + 4); V::vNormRad = get4(s + 8);
+    V::shader_main();
+    if (glsl::gl_Position.w != 1.0f) continue;
+    float size = glsl::gl_PointSize;
+    if (std::isnan(size) || std::isnan(glsl::gl_Position.x) || std::isnan(glsl::gl_Position.y)) continue;
+    size = std::min(std::max(size, 1.0f), 2047.0f);
+    const double u = window_coord(glsl::gl_Position.x, cols), v = window_coord(glsl::gl_Position.y, rows);
+    if (!(u >= 0 && u < cols && v >= 0 && v < rows)) continue;
+    const double hs = (double)size * 0.5;
+    const int px0 = std::max(0, (int)std::ceil(u - hs - 0.5)), px1 = std::min(cols - 1, (int)std::ceil(u + hs - 0.5) - 1);
+    const int py0 = std::max(0, (int)std::ceil(v - hs - 0.5)), py1 = std::min(rows - 1, (int)std::ceil(v + hs - 0.5) - 1);
+    F::position = V::position; F::normRad = V::normRad;
+    for (int py = py0; py <= py1; ++py)
+      for (int px = px0; px <= px1; ++px) {
+        glsl::gl_FragCoord = vec4((float)px + 0.5f, (float)py + 0.5f, glsl::gl_Position.z, 1.0f);
+        glsl::discard_flag = false;
+        F::shader_main();
+        if (glsl::discard_flag) continue;
+        const int pi = py * cols + px;
+        const float zkey = g_depth_mode ? F::FragColor : glsl::gl_FragDepth;
+        if (!(zkey < zbuf[pi])) continue;
+        zbuf[pi] = zkey;
+        depth[pi] = F::FragColor;
+      }
+  }
+}
+
 // FillIn::{vertex,normal,image}: quad + fill_vertex.frag / fill_normal.frag / fill_rgb.frag (FillIn.cpp:62-191)
 void efg_fill_in(const efo_cam* cam, const uint8_t* image, const float* vertex, const float* normal, const uint16_t* depthFiltered,
                  const uint8_t* rgb, int passthrough, int passthroughImage, uint8_t* fimage, float* fvertex, float* fnormal) {

@@ -37,7 +37,7 @@ class _Proxy:
                                 "pyr_down_gauss_f", "pyr_down_uchar_gauss", "vertices_to_depth", "bgr_to_intensity",
                                 "derivative_images", "project_to_point_cloud", "icp_step", "rgb_residual", "rgb_step", "so3_step")}
 
-    MAP_OPS = {"efo_" + n for n in ("filter_depth", "metricise_depth", "seed_map", "predict_indices", "combined_predict", "fill_in", "fuse",
+    MAP_OPS = {"efo_" + n for n in ("filter_depth", "metricise_depth", "seed_map", "predict_indices", "combined_predict", "synthesize_depth", "fill_in", "fuse",
                                     "clean")}
 
     def __init__(self, so, prefix, default, ops=None):
@@ -328,6 +328,14 @@ def combined_predict(cam, T_wc, surfels, maxDepth, confThreshold, time, maxTime,
     lib().efo_combined_predict(C.byref(cam), ptr(_T(T_wc)), ptr(s), c_i(len(s)), c_f(maxDepth), c_f(confThreshold),
                                c_i(time), c_i(maxTime), c_i(timeDelta), ptr(img), ptr(vt), ptr(nm), ptr(tm))
     return img, vt, nm, tm
+
+
+def synthesize_depth(cam, T_wc, surfels, maxDepth, confThreshold, time, maxTime, timeDelta):
+    d = np.zeros((cam.rows, cam.cols), np.float32)
+    s = f32(surfels)
+    lib().efo_synthesize_depth(C.byref(cam), ptr(_T(T_wc)), ptr(s), c_i(len(s)), c_f(maxDepth), c_f(confThreshold), c_i(time),
+                               c_i(maxTime), c_i(timeDelta), ptr(d))
+    return d
 
 
 def fill_in(cam, image, vertex, normal, depthFiltered, rgb, passthrough=0, passthroughImage=0):

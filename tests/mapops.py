@@ -69,6 +69,9 @@ def run_passes(be, inp, cam=None):
     out["index"], out["index_vertConf"], out["index_colorTime"], out["index_normRad"] = be.predict_indices(cam, T, tick, inp["surf"], MAXD, TD)
     out["predict_image"], out["predict_vertex"], out["predict_normal"], out["predict_time"] = be.combined_predict(
         cam, T, inp["surf"], MAXD, CONF, tick, tick, TD)
+    # synthesizeDepth as ElasticFusion.cpp:561-570 calls it: only surfels outside the time window (maxTime = time - timeDelta)
+    out["synth_depth"] = be.synthesize_depth(cam, T, inp["surf"], MAXD, CONF, tick, tick, TD)
+    out["synth_depth_old"] = be.synthesize_depth(cam, T, inp["surf"], MAXD, CONF, tick, tick - 2, TD)
     out["fill_image"], out["fill_vertex"], out["fill_normal"] = be.fill_in(cam, inp["img"], inp["vt"], inp["nm"], inp["depth_filtered"],
                                                                            inp["rgb_prev"])
     out["passthrough_image"], out["passthrough_vertex"], out["passthrough_normal"] = be.fill_in(

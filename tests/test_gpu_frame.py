@@ -112,6 +112,27 @@ def test_pipelined_frames_match_oracle(hip, seq):
         assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
 
 
+def test_frames_at_1280x960_match_oracle(hip):
+    """BASELINE.json configs[2] shape: 1280x960, the first frame seeds ~1.2 M surfels.  Same bar as at 640x480: tracker
+    statistics, float pose and every surfel identical to the oracle's (the kernels take the resolution at run time)."""
+    from elasticfusion_amd import synth
+    w, h = 1280, 960
+    s = synth.Sequence(0xEF0003, width=w, height=h)
+    ef = hip.ElasticFusion(width=w, height=h, fx=s.fx, fy=s.fy, cx=s.cx, cy=s.cy, maxSurfels=8 * 1024 * 1024)
+    o = efo.Fusion(width=w, height=h, fx=s.fx, fy=s.fy, cx=s.cx, cy=s.cy)
+    for k in range(3):
+        rgb, depth, _ = s.frame(k)
+        ef.processFrame(rgb, depth, k * 33333)
+        o.process_frame(rgb, depth, k * 33333)
+        if k > 0:
+            st, _, _ = ef.trackingStats()
+            assert np.array_equal(np.asarray(st, np.float32).view(np.uint32), np.asarray(o.stats(), np.float32).view(np.uint32)), k
+        assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32)), k
+    assert ef.lastCount() == o.map_count() > 1000000
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    ef.close()
+
+
 def test_fusion_with_injected_poses(hip, seq):
     """Ground-truth poses injected (in_T_wc), the reference's own way of decoupling fusion from tracking
     (ElasticFusion.cpp:302,367-369): identical poses => the map must match surfel for surfel."""
