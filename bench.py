@@ -163,6 +163,14 @@ def main():
                         "avg_us": round(float(kt.avg_us), 3), "event_pair_raw_us": round(float(kt.raw_avg_us), 3),
                         "event_pair_empty_us": round(float(kt.empty_pair_us), 3), "launches_sampled": int(kt.launches),
                         "algorithmic_bytes_per_launch": int(kt.bytes_per_launch)}
+    roofline_splat = None
+    if have_ktime and hasattr(lib, "ef_get_splat_timing"):
+        ks = KT()
+        if lib.ef_get_splat_timing(ef.h, C.byref(ks)) == 0 and ks.launches > 0:
+            ach = ks.bytes_per_launch / (ks.avg_us * 1e-6) / 1e9
+            roofline_splat = {"bound": "hbm", "kernel": ks.name.decode(), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(float(ks.avg_us), 3),
+                              "launches_sampled": int(ks.launches), "algorithmic_bytes_per_launch": int(ks.bytes_per_launch)}
     out = {
         "metric": f"frames/s per GPU, {w}x{h} 3-level ICP+fuse",
         "value": round(value, 2),
@@ -184,6 +192,7 @@ def main():
                    "pose_err_vs_generating_traj_m": round(err_t, 5),
                    "per_rank_fps": [round(x, 2) for x in agg["per_rank_fps"]]},
         "roofline": roofline,
+        "roofline_index_splat": roofline_splat,
     }
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(frames[: min(len(frames), 40)], w=w, h=h)

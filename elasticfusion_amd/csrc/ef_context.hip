@@ -89,6 +89,9 @@ struct ef_ctx {
   float kt_empty_pair_us = 0.f;   // what an event pair measures with nothing between the two records
   std::vector<hipEvent_t> kt_start, kt_stop;
   eft::KernelProbe probe{nullptr, nullptr, 0, 0};
+  // second sampled kernel: the IndexMap point splat (k_index_splat of the first predictIndices of a frame)
+  std::vector<hipEvent_t> ks_start, ks_stop;
+  eft::KernelProbe probe_splat{nullptr, nullptr, 0, 0};
 };
 
 namespace {
@@ -131,6 +134,14 @@ __global__ void k_init_state(eft::TrackState* st, int dense_samples) {
   st->dense_count = 0;
   st->dense_samples = dense_samples;
   st->map_counts[0] = st->map_counts[1] = 0;
+}
+// API boundary: the frame tier's column-major index maps are handed out in the reference's row-major order
+template <typename T>
+__global__ void k_to_rowmajor(const T* __restrict__ src, int cols, int rows, T* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cols * rows) return;
+  const int y = i / cols, x = i - y * cols;
+  dst[i] = src[x * rows + y];
 }
 __global__ void k_set_count(unsigned* count_dev, unsigned v) {
   if (threadIdx.x == 0) *count_dev = v;
@@ -239,8 +250,9 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
     // mid-frame predict() of ElasticFusion.cpp:387 is dead work without loop closure: skipped
     if (!rgbOnly) {  // ElasticFusion.cpp:536-585
       timer_begin(c, "indexMap");
+      const bool sample_splat = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0 && c->probe_splat.start;
       efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
-                           c->im, s);
+                           c->im, s, sample_splat ? &c->probe_splat : nullptr);
       timer_end(c, "indexMap");
       timer_begin(c, "Fuse::Data+Update");
       efm::fuse(c->cam, c->st->pose_f, c->tick, c->rgb, c->depth_metric, c->depth_metric_filtered, c->im, c->maxDepthProcessed,
@@ -322,6 +334,7 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->im.vert_conf, P);
   EF_ALLOC(c, c->im.color_time, P);
   EF_ALLOC(c, c->im.norm_rad, P);
+  c->im.colmajor = 1;
   EF_ALLOC(c, c->pm.image, P);
   EF_ALLOC(c, c->pm.vertex, P);
   EF_ALLOC(c, c->pm.normal, P);
@@ -372,6 +385,8 @@ void ctx_free(ef_ctx* c) {
   for (auto& t : c->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : c->kt_start) (void)hipEventDestroy(e);
   for (auto e : c->kt_stop) (void)hipEventDestroy(e);
+  for (auto e : c->ks_start) (void)hipEventDestroy(e);
+  for (auto e : c->ks_stop) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
 }
 
@@ -631,8 +646,19 @@ int ef_get_image(ef_ctx* c, int which, void* dst, size_t bytes) {
     default: c->err = "ef_get_image: unknown image"; return EF_EINVAL;
   }
   if (bytes < need) { c->err = "ef_get_image: destination too small"; return EF_EINVAL; }
-  EF_HIP(c, hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, c->stream));
-  EF_HIP(c, hipStreamSynchronize(c->stream));
+  void* tmp = nullptr;
+  if (c->im.colmajor && which >= EF_IMG_INDEX && which <= EF_IMG_NORM_RAD) {
+    EF_HIP(c, hipMalloc(&tmp, need));
+    const int W = c->cam.cols, H = c->cam.rows;
+    const dim3 g((unsigned)((P + 255) / 256));
+    if (which == EF_IMG_INDEX) hipLaunchKernelGGL(k_to_rowmajor<uint32_t>, g, dim3(256), 0, c->stream, (const uint32_t*)src, W, H, (uint32_t*)tmp);
+    else hipLaunchKernelGGL(k_to_rowmajor<float4>, g, dim3(256), 0, c->stream, (const float4*)src, W, H, (float4*)tmp);
+    src = tmp;
+  }
+  hipError_t e = hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (tmp) (void)hipFree(tmp);
+  EF_HIP(c, e);
   return EF_OK;
 }
 int ef_get_tracker_buffer(ef_ctx* c, int which, int level, void* dst, size_t bytes) {
@@ -683,6 +709,17 @@ int ef_kernel_timing(ef_ctx* c, int every_n_frames) {
   EF_HIP(c, hipStreamSynchronize(c->stream));
   c->ktime_every = every_n_frames;
   c->probe.used = 0;
+  c->probe_splat.used = 0;
+  if (every_n_frames > 0 && c->ks_start.empty()) {
+    const int cap = 1024;
+    c->ks_start.resize(cap);
+    c->ks_stop.resize(cap);
+    for (int i = 0; i < cap; ++i) {
+      EF_HIP(c, hipEventCreate(&c->ks_start[i]));
+      EF_HIP(c, hipEventCreate(&c->ks_stop[i]));
+    }
+    c->probe_splat = eft::KernelProbe{c->ks_start.data(), c->ks_stop.data(), cap, 0};
+  }
   if (every_n_frames > 0 && c->kt_start.empty()) {
     const int cap = 4096;
     c->kt_start.resize(cap);
@@ -731,6 +768,28 @@ int ef_get_kernel_timing(ef_ctx* c, ef_kernel_time* out) {
   // reference's 16-byte DataTerm + 12-byte cloud are gone, so they are not counted — the ~10 % valid pixels' gathers
   // (depth + 2 gradients) are left out (data dependent): a lower bound, which can only understate `achieved`
   out->bytes_per_launch = (double)c->cam.cols * c->cam.rows * ((icp ? 48.0 : 0.0) + (rgb ? 4.0 : 0.0));
+  return EF_OK;
+}
+
+int ef_get_splat_timing(ef_ctx* c, ef_kernel_time* out) {
+  if (!c || !out) return EF_EINVAL;
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  double total_ms = 0;
+  for (int i = 0; i < c->probe_splat.used; ++i) {
+    float ms = 0;
+    EF_HIP(c, hipEventElapsedTime(&ms, c->ks_start[i], c->ks_stop[i]));
+    total_ms += ms;
+  }
+  unsigned count = 0;
+  EF_HIP(c, hipMemcpy(&count, &c->st->map_counts[c->cur], sizeof(count), hipMemcpyDeviceToHost));
+  out->name = "k_index_splat (IndexMap::predictIndices: per-surfel transform + project + 64-bit atomicMin z-buffer)";
+  out->launches = c->probe_splat.used;
+  out->raw_avg_us = c->probe_splat.used ? (float)(1e3 * total_ms / c->probe_splat.used) : 0.f;
+  out->empty_pair_us = c->kt_empty_pair_us;
+  out->avg_us = out->raw_avg_us > out->empty_pair_us ? out->raw_avg_us - out->empty_pair_us : out->raw_avg_us;
+  // algorithmic bytes: the two float4 streams the pass needs (position+confidence, colour+times: 32 B / surfel; the
+  // reference's vertex shader fetches all 48) + one 8-byte z-buffer update per surfel (an upper bound: culled surfels issue none)
+  out->bytes_per_launch = 40.0 * (double)count;
   return EF_OK;
 }
 

@@ -32,7 +32,16 @@ struct IndexMaps {   // IndexMap::predictIndices outputs (IndexMap.h:74-88)
   float4* vert_conf;
   float4* color_time;
   float4* norm_rad;
+  // Storage order of the four images (and of the z-buffer they are resolved from).  The frame tier keeps them
+  // COLUMN-major (texel (x, y) at x * rows + y): surfels are created in column-major pixel order (the reference's draw
+  // order, FeedbackBuffer.cpp:44-52) and move little between frames, so consecutive surfel ids project to vertically
+  // adjacent pixels — with this layout the per-surfel taps of clean() and the per-pixel gathers of the resolve pass
+  // touch consecutive addresses instead of one cache line per lane.  The operator tier passes row-major host images.
+  int colmajor = 0;
 };
+__host__ __device__ inline int im_texel(const IndexMaps& im, const Cam& cam, int px, int py) {
+  return im.colmajor ? px * cam.rows + py : py * cam.cols + px;
+}
 struct PredictMaps { // IndexMap::combinedPredict outputs (IndexMap.h:98-112)
   uchar4* image;
   float4* vertex;
@@ -79,7 +88,7 @@ void seed_map(const Cam& cam, const uint8_t* rgb3, const float* depth_metric, co
 // ---- model prediction ----
 // T_cw16_dev: device pointer to the float 4x4 T_wc^-1; count_dev: device surfel count
 void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSoA map, const unsigned* count_dev, float maxDepth,
-                     int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s);
+                     int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s, eft::KernelProbe* probe = nullptr);
 void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
                       float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, PredictMaps out,
                       // optional fused fill-in + denseEnough sampling (null fill.image => skipped)

@@ -5,6 +5,7 @@
 // with order-preserving chunked stream compaction instead of transform feedback.
 // GL-defined behaviour is specified as N1-N5 in SURVEY.md §8a (restated in DESIGN.md).
 #include "ef_device.hpp"
+#include <stdlib.h>
 #include "ef_map.hpp"
 
 using namespace ef;
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(BLK) k_seed_scatter(const SeedArgs A, const ui
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLK) k_index_splat(const Cam cam, const float* __restrict__ T16, int time, SurfelSoA map,
                                                       const unsigned* __restrict__ count_dev, float maxDepth, int timeDelta,
-                                                      unsigned long long* zbuf) {
+                                                      unsigned long long* zbuf, int colmajor) {
   const rt34 T = rt34_load16(T16);
   const unsigned count = *count_dev;
   const float ftime = (float)time, ftd = (float)timeDelta;
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(BLK) k_index_splat(const Cam cam, const float*
     const float v = ((cam.fy * p.y) / p.z) + cam.cy;
     if (!(u >= 0 && u < (float)cam.cols && v >= 0 && v < (float)cam.rows)) continue;  // N1
     const int px = (int)floorf(u), py = (int)floorf(v);
-    atomicMin(&zbuf[py * cam.cols + px], zkey(p.z, id));                              // N2
+    atomicMin(&zbuf[colmajor ? px * cam.rows + py : py * cam.cols + px], zkey(p.z, id));   // N2
   }
 }
 __global__ void __launch_bounds__(BLK) k_index_resolve(const Cam cam, const float* __restrict__ T16, SurfelSoA map,
@@ -605,12 +606,14 @@ struct FuseArgs {
 };
 // data.vert:76-193.  One thread per fused pixel (W/2 x H/2, parity-selected: quirk Q12), threads walk rows
 // (coalesced taps); the candidate lands in slot r = column-major rank == the reference's draw order.
-__global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates cand, uint32_t* winner) {
+__global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates cand, uint32_t* winner, int colwalk) {
   const Cam cam = A.cam;
   const int qc = cam.cols / 2, qr = cam.rows / 2;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= qc * qr) return;
-  const int qy = q / qc, qx = q - qy * qc;
+  // colwalk: consecutive lanes go down a column (the order of the candidate slots and of a column-major index map);
+  // otherwise along a row (the order of the depth and colour images)
+  const int qy = colwalk ? q % qr : q / qc, qx = colwalk ? q / qr : q - (q / qc) * qc;
   const int par = A.time % 2;
   const int i = 2 * qx + par, j = 2 * qy + par;
   const int r = qx * qr + qy;
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates 
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int ty = clampi(j + (b == 0 ? -1 : (b == 3 ? 1 : 0)), 0, cam.rows - 1);
-          const int ti = ty * cam.cols + tx;
+          const int ti = im_texel(A.im, cam, tx, ty);
           const uint32_t current = A.im.index[ti];
           if (current > 0U) {
             const float4 vc = A.im.vert_conf[ti];
@@ -759,7 +762,7 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& A, const rt34& T, fl
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
-        const int ti = ty.u[b] * cam.cols + tx.u[a];
+        const int ti = im_texel(A.im, cam, tx.u[a], ty.u[b]);
         idx[a * 3 + b] = A.im.index[ti];
         vcs[a * 3 + b] = A.im.vert_conf[ti];
         c2s[a * 3 + b] = A.im.color_time[ti];
@@ -938,8 +941,12 @@ void seed_map(const Cam& cam, const uint8_t* rgb3, const float* dm, const float*
 }
 
 void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSoA map, const unsigned* count_dev, float maxDepth,
-                     int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s) {
-  hipLaunchKernelGGL(k_index_splat, dim3(SURFEL_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, time, map, count_dev, maxDepth, timeDelta, zbuf);
+                     int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s, eft::KernelProbe* probe) {
+  const bool sample = probe && probe->used < probe->capacity;
+  if (sample) (void)hipEventRecord(probe->start[probe->used], s);
+  hipLaunchKernelGGL(k_index_splat, dim3(SURFEL_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, time, map, count_dev, maxDepth, timeDelta, zbuf,
+                     out.colmajor);
+  if (sample) (void)hipEventRecord(probe->stop[probe->used++], s);
   hipLaunchKernelGGL(k_index_resolve, dim3(ceil_div(cam.cols * cam.rows, BLK)), dim3(BLK), 0, s, cam, T_cw16_dev, map, zbuf, out);
 }
 
@@ -978,7 +985,8 @@ void fuse(const Cam& cam, const float* pose_f16_dev, int time, const uint8_t* rg
           hipStream_t s) {
   (void)count_dev;
   FuseArgs A{cam, pose_f16_dev, time, rgb3, dm, dmf, im, maxDepth, weighting_dev};
-  hipLaunchKernelGGL(k_associate, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, A, cand, winner);
+  static const int rowwalk = getenv("EF_ASSOC_ROWWALK") ? atoi(getenv("EF_ASSOC_ROWWALK")) : 0;
+  hipLaunchKernelGGL(k_associate, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, A, cand, winner, (im.colmajor && !rowwalk) ? 1 : 0);
   hipLaunchKernelGGL(k_merge, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, cand, (const uint32_t*)winner, map, time);
 }
 

@@ -139,6 +139,8 @@ typedef struct ef_kernel_time {
 } ef_kernel_time;
 int ef_kernel_timing(ef_ctx* ctx, int every_n_frames);
 int ef_get_kernel_timing(ef_ctx* ctx, ef_kernel_time* out);
+/* same sampling (switched on by ef_kernel_timing) of the IndexMap point splat: k_index_splat of the frame's first predictIndices */
+int ef_get_splat_timing(ef_ctx* ctx, ef_kernel_time* out);
 
 /* developer instrumentation: the 16 wall_clock64() (100 MHz) stamps the last tracking solve left in the device state;
  * all zero unless the library was built with -DEF_STAGE_CLOCKS (EF_HIPCC_FLAGS=-DEF_STAGE_CLOCKS python -m elasticfusion_amd.build) */
