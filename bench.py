@@ -95,7 +95,11 @@ def main():
     n_frames = a.warmup + a.steps + 1  # frame 0 seeds the map (tick 1) and is never timed
     frames = generate_frames(multi.sequence_seed(rank), n_frames, w, h)
 
-    stream = torch.cuda.current_stream().cuda_stream
+    # a real (non-null) stream, made torch's current one: the engine enqueues on it, torch.cuda.synchronize() covers it,
+    # and it can be captured into a hipGraph (EF_GRAPH=1), which the legacy null stream cannot
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
     sc = w / 640.0
     ef = api.ElasticFusion(width=w, height=h, fx=528.0 * sc, fy=528.0 * sc, cx=320.0 * sc, cy=240.0 * sc, device=local_rank, stream=stream,
                            maxSurfels=max(4 * 1024 * 1024, 6 * w * h))

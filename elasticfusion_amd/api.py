@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libefusion_hip.so")
+# EF_HIP_LIB: developer override (A/B of two builds on one GPU box, tools/gpu_ab.sh); never a CPU fallback
+LIB_PATH = os.environ.get("EF_HIP_LIB") or os.path.join(_HERE, "libefusion_hip.so")
 _lib = None
 
 c_f, c_i, c_u32, P = C.c_float, C.c_int, C.c_uint32, C.c_void_p
@@ -256,6 +257,11 @@ class ElasticFusion:
     def setConfidenceThreshold(self, v): _chk(lib().ef_set_confidence_threshold(self.h, c_f(v)), self.h)
     def setDepthCutoff(self, v): _chk(lib().ef_set_depth_cutoff(self.h, c_f(v)), self.h)
     def setInputOverlap(self, on): _chk(lib().ef_set_input_overlap(self.h, c_i(int(on))), self.h)
+    def setDeformation(self, graph, isFern=False):
+        g = np.ascontiguousarray(graph, np.float32).reshape(-1, 16)
+        _chk(lib().ef_set_deformation(self.h, _ptr(g), c_i(len(g)), c_i(int(isFern))), self.h)
+
+    def setGraphReplay(self, on): _chk(lib().ef_set_graph_replay(self.h, c_i(int(on))), self.h)
 
     def image(self, name: str) -> np.ndarray:
         which, dt, ch = self.IMAGES[name]
@@ -420,6 +426,20 @@ class ops:
         _chk(lib().ef_op_so3_step(li.p, ni.p, _ptr(ops._f32(imageBasis).reshape(9)), _ptr(ops._f32(kinv).reshape(9)),
                                   _ptr(ops._f32(krlr).reshape(9)), c_i(w), c_i(h), _ptr(A), _ptr(b), _ptr(res), None))
         return A, b, res
+
+    @staticmethod
+    def clean_deform(cam, T_wc, time, idx, vc, ct, nr, confThreshold, timeDelta, maxDepth, surfels, newUnstable, graph, depth, isFern=0):
+        s = ops._f32(surfels).reshape(-1, 12)
+        nu = ops._f32(newUnstable).reshape(-1, 12)
+        g = ops._f32(graph).reshape(-1, 16)
+        bufs = [DevBuf.from_array(a) for a in (idx, ops._f32(vc), ops._f32(ct), ops._f32(nr), g, ops._f32(depth))]
+        sb, nb = DevBuf.from_array(s), DevBuf.from_array(nu if len(nu) else np.zeros((1, 12), np.float32))
+        out = DevBuf((len(s) + len(nu) + 1) * 48)
+        n = c_u32(0)
+        _chk(lib().ef_op_clean_deform(C.byref(cam), _ptr(ops._T(T_wc)), c_i(time), bufs[0].p, bufs[1].p, bufs[2].p, bufs[3].p,
+                                      c_f(confThreshold), c_i(timeDelta), c_f(maxDepth), sb.p, c_u32(len(s)), nb.p, c_u32(len(nu)),
+                                      bufs[4].p, c_i(len(g)), bufs[5].p, c_i(int(isFern)), out.p, C.byref(n), None))
+        return out.to_array(np.float32, (n.value, 12))
 
     LINALG = dict(ldlt6=0, ldlt3f=1, polar3=2, rodrigues=3, se3_inverse=4, se3_log_norm=5, scalar=6, ldlt6_wave=7)
 

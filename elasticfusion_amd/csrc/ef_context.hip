@@ -84,6 +84,15 @@ struct ef_ctx {
   // timing
   bool timing = false;
   std::vector<StageTimer> timers;
+  // deformation graph to be applied by the next frame's clean() (ef_set_deformation): the device half of loop closure
+  float* graph_dev = nullptr;
+  int graph_nodes = 0, graph_is_fern = 0;
+  float* synth_depth = nullptr;
+  // hipGraph replay of the tracker (BASELINE.json configs[4]): the ~70 launches of getIncrementalTransformation are
+  // captured once per pyramid parity (the SO(3) reference / frame intensity buffers swap every frame) and replayed
+  bool use_graph = false;
+  struct TrackGraph { hipGraphExec_t exec = nullptr; const void* key = nullptr; eft::TrackParams tp{}; };
+  TrackGraph tgraph[2];
   // HIP-event sampling of the dominant kernel (ef_kernel_timing)
   int ktime_every = 0;
   float kt_empty_pair_us = 0.f;   // what an event pair measures with nothing between the two records
@@ -238,7 +247,30 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       timer_end(c, "odomInit");
       timer_begin(c, "odom");
       const bool sample = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0;
-      eft::track(c->pyr, c->st, c->intr, tp, s, sample ? &c->probe : nullptr);
+      if (c->use_graph && !sample && !c->timing) {
+        // key: which of the two intensity pyramids is "next" this frame + the knobs baked into the launch arguments
+        const void* key = c->pyr.nextImage[0];
+        ef_ctx::TrackGraph* g = nullptr;
+        for (auto& cand : c->tgraph)
+          if (cand.exec && cand.key == key && !memcmp(&cand.tp, &tp, sizeof(tp))) g = &cand;
+        if (!g) {
+          g = (c->tgraph[0].exec && c->tgraph[0].key != key) ? &c->tgraph[1] : &c->tgraph[0];
+          if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+          eft::Pyramid pyr_copy = c->pyr;   // track() swaps the copy's pointers; the real swap is done below
+          hipGraph_t graph = nullptr;
+          EF_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+          eft::track(pyr_copy, c->st, c->intr, tp, s, nullptr);
+          EF_HIP(c, hipStreamEndCapture(s, &graph));
+          EF_HIP(c, hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0));
+          (void)hipGraphDestroy(graph);
+          g->key = key;
+          memcpy(&g->tp, &tp, sizeof(tp));
+        }
+        EF_HIP(c, hipGraphLaunch(g->exec, s));
+        eft::track_swap(c->pyr, tp);
+      } else {
+        eft::track(c->pyr, c->st, c->intr, tp, s, sample ? &c->probe : nullptr);
+      }
       eft::track_end(c->st, rgb, weightMultiplier, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
       timer_end(c, "odom");
     } else {
@@ -262,9 +294,17 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
                            c->im, s);
       timer_end(c, "indexMap2");
+      // a pending deformation (ElasticFusion.cpp:558-585): re-predict the depth of the surfels outside the time window, then let
+      // clean() move every kept surfel with the graph
+      efm::Deformation def{c->graph_dev, c->graph_nodes, c->synth_depth, c->graph_is_fern, c->maxDepthProcessed};
+      if (c->graph_nodes > 0 && !c->graph_is_fern)
+        efm::synthesize_depth(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence, c->tick,
+                              c->tick - c->cfg.time_delta, 65535, c->zbuf, c->synth_depth, s);
       timer_begin(c, "Fuse::Copy");
       efm::clean(c->cam, c->st->T_cw, c->tick, c->im, c->cfg.confidence, c->cfg.time_delta, c->maps[c->cur], &c->st->map_counts[c->cur], c->cand,
-                 c->winner, c->maps[c->cur ^ 1], &c->st->map_counts[c->cur ^ 1], c->capacity, c->cs, c->overflow, s);
+                 c->winner, c->maps[c->cur ^ 1], &c->st->map_counts[c->cur ^ 1], c->capacity, c->cs, c->overflow, s,
+                 c->graph_nodes > 0 ? &def : nullptr);
+      c->graph_nodes = 0;
       c->cur ^= 1;
       timer_end(c, "Fuse::Copy");
     }
@@ -300,6 +340,7 @@ int ctx_init(ef_ctx* c) {
     EF_HIP(c, hipStreamCreateWithPriority(&c->in_stream, hipStreamNonBlocking, low ? lo : 0));
   }
   for (auto& e : c->ev_frame_done) EF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  c->use_graph = getenv("EF_GRAPH") != nullptr && atoi(getenv("EF_GRAPH")) != 0;
   if (getenv("EF_OVERLAP")) c->overlap_mode = atoi(getenv("EF_OVERLAP")) == 2 ? 2 : 1;
   if (getenv("EF_PRE_LDS")) c->pre_lds = (unsigned)atoi(getenv("EF_PRE_LDS"));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_input_done, hipEventDisableTiming));
@@ -343,6 +384,8 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->fm.vertex, P);
   EF_ALLOC(c, c->fm.normal, P);
   EF_ALLOC(c, c->zbuf, P, 0xFF);
+  EF_ALLOC(c, c->graph_dev, 1024 * 16);     // GlobalModel::MAX_NODES x 16 (GlobalModel.cpp:24)
+  EF_ALLOC(c, c->synth_depth, P);
   EF_ALLOC(c, c->overflow, 1);
   // global model
   c->capacity = g.max_surfels;
@@ -385,6 +428,8 @@ void ctx_free(ef_ctx* c) {
   for (auto& t : c->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : c->kt_start) (void)hipEventDestroy(e);
   for (auto e : c->kt_stop) (void)hipEventDestroy(e);
+  for (auto& g : c->tgraph)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
   for (auto e : c->ks_start) (void)hipEventDestroy(e);
   for (auto e : c->ks_stop) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -478,6 +523,16 @@ int ef_process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* dept
   return process_frame(c, rgb_dev, depth_dev, hipMemcpyDeviceToDevice, timestamp, wm, T);
 }
 int ef_set_input_overlap(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->overlap = on != 0; return EF_OK; }
+int ef_set_deformation(ef_ctx* c, const float* graph, int nodes, int is_fern) {
+  if (!c || nodes < 0 || (nodes > 0 && !graph)) return EF_EINVAL;
+  if (nodes >= 1024) { c->err = "ef_set_deformation: at most 1023 nodes (GlobalModel::MAX_NODES)"; return EF_EINVAL; }
+  if (nodes > 0) EF_HIP(c, hipMemcpyAsync(c->graph_dev, graph, (size_t)nodes * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (nodes > 0) EF_HIP(c, hipStreamSynchronize(c->stream));   // the caller's buffer is borrowed for the call only
+  c->graph_nodes = nodes;
+  c->graph_is_fern = is_fern != 0;
+  return EF_OK;
+}
+int ef_set_graph_replay(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->use_graph = on != 0; return EF_OK; }
 int ef_predict(ef_ctx* c) {
   if (!c) return EF_EINVAL;
   EF_HIP(c, hipMemsetAsync(&c->st->dense_count, 0, sizeof(unsigned), c->stream));
@@ -1186,10 +1241,10 @@ __global__ void k_aos_to_cand(const float4* __restrict__ aos, uint32_t n, efm::C
 }  // namespace
 extern "C" {
 
-int ef_op_clean(const ef_cam* cam, const double* T16, int time, const uint32_t* index, const float* vc, const float* ct, const float* nr,
-                float confThreshold, int timeDelta, float maxDepth, const float* surfels, uint32_t count, const float* newUnstable,
-                uint32_t newCount, float* surfels_out, uint32_t* outCount, void* s_) {
-  (void)maxDepth;
+int ef_op_clean_deform(const ef_cam* cam, const double* T16, int time, const uint32_t* index, const float* vc, const float* ct, const float* nr,
+                       float confThreshold, int timeDelta, float maxDepth, const float* surfels, uint32_t count, const float* newUnstable,
+                       uint32_t newCount, const float* graph, int nodes, const float* depth, int isFern, float* surfels_out,
+                       uint32_t* outCount, void* s_) {
   hipStream_t s = (hipStream_t)s_;
   OpMap m;
   const uint32_t cap = count + newCount;
@@ -1217,7 +1272,9 @@ int ef_op_clean(const ef_cam* cam, const double* T16, int time, const uint32_t* 
   cs.totals = m.alloc<uint32_t>(8);
   efm::IndexMaps im{(uint32_t*)index, (float4*)vc, (float4*)ct, (float4*)nr};
   unsigned* cnt_out = m.alloc<unsigned>(1);
-  efm::clean(to_cam(cam), mats, time, im, confThreshold, timeDelta, soa, cnt, cand, winner, out, cnt_out, cap, cs, nullptr, s);
+  const efm::Deformation def{graph, nodes, depth, isFern, maxDepth};
+  efm::clean(to_cam(cam), mats, time, im, confThreshold, timeDelta, soa, cnt, cand, winner, out, cnt_out, cap, cs, nullptr, s,
+             nodes > 0 ? &def : nullptr);
   unsigned hn = 0;
   (void)hipMemcpyAsync(&hn, cnt_out, sizeof(hn), hipMemcpyDeviceToHost, s);
   OP_SYNC(s);
@@ -1225,6 +1282,12 @@ int ef_op_clean(const ef_cam* cam, const double* T16, int time, const uint32_t* 
   OP_SYNC(s);
   *outCount = hn;
   return EF_OK;
+}
+int ef_op_clean(const ef_cam* cam, const double* T16, int time, const uint32_t* index, const float* vc, const float* ct, const float* nr,
+                float confThreshold, int timeDelta, float maxDepth, const float* surfels, uint32_t count, const float* newUnstable,
+                uint32_t newCount, float* surfels_out, uint32_t* outCount, void* s_) {
+  return ef_op_clean_deform(cam, T16, time, index, vc, ct, nr, confThreshold, timeDelta, maxDepth, surfels, count, newUnstable, newCount,
+                            nullptr, 0, nullptr, 0, surfels_out, outCount, s_);
 }
 
 }  // extern "C"

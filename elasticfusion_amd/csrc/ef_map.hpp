@@ -107,10 +107,19 @@ void dense_count(const Cam& cam, const uchar4* image, unsigned* counter, hipStre
 void fuse(const Cam& cam, const float* pose_f16_dev, int time, const uint8_t* rgb3, const float* depth_metric,
           const float* depth_metric_filtered, IndexMaps im, float maxDepth, const float* weighting_dev, SurfelSoA map,
           const unsigned* count_dev, Candidates cand, uint32_t* winner, hipStream_t s);
+// deformation graph handed to clean() after a loop closure (copy_unstable.vert:128-322): nodes x 16 floats sorted by time
+// {position 3, rotation 9 column-major, translation 3, time}; depth = synthesize_depth image (read unless is_fern)
+struct Deformation {
+  const float* graph_dev;
+  int nodes;
+  const float* depth_dev;
+  int is_fern;
+  float max_depth;
+};
 // clean + append; writes the compacted map to `out` and the new count (clamped to capacity) to *count_out_dev
 void clean(const Cam& cam, const float* T_cw16_dev, int time, IndexMaps im, float confThreshold, int timeDelta, SurfelSoA map,
            const unsigned* count_dev, Candidates cand, uint32_t* winner, SurfelSoA out, unsigned* count_out_dev, uint32_t capacity,
-           const CompactScratch& cs, int* overflow_flag, hipStream_t s);
+           const CompactScratch& cs, int* overflow_flag, hipStream_t s, const Deformation* deform = nullptr);
 // candidates -> AoS "newUnstable" list in draw order (operator tier / tests)
 void candidates_to_aos(Candidates cand, float* aos, unsigned* count_dev, const CompactScratch& cs, hipStream_t s);
 

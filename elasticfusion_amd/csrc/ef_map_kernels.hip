@@ -803,6 +803,142 @@ __device__ __forceinline__ bool load_element(const SurfelSoA& map, const Candida
   pc = cand.pos_conf[r]; nr = cand.nrm_rad[r];
   return true;
 }
+// ---- deformation-graph application, copy_unstable.vert:128-322 ----
+// graph: nodes x 16 floats sorted by time {position 3, rotation 9 column-major, translation 3, time}, the content of the
+// reference's 1 x 16384 node texture (GlobalModel.cpp:540-546); texel index = float index, CLAMP_TO_EDGE, zeros past the end.
+struct DeformArgs {
+  const float* graph;
+  int nodes;
+  const float* depth;     // IndexMap::synthesizeDepth image (row-major), read when !isFern
+  int isFern;
+  float maxDepth;
+};
+__device__ __forceinline__ float node_tex(const DeformArgs& D, int idx) {
+  idx = clampi(idx, 0, 16384 - 1);
+  return idx < D.nodes * 16 ? D.graph[idx] : 0.0f;
+}
+__device__ __forceinline__ f3 node_pos(const DeformArgs& D, int j) { return f3{node_tex(D, j * 16), node_tex(D, j * 16 + 1), node_tex(D, j * 16 + 2)}; }
+__device__ __forceinline__ float node_dist(const DeformArgs& D, f3 pos, int j) {
+  const f3 d = pos - node_pos(D, j);
+  return sqrtf(dot(d, d));
+}
+struct M3c { float m[3][3]; };   // column-major mat3, m[col][row]
+__device__ __forceinline__ f3 mulc(const M3c& a, f3 v) {
+  return {dot(f3{a.m[0][0], a.m[1][0], a.m[2][0]}, v), dot(f3{a.m[0][1], a.m[1][1], a.m[2][1]}, v), dot(f3{a.m[0][2], a.m[1][2], a.m[2][2]}, v)};
+}
+__device__ __forceinline__ M3c inverse3(const M3c& a) {   // adjugate x 1/det: GLSL leaves inverse() to the implementation, this formula is the specification
+  const float (*m)[3] = a.m;
+  const float c00 = m[1][1] * m[2][2] - m[2][1] * m[1][2], c01 = m[2][1] * m[0][2] - m[0][1] * m[2][2], c02 = m[0][1] * m[1][2] - m[1][1] * m[0][2];
+  const float det = (m[0][0] * c00 + m[1][0] * c01) + m[2][0] * c02;
+  const float id = 1.0f / det;
+  M3c r;
+  r.m[0][0] = c00 * id; r.m[0][1] = c01 * id; r.m[0][2] = c02 * id;
+  r.m[1][0] = (m[2][0] * m[1][2] - m[1][0] * m[2][2]) * id; r.m[1][1] = (m[0][0] * m[2][2] - m[2][0] * m[0][2]) * id; r.m[1][2] = (m[1][0] * m[0][2] - m[0][0] * m[1][2]) * id;
+  r.m[2][0] = (m[1][0] * m[2][1] - m[2][0] * m[1][1]) * id; r.m[2][1] = (m[2][0] * m[0][1] - m[0][0] * m[2][1]) * id; r.m[2][2] = (m[0][0] * m[1][1] - m[1][0] * m[0][1]) * id;
+  return r;
+}
+__device__ void deform_vertex(const CleanArgs& A, const DeformArgs& D, const rt34& T, float4& pc, float4& ct, float4& nr) {
+  constexpr int k = 4, lookBack = 20;
+  const int nodes = D.nodes;
+  int nearNodes[lookBack];
+  float nearDists[lookBack];
+  for (int i = 0; i < lookBack; ++i) { nearNodes[i] = -1; nearDists[i] = 16777216.0f; }
+  const int poseTime = (int)ct.z;
+  int foundIndex = 0, imin = 0, imax = nodes - 1, imid = (imin + imax) / 2;
+  while (imax >= imin) {
+    imid = (imin + imax) / 2;
+    const int nodeTime = (int)node_tex(D, imid * 16 + 15);
+    if (nodeTime < poseTime) imin = imid + 1;
+    else if (nodeTime > poseTime) imax = imid - 1;
+    else break;
+  }
+  imin = min(imin, nodes - 1);
+  const int nodeMin = (int)node_tex(D, imin * 16 + 15), nodeMid = (int)node_tex(D, imid * 16 + 15), nodeMax = (int)node_tex(D, imax * 16 + 15);
+  if (abs(nodeMin - poseTime) <= abs(nodeMid - poseTime) && abs(nodeMin - poseTime) <= abs(nodeMax - poseTime)) foundIndex = imin;
+  else if (abs(nodeMid - poseTime) <= abs(nodeMin - poseTime) && abs(nodeMid - poseTime) <= abs(nodeMax - poseTime)) foundIndex = imid;
+  else foundIndex = imax;
+  if (foundIndex == nodes) foundIndex = nodes - 1;
+  const f3 pos{pc.x, pc.y, pc.z};
+  int nearNodeIndex = 0, distanceBack = 0;
+  for (int j = foundIndex; j >= 0; --j) {
+    nearNodes[nearNodeIndex] = j;
+    nearDists[nearNodeIndex] = node_dist(D, pos, j);
+    nearNodeIndex++;
+    if (++distanceBack == lookBack / 2) break;
+  }
+  for (int j = foundIndex + 1; j < nodes; ++j) {
+    nearNodes[nearNodeIndex] = j;
+    nearDists[nearNodeIndex] = node_dist(D, pos, j);
+    nearNodeIndex++;
+    if (++distanceBack == lookBack) break;
+  }
+  for (int i = 0; i < lookBack - 1; ++i)     // the shader's exchange sort, tie behaviour included
+    for (int j = i + 1; j < lookBack; ++j)
+      if (nearDists[j] < nearDists[i]) {
+        const float tf = nearDists[i]; nearDists[i] = nearDists[j]; nearDists[j] = tf;
+        const int ti = nearNodes[i]; nearNodes[i] = nearNodes[j]; nearNodes[j] = ti;
+      }
+  const float dMax = nearDists[k];
+  float nodeWeights[k];
+  float weightSum = 0;
+  for (int j = 0; j < k; ++j) {
+    const float q = 1.0f - (node_dist(D, pos, nearNodes[j]) / dMax);
+    nodeWeights[j] = q * q;
+    weightSum += nodeWeights[j];
+  }
+  for (int j = 0; j < k; ++j) nodeWeights[j] /= weightSum;
+  f3 newPos{0.f, 0.f, 0.f}, newNorm{0.f, 0.f, 0.f};
+  const f3 nrm{nr.x, nr.y, nr.z};
+  for (int i = 0; i < k; ++i) {
+    const int n = nearNodes[i];
+    const f3 g = node_pos(D, n);
+    M3c R;
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r) R.m[c][r] = node_tex(D, n * 16 + 3 + c * 3 + r);
+    const f3 t{node_tex(D, n * 16 + 12), node_tex(D, n * 16 + 13), node_tex(D, n * 16 + 14)};
+    const f3 moved = (mulc(R, pos - g) + g) + t;
+    newPos = newPos + f3{nodeWeights[i] * moved.x, nodeWeights[i] * moved.y, nodeWeights[i] * moved.z};
+    const M3c Ri = inverse3(R);
+    M3c Rit;
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r) Rit.m[c][r] = Ri.m[r][c];
+    const f3 rn = mulc(Rit, nrm);
+    newNorm = newNorm + f3{nodeWeights[i] * rn.x, nodeWeights[i] * rn.y, nodeWeights[i] * rn.z};
+  }
+  pc.x = newPos.x; pc.y = newPos.y; pc.z = newPos.z;
+  const f3 nn = normalized(newNorm);
+  nr.x = nn.x; nr.y = nn.y; nr.z = nn.z;
+  if (pc.w > A.confThreshold && D.isFern == 0) {
+    const Cam& cam = A.cam;
+    const f3 lp = xform(T, f3{pc.x, pc.y, pc.z});
+    const float x = ((cam.fx * lp.x) / lp.z) + cam.cx, y = ((cam.fy * lp.y) / lp.z) + cam.cy;
+    if (lp.z > 0 && lp.z < D.maxDepth && x > 0 && y > 0 && x < (float)cam.cols && y < (float)cam.rows) {
+      const float currentDepth = D.depth[clampi((int)floorf(y), 0, cam.rows - 1) * cam.cols + clampi((int)floorf(x), 0, cam.cols - 1)];   // N4
+      if (currentDepth > 0.0f && lp.z < currentDepth + 0.1f) ct.w = (float)A.time;
+    }
+  }
+}
+// runs between the keep-test and the scatter: kept elements (flag 1) not initialised this frame are deformed IN PLACE in
+// the source buffers (the old map / the candidate slots are dead after this clean()); a new point's -2 tag is resolved
+// first, as the shader does before its deformation block
+__global__ void __launch_bounds__(BLK) k_clean_deform(const CleanArgs A, const DeformArgs D, SurfelSoA map, const unsigned* __restrict__ count_dev,
+                                                       Candidates cand, const uint8_t* __restrict__ flags) {
+  const unsigned count = *count_dev;
+  const unsigned n = count + (unsigned)cand.n;
+  const rt34 T = rt34_load16(A.T16);
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    if (!flags[e]) continue;
+    float4* ppc = e < count ? &map.pos_conf[e] : &cand.pos_conf[e - count];
+    float4* pct = e < count ? &map.col_time[e] : &cand.col_time[e - count];
+    float4* pnr = e < count ? &map.nrm_rad[e] : &cand.nrm_rad[e - count];
+    float4 pc = *ppc, ct = *pct, nr = *pnr;
+    if (ct.w == -2.0f) ct.w = (float)A.time;
+    if (ct.z == (float)A.time) { *pct = ct; continue; }
+    deform_vertex(A, D, T, pc, ct, nr);
+    *ppc = pc; *pct = ct; *pnr = nr;
+  }
+}
+
 // one element per thread, one CLEAN_ROW-element compaction chunk per workgroup iteration: everything a row needs
 // is in flight at once (the element count is device-resident, hence the grid-stride over rows)
 __global__ void __launch_bounds__(BLK) k_clean_flags(const CleanArgs A, SurfelSoA map, const unsigned* __restrict__ count_dev,
@@ -992,10 +1128,14 @@ void fuse(const Cam& cam, const float* pose_f16_dev, int time, const uint8_t* rg
 
 void clean(const Cam& cam, const float* T_cw16_dev, int time, IndexMaps im, float confThreshold, int timeDelta, SurfelSoA map,
            const unsigned* count_dev, Candidates cand, uint32_t* winner, SurfelSoA out, unsigned* count_out_dev, uint32_t capacity,
-           const CompactScratch& cs, int* overflow_flag, hipStream_t s) {
+           const CompactScratch& cs, int* overflow_flag, hipStream_t s, const Deformation* deform) {
   CleanArgs A{cam, T_cw16_dev, time, im, confThreshold, timeDelta};
   hipLaunchKernelGGL(k_clean_flags, dim3(CLEAN_GRID), dim3(BLK), 0, s, A, map, count_dev, cand, winner, cs.flags,
                      cs.chunk_count);
+  if (deform && deform->nodes > 0) {
+    const DeformArgs D{deform->graph_dev, deform->nodes, deform->depth_dev, deform->is_fern, deform->max_depth};
+    hipLaunchKernelGGL(k_clean_deform, dim3(CLEAN_GRID), dim3(BLK), 0, s, A, D, map, count_dev, cand, (const uint8_t*)cs.flags);
+  }
   hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, (const uint32_t*)cs.chunk_count, (const unsigned*)count_dev, (unsigned)cand.n,
                      cs.chunk_offset, cs.totals, count_out_dev, capacity, overflow_flag, (unsigned)CLEAN_ROW);
   hipLaunchKernelGGL(k_clean_scatter, dim3(CLEAN_GRID), dim3(BLK), 0, s, map, count_dev, cand, (const uint8_t*)cs.flags,

@@ -172,6 +172,7 @@ void init_rgb_sobel(const Pyramid& p, hipStream_t s);
 void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
 // getIncrementalTransformation, RGBDOdometry.cpp:259-571, entirely enqueued
 void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe = nullptr);
+void track_swap(Pyramid& p, const TrackParams& tp);   // the pointer swap track() ends with (for hipGraph replay)
 // tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +
 // velocity weighting (ElasticFusion.cpp:369-383) + the float matrices of the map passes
 // traj / slot: device trajectory log (16 doubles per frame; t_T_wc of ElasticFusion.cpp:588) or null

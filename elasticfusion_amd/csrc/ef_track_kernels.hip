@@ -9,6 +9,7 @@
 #include "ef_device.hpp"
 #include "ef_linalg_dev.hpp"
 #include "ef_solve_dev.hpp"
+#include <stddef.h>
 #include "ef_track.hpp"
 
 using namespace ef;
@@ -672,37 +673,52 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_residual(const ResidualPac
                                                                 const float* __restrict__ ktp, int* sums,
                                                                 const int* __restrict__ skip_flag) {
   __shared__ int lds[2 * REDUCE_BLOCK / 64];
-  if (*skip_flag) return;
+  const int N = V.cols * V.rows, cols = V.cols, rows = V.rows;
+  const int base = blockIdx.x * REDUCE_BLOCK * PPT + threadIdx.x;
+  // stage 1: everything addressed by the pixel itself, branch-free (an out-of-range lane reads pixel N-1 and is masked
+  // out), issued together with the flag and the warp matrix so that one memory round trip covers all of it
+  const int skip = *skip_flag;
+  uint8_t m[PPT], ni[PPT];
+  float d1s[PPT];
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int k = base + j * REDUCE_BLOCK, q = k < N ? k : N - 1;
+    m[j] = V.mask[q];
+    d1s[j] = V.lastDepth[q];  // mask guarantees !isnan(d1)
+    ni[j] = V.nextImage[q];
+    if (k >= N) m[j] = 0;
+  }
   const m33 K = m33_load(krkinv);
   const f3 kt{ktp[0], ktp[1], ktp[2]};
-  const int N = V.cols * V.rows, cols = V.cols, rows = V.rows;
+  if (skip) return;
+  // stage 2: the warped pixel's gathers of all PPT pixels in flight together
   int cnt = 0, sq = 0;
-  const int base = blockIdx.x * REDUCE_BLOCK * PPT + threadIdx.x;
-  uint8_t m[PPT];
+  int gi[PPT], u0s[PPT], v0s[PPT];
+  float td1[PPT], d0s[PPT];
+  int lis[PPT];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     const int k = base + j * REDUCE_BLOCK;
-    m[j] = k < N ? V.mask[k] : (uint8_t)0;
+    const int y = k / cols, x = k - y * cols;
+    const float d1 = d1s[j];
+    td1[j] = (float)(d1 * (K.r[2].x * x + K.r[2].y * y + K.r[2].z) + kt.z);
+    u0s[j] = f2i_rn((d1 * (K.r[0].x * x + K.r[0].y * y + K.r[0].z) + kt.x) / td1[j]);
+    v0s[j] = f2i_rn((d1 * (K.r[1].x * x + K.r[1].y * y + K.r[1].z) + kt.y) / td1[j]);
+    gi[j] = (m[j] && u0s[j] >= 0 && v0s[j] >= 0 && u0s[j] < cols && v0s[j] < rows) ? v0s[j] * cols + u0s[j] : -1;
+    d0s[j] = 0.f;
+    lis[j] = 0;
+    if (gi[j] >= 0) { d0s[j] = V.lastDepth[gi[j]]; lis[j] = V.lastImage[gi[j]]; }
   }
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
     if (!m[j]) continue;
     const int k = base + j * REDUCE_BLOCK;
-    const int y = k / cols, x = k - y * cols;
     uint32_t packed = 0u;
-    const float d1 = V.lastDepth[k];  // mask guarantees !isnan(d1)
-    const float transformed_d1 = (float)(d1 * (K.r[2].x * x + K.r[2].y * y + K.r[2].z) + kt.z);
-    const int u0 = f2i_rn((d1 * (K.r[0].x * x + K.r[0].y * y + K.r[0].z) + kt.x) / transformed_d1);
-    const int v0 = f2i_rn((d1 * (K.r[1].x * x + K.r[1].y * y + K.r[1].z) + kt.y) / transformed_d1);
-    if (u0 >= 0 && v0 >= 0 && u0 < cols && v0 < rows) {
-      const float d0 = V.lastDepth[v0 * cols + u0];
-      const int li = V.lastImage[v0 * cols + u0];
-      if (d0 > 0 && fabsf(transformed_d1 - d0) <= V.maxDepthDelta && li != 0) {
-        const int idiff = (int)V.nextImage[k] - li;   // exact: float(next) - float(last) of two u8
-        packed = pack_corres(u0, v0, idiff);
-        cnt += 1;
-        sq += idiff * idiff;                          // (int)(diff*diff), exact for |diff| <= 255
-      }
+    if (gi[j] >= 0 && d0s[j] > 0 && fabsf(td1[j] - d0s[j]) <= V.maxDepthDelta && lis[j] != 0) {
+      const int idiff = (int)ni[j] - lis[j];   // exact: float(next) - float(last) of two u8
+      packed = pack_corres(u0s[j], v0s[j], idiff);
+      cnt += 1;
+      sq += idiff * idiff;                      // (int)(diff*diff), exact for |diff| <= 255
     }
     V.corres[k] = packed;
   }
@@ -823,16 +839,141 @@ __device__ __forceinline__ void coherent_store(float* p, float v) { __hip_atomic
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned take_ticket(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Phase A of one pixel-visit, split by data dependence so that a thread has TWO memory round trips in flight at most
+// instead of six: stage 1 = everything addressed by the pixel itself (current vertex + normal, packed correspondence,
+// image gradients), issued before the pose / sigma are even known; stage 2 = the gathers addressed through the
+// projective association (model vertex + normal) and through the photometric correspondence (model depth).  The
+// arithmetic is icp_row / rgb_row operation for operation.
+struct VisitLoads {
+  f3 vcurr, ncurr;
+  uint32_t corr;
+  int gx, gy;
+  bool inb;
+};
+template <bool HAS_ICP, bool HAS_RGB>
+__device__ __forceinline__ VisitLoads visit_stage1(const IcpView& IV, const RgbView& RV, int p, int N) {
+  VisitLoads L;
+  L.inb = p < N;
+  // branch-free: an out-of-range visit (tail of the last pass) reads pixel N-1 and is discarded through `inb`, so the
+  // compiler has no control-flow join at which it would have to wait for the loads
+  const int q = L.inb ? p : N - 1;
+  L.vcurr = L.ncurr = f3{0.f, 0.f, 0.f};
+  L.corr = 0u;
+  L.gx = L.gy = 0;
+  if (HAS_ICP) {
+    const int plane = IV.cols * IV.rows;
+    L.vcurr = f3{IV.vmap_curr[q], IV.vmap_curr[q + plane], IV.vmap_curr[q + 2 * plane]};
+    L.ncurr = f3{IV.nmap_curr[q], IV.nmap_curr[q + plane], IV.nmap_curr[q + 2 * plane]};
+  }
+  if (HAS_RGB) {
+    L.corr = ((const uint32_t*)RV.corres)[q];
+    L.gx = RV.dIdx[q];
+    L.gy = RV.dIdy[q];
+  }
+  return L;
+}
+// stage 2a: addresses of the dependent gathers + the gathers themselves (issued, not waited for)
+struct VisitGathers {
+  f3 vcurr_g, vprev_g, nprev_g;
+  float d0;
+  int pidx, zi, zx, zy;
+};
+template <bool HAS_ICP, bool HAS_RGB>
+__device__ __forceinline__ VisitGathers visit_stage2a(const IcpView& IV, const RgbView& RV, const IcpPose& P, const VisitLoads& L) {
+  VisitGathers G;
+  G.vcurr_g = G.vprev_g = G.nprev_g = f3{0.f, 0.f, 0.f};
+  G.d0 = 0.f;
+  G.pidx = G.zi = -1;
+  G.zx = G.zy = 0;
+  if (HAS_ICP && L.inb) {
+    G.vcurr_g = mul(P.Rcurr, L.vcurr) + P.tcurr;
+    const f3 vcurr_cp = mul(P.Rprev_inv, G.vcurr_g - P.tprev);
+    const int ux = f2i_rn(vcurr_cp.x * IV.k.fx / vcurr_cp.z + IV.k.cx);
+    const int uy = f2i_rn(vcurr_cp.y * IV.k.fy / vcurr_cp.z + IV.k.cy);
+    if (!(ux < 0 || uy < 0 || ux >= IV.cols || uy >= IV.rows || vcurr_cp.z < 0)) G.pidx = uy * IV.cols + ux;
+  }
+  if (HAS_RGB && L.inb && (L.corr & 0x80000000u)) {
+    G.zx = (int)(L.corr & 0x7FFu); G.zy = (int)((L.corr >> 11) & 0x7FFu);
+    G.zi = G.zy * RV.cols + G.zx;
+  }
+  if (G.pidx >= 0) {
+    const int plane = IV.cols * IV.rows;
+    G.vprev_g = f3{IV.vmap_g_prev[G.pidx], IV.vmap_g_prev[G.pidx + plane], IV.vmap_g_prev[G.pidx + 2 * plane]};
+    G.nprev_g = f3{IV.nmap_g_prev[G.pidx], IV.nmap_g_prev[G.pidx + plane], IV.nmap_g_prev[G.pidx + 2 * plane]};
+  }
+  if (G.zi >= 0) G.d0 = RV.lastDepth[G.zi];
+  return G;
+}
+// stage 2b: the arithmetic of icp_row (reduce.cu:241-309) and rgb_row<PACKED> (reduce.cu:420-476) on the gathered values
+template <bool HAS_ICP, bool HAS_RGB>
+__device__ __forceinline__ void visit_stage2b(const IcpView& IV, const RgbView& RV, const IcpPose& P, float sigma, const VisitLoads& L,
+                                              const VisitGathers& G, float (&irow)[7], float& ifound, float (&grow)[7], float& gfound) {
+  ifound = gfound = 0.f;
+  if (G.pidx >= 0) {
+    const f3 ncurr_g = mul(P.Rcurr, L.ncurr);
+    const float dist = norm(G.vprev_g - G.vcurr_g);
+    const float sine = norm(cross(ncurr_g, G.nprev_g));
+    if (sine < IV.angleThres && dist <= IV.distThres && !isnan(L.ncurr.x) && !isnan(G.nprev_g.x)) {
+      const f3 s_cp = mul(P.Rprev_inv, G.vcurr_g - P.tprev);
+      const f3 d_cp = mul(P.Rprev_inv, G.vprev_g - P.tprev);
+      const f3 n_cp = mul(P.Rprev_inv, G.nprev_g);
+      const f3 c = cross(s_cp, n_cp);
+      irow[0] = n_cp.x; irow[1] = n_cp.y; irow[2] = n_cp.z;
+      irow[3] = c.x; irow[4] = c.y; irow[5] = c.z;
+      irow[6] = dot(n_cp, s_cp - d_cp);
+      ifound = 1.f;
+    }
+  }
+  if (G.zi >= 0) {
+    const float diff = (float)((int)((L.corr >> 22) & 0x1FFu) - 255);
+    float w = sigma + fabsf(diff);
+    w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
+    if (sigma == -1) w = 1;
+    grow[6] = -w * diff;
+    const f3 p = project_point(G.zx, G.zy, G.d0, 1.0f / RV.k.fx, 1.0f / RV.k.fy, RV.k.cx, RV.k.cy);
+    const float invz = (float)(1.0 / (double)p.z);
+    const float dI_dx_val = w * RV.sobelScale * L.gx;
+    const float dI_dy_val = w * RV.sobelScale * L.gy;
+    const float v0 = dI_dx_val * RV.k.fx * invz;
+    const float v1 = dI_dy_val * RV.k.fy * invz;
+    const float v2 = -(v0 * p.x + v1 * p.y) * invz;
+    grow[0] = v0; grow[1] = v1; grow[2] = v2;
+    grow[3] = -p.z * v1 + p.y * v2;
+    grow[4] = p.z * v0 - p.x * v2;
+    grow[5] = -p.y * v0 + p.x * v1;
+    gfound = 1.f;
+  }
+}
+
+// developer instrumentation (-DEF_ACCUM_CLOCKS): wall_clock64() stamps of the first and the last workgroup of the level-0
+// launch into TrackState::dbg_clock (the state block is found from the Rcurr pointer the kernel gets)
+#ifdef EF_ACCUM_CLOCKS
+#define EF_ASTAMP(i)                                                                                              \
+  do {                                                                                                            \
+    if (N > 8 * VTHREADS && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == VWARPS - 1)) {                      \
+      TrackState* st_ = (TrackState*)((char*)in.Rcurr - offsetof(TrackState, Rcurr));                             \
+      st_->dbg_clock[(blockIdx.x ? 8 : 0) + (i)] = wall_clock64();                                                \
+    }                                                                                                             \
+  } while (0)
+#else
+#define EF_ASTAMP(i) do { } while (0)
+#endif
 template <int BLOCK, int KC, bool HAS_ICP, bool HAS_RGB, bool PACKED>
 __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, float* __restrict__ partials_icp,
                                                      float* __restrict__ partials_rgb) {
   static_assert(BLOCK >= 256 && BLOCK % 64 == 0, "phase B needs 256 threads");
   __shared__ float rows[2][KC * ROW_STRIDE];
   const int t = threadIdx.x, W = blockIdx.x;
-  if (in.broken && *in.broken) return;  // rgbOnly "break": the level is over (k_se3_finish does the bookkeeping)
   const int cols = HAS_ICP ? IV.cols : RV.cols, nrows = HAS_ICP ? IV.rows : RV.rows;
   const int N = cols * nrows;
   const int K = (N + VTHREADS - 1) / VTHREADS;
+  EF_ASTAMP(0);
+  const int broken = in.broken ? *in.broken : 0;   // consumed below, after the loads are in flight
+  // Issue order = everything that needs no other load first: the residual-pass sums (sigma), the pose (scalar loads),
+  // then the first task's pixel-addressed loads (frame tier); only then is anything waited for.
+  int slot_a = 0, slot_b = 0;
+  const bool with_slots = HAS_RGB && in.rgb_slots;
+  if (with_slots && t < 64) { slot_a = in.rgb_slots[t * 16]; slot_b = in.rgb_slots[t * 16 + 1]; }
   IcpPose P;
   if (HAS_ICP) {
     P.Rcurr = m33_load(in.Rcurr);
@@ -840,17 +981,33 @@ __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const Rgb
     P.Rprev_inv = m33_load(in.Rprev_inv);
     P.tprev = {in.tprev[0], in.tprev[1], in.tprev[2]};
   }
+  __builtin_amdgcn_sched_barrier(0);   // keep the (scalar) pose loads ahead of the vector loads below: they overlap
+  // every thread owns up to MAXT pixel-visits of a chunk (task s = t + j * BLOCK); their stage-1 loads all go out together
+  constexpr int MAXT = (KC * 32 + BLOCK - 1) / BLOCK;
+  VisitLoads L0[MAXT];
+  if (PACKED) {
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int s0 = t + j * BLOCK;
+      L0[j] = visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, s0 < min(KC, K) * 32 ? (s0 >> 5) * VTHREADS + W * 32 + (s0 & 31) : N, N);
+    }
+  }
+  if (broken) return;  // rgbOnly "break": the level is over (k_se3_finish does the bookkeeping)
   float sigma = in.sigma_fixed;
-  if (HAS_RGB && in.rgb_slots) {
+  if (with_slots) {
     __shared__ float sigma_s;
     if (t < 64) {
-      int cnt, sq;
-      sum_rgb_slots(in.rgb_slots, cnt, sq);
-      if (t == 0) sigma_s = sigma_from_sums(sq, cnt, in.rgbOnly);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        slot_a += __shfl_down(slot_a, off, 64);
+        slot_b += __shfl_down(slot_b, off, 64);
+      }
+      if (t == 0) sigma_s = sigma_from_sums(slot_b, slot_a, in.rgbOnly);
     }
     __syncthreads();
     sigma = sigma_s;
   }
+  EF_ASTAMP(1);
   // phase-B identity of this thread
   const int l = t & 31, term = (t >> 5) & 1, part = t >> 6;
   const bool chain_thread = t < 256 && (term == 0 ? HAS_ICP : HAS_RGB);
@@ -862,28 +1019,53 @@ __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const Rgb
 
   for (int k0 = 0; k0 < K; k0 += KC) {
     const int kc = min(KC, K - k0);
-    for (int s = t; s < kc * 32; s += BLOCK) {
-      const int k = s >> 5, sl = s & 31;
-      const int p = (k0 + k) * VTHREADS + W * 32 + sl;
-      if (HAS_ICP) {
-        float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float found = 0.f;
-        if (p < N) {
-          const int y = p / cols, x = p - y * cols;
-          if (icp_row(IV, P, x, y, row)) found = 1.f;
-        }
-        store_row(rows[0], k, sl, row, found);
+    if (PACKED) {
+      VisitLoads L[MAXT];
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        const int s1 = t + j * BLOCK;
+        L[j] = k0 == 0 ? L0[j] : visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, s1 < kc * 32 ? (k0 + (s1 >> 5)) * VTHREADS + W * 32 + (s1 & 31) : N, N);
       }
-      if (HAS_RGB) {
-        float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float found = 0.f;
-        if (p < N && rgb_row<PACKED>(RV, sigma, p, row)) found = 1.f;
-        store_row(rows[1], k, sl, row, found);
+      VisitGathers G[MAXT];
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) G[j] = visit_stage2a<HAS_ICP, HAS_RGB>(IV, RV, P, L[j]);
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) {
+        const int s1 = t + j * BLOCK;
+        if (s1 < kc * 32) {
+          float irow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, grow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          float ifound, gfound;
+          visit_stage2b<HAS_ICP, HAS_RGB>(IV, RV, P, sigma, L[j], G[j], irow, ifound, grow, gfound);
+          if (HAS_ICP) store_row(rows[0], s1 >> 5, s1 & 31, irow, ifound);
+          if (HAS_RGB) store_row(rows[1], s1 >> 5, s1 & 31, grow, gfound);
+        }
+      }
+    } else {
+      for (int s = t; s < kc * 32; s += BLOCK) {
+        const int k = s >> 5, sl = s & 31;
+        const int p = (k0 + k) * VTHREADS + W * 32 + sl;
+        if (HAS_ICP) {
+          float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          float found = 0.f;
+          if (p < N) {
+            const int y = p / cols, x = p - y * cols;
+            if (icp_row(IV, P, x, y, row)) found = 1.f;
+          }
+          store_row(rows[0], k, sl, row, found);
+        }
+        if (HAS_RGB) {
+          float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          float found = 0.f;
+          if (p < N && rgb_row<PACKED>(RV, sigma, p, row)) found = 1.f;
+          store_row(rows[1], k, sl, row, found);
+        }
       }
     }
     __syncthreads();
+    EF_ASTAMP(2);
     if (chain_thread) se3_chains(rows[term], l, part, min(kc, nk - k0), acc);
     __syncthreads();
+    EF_ASTAMP(3);
   }
   if (chain_thread) {
     // warpReduceSum, reduce.cu:57-95: val += shfl_down(val, offset) for offset = 16..1 (lane 0 of each virtual warp)
@@ -900,6 +1082,7 @@ __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const Rgb
       }
     }
   }
+  EF_ASTAMP(4);
 }
 
 // The rest of the reference tree over the 512 virtual-warp partials of `na` accumulators (acc-major):
@@ -1380,7 +1563,14 @@ constexpr int ACC_BLOCK_BIG = 640, ACC_BLOCK_SMALL = 256, ACC_KC = 19;
 // one normal-equation accumulation launch (either tier)
 template <bool HAS_ICP, bool HAS_RGB, bool PACKED>
 void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int N, float* partials_icp, float* partials_rgb, hipStream_t s) {
-  if (N > 8 * VTHREADS)
+  static const int big = getenv("EF_ACCUM_BLOCK") ? atoi(getenv("EF_ACCUM_BLOCK")) : ACC_BLOCK_BIG;   // developer knob
+  if (N > 8 * VTHREADS && big == 320)
+    hipLaunchKernelGGL((k_se3_accum<320, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(320), 0, s, IV, RV, in, partials_icp, partials_rgb);
+  else if (N > 8 * VTHREADS && big == 384)
+    hipLaunchKernelGGL((k_se3_accum<384, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(384), 0, s, IV, RV, in, partials_icp, partials_rgb);
+  else if (N > 8 * VTHREADS && big == 512)
+    hipLaunchKernelGGL((k_se3_accum<512, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(512), 0, s, IV, RV, in, partials_icp, partials_rgb);
+  else if (N > 8 * VTHREADS && big != 256)
     hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_BIG, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(ACC_BLOCK_BIG), 0, s, IV, RV, in,
                        partials_icp, partials_rgb);
   else
@@ -1575,6 +1765,11 @@ void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_
       launch_iteration(p, st, i, kl, tp, icp, rgb, intr_level(k, next_level), last_of_level, s, probe);
     }
   }
+  track_swap(p, tp);
+}
+// host-side tail of getIncrementalTransformation: the frame's intensity pyramid becomes the SO(3) reference of the next
+// (RGBDOdometry.cpp:284-288 swaps lastNextImage / nextImage); separate so that a replayed hipGraph can do it without launching
+void track_swap(Pyramid& p, const TrackParams& tp) {
   if (tp.so3)
     for (int i = 0; i < NUM_PYRS; ++i) { uint8_t* tmp = p.lastNextImage[i]; p.lastNextImage[i] = p.nextImage[i]; p.nextImage[i] = tmp; }
 }

@@ -77,6 +77,15 @@ int ef_process_frame_dev(ef_ctx* ctx, const uint8_t* rgb_dev, const uint16_t* de
  * needs only the new images (copy-in, bilateral filter + metric depth, frame-side pyramids) is enqueued on a second
  * internal stream and runs while the previous frame is still being fused.  Results are identical either way. */
 int ef_set_input_overlap(ef_ctx* ctx, int on);
+/* hipGraph replay of the tracker (default off; EF_GRAPH=1): the ~70 kernel launches of one getIncrementalTransformation
+ * (RGBDOdometry.cpp:259-571) are captured once per pyramid parity and replayed with one hipGraphLaunch per frame.
+ * Identical results; it only trims host-side launch work (BASELINE.json configs[4]). */
+int ef_set_graph_replay(ef_ctx* ctx, int on);
+/* Device half of a loop closure: hands a deformation graph (HOST pointer, nodes x 16 floats sorted by time, layout of
+ * GlobalModel::clean's rawGraph, GlobalModel.cpp:536-546) to the NEXT ef_process_frame, whose clean pass applies it to the
+ * whole map exactly as ElasticFusion.cpp:558-585 does (synthesizeDepth first unless is_fern).  Finding the loop closure and
+ * optimising the graph stay with the caller (Ferns / Deformation are out of scope). */
+int ef_set_deformation(ef_ctx* ctx, const float* graph_host, int nodes, int is_fern);
 int ef_predict(ef_ctx* ctx);                                  /* ElasticFusion::predict() */
 int ef_get_pose(ef_ctx* ctx, double* T_wc16);                 /* get_T_wc(); synchronises */
 int ef_get_tick(ef_ctx* ctx, int* tick);                      /* getTick() */
@@ -246,6 +255,15 @@ int ef_op_clean(const ef_cam* cam, const double* T_wc16, int time, const uint32_
                 const float* color_time, const float* norm_rad, float conf_threshold, int time_delta, float max_depth,
                 const float* surfels_aos, uint32_t count, const float* new_unstable_aos, uint32_t new_count,
                 float* surfels_out_aos, uint32_t* out_count_host, void* stream);
+/* GlobalModel::clean with the deformation graph applied to every kept surfel (copy_unstable.vert:128-322):
+ * graph = nodes x 16 floats sorted by time {position 3, rotation 9 column-major, translation 3, time} (device pointer), the
+ * content of the reference's node texture (GlobalModel.cpp:540-546); depth = ef_op_synthesize_depth image (device, read
+ * unless is_fern).  nodes == 0 is ef_op_clean. */
+int ef_op_clean_deform(const ef_cam* cam, const double* T_wc16, int time, const uint32_t* index_map, const float* vert_conf,
+                       const float* color_time, const float* norm_rad, float conf_threshold, int time_delta, float max_depth,
+                       const float* surfels_aos, uint32_t count, const float* new_unstable_aos, uint32_t new_count,
+                       const float* graph, int nodes, const float* depth, int is_fern, float* surfels_out_aos,
+                       uint32_t* out_count_host, void* stream);
 
 #ifdef __cplusplus
 }

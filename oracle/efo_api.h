@@ -89,6 +89,13 @@ int efo_clean(const efo_cam* cam, const double* T_wc16, int time, const uint32_t
               const float* colorTime, const float* normRad, float confThreshold, int timeDelta, float maxDepth,
               const float* surfels, int count, const float* newUnstable, int newCount, float* surfels_out);
 
+/* clean with the deformation graph applied (copy_unstable.vert:128-322): graph = nodes x 16 floats sorted by time
+ * {position 3, rotation 9 column-major, translation 3, time}; depth = synthesizeDepth image; nodes == 0 => efo_clean */
+int efo_clean_deform(const efo_cam* cam, const double* T_wc16, int time, const uint32_t* indexMap, const float* vertConf,
+                     const float* colorTime, const float* normRad, float confThreshold, int timeDelta, float maxDepth,
+                     const float* surfels, int count, const float* newUnstable, int newCount, const float* graph, int nodes,
+                     const float* depth, int isFern, float* surfels_out);
+
 /* ---- whole-frame orchestration (Core/ElasticFusion.cpp:270-653, open loop) ---- */
 typedef struct efo_fusion efo_fusion;
 typedef struct efo_fusion_params {
@@ -108,6 +115,8 @@ void efo_fusion_get_pose(const efo_fusion*, double* T_wc16);
 int efo_fusion_map_count(const efo_fusion*);
 void efo_fusion_map_download(const efo_fusion*, float* surfels /* count*12 */);
 int efo_fusion_tick(const efo_fusion*);
+/* deformation graph (nodes x 16, sorted by time) applied by the next frame's clean, as after a loop closure */
+void efo_fusion_set_deformation(efo_fusion*, const float* graph, int nodes, int isFern);
 void efo_fusion_stats(const efo_fusion*, float* out6);
 /* which: 0 image_rgba(u8x4) 1 vertex(f4) 2 normal(f4) 3 time(u16) 4 fill_image 5 fill_vertex 6 fill_normal
  * 7 indexMap(u32) 8 vertConf 9 colorTime 10 normRad 11 depthFiltered(u16) 12 depthMetric 13 depthMetricFiltered */

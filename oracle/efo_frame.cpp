@@ -16,6 +16,8 @@ struct efo_fusion {
   efo_cam cam;
   efo_odometry* frameToModel;
   int tick = 1;
+  std::vector<float> pendingGraph;   // nodes x 16, applied by the next frame's clean (efo_fusion_set_deformation)
+  int pendingFern = 0;
   SE3 T_wc = se3_identity();
   const float maxDepthProcessed = 20.0f;  // ElasticFusion.cpp:83
   // "textures"
@@ -116,9 +118,19 @@ struct efo_fusion {
                             vertConf.data(), colorTime.data(), normRad.data());
         int room = p.maxSurfels;
         (void)room;
-        count = efo_clean(&cam, M, tick, indexMap.data(), vertConf.data(), colorTime.data(), normRad.data(),
-                          p.confidence, p.timeDelta, maxDepthProcessed, surfels.data(), count, newUnstable.data(), nNew,
-                          surfelsTmp.data());
+        // a deformation handed over for this frame (rawGraph of ElasticFusion.cpp:558-585; loop-closure detection itself is
+        // out of scope): synthesizeDepth of the surfels outside the time window unless a fern was accepted, then clean with the graph
+        std::vector<float> synth;
+        const int nodes = (int)(pendingGraph.size() / 16);
+        if (nodes > 0 && !pendingFern) {
+          synth.resize((size_t)cam.cols * cam.rows);
+          efo_synthesize_depth(&cam, M, surfels.data(), count, maxDepthProcessed, p.confidence, tick, tick - p.timeDelta, 65535, synth.data());
+        }
+        count = efo_clean_deform(&cam, M, tick, indexMap.data(), vertConf.data(), colorTime.data(), normRad.data(),
+                                 p.confidence, p.timeDelta, maxDepthProcessed, surfels.data(), count, newUnstable.data(), nNew,
+                                 nodes > 0 ? pendingGraph.data() : nullptr, nodes, synth.empty() ? nullptr : synth.data(), pendingFern,
+                                 surfelsTmp.data());
+        pendingGraph.clear();
         surfels.swap(surfelsTmp);
       }
     }
@@ -147,6 +159,10 @@ void efo_fusion_get_pose(const efo_fusion* f, double* T) { f->pose16(T); }
 int efo_fusion_map_count(const efo_fusion* f) { return f->count; }
 void efo_fusion_map_download(const efo_fusion* f, float* s) { std::memcpy(s, f->surfels.data(), (size_t)f->count * 48); }
 int efo_fusion_tick(const efo_fusion* f) { return f->tick; }
+void efo_fusion_set_deformation(efo_fusion* f, const float* graph, int nodes, int isFern) {
+  f->pendingGraph.assign(graph, graph + (size_t)nodes * 16);
+  f->pendingFern = isFern;
+}
 void efo_fusion_stats(const efo_fusion* f, float* out6) {
   efo_odom_stats(f->frameToModel, out6, nullptr, nullptr);
 }

@@ -433,11 +433,122 @@ int efo_fuse(const efo_cam* cam, const double* T_wc16, int time, const uint8_t* 
   return nNew;
 }
 
-// GlobalModel::clean + copy_unstable.{vert,geom}, nodes == 0 (G11)
-int efo_clean(const efo_cam* cam, const double* T_wc16, int time, const uint32_t* indexMap, const float* vertConf,
-              const float* colorTime, const float* normRad, float confThreshold, int timeDelta, float maxDepth,
-              const float* surfels, int count, const float* newUnstable, int newCount, float* out) {
-  (void)normRad; (void)maxDepth;
+// GlobalModel::clean + copy_unstable.{vert,geom} (G11), with the deformation-graph application of
+// copy_unstable.vert:128-322 when nodes > 0: graph = nodes x 16 floats as GlobalModel.cpp:540-546
+// uploads them into the 1-row node texture {position 3, rotation 9 (column major), translation 3, time 1}, sorted by time.
+// depth = IndexMap::synthesizeDepth's image (G6) for the "seen again" test, may be null when nodes == 0.
+}  // extern "C"
+namespace {
+// 3x3 inverse as glsl_on_cpu specifies it: adjugate (cofactors from 2x2 products) times 1/det; m[col][row]
+struct M3c { float m[3][3]; };
+inline M3c inverse3(const M3c& a) {
+  const float (*m)[3] = a.m;
+  const float c00 = m[1][1] * m[2][2] - m[2][1] * m[1][2], c01 = m[2][1] * m[0][2] - m[0][1] * m[2][2], c02 = m[0][1] * m[1][2] - m[1][1] * m[0][2];
+  const float det = (m[0][0] * c00 + m[1][0] * c01) + m[2][0] * c02;
+  const float id = 1.0f / det;
+  M3c r;
+  r.m[0][0] = c00 * id; r.m[0][1] = c01 * id; r.m[0][2] = c02 * id;
+  r.m[1][0] = (m[2][0] * m[1][2] - m[1][0] * m[2][2]) * id; r.m[1][1] = (m[0][0] * m[2][2] - m[2][0] * m[0][2]) * id; r.m[1][2] = (m[1][0] * m[0][2] - m[0][0] * m[1][2]) * id;
+  r.m[2][0] = (m[1][0] * m[2][1] - m[2][0] * m[1][1]) * id; r.m[2][1] = (m[2][0] * m[0][1] - m[0][0] * m[2][1]) * id; r.m[2][2] = (m[0][0] * m[1][1] - m[1][0] * m[0][1]) * id;
+  return r;
+}
+// mat3 * vec3, column-major storage: row i = dot((m[0][i], m[1][i], m[2][i]), v), like every other mat * vec of this file
+inline f3 mulc(const M3c& a, f3 v) {
+  return {dot(f3{a.m[0][0], a.m[1][0], a.m[2][0]}, v), dot(f3{a.m[0][1], a.m[1][1], a.m[2][1]}, v), dot(f3{a.m[0][2], a.m[1][2], a.m[2][2]}, v)};
+}
+
+// copy_unstable.vert:128-322 for one kept vertex; v = {pos conf | colour 0 initTime lastTime | normal radius}
+void deform_vertex(float* v, const float* graph, int nodes, const Mat4f& T, const efo_cam* cam, const float* depth, float confThreshold,
+                   float maxDepth, float ftime, int isFern) {
+  const int k = 4, lookBack = 20;
+  auto node = [&](int idx) {   // 1-row node texture, NEAREST + CLAMP_TO_EDGE (texel = idx: the shader's coordinates are exact)
+    const int width = 16384;   // GlobalModel::NODE_TEXTURE_DIMENSION
+    idx = clampi(idx, 0, width - 1);
+    return idx < nodes * 16 ? graph[idx] : 0.0f;
+  };
+  int nearNodes[lookBack];
+  float nearDists[lookBack];
+  for (int i = 0; i < lookBack; ++i) { nearNodes[i] = -1; nearDists[i] = 16777216.0f; }
+  const int poseTime = (int)v[6];
+  int foundIndex = 0, imin = 0, imax = nodes - 1, imid = (imin + imax) / 2;
+  while (imax >= imin) {
+    imid = (imin + imax) / 2;
+    const int nodeTime = (int)node(imid * 16 + 15);
+    if (nodeTime < poseTime) imin = imid + 1;
+    else if (nodeTime > poseTime) imax = imid - 1;
+    else break;
+  }
+  imin = std::min(imin, nodes - 1);
+  const int nodeMin = (int)node(imin * 16 + 15), nodeMid = (int)node(imid * 16 + 15), nodeMax = (int)node(imax * 16 + 15);
+  if (std::abs(nodeMin - poseTime) <= std::abs(nodeMid - poseTime) && std::abs(nodeMin - poseTime) <= std::abs(nodeMax - poseTime)) foundIndex = imin;
+  else if (std::abs(nodeMid - poseTime) <= std::abs(nodeMin - poseTime) && std::abs(nodeMid - poseTime) <= std::abs(nodeMax - poseTime)) foundIndex = imid;
+  else foundIndex = imax;
+  if (foundIndex == nodes) foundIndex = nodes - 1;
+  const f3 pos{v[0], v[1], v[2]};
+  auto node_pos = [&](int j) { return f3{node(j * 16), node(j * 16 + 1), node(j * 16 + 2)}; };
+  auto dist_to = [&](int j) { const f3 d = pos - node_pos(j); return sqrtf(dot(d, d)); };
+  int nearNodeIndex = 0, distanceBack = 0;
+  for (int j = foundIndex; j >= 0; --j) {
+    nearNodes[nearNodeIndex] = j;
+    nearDists[nearNodeIndex] = dist_to(j);
+    nearNodeIndex++;
+    if (++distanceBack == lookBack / 2) break;
+  }
+  for (int j = foundIndex + 1; j < nodes; ++j) {
+    nearNodes[nearNodeIndex] = j;
+    nearDists[nearNodeIndex] = dist_to(j);
+    nearNodeIndex++;
+    if (++distanceBack == lookBack) break;
+  }
+  for (int i = 0; i < lookBack - 1; ++i)
+    for (int j = i + 1; j < lookBack; ++j)
+      if (nearDists[j] < nearDists[i]) { std::swap(nearDists[i], nearDists[j]); std::swap(nearNodes[i], nearNodes[j]); }
+  const float dMax = nearDists[k];
+  float nodeWeights[k];
+  float weightSum = 0;
+  for (int j = 0; j < k; ++j) {
+    const float q = 1.0f - (dist_to(nearNodes[j]) / dMax);
+    nodeWeights[j] = q * q;   // pow(x, 2)
+    weightSum += nodeWeights[j];
+  }
+  for (int j = 0; j < k; ++j) nodeWeights[j] /= weightSum;
+  f3 newPos{0, 0, 0}, newNorm{0, 0, 0};
+  const f3 nrm{v[8], v[9], v[10]};
+  for (int i = 0; i < k; ++i) {
+    const int n = nearNodes[i];
+    const f3 g = node_pos(n);
+    M3c R;
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) R.m[c][r] = node(n * 16 + 3 + c * 3 + r);
+    const f3 t{node(n * 16 + 12), node(n * 16 + 13), node(n * 16 + 14)};
+    const f3 moved = (mulc(R, pos - g) + g) + t;
+    newPos = newPos + f3{nodeWeights[i] * moved.x, nodeWeights[i] * moved.y, nodeWeights[i] * moved.z};
+    const M3c Ri = inverse3(R);
+    M3c Rit;   // transpose(inverse(rotation))
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) Rit.m[c][r] = Ri.m[r][c];
+    const f3 rn = mulc(Rit, nrm);
+    newNorm = newNorm + f3{nodeWeights[i] * rn.x, nodeWeights[i] * rn.y, nodeWeights[i] * rn.z};
+  }
+  v[0] = newPos.x; v[1] = newPos.y; v[2] = newPos.z;
+  const f3 nn = normalized(newNorm);
+  v[8] = nn.x; v[9] = nn.y; v[10] = nn.z;
+  if (v[3] > confThreshold && isFern == 0) {
+    const f3 lp = xform(T, f3{v[0], v[1], v[2]});
+    const float x = ((cam->fx * lp.x) / lp.z) + cam->cx, y = ((cam->fy * lp.y) / lp.z) + cam->cy;
+    if (lp.z > 0 && lp.z < maxDepth && x > 0 && y > 0 && x < (float)cam->cols && y < (float)cam->rows) {
+      // textureLod(depthSampler, vec2(x / cols, y / rows)): NEAREST -> texel floor(x), floor(y) (N4)
+      const float currentDepth = depth[clampi((int)floorf(y), 0, cam->rows - 1) * cam->cols + clampi((int)floorf(x), 0, cam->cols - 1)];
+      if (currentDepth > 0.0f && lp.z < currentDepth + 0.1f) v[7] = ftime;
+    }
+  }
+}
+}  // namespace
+extern "C" {
+
+int efo_clean_deform(const efo_cam* cam, const double* T_wc16, int time, const uint32_t* indexMap, const float* vertConf,
+                     const float* colorTime, const float* normRad, float confThreshold, int timeDelta, float maxDepth,
+                     const float* surfels, int count, const float* newUnstable, int newCount, const float* graph, int nodes,
+                     const float* depth, int isFern, float* out) {
+  (void)normRad;
   const int cols = cam->cols, rows = cam->rows;
   const float fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
   const Mat4f T = T_cw_float(T_wc16);
@@ -477,12 +588,21 @@ int efo_clean(const efo_cam* cam, const double* T_wc16, int time, const uint32_t
     if (v[7] == -2) v[7] = ftime;                                        // new unstable point
     if (v[7] == -1 || ((ftime - v[7]) > 20 && v[3] < confThreshold)) test = 0;
     if (v[7] > 0 && ftime - v[7] > ftd) test = 1;
+    // vColor.z != time: points initialised this frame were fused with the updated pose already (copy_unstable.vert:130-131)
+    if (test == 1 && nodes > 0 && v[6] != ftime) deform_vertex(v, graph, nodes, T, cam, depth, confThreshold, maxDepth, ftime, isFern);
     if (test) {
       std::memcpy(out + (size_t)outCount * 12, v, sizeof(v));
       ++outCount;
     }
   }
   return outCount;
+}
+
+int efo_clean(const efo_cam* cam, const double* T_wc16, int time, const uint32_t* indexMap, const float* vertConf,
+              const float* colorTime, const float* normRad, float confThreshold, int timeDelta, float maxDepth,
+              const float* surfels, int count, const float* newUnstable, int newCount, float* out) {
+  return efo_clean_deform(cam, T_wc16, time, indexMap, vertConf, colorTime, normRad, confThreshold, timeDelta, maxDepth, surfels, count,
+                          newUnstable, newCount, nullptr, 0, nullptr, 0, out);
 }
 
 }  // extern "C"

@@ -100,7 +100,8 @@ inline float inversesqrt(float a) { return 1.0f / sqrtf(a); }
 inline float floor(float a) { return floorf(a); }
 inline float round(float a) { return roundf(a); }
 inline float acos(float a) { return acosf(a); }
-template <class B, arith<B> = 0> inline float pow(float a, B b) { return powf(a, (float)b); }
+// pow(x, 2) is x * x (the exactly rounded square); anything else goes to libm
+template <class B, arith<B> = 0> inline float pow(float a, B b) { return (float)b == 2.0f ? a * a : powf(a, (float)b); }
 extern float (*exp_hook)(float);
 inline float exp(float a) { return exp_hook(a); }
 inline float min(float a, float b) { return b < a ? b : a; }   // GLSL: y < x ? y : x

@@ -345,19 +345,26 @@ int efg_fuse(const efo_cam* cam, const double* T_wc16, int time, const uint8_t* 
 }
 
 // GlobalModel::clean: copy_unstable.vert + copy_unstable.geom over the model then over the new-unstable stream,
-// transform feedback (GlobalModel.cpp:527-671); no deformation graph (nodes == 0)
-int efg_clean(const efo_cam* cam, const double* T_wc16, int time, const uint32_t* indexMap, const float* vertConf, const float* colorTime,
-              const float* normRad, float confThreshold, int timeDelta, float maxDepth, const float* surfels, int count,
-              const float* newUnstable, int newCount, float* out) {
+// transform feedback (GlobalModel.cpp:527-671).  graph / nodes: the deformation graph as GlobalModel.cpp:540-546 uploads it
+// into the 1 x 16384 LUMINANCE32F node texture (16 floats per node); depth: IndexMap::synthesizeDepth's image.
+int efg_clean_deform(const efo_cam* cam, const double* T_wc16, int time, const uint32_t* indexMap, const float* vertConf,
+                     const float* colorTime, const float* normRad, float confThreshold, int timeDelta, float maxDepth, const float* surfels,
+                     int count, const float* newUnstable, int newCount, const float* graph, int nodes, const float* depth, int isFern,
+                     float* out) {
   namespace V = glsl::sh_copy_unstable_vert;
   namespace G = glsl::sh_copy_unstable_geom;
   const int cols = cam->cols, rows = cam->rows;
+  const int kNodeDim = 16384;   // GlobalModel::NODE_TEXTURE_DIMENSION, GlobalModel.cpp:23
   const Texture tix = tex(indexMap, cols, rows, 1, Texture::U32), tvc = tex(vertConf, cols, rows, 4, Texture::F32);
   const Texture tct = tex(colorTime, cols, rows, 4, Texture::F32), tnr = tex(normRad, cols, rows, 4, Texture::F32);
+  std::vector<float> nodeRow(kNodeDim, 0.f);
+  if (nodes > 0) std::copy(graph, graph + (size_t)nodes * 16, nodeRow.begin());
+  const Texture tnode = tex(nodeRow.data(), kNodeDim, 1, 1, Texture::F32);
+  const Texture tdepth = tex(depth, cols, rows, 1, Texture::F32);
   V::indexSampler.t = &tix; V::vertConfSampler.t = &tvc; V::colorTimeSampler.t = &tct; V::normRadSampler.t = &tnr;
-  V::nodeSampler.t = nullptr; V::depthSampler.t = nullptr;
-  V::time = time; V::confThreshold = confThreshold; V::scale = 1.0f; V::nodes = 0.0f; V::nodeCols = 16384.0f; V::timeDelta = timeDelta;
-  V::maxDepth = maxDepth; V::isFern = 0;
+  V::nodeSampler.t = &tnode; V::depthSampler.t = depth ? &tdepth : nullptr;
+  V::time = time; V::confThreshold = confThreshold; V::scale = 1.0f; V::nodes = (float)nodes; V::nodeCols = (float)kNodeDim;
+  V::timeDelta = timeDelta; V::maxDepth = maxDepth; V::isFern = isFern;
   V::t_inv = to_mat4(efo::T_cw_float(T_wc16));
   V::cam = vec4(cam->cx, cam->cy, cam->fx, cam->fy);   // GlobalModel.cpp:570-575
   V::cols = (float)cols; V::rows = (float)rows;
@@ -376,6 +383,12 @@ int efg_clean(const efo_cam* cam, const double* T_wc16, int time, const uint32_t
   }
   glsl::emit_hook = nullptr;
   return outCount;
+}
+int efg_clean(const efo_cam* cam, const double* T_wc16, int time, const uint32_t* indexMap, const float* vertConf, const float* colorTime,
+              const float* normRad, float confThreshold, int timeDelta, float maxDepth, const float* surfels, int count,
+              const float* newUnstable, int newCount, float* out) {
+  return efg_clean_deform(cam, T_wc16, time, indexMap, vertConf, colorTime, normRad, confThreshold, timeDelta, maxDepth, surfels, count,
+                          newUnstable, newCount, nullptr, 0, nullptr, 0, out);
 }
 
 const char* efg_about() {

@@ -37,7 +37,7 @@ class _Proxy:
                                 "pyr_down_gauss_f", "pyr_down_uchar_gauss", "vertices_to_depth", "bgr_to_intensity",
                                 "derivative_images", "project_to_point_cloud", "icp_step", "rgb_residual", "rgb_step", "so3_step")}
 
-    MAP_OPS = {"efo_" + n for n in ("filter_depth", "metricise_depth", "seed_map", "predict_indices", "combined_predict", "synthesize_depth", "fill_in", "fuse",
+    MAP_OPS = {"efo_" + n for n in ("filter_depth", "metricise_depth", "seed_map", "predict_indices", "combined_predict", "synthesize_depth", "fill_in", "fuse", "clean_deform",
                                     "clean")}
 
     def __init__(self, so, prefix, default, ops=None):
@@ -368,6 +368,19 @@ def clean(cam, T_wc, time, idx, vc, ct, nr, confThreshold, timeDelta, maxDepth, 
     return out[:n].copy()
 
 
+def clean_deform(cam, T_wc, time, idx, vc, ct, nr, confThreshold, timeDelta, maxDepth, surfels, newUnstable, graph, depth, isFern=0):
+    """clean with the deformation graph applied: graph = (nodes, 16) float32 sorted by time, depth = synthesizeDepth image"""
+    s = f32(surfels)
+    nu = f32(newUnstable).reshape(-1, 12)
+    g = f32(graph).reshape(-1, 16)
+    d = f32(depth)
+    out = np.zeros((len(s) + len(nu), 12), np.float32)
+    n = lib().efo_clean_deform(C.byref(cam), ptr(_T(T_wc)), c_i(time), ptr(idx), ptr(vc), ptr(ct), ptr(nr), c_f(confThreshold),
+                               c_i(timeDelta), c_f(maxDepth), ptr(s), c_i(len(s)), ptr(nu), c_i(len(nu)), ptr(g), c_i(len(g)), ptr(d),
+                               c_i(isFern), ptr(out))
+    return out[:n].copy()
+
+
 # ------------------------------------------------------------------------------------------------
 # tracking driver + whole-frame objects
 # ------------------------------------------------------------------------------------------------
@@ -440,6 +453,10 @@ class Fusion:
     def process_frame(self, rgb, depth, ts=0, weight=1.0, T_wc=None):
         lib().efo_fusion_process_frame(self.h_, ptr(rgb), ptr(depth), C.c_int64(ts), c_f(weight),
                                        ptr(_T(T_wc)) if T_wc is not None else None)
+
+    def set_deformation(self, graph, isFern=False):
+        g = f32(graph).reshape(-1, 16)
+        lib().efo_fusion_set_deformation(self.h_, ptr(g), c_i(len(g)), c_i(int(isFern)))
 
     def pose(self):
         T = np.zeros(16, np.float64)

@@ -43,11 +43,44 @@ def make_inputs(width=640, height=480, seed=0xEF0002, frames=6):
         img, vt, nm, tm = efo.combined_predict(cam, T, surf, MAXD, CONF, tick, tick, TD)
         s2, nu = efo.fuse(cam, T, tick, rgb, dm, dmf, idx, vc, ct, nr, MAXD, 0.8, surf)
         idx2, vc2, ct2, nr2 = efo.predict_indices(cam, T, tick, s2, MAXD, TD)
+        synth = efo.synthesize_depth(cam, T, surf, MAXD, CONF, tick, tick, TD)
     inp = dict(cam=np.array([width, height, seq.fx, seq.fy, seq.cx, seq.cy], np.float64), T=np.asarray(T, np.float64), tick=np.int32(tick),
                raw=fr[1][1], rgb0=fr[0][0], dm0=dm0, dmf0=dmf0, surf=surf, rgb=rgb, rgb_prev=fr[frames - 2][0], dm=dm, dmf=dmf,
                depth_filtered=f.buffer("depthFiltered"), idx=idx, vc=vc, ct=ct, nr=nr, img=img, vt=vt, nm=nm, s2=s2, nu=nu,
-               idx2=idx2, vc2=vc2, ct2=ct2, nr2=nr2)
+               idx2=idx2, vc2=vc2, ct2=ct2, nr2=nr2, synth=synth)
     return {k: np.ascontiguousarray(v) for k, v in inp.items()}
+
+
+def make_graph(inp, n_nodes=48, seed=7):
+    """A deformation graph in the reference's node-texture layout (GlobalModel.cpp:540-546): per node {position 3,
+    rotation 9 column-major, translation 3, time}, sorted by time.  Nodes sit on surfels of the map (as
+    Deformation::sampleGraphModel picks them), rotations a few degrees off identity, translations a few centimetres."""
+    rng = np.random.RandomState(seed)
+    surf = inp["surf"]
+    pick = np.sort(rng.choice(len(surf), n_nodes, replace=False))
+    g = np.zeros((n_nodes, 16), np.float32)
+    g[:, 0:3] = surf[pick, 0:3]
+    for i in range(n_nodes):
+        w = rng.uniform(-0.05, 0.05, 3)
+        th = np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
+        g[i, 3:12] = R.T.reshape(9)          # column-major
+        g[i, 12:15] = rng.uniform(-0.03, 0.03, 3)
+    tick = int(_scalar(inp["tick"]))
+    g[:, 15] = np.sort(rng.randint(0, max(tick, 2), n_nodes)).astype(np.float32)
+    return g
+
+
+def run_deform(be, inp, graph, cam=None, isFern=0):
+    """GlobalModel::clean with the deformation graph applied, as after a loop closure (ElasticFusion.cpp:561-585):
+    depth = synthesizeDepth of the surfels outside the time window."""
+    c = inp["cam"]
+    if cam is None:
+        cam = be.make_cam(int(c[0]), int(c[1]), float(c[2]), float(c[3]), float(c[4]), float(c[5]))
+    T, tick = inp["T"].reshape(4, 4), int(_scalar(inp["tick"]))
+    return be.clean_deform(cam, T, tick, inp["idx2"], inp["vc2"], inp["ct2"], inp["nr2"], CONF, TD, MAXD, inp["s2"], inp["nu"], graph,
+                           inp["synth"], isFern)
 
 
 def _scalar(x):

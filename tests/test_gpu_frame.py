@@ -112,6 +112,26 @@ def test_pipelined_frames_match_oracle(hip, seq):
         assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
 
 
+def test_graph_replayed_tracker_matches_oracle(hip, seq):
+    """BASELINE.json configs[4]: the tracker's ~70 launches captured into a hipGraph (one per pyramid parity) and replayed.
+    Trajectory, tracker statistics and map must be the oracle's bit for bit, as without the graph."""
+    n = 10
+    o = efo.Fusion()
+    ef = hip.ElasticFusion()
+    ef.setGraphReplay(True)
+    for k in range(n):
+        rgb, depth, _ = seq.frame(k)
+        o.process_frame(rgb, depth, k * 33333)
+        ef.processFrame(rgb, depth, k * 33333)
+        if k in (1, 2, 5, n - 1):   # capture frames (1, 2) and replays
+            st, _, _ = ef.trackingStats()
+            assert np.array_equal(np.asarray(st, np.float32).view(np.uint32), np.asarray(o.stats(), np.float32).view(np.uint32)), k
+            assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32)), k
+    assert ef.lastCount() == o.map_count()
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    ef.close()
+
+
 def test_frames_at_1280x960_match_oracle(hip):
     """BASELINE.json configs[2] shape: 1280x960, the first frame seeds ~1.2 M surfels.  Same bar as at 640x480: tracker
     statistics, float pose and every surfel identical to the oracle's (the kernels take the resolution at run time)."""

@@ -149,3 +149,43 @@ def test_clean_time_window(ops, cams, mature):
     out_ref = efo.clean(ocam, T, tick, idx, vc, ct, nr, 1.0, 3, MAXD, surf, nu)
     out_got = ops.clean(cam, T, tick, idx, vc, ct, nr, 1.0, 3, MAXD, surf, nu)
     assert len(out_got) == len(out_ref) and bits_equal(out_got, out_ref)
+
+
+def test_clean_with_deformation_graph(ops, cams):
+    """SURVEY §8f row 3: GlobalModel::clean with a deformation graph (copy_unstable.vert:128-322) + the synthesized depth it
+    tests against (G6).  HIP vs oracle on the same inputs: every surfel bit-identical, and the graph really moved the map."""
+    import mapops
+    cam, ocam = cams
+    inp = mapops.make_inputs(W, H)
+    graph = mapops.make_graph(inp)
+    T, tick = inp["T"].reshape(4, 4), int(inp["tick"].reshape(-1)[0])
+    d_ref = efo.synthesize_depth(ocam, T, inp["surf"], MAXD, mapops.CONF, tick, tick - 2, 65535)
+    d_got = ops.synthesize_depth(cam, T, inp["surf"], MAXD, mapops.CONF, tick, tick - 2, 65535)
+    assert bits_equal(d_got, d_ref) and (d_ref > 0).sum() > 10000
+    for fern in (0, 1):
+        ref = mapops.run_deform(efo, inp, graph, cam=ocam, isFern=fern)
+        got = mapops.run_deform(mapops.HipMapOps(__import__("elasticfusion_amd.api", fromlist=["api"])), inp, graph, cam=cam, isFern=fern)
+        assert got.shape == ref.shape and bits_equal(got, ref), fern
+    plain = efo.clean(ocam, T, tick, inp["idx2"], inp["vc2"], inp["ct2"], inp["nr2"], mapops.CONF, mapops.TD, MAXD, inp["s2"], inp["nu"])
+    assert (np.linalg.norm(ref[:, :3] - plain[:, :3], axis=1) > 1e-3).mean() > 0.9
+
+
+def test_frame_tier_deformation(cams):
+    """ef_set_deformation: the graph handed over before a frame is applied by that frame's clean (synthesizeDepth first),
+    exactly as the oracle's frame loop does; the maps stay bit-identical afterwards, also on the following frames."""
+    import mapops
+    from elasticfusion_amd import api, synth
+    seq = synth.Sequence(0xEF0002)
+    ef, o = api.ElasticFusion(confidence=1.0), efo.Fusion(confidence=1.0)
+    for k in range(8):
+        rgb, depth, Tgt = seq.frame(k)
+        if k == 5:
+            g = mapops.make_graph(dict(surf=o.map(), tick=np.int32(o.tick())), n_nodes=32)
+            ef.setDeformation(g)
+            o.set_deformation(g)
+        ef.processFrame(rgb, depth, k, in_T_wc=None if k == 0 else Tgt)
+        o.process_frame(rgb, depth, k, T_wc=None if k == 0 else Tgt)
+        assert ef.lastCount() == o.map_count(), k
+        if k >= 5:
+            assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32)), k
+    ef.close()

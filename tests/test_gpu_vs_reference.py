@@ -98,3 +98,21 @@ def test_hip_nofma_map_passes_equal_live_compiled_shaders(nofma_map_ops):
     with efo.backend("reference_glsl"):
         ref = mapops.run_passes(efo, inp)
     _check_map(mapops.run_passes(nofma_map_ops, inp), ref)
+
+
+def test_hip_nofma_deformation_equals_compiled_shader(nofma_map_ops):
+    """copy_unstable.vert:128-322 (deformation graph) through the compiled shader vs the no-FMA HIP build: bit for bit except
+    the lastTime of the handful of surfels whose "seen again" depth lookup sits on a texel edge (N4)."""
+    import mapops
+    if not efo.have_reference_glsl():
+        pytest.skip("oracle/_ref/libefr_glsl.so did not travel with the snapshot")
+    so = efo.reference_glsl_lib()
+    so.efg_use_specified_exp(1)
+    inp = mapops.make_inputs(640, 480)
+    graph = mapops.make_graph(inp)
+    with efo.backend("reference_glsl"):
+        ref = mapops.run_deform(efo, inp, graph)
+    got = mapops.run_deform(nofma_map_ops, inp, graph)
+    cols = [c for c in range(12) if c != 7]
+    assert got.shape == ref.shape and trackops.bits_differ(got[:, cols], ref[:, cols]) == 0
+    assert (got[:, 7] != ref[:, 7]).sum() <= 1e-5 * len(got)

@@ -84,3 +84,35 @@ def test_bilateral_with_libm_exp(inputs):
     b = efo.filter_depth(raw, 3.0)
     d = np.abs(a.astype(np.int32) - b.astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+
+
+def test_deformation_graph_application_against_compiled_shader(inputs):
+    """copy_unstable.vert:128-322 — binary search of the node by time, 20 nearest-in-time candidates,
+    the shader's exchange sort, k = 4 blend weights, rigid blend of position and normal, the "seen again" test against the
+    synthesized depth.  No-FMA oracle vs the compiled shader: bit for bit, and the graph really moves the map."""
+    so = efo.reference_glsl_lib()
+    so.efg_use_specified_exp(1)
+    graph = mapops.make_graph(inputs)
+    with efo.backend("reference_glsl"):
+        ref = mapops.run_deform(efo, inputs, graph)
+        ref_fern = mapops.run_deform(efo, inputs, graph, isFern=1)
+    with efo.backend("nofma"):
+        got = mapops.run_deform(efo, inputs, graph)
+        got_fern = mapops.run_deform(efo, inputs, graph, isFern=1)
+        undeformed = efo.clean(efo.make_cam(*[int(x) for x in inputs["cam"][:2]], *[float(x) for x in inputs["cam"][2:]]),
+                               inputs["T"].reshape(4, 4), int(inputs["tick"].reshape(-1)[0]), inputs["idx2"], inputs["vc2"], inputs["ct2"],
+                               inputs["nr2"], mapops.CONF, mapops.TD, mapops.MAXD, inputs["s2"], inputs["nu"])
+    assert got.shape == ref.shape == undeformed.shape
+    assert trackops.bits_differ(got_fern, ref_fern) == 0
+    # the only data-dependent NEAREST lookup at an arbitrary coordinate is the "seen again" depth test
+    # (textureLod(depthSampler, vec2(x / cols, y / rows))): x / cols * cols can land on the other side of a texel edge than
+    # floor(x) (N4) -> lastTime of at most a handful of surfels; everything else bit for bit
+    cols_but_last_time = [c for c in range(12) if c != 7]
+    assert trackops.bits_differ(got[:, cols_but_last_time], ref[:, cols_but_last_time]) == 0
+    assert (got[:, 7] != ref[:, 7]).sum() <= 1e-5 * len(got)
+    moved = np.linalg.norm(got[:, :3] - undeformed[:, :3], axis=1)
+    assert (moved > 1e-3).mean() > 0.9 and moved.max() < 0.5          # everything but this frame's points was deformed
+    assert (got[:, 7] != got_fern[:, 7]).any()                         # the depth test updates lastTime only when !isFern
+    spec = mapops.run_deform(efo, inputs, graph)
+    assert trackops.max_rel(spec[:, :3], ref[:, :3]) <= 1e-5 and np.array_equal(spec[:, 4:7], ref[:, 4:7])
+    assert (spec[:, 7] != ref[:, 7]).sum() <= 1e-5 * len(spec)
