@@ -16,5 +16,11 @@ tail -3 $out/${tag}_bench.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${tag} --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $out/${tag}_prof_stdout.log 2>&1
 find /tmp/prof -name "${tag}_kernel_stats.csv" -exec cp {} $out/ \;
-find /tmp/prof -name "${tag}_domain_stats.csv" -exec cp {} $out/ \;
 head -12 $out/${tag}_kernel_stats.csv | cut -c1-200
+# configs[2]: 1280x960, ~1 M surfels
+cd $GRAFT_REPO_ROOT
+timeout 600 python bench.py --no-cpu-baseline --width 1280 --height 960 --steps 100 --warmup 10 > $out/${tag}_1280x960_bench.json 2>/dev/null
+cat $out/${tag}_1280x960_bench.json
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof3 -o ${tag}c3 --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --width 1280 --height 960 --steps 50 --warmup 5 > /dev/null 2>&1
+find /tmp/prof3 -name "${tag}c3_kernel_stats.csv" -exec cp {} $out/${tag}_1280x960_kernel_stats.csv \;
