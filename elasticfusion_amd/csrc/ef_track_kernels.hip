@@ -948,6 +948,11 @@ __device__ __forceinline__ void visit_stage2b(const IcpView& IV, const RgbView& 
 // developer instrumentation (-DEF_ACCUM_CLOCKS): wall_clock64() stamps of the first and the last workgroup of the level-0
 // launch into TrackState::dbg_clock (the state block is found from the Rcurr pointer the kernel gets)
 #ifdef EF_ACCUM_CLOCKS
+__device__ unsigned long long g_accum_stamps[2 * VWARPS];   // entry / exit of every workgroup of the last level-0 launch
+#define EF_ASTAMP_ALL(slot)                                                                                       \
+  do {                                                                                                            \
+    if (N > 8 * VTHREADS && threadIdx.x == 0) g_accum_stamps[(slot) * VWARPS + blockIdx.x] = wall_clock64();      \
+  } while (0)
 #define EF_ASTAMP(i)                                                                                              \
   do {                                                                                                            \
     if (N > 8 * VTHREADS && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == VWARPS - 1)) {                      \
@@ -957,10 +962,11 @@ __device__ __forceinline__ void visit_stage2b(const IcpView& IV, const RgbView& 
   } while (0)
 #else
 #define EF_ASTAMP(i) do { } while (0)
+#define EF_ASTAMP_ALL(slot) do { } while (0)
 #endif
 template <int BLOCK, int KC, bool HAS_ICP, bool HAS_RGB, bool PACKED>
-__global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, float* __restrict__ partials_icp,
-                                                     float* __restrict__ partials_rgb) {
+__device__ __forceinline__ void se3_accum_body(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, float* __restrict__ partials_icp,
+                                               float* __restrict__ partials_rgb) {
   static_assert(BLOCK >= 256 && BLOCK % 64 == 0, "phase B needs 256 threads");
   __shared__ float rows[2][KC * ROW_STRIDE];
   const int t = threadIdx.x, W = blockIdx.x;
@@ -968,6 +974,7 @@ __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const Rgb
   const int N = cols * nrows;
   const int K = (N + VTHREADS - 1) / VTHREADS;
   EF_ASTAMP(0);
+  EF_ASTAMP_ALL(0);
   const int broken = in.broken ? *in.broken : 0;   // consumed below, after the loads are in flight
   // Issue order = everything that needs no other load first: the residual-pass sums (sigma), the pose (scalar loads),
   // then the first task's pixel-addressed loads (frame tier); only then is anything waited for.
@@ -1083,7 +1090,18 @@ __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const Rgb
     }
   }
   EF_ASTAMP(4);
+  EF_ASTAMP_ALL(1);
 }
+template <int BLOCK, int KC, bool HAS_ICP, bool HAS_RGB, bool PACKED>
+__global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, float* __restrict__ partials_icp,
+                                                     float* __restrict__ partials_rgb) {
+  se3_accum_body<BLOCK, KC, HAS_ICP, HAS_RGB, PACKED>(IV, RV, in, partials_icp, partials_rgb);
+}
+#ifdef EF_ACCUM_CLOCKS
+extern "C" int ef_debug_accum_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_accum_stamps), sizeof(unsigned long long) * 2 * VWARPS) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // The rest of the reference tree over the 512 virtual-warp partials of `na` accumulators (acc-major):
 //   blockReduceSum's second stage: lanes 0..7 of warp 0 hold the 8 warp sums, the other 24 lanes hold 0.0f
@@ -1563,14 +1581,10 @@ constexpr int ACC_BLOCK_BIG = 640, ACC_BLOCK_SMALL = 256, ACC_KC = 19;
 // one normal-equation accumulation launch (either tier)
 template <bool HAS_ICP, bool HAS_RGB, bool PACKED>
 void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int N, float* partials_icp, float* partials_rgb, hipStream_t s) {
-  static const int big = getenv("EF_ACCUM_BLOCK") ? atoi(getenv("EF_ACCUM_BLOCK")) : ACC_BLOCK_BIG;   // developer knob
-  if (N > 8 * VTHREADS && big == 320)
-    hipLaunchKernelGGL((k_se3_accum<320, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(320), 0, s, IV, RV, in, partials_icp, partials_rgb);
-  else if (N > 8 * VTHREADS && big == 384)
-    hipLaunchKernelGGL((k_se3_accum<384, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(384), 0, s, IV, RV, in, partials_icp, partials_rgb);
-  else if (N > 8 * VTHREADS && big == 512)
-    hipLaunchKernelGGL((k_se3_accum<512, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(512), 0, s, IV, RV, in, partials_icp, partials_rgb);
-  else if (N > 8 * VTHREADS && big != 256)
+  // developer knob: EF_ACCUM_BLOCK=256 runs level 0 with 4-wave workgroups too (all 512 resident at once, three
+  // pixel-visits per thread) instead of 10-wave ones (one visit per thread, two dispatch rounds): same end-to-end time
+  static const int big = getenv("EF_ACCUM_BLOCK") ? atoi(getenv("EF_ACCUM_BLOCK")) : ACC_BLOCK_BIG;
+  if (N > 8 * VTHREADS && big != 256)
     hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_BIG, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(ACC_BLOCK_BIG), 0, s, IV, RV, in,
                        partials_icp, partials_rgb);
   else
