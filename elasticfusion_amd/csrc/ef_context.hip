@@ -200,15 +200,23 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   if (overlap) EF_HIP(c, hipStreamWaitEvent(sb, c->overlap_mode == 2 ? c->ev_frame_done[c->frame_parity] : c->ev_track_done, 0));
   // the frame images are referenced by later stages of this frame and by the next frame's tracker
   // (fill-in / predict read depth_filtered + rgb), so they are copied into context-owned buffers
-  EF_HIP(c, hipMemcpyAsync(c->rgb, rgb_src, (size_t)W * H * 3, kind, sb));
-  EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_src, (size_t)W * H * 2, kind, sb));
+  // Frames that are already in HBM are not copied by separate launches in the single-stream script: the bilateral filter
+  // reads the caller's depth directly (nothing later needs the raw image) and the RGB copy rides on the intensity kernel.
+  const bool fold_copies = kind == hipMemcpyDeviceToDevice && !overlap && track_this;
+  const uint16_t* depth_in = c->depth_raw;
+  if (fold_copies) {
+    depth_in = depth_src;
+  } else {
+    EF_HIP(c, hipMemcpyAsync(c->rgb, rgb_src, (size_t)W * H * 3, kind, sb));
+    EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_src, (size_t)W * H * 2, kind, sb));
+  }
   if (kind == hipMemcpyHostToDevice) { EF_HIP(c, hipEventRecord(c->ev_staged, sb)); c->staged_pending = true; }
   timer_begin(c, "Preprocess");
-  efm::preprocess_depth(c->depth_raw, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb,
+  efm::preprocess_depth(depth_in, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb,
                         overlap ? c->pre_lds : 0u);
   timer_end(c, "Preprocess");
   if (overlap && c->overlap_mode == 2) EF_HIP(c, hipStreamWaitEvent(sb, c->ev_track_done, 0));
-  if (track_this) {
+  if (track_this && overlap) {   // the single-stream script builds all pyramids together below (eft::build_pyramids)
     eft::init_icp(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, sb);
     eft::init_rgb_frame(c->pyr, c->rgb, sb);
   }
@@ -241,8 +249,13 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       timer_begin(c, "odomInit");
       eft::init_icp_model(c->pyr, (const float*)c->pm.vertex, (const float*)c->pm.normal, (const float*)c->fm.vertex,
                           (const float*)c->fm.normal, c->st, 6.0f /* maxDepthRGB, RGBDOdometry.cpp:42 */, s);
-      eft::init_rgb_model(c->pyr, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, c->st, s);
-      if (overlap) EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
+      if (overlap) {
+        eft::init_rgb_model(c->pyr, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, c->st, s);
+        EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
+      } else {
+        eft::build_pyramids(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image,
+                            c->cfg.frame_to_frame_rgb != 0, fold_copies ? rgb_src : c->rgb, c->st, s, fold_copies ? c->rgb : nullptr);
+      }
       if (rgb) eft::init_rgb_sobel(c->pyr, s);
       timer_end(c, "odomInit");
       timer_begin(c, "odom");

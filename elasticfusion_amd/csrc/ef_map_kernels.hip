@@ -462,12 +462,17 @@ __device__ __forceinline__ bool sprite_fragment(const Cam& cam, const Sprite& S,
   z = cp.z;
   return true;
 }
+// SPLAT_LANES consecutive lanes share one surfel and take every SPLAT_LANES-th fragment of its sprite: sprite areas vary
+// from 1 to dozens of pixels, and with one surfel per lane a wave waits for its largest sprite
+constexpr int SPLAT_LANES = 4;
 __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const float* __restrict__ T16, SurfelSoA map,
                                                         const unsigned* __restrict__ count_dev, float maxDepth, float confThreshold,
                                                         int time, int maxTime, int timeDelta, unsigned long long* zbuf) {
   const rt34 T = rt34_load16(T16);
   const unsigned count = *count_dev;
-  for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < count; id += gridDim.x * blockDim.x) {
+  const unsigned sub = threadIdx.x % SPLAT_LANES;
+  const unsigned stride = gridDim.x * blockDim.x / SPLAT_LANES;
+  for (unsigned id = (blockIdx.x * blockDim.x + threadIdx.x) / SPLAT_LANES; id < count; id += stride) {
     const float4 pc = map.pos_conf[id];
     if (pc.w < confThreshold) continue;  // unstable surfels (the bulk of a young map) never reach the normal stream
     const float4 ct = map.col_time[id];
@@ -476,13 +481,14 @@ __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const floa
     if (!S.ok) continue;
     const int px0 = max(0, (int)ceilf(S.u - S.hs - 0.5f)), px1 = min(cam.cols - 1, (int)ceilf(S.u + S.hs - 0.5f) - 1);
     const int py0 = max(0, (int)ceilf(S.v - S.hs - 0.5f)), py1 = min(cam.rows - 1, (int)ceilf(S.v + S.hs - 0.5f) - 1);
-    for (int py = py0; py <= py1; ++py)
-      for (int px = px0; px <= px1; ++px) {
-        float z;
-        if (!sprite_fragment(cam, S, px, py, z)) continue;
-        if (z != z) continue;
-        atomicMin(&zbuf[py * cam.cols + px], zkey(z, id));
-      }
+    const int w = px1 - px0 + 1, nfrag = w * (py1 - py0 + 1);
+    for (int f = (int)sub; f < nfrag; f += SPLAT_LANES) {
+      const int fy = f / w, px = px0 + (f - fy * w), py = py0 + fy;
+      float z;
+      if (!sprite_fragment(cam, S, px, py, z)) continue;
+      if (z != z) continue;
+      atomicMin(&zbuf[py * cam.cols + px], zkey(z, id));
+    }
   }
 }
 
@@ -1089,8 +1095,8 @@ void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSo
 void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
                       float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, PredictMaps out, FillMaps fill,
                       const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthroughImage, unsigned* dense_counter, hipStream_t s) {
-  hipLaunchKernelGGL(k_surface_splat, dim3(SURFEL_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold, time,
-                     maxTime, timeDelta, zbuf);
+  hipLaunchKernelGGL(k_surface_splat, dim3(SURFEL_GRID * SPLAT_LANES), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
+                     time, maxTime, timeDelta, zbuf);
   const dim3 g(ceil_div(cam.cols * cam.rows, BLK));
   if (fill.image)
     hipLaunchKernelGGL(k_surface_resolve<true>, g, dim3(BLK), 0, s, cam, T_cw16_dev, map, maxDepth, confThreshold, time, maxTime, timeDelta,
@@ -1101,8 +1107,8 @@ void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, co
 }
 void synthesize_depth(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth, float confThreshold,
                       int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s) {
-  hipLaunchKernelGGL(k_surface_splat, dim3(SURFEL_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold, time,
-                     maxTime, timeDelta, zbuf);
+  hipLaunchKernelGGL(k_surface_splat, dim3(SURFEL_GRID * SPLAT_LANES), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
+                     time, maxTime, timeDelta, zbuf);
   const int n = cam.cols * cam.rows;
   hipLaunchKernelGGL(k_depth_resolve, dim3(ceil_div(n, BLK)), dim3(BLK), 0, s, n, zbuf, depth);
 }

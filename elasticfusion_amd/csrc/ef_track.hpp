@@ -168,6 +168,10 @@ void init_rgb_model(const Pyramid& p, const uint8_t* pred_image_rgba, const uint
                     const TrackState* st, hipStream_t s);
 void init_rgb_frame(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
 void init_rgb_sobel(const Pyramid& p, hipStream_t s);
+// init_icp + init_rgb_model + init_rgb_frame in three launches (single-stream frame script; needs init_icp_model first)
+void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, const uint8_t* pred_image_rgba,
+                    const uint8_t* fill_image_rgba, bool frameToFrameRGB, const uint8_t* rgb3, const TrackState* st, hipStream_t s,
+                    uint8_t* rgb_keep = nullptr);   // rgb_keep: also store the frame's RGB there (the caller's buffer is only borrowed)
 // initFirstRGB, RGBDOdometry.cpp:246-257
 void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
 // getIncrementalTransformation, RGBDOdometry.cpp:259-571, entirely enqueued

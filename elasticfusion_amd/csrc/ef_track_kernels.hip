@@ -28,10 +28,8 @@ inline dim3 tile_block() { return dim3(TILE_X, TILE_Y); }
 // ------------------------------------------------------------------------------------------
 
 // pyrDownGaussKernel, cudafuncs.cu:75-109
-__global__ void k_pyr_down_u16(const uint16_t* __restrict__ src, int scols, int srows, uint16_t* __restrict__ dst) {
-  const int dcols = scols / 2, drows = srows / 2;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dcols || y >= drows) return;
+__device__ __forceinline__ void pyr_down_u16_px(const uint16_t* __restrict__ src, int scols, int srows, uint16_t* __restrict__ dst, int x, int y) {
+  const int dcols = scols / 2;
   const int D = 5;
   const float sigma_color = 30.f;
   const int center = src[(2 * y) * scols + 2 * x];
@@ -50,6 +48,11 @@ __global__ void k_pyr_down_u16(const uint16_t* __restrict__ src, int scols, int 
       }
     }
   dst[y * dcols + x] = (uint16_t) static_cast<int>(sum / wall);
+}
+__global__ void k_pyr_down_u16(const uint16_t* __restrict__ src, int scols, int srows, uint16_t* __restrict__ dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= scols / 2 || y >= srows / 2) return;
+  pyr_down_u16_px(src, scols, srows, dst, x, y);
 }
 
 // computeVmapKernel, cudafuncs.cu:123-149
@@ -214,10 +217,8 @@ __device__ __forceinline__ float gauss25(int idx) {  // {1 4 6 4 1} (x) {1 4 6 4
 }
 
 // pyrDownKernelGaussF, cudafuncs.cu:383-411 (quirk Q7 kept)
-__global__ void k_pyr_down_gauss_f(const float* __restrict__ src, int scols, int srows, float* __restrict__ dst) {
-  const int dcols = scols / 2, drows = srows / 2, D = 5;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dcols || y >= drows) return;
+__device__ __forceinline__ void pyr_down_gauss_f_px(const float* __restrict__ src, int scols, int srows, float* __restrict__ dst, int x, int y) {
+  const int dcols = scols / 2, D = 5;
   const int tx = min(2 * x - D / 2 + D, scols - 1), ty = min(2 * y - D / 2 + D, srows - 1);
   float sum = 0;
   int count = 0;
@@ -232,12 +233,15 @@ __global__ void k_pyr_down_gauss_f(const float* __restrict__ src, int scols, int
     }
   dst[y * dcols + x] = (float)(sum / (float)count);
 }
+__global__ void k_pyr_down_gauss_f(const float* __restrict__ src, int scols, int srows, float* __restrict__ dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= scols / 2 || y >= srows / 2) return;
+  pyr_down_gauss_f_px(src, scols, srows, dst, x, y);
+}
 
 // pyrDownKernelIntensityGauss, cudafuncs.cu:512-542
-__global__ void k_pyr_down_uchar_gauss(const uint8_t* __restrict__ src, int scols, int srows, uint8_t* __restrict__ dst) {
-  const int dcols = scols / 2, drows = srows / 2, D = 5;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= dcols || y >= drows) return;
+__device__ __forceinline__ void pyr_down_uchar_gauss_px(const uint8_t* __restrict__ src, int scols, int srows, uint8_t* __restrict__ dst, int x, int y) {
+  const int dcols = scols / 2, D = 5;
   const int tx = min(2 * x - D / 2 + D, scols - 1), ty = min(2 * y - D / 2 + D, srows - 1);
   float sum = 0;
   int count = 0;
@@ -253,6 +257,27 @@ __global__ void k_pyr_down_uchar_gauss(const uint8_t* __restrict__ src, int scol
   const float q = sum / (float)count;
   const int iv = (q != q) ? 0 : (int)fminf(fmaxf(q, 0.0f), 255.0f);
   dst[y * dcols + x] = (uint8_t)iv;
+}
+__global__ void k_pyr_down_uchar_gauss(const uint8_t* __restrict__ src, int scols, int srows, uint8_t* __restrict__ dst) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= scols / 2 || y >= srows / 2) return;
+  pyr_down_uchar_gauss_px(src, scols, srows, dst, x, y);
+}
+// One launch for one pyramid step of SEVERAL images of the same size (blockIdx.z = job): the frame's u16 depth, the
+// model's f32 depth and both intensity images are each only a 5-9 us, launch-bound kernel on their own.
+struct PyrJobs {
+  const void* src[4];
+  void* dst[4];
+  int type[4];   // 0: u16 (pyrDownGaussKernel)  1: f32 (pyrDownKernelGaussF)  2: u8 (pyrDownKernelIntensityGauss)
+  int scols, srows;
+};
+__global__ void k_pyr_down_multi(const PyrJobs J) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= J.scols / 2 || y >= J.srows / 2) return;
+  const int j = blockIdx.z;
+  if (J.type[j] == 0) pyr_down_u16_px((const uint16_t*)J.src[j], J.scols, J.srows, (uint16_t*)J.dst[j], x, y);
+  else if (J.type[j] == 1) pyr_down_gauss_f_px((const float*)J.src[j], J.scols, J.srows, (float*)J.dst[j], x, y);
+  else pyr_down_uchar_gauss_px((const uint8_t*)J.src[j], J.scols, J.srows, (uint8_t*)J.dst[j], x, y);
 }
 
 // verticesToDepthKernel, cudafuncs.cu:564-574
@@ -1697,6 +1722,59 @@ void init_rgb_frame(const Pyramid& p, const uint8_t* rgb3, hipStream_t s) {
   // populateRGBDData(frame): nextDepth == lastDepth (Q1), only the intensity pyramid is new
   bgr_to_intensity(rgb3, 3, p.W(0), p.H(0), p.nextImage[0], s);
   for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_uchar_gauss(p.nextImage[i], p.W(i), p.H(i), p.nextImage[i + 1], s);
+}
+namespace {
+// both level-0 intensity images in one launch: blockIdx.y 0 = the camera frame ("next"), 1 = the model image ("last")
+__global__ void k_intensity_both(const uint8_t* __restrict__ rgb3, const uint8_t* __restrict__ pred, const uint8_t* __restrict__ fill,
+                                 bool force_fill, const TrackState* __restrict__ st, int n, uint8_t* __restrict__ next0,
+                                 uint8_t* __restrict__ last0, uint8_t* __restrict__ rgb_keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (blockIdx.y == 0) {
+    const uint8_t* sp = rgb3 + (size_t)i * 3;
+    const uint8_t r = sp[0], g = sp[1], b = sp[2];
+    next0[i] = intensity_of((float)r, (float)g, (float)b);
+    if (rgb_keep) { rgb_keep[(size_t)i * 3] = r; rgb_keep[(size_t)i * 3 + 1] = g; rgb_keep[(size_t)i * 3 + 2] = b; }   // the context's copy of the frame
+  } else {
+    const uint8_t* src = (force_fill || use_fill_in(st)) ? fill : pred;
+    const uchar4 c = ((const uchar4*)src)[i];
+    last0[i] = intensity_of((float)c.x, (float)c.y, (float)c.z);
+  }
+}
+}  // namespace
+// initICP's depth pyramid + both halves of populateRGBDData in THREE launches instead of twelve (single-stream frame
+// script): level-0 intensities, then one k_pyr_down_multi per pyramid step over {frame depth u16, model depth f32,
+// model intensity, frame intensity}; then the per-level vertex/normal maps.  Same per-pixel functions, same results.
+void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, const uint8_t* pred_image_rgba,
+                    const uint8_t* fill_image_rgba, bool frameToFrameRGB, const uint8_t* rgb3, const TrackState* st, hipStream_t s,
+                    uint8_t* rgb_keep) {
+  const int n = p.W(0) * p.H(0);
+  hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 2), dim3(256), 0, s, rgb3, pred_image_rgba, fill_image_rgba, frameToFrameRGB, st,
+                     n, p.nextImage[0], p.lastImage[0], rgb_keep);
+  for (int i = 0; i + 1 < NUM_PYRS; ++i) {
+    PyrJobs J;
+    J.src[0] = i == 0 ? (const void*)depth_filtered : (const void*)p.depth_tmp[i]; J.dst[0] = p.depth_tmp[i + 1]; J.type[0] = 0;
+    J.src[1] = p.lastDepth[i]; J.dst[1] = p.lastDepth[i + 1]; J.type[1] = 1;
+    J.src[2] = p.lastImage[i]; J.dst[2] = p.lastImage[i + 1]; J.type[2] = 2;
+    J.src[3] = p.nextImage[i]; J.dst[3] = p.nextImage[i + 1]; J.type[3] = 2;
+    J.scols = p.W(i); J.srows = p.H(i);
+    dim3 g = tile_grid(p.W(i + 1), p.H(i + 1));
+    g.z = 4;
+    hipLaunchKernelGGL(k_pyr_down_multi, g, tile_block(), 0, s, J);
+  }
+  VNLevels L;
+  for (int i = 0; i < NUM_PYRS; ++i) {
+    L.depth[i] = i == 0 ? depth_filtered : p.depth_tmp[i];
+    L.vmap[i] = p.vmap_curr[i];
+    L.nmap[i] = p.nmap_curr[i];
+    L.cols[i] = p.W(i);
+    L.rows[i] = p.H(i);
+    L.k[i] = intr_level(k, i);
+  }
+  L.cutoff = cutoff;
+  dim3 g = tile_grid(p.W(0), p.H(0));
+  g.z = NUM_PYRS;
+  hipLaunchKernelGGL(k_vmap_nmap_levels, g, tile_block(), 0, s, L);
 }
 void init_rgb_sobel(const Pyramid& p, hipStream_t s) {
   SobelLevels L;
