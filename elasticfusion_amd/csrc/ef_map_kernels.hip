@@ -464,7 +464,10 @@ __device__ __forceinline__ bool sprite_fragment(const Cam& cam, const Sprite& S,
 }
 // SPLAT_LANES consecutive lanes share one surfel and take every SPLAT_LANES-th fragment of its sprite: sprite areas vary
 // from 1 to dozens of pixels, and with one surfel per lane a wave waits for its largest sprite
-constexpr int SPLAT_LANES = 4;
+#ifndef EF_SPLAT_LANES
+#define EF_SPLAT_LANES 4
+#endif
+constexpr int SPLAT_LANES = EF_SPLAT_LANES;
 __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const float* __restrict__ T16, SurfelSoA map,
                                                         const unsigned* __restrict__ count_dev, float maxDepth, float confThreshold,
                                                         int time, int maxTime, int timeDelta, unsigned long long* zbuf) {

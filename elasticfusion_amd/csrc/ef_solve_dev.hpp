@@ -42,7 +42,33 @@ struct SolveScratch {     // LDS, one per workgroup that runs a solve
   double ti[3];
   double KR[9];
   float pose[12];         // scratch for the float composition
+  // state of the previous iteration, fetched by every workgroup's first wave while the partial sums are still in flight
+  // (which workgroup will run the update is not known until the ticket is drawn): resultRt, Rprev | tprev
+  double prevRt[16];
+  float prevPose[12];
 };
+// the per-lane part of that prefetch (registers until the update starts)
+struct SolvePrefetch {
+  double rt;      // resultRt[lane & 15]
+  float pose;     // lane < 9: Rprev[lane]; 9..11: tprev[lane - 9]
+  int slot_a, slot_b;
+  float lastRGBErrorLevel;
+};
+__device__ __forceinline__ SolvePrefetch solve_prefetch(const eft::TrackState* st) {
+  const int lane = threadIdx.x & 63;
+  SolvePrefetch P;
+  P.rt = st->resultRt[lane & 15];
+  P.pose = lane < 9 ? st->Rprev[lane] : st->tprev[lane < 12 ? lane - 9 : 0];
+  P.slot_a = st->rgb_slots[lane][0];
+  P.slot_b = st->rgb_slots[lane][1];
+  P.lastRGBErrorLevel = st->lastRGBErrorLevel;
+  return P;
+}
+__device__ __forceinline__ void solve_prefetch_publish(const SolvePrefetch& P, SolveScratch& S) {
+  const int lane = threadIdx.x & 63;
+  if (lane < 16) S.prevRt[lane] = P.rt;
+  if (lane < 12) S.prevPose[lane] = P.pose;
+}
 
 // index of member (i,j), i <= j <= 6, in the JtJJtrSE3 order (types.cuh:98-143): rows 0..5 start at 0,7,13,18,22,25
 __device__ __forceinline__ int se3_member_of(int i, int j) {
@@ -205,7 +231,7 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, co
     const int r = lane >> 2, c = lane & 3;
     double s = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s += S.upd[r * 4 + k] * st->resultRt[k * 4 + c];
+    for (int k = 0; k < 4; ++k) s += S.upd[r * 4 + k] * S.prevRt[k * 4 + c];
     S.Rt[lane] = s;
   }
   wave_sync();
@@ -222,7 +248,7 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, co
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) it[r] = -(iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1] + iR[r * 3 + 2] * ot[2]);
-    const float* Rp = st->Rprev;
+    const float* Rp = S.prevPose;
     if (lane < 9) {
       const int r = lane / 3, c = lane - r * 3;
       float i0 = iR[0], i1 = iR[3], i2 = iR[6];
@@ -231,7 +257,7 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, co
       st->Rcurr[lane] = Rp[r * 3] * i0 + Rp[r * 3 + 1] * i1 + Rp[r * 3 + 2] * i2;
     } else {
       const int r = lane - 9;
-      st->tcurr[r] = (Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2]) + st->tprev[r];
+      st->tcurr[r] = (Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2]) + S.prevPose[9 + r];
     }
   }
   EF_STAMP(st, 7);

@@ -853,7 +853,8 @@ struct Se3Inputs {            // device pointers: the Gauss-Newton state the acc
   bool rgbOnly;
 };
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sums, bool broken, bool icp, bool rgb, bool rgbOnly,
-                                                float icpWeight, Intr knext, bool level_changes, efs::SolveScratch& S);
+                                                float icpWeight, Intr knext, bool level_changes, efs::SolveScratch& S,
+                                                const efs::SolvePrefetch& PF);
 // In-launch hand-off of partial sums between workgroups (which may sit on different XCDs, each with its own L2):
 // payload goes out with agent-scope (write-through) stores, the writer drains them (s_waitcnt vmcnt(0)) before its
 // workgroup takes a ticket with a relaxed atomic, and the last arriver reads with agent-scope loads.  No
@@ -1245,13 +1246,21 @@ __global__ void k_track_begin(TrackState* st, bool so3, Intr kso3, Intr kfirst) 
 constexpr int SOLVE_BLOCK = 512;
 // bookkeeping around the update (rgbOnly early exit, statistics); all lanes of wave 0 take the same path
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sums, bool broken, bool icp, bool rgb, bool rgbOnly,
-                                                float icpWeight, Intr knext, bool level_changes, efs::SolveScratch& S) {
+                                                float icpWeight, Intr knext, bool level_changes, efs::SolveScratch& S,
+                                                const efs::SolvePrefetch& PF) {
   const int lane = threadIdx.x & 63;
-  int sigma = 0, rgbSize = 0;
-  sum_rgb_slots((const int*)&st->rgb_slots[0][0], rgbSize, sigma);
+  int sigma = PF.slot_b, rgbSize = PF.slot_a;   // {count, sum diff^2} slots of the residual pass, prefetched
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    rgbSize += __shfl_down(rgbSize, off, 64);
+    sigma += __shfl_down(sigma, off, 64);
+  }
+  rgbSize = __shfl(rgbSize, 0, 64);
+  sigma = __shfl(sigma, 0, 64);
   st->rgb_slots[lane][0] = 0;
   st->rgb_slots[lane][1] = 0;
-  const float lastLevelErr = st->lastRGBErrorLevel;
+  efs::solve_prefetch_publish(PF, S);
+  const float lastLevelErr = PF.lastRGBErrorLevel;
   const float rgbError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
   const bool brk = !broken && rgbOnly && rgbError > lastLevelErr;   // "break": skip the rest of this level
   if (broken || brk) {
@@ -1294,8 +1303,10 @@ __global__ void __launch_bounds__(FINISH_BLOCK) k_se3_finish(TrackState* st, con
   __shared__ float sums_s[2 * SE3_ACCS];
   __shared__ int last_s;
   const int t = threadIdx.x, b = blockIdx.x;
+  efs::SolvePrefetch PF{};
+  if (t < 64) PF = efs::solve_prefetch(st);   // in flight while the partial sums are reduced
   if (st->rgb_broken) {  // rgbOnly "break": only the bookkeeping of the update step runs
-    if (b == 0 && t < 64) solve_step_wave(st, nullptr, true, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S);
+    if (b == 0 && t < 64) solve_step_wave(st, nullptr, true, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S, PF);
     return;
   }
   const int na = (A.icp ? SE3_ACCS : 0) + (A.rgb ? SE3_ACCS : 0);
@@ -1332,7 +1343,7 @@ __global__ void __launch_bounds__(FINISH_BLOCK) k_se3_finish(TrackState* st, con
   }
   if (t == 0) st->acc_ticket_final = 0;
   __syncthreads();
-  if (t < 64) solve_step_wave(st, sums_s, false, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S);
+  if (t < 64) solve_step_wave(st, sums_s, false, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S, PF);
 }
 
 // tail of getIncrementalTransformation (RGBDOdometry.cpp:555-570) + velocity weighting
