@@ -51,18 +51,28 @@ def cpu_baseline(frames, budget_s: float = 20.0, w: int = W, h: int = H):
     on the same frames, single thread, bounded to ~budget_s of CPU work.  Checker code used as a *baseline leg* only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import efo
-    o = efo.Fusion(width=w, height=h, fx=528.0 * w / 640, fy=528.0 * w / 640, cx=320.0 * w / 640, cy=240.0 * w / 640)
-    t0 = time.perf_counter()
-    n = 0
-    for rgb, depth, _ in frames:
-        o.process_frame(rgb, depth, n)
-        n += 1
-        if time.perf_counter() - t0 > budget_s and n >= 3:
-            break
-    dt = time.perf_counter() - t0
+    def run(threads, budget):
+        efo.set_threads(threads)
+        o = efo.Fusion(width=w, height=h, fx=528.0 * w / 640, fy=528.0 * w / 640, cx=320.0 * w / 640, cy=240.0 * w / 640)
+        t0 = time.perf_counter()
+        n = 0
+        for rgb, depth, _ in frames:
+            o.process_frame(rgb, depth, n)
+            n += 1
+            if time.perf_counter() - t0 > budget and n >= 3:
+                break
+        return n, time.perf_counter() - t0
+
+    n, dt = run(1, budget_s * 0.6)
+    cores = os.cpu_count() or 1
+    nm, dtm = run(cores, budget_s * 0.4) if cores > 1 else (n, dt)
+    efo.set_threads(1)
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"first {n} frames of the same {w}x{h} sequence through the oracle's full processFrame "
-                      f"(tracking + fuse), single thread, {dt:.1f} s"}
+                      f"(tracking + fuse), single thread, {dt:.1f} s",
+            "all_cores": {"value": nm / dtm, "cores": cores,
+                          "sample": f"first {nm} frames, bilateral rows and the reduction blocks on {cores} std::threads "
+                                    f"(the map passes stay serial), {dtm:.1f} s"}}
 
 
 def main():
@@ -82,6 +92,10 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
+    # synthetic frames first: the generator forks worker processes, which must happen before HIP / RCCL are initialised
+    n_frames = a.warmup + a.steps + 1  # frame 0 seeds the map (tick 1) and is never timed
+    frames = generate_frames(multi.sequence_seed(rank), n_frames, w, h)
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -91,9 +105,6 @@ def main():
         multi.init_process_group("nccl", local_rank)
 
     from elasticfusion_amd import api
-
-    n_frames = a.warmup + a.steps + 1  # frame 0 seeds the map (tick 1) and is never timed
-    frames = generate_frames(multi.sequence_seed(rank), n_frames, w, h)
 
     # a real (non-null) stream, made torch's current one: the engine enqueues on it, torch.cuda.synchronize() covers it,
     # and it can be captured into a hipGraph (EF_GRAPH=1), which the legacy null stream cannot
@@ -198,7 +209,7 @@ def main():
         "roofline": roofline,
         "roofline_index_splat": roofline_splat,
     }
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (the scaling runs reuse the N=1 figure)
         out["cpu_baseline"] = cpu_baseline(frames[: min(len(frames), 40)], w=w, h=h)
     print(json.dumps(out), flush=True)
     if world > 1:

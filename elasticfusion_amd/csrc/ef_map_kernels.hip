@@ -1130,8 +1130,8 @@ void fuse(const Cam& cam, const float* pose_f16_dev, int time, const uint8_t* rg
           hipStream_t s) {
   (void)count_dev;
   FuseArgs A{cam, pose_f16_dev, time, rgb3, dm, dmf, im, maxDepth, weighting_dev};
-  static const int rowwalk = getenv("EF_ASSOC_ROWWALK") ? atoi(getenv("EF_ASSOC_ROWWALK")) : 0;
-  hipLaunchKernelGGL(k_associate, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, A, cand, winner, (im.colmajor && !rowwalk) ? 1 : 0);
+  // column-major index maps: walking columns measured 24.7 us vs 34.8 us for walking rows (profiles/, round 1)
+  hipLaunchKernelGGL(k_associate, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, A, cand, winner, im.colmajor ? 1 : 0);
   hipLaunchKernelGGL(k_merge, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, cand, (const uint32_t*)winner, map, time);
 }
 

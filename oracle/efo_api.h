@@ -115,6 +115,8 @@ void efo_fusion_get_pose(const efo_fusion*, double* T_wc16);
 int efo_fusion_map_count(const efo_fusion*);
 void efo_fusion_map_download(const efo_fusion*, float* surfels /* count*12 */);
 int efo_fusion_tick(const efo_fusion*);
+/* host threads used by the parallel loops of the restatement (bilateral rows, reduction blocks); results do not depend on it */
+void efo_set_threads(int n);
 /* deformation graph (nodes x 16, sorted by time) applied by the next frame's clean, as after a loop closure */
 void efo_fusion_set_deformation(efo_fusion*, const float* graph, int nodes, int isFern);
 void efo_fusion_stats(const efo_fusion*, float* out6);

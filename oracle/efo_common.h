@@ -17,6 +17,8 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <thread>
+#include <vector>
 
 // Fused multiply-adds of the tracking side appear only through EFO_FMA.  The default build fuses them (the
 // specification the HIP kernels restate).  -DEFO_NO_FMA builds the same restatement with every EFO_FMA split into an
@@ -31,6 +33,19 @@
 #endif
 
 namespace efo {
+
+// cpu_baseline leg of bench.py, "all host cores" variant: the embarrassingly parallel loops of the
+// restatement (bilateral rows, the 64 independent blocks of each two-stage reduction) are split over efo::threads()
+// std::threads.  Every element is computed by the same code in the same order, so results do not depend on the count.
+inline int& threads() { static int n = 1; return n; }
+template <typename F>
+inline void parallel_for(int n, F&& body) {   // body(begin, end)
+  const int nt = threads() < n ? threads() : n;
+  if (nt <= 1) { body(0, n); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nt; ++t) pool.emplace_back([&, t] { body((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt)); });
+  for (auto& th : pool) th.join();
+}
 
 struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };

@@ -159,6 +159,7 @@ void efo_fusion_get_pose(const efo_fusion* f, double* T) { f->pose16(T); }
 int efo_fusion_map_count(const efo_fusion* f) { return f->count; }
 void efo_fusion_map_download(const efo_fusion* f, float* s) { std::memcpy(s, f->surfels.data(), (size_t)f->count * 48); }
 int efo_fusion_tick(const efo_fusion* f) { return f->tick; }
+void efo_set_threads(int n) { efo::threads() = n < 1 ? 1 : n; }
 void efo_fusion_set_deformation(efo_fusion* f, const float* graph, int nodes, int isFern) {
   f->pendingGraph.assign(graph, graph + (size_t)nodes * 16);
   f->pendingFern = isFern;

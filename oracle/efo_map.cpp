@@ -103,7 +103,8 @@ void efo_filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint1
   const float sigma_space2_inv_half = 0.024691358f, sigma_color2_inv_half = 0.000555556f;
   const int R = 6, D = R * 2 + 1;
   const unsigned maxv = (unsigned)(maxD * 1000.0f);
-  for (int y = 0; y < rows; ++y)
+  efo::parallel_for(rows, [&](int y0, int y1) {
+  for (int y = y0; y < y1; ++y)
     for (int x = 0; x < cols; ++x) {
       unsigned value = raw[y * cols + x];
       if (value > maxv || value < 300U) { filtered[y * cols + x] = 0; continue; }
@@ -120,6 +121,7 @@ void efo_filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint1
         }
       filtered[y * cols + x] = (uint16_t)(unsigned)roundf(sum1 / sum2);
     }
+  });
 }
 
 // depth_metric.frag:28-40 (G2)

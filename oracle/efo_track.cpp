@@ -311,16 +311,18 @@ Acc<T, K> block_reduce(const std::vector<Acc<T, K>>& threads) {  // threads.size
 template <typename T, int K, typename F>
 Acc<T, K> two_stage_reduce(int N, F&& products) {
   std::vector<Acc<T, K>> partial(kReduceBlocks);
-  std::vector<Acc<T, K>> threads(kReduceThreads);
-  for (int b = 0; b < kReduceBlocks; ++b) {
-    for (int t = 0; t < kReduceThreads; ++t) {
-      Acc<T, K> sum;
-      for (int k = 0; k < K; ++k) sum.v[k] = T(0);
-      for (int i = b * kReduceThreads + t; i < N; i += kReduceThreads * kReduceBlocks) products(i, sum);
-      threads[t] = sum;
+  efo::parallel_for(kReduceBlocks, [&](int b0, int b1) {   // the 64 blocks are independent (reduce.cu:313-317)
+    std::vector<Acc<T, K>> threads(kReduceThreads);
+    for (int b = b0; b < b1; ++b) {
+      for (int t = 0; t < kReduceThreads; ++t) {
+        Acc<T, K> sum;
+        for (int k = 0; k < K; ++k) sum.v[k] = T(0);
+        for (int i = b * kReduceThreads + t; i < N; i += kReduceThreads * kReduceBlocks) products(i, sum);
+        threads[t] = sum;
+      }
+      partial[b] = block_reduce<T, K>(threads);
     }
-    partial[b] = block_reduce<T, K>(threads);
-  }
+  });
   std::vector<Acc<T, K>> th2(kMaxThreads);
   for (int t = 0; t < kMaxThreads; ++t) {
     for (int k = 0; k < K; ++k) th2[t].v[k] = T(0);

@@ -121,6 +121,11 @@ def lib():
     return _LIB
 
 
+def set_threads(n: int):
+    """host threads for the parallel loops of the oracle (cpu_baseline "all cores" leg); results do not depend on it"""
+    lib().efo_set_threads(c_i(int(n)))
+
+
 def ptr(a: np.ndarray):
     assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
     return a.ctypes.data_as(P)

@@ -155,3 +155,23 @@ def test_fill_in_passthrough_equals_raw_frame(oracle_state, frames):
     assert np.array_equal(fi[..., :3], rgb) and np.all(fi[..., 3] == 255)
     z = oracle_state.buffer("depthFiltered").astype(np.float32) / np.float32(1000.0)
     assert np.array_equal(fv[..., 2], z)
+
+
+def test_oracle_results_do_not_depend_on_thread_count(seq):
+    """bench.py's "all cores" CPU baseline runs the same oracle with its parallel loops (bilateral rows, reduction blocks)
+    split over std::threads: poses and maps must be bit-identical to the single-threaded run."""
+    import efo
+    out = []
+    try:
+        for n in (1, 5):
+            efo.set_threads(n)
+            f = efo.Fusion()
+            for k in range(3):
+                rgb, depth, _ = seq.frame(k)
+                f.process_frame(rgb, depth, k)
+            out.append((f.pose().copy(), f.map().copy(), np.asarray(f.stats(), np.float32)))
+    finally:
+        efo.set_threads(1)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    assert np.array_equal(out[0][2].view(np.uint32), out[1][2].view(np.uint32))
