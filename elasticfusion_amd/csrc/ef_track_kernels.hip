@@ -1487,6 +1487,16 @@ __global__ void __launch_bounds__(SO3_BLOCK) k_so3_iteration(const uint8_t* __re
   __shared__ int is_last;
   if (st->so3_done) return;
   const int t = threadIdx.x;
+  // state the update step will need, fetched by thread 0 of EVERY workgroup while the rows are accumulated (which
+  // workgroup arrives last is not known yet): a dependent global load costs ~1 us on the serial tail otherwise
+  float p_lastError = 0.f, p_lastCount = 0.f, p_Rlr[9];
+  double p_resR[9];
+  if (t == 0) {
+    p_lastError = st->so3_lastError;
+    p_lastCount = st->so3_lastCount;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { p_Rlr[i] = st->so3_R_lr[i]; p_resR[i] = st->so3_resultR[i]; }
+  }
   {
     const m33 IB = m33_load(st->so3_mats), KI = m33_load(st->so3_mats + 9), KR = m33_load(st->so3_mats + 18);
     so3_accumulate(lastImage, nextImage, cols, rows, IB, KI, KR, lds_rows, partials);
@@ -1511,15 +1521,18 @@ __global__ void __launch_bounds__(SO3_BLOCK) k_so3_iteration(const uint8_t* __re
   float err = sqrtf(red[9]) / red[10];
   float cnt = red[10];
   bool done = false;
-  if (err < st->so3_lastError && st->so3_lastCount == cnt) {
+  double resR[9];   // so3_resultR as the rest of this step sees it
+#pragma unroll
+  for (int i = 0; i < 9; ++i) resR[i] = p_resR[i];
+  if (err < p_lastError && p_lastCount == cnt) {
     done = true;
-  } else if ((double)err > (double)st->so3_lastError + 0.001) {
-    err = st->so3_lastError; cnt = st->so3_lastCount;
-    for (int i = 0; i < 9; ++i) st->so3_resultR[i] = st->so3_lastResultR[i];
+  } else if ((double)err > (double)p_lastError + 0.001) {
+    err = p_lastError; cnt = p_lastCount;
+    for (int i = 0; i < 9; ++i) { resR[i] = st->so3_lastResultR[i]; st->so3_resultR[i] = resR[i]; }
     done = true;
   } else {
     st->so3_lastError = err; st->so3_lastCount = cnt;
-    for (int i = 0; i < 9; ++i) st->so3_lastResultR[i] = st->so3_resultR[i];
+    for (int i = 0; i < 9; ++i) st->so3_lastResultR[i] = p_resR[i];
     float delta[3];
     efl::ldlt_solve<float, 3>(jtj, jtr, delta);
     const double dv[3] = {(double)delta[0], (double)delta[1], (double)delta[2]};
@@ -1530,21 +1543,23 @@ __global__ void __launch_bounds__(SO3_BLOCK) k_so3_iteration(const uint8_t* __re
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) {
         float s = 0;
-        for (int kk = 0; kk < 3; ++kk) s += ruf[r * 3 + kk] * st->so3_R_lr[kk * 3 + c];
+        for (int kk = 0; kk < 3; ++kk) s += ruf[r * 3 + kk] * p_Rlr[kk * 3 + c];
         nR[r * 3 + c] = s;
       }
-    for (int i = 0; i < 9; ++i) { st->so3_R_lr[i] = nR[i]; st->so3_resultR[i] = (double)nR[i]; }
+    for (int i = 0; i < 9; ++i) { st->so3_R_lr[i] = nR[i]; resR[i] = (double)nR[i]; st->so3_resultR[i] = resR[i]; }
   }
   st->lastSO3Error = err;
   st->lastSO3Count = cnt;
   if (done || it == 9) {
     // resultRt.topLeftCorner(3,3) = resultR (RGBDOdometry.cpp:381-388) and the first level's K R K^-1, K t
+    // the rest of resultRt is the identity k_track_begin wrote (nothing touches it before the first SE(3) iteration)
+    double Rt[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (int x = 0; x < 3; ++x)
-      for (int y = 0; y < 3; ++y) st->resultRt[x * 4 + y] = st->so3_resultR[x * 3 + y];
-    compute_krk(st->resultRt, kfirst, st->krkinv, st->kt);
+      for (int y = 0; y < 3; ++y) { Rt[x * 4 + y] = resR[x * 3 + y]; st->resultRt[x * 4 + y] = resR[x * 3 + y]; }
+    compute_krk(Rt, kfirst, st->krkinv, st->kt);
     st->so3_done = 1;
   } else {
-    so3_matrices(st->so3_resultR, k, st->so3_mats);
+    so3_matrices(resR, k, st->so3_mats);
   }
 }
 
