@@ -217,6 +217,11 @@ class ElasticFusion:
         _chk(lib().ef_get_tracking_stats(self.h, _ptr(out), _ptr(A), _ptr(b)), self.h)
         return out, A, b
 
+    def getCovariance(self) -> np.ndarray:
+        c = np.zeros(36, np.float64)
+        _chk(lib().ef_get_covariance(self.h, _ptr(c)), self.h)
+        return c.reshape(6, 6)
+
     def trajectory(self):
         n = c_i(0)
         _chk(lib().ef_get_trajectory(self.h, None, None, c_i(0), C.byref(n)), self.h)

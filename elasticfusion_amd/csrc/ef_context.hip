@@ -575,6 +575,14 @@ int ef_get_tracking_stats(ef_ctx* c, float* out6, double* A36, double* b6) {
   if (b6) memcpy(b6, h.lastb, sizeof(h.lastb));
   return EF_OK;
 }
+int ef_get_covariance(ef_ctx* c, double* cov36) {
+  if (!c || !cov36) return EF_EINVAL;
+  eft::TrackState h;
+  EF_HIP(c, hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  efl::lu_inverse<double, 6>(h.lastA, cov36);   // host side, like the reference (Eigen on the CPU)
+  return EF_OK;
+}
 int ef_debug_clocks(ef_ctx* c, unsigned long long* out16) {
   if (!c || !out16) return EF_EINVAL;
   eft::TrackState h;

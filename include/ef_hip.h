@@ -92,6 +92,8 @@ int ef_get_tick(ef_ctx* ctx, int* tick);                      /* getTick() */
 int ef_set_tick(ef_ctx* ctx, int tick);                       /* setTick() */
 /* lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count (RGBDOdometry.h:74-79) */
 int ef_get_tracking_stats(ef_ctx* ctx, float* out6, double* lastA36_or_null, double* lastb6_or_null);
+/* RGBDOdometry::getCovariance (RGBDOdometry.cpp:573-575): lastA.lu().inverse(), 36 doubles row-major; synchronises */
+int ef_get_covariance(ef_ctx* ctx, double* cov36);
 int ef_get_trajectory(ef_ctx* ctx, double* T_wc16_array, int64_t* timestamps, int max_frames, int* n_frames);
 int ef_map_count(ef_ctx* ctx, uint32_t* count);               /* GlobalModel::lastCount(); synchronises */
 int ef_map_download(ef_ctx* ctx, float* surfels, uint32_t max_surfels, uint32_t* count); /* downloadMap(), 12 floats each */

@@ -55,6 +55,7 @@ void efo_rodrigues(const double* v3, double* R9);
 void efo_se3_inverse(const double* T16, double* out16);
 double efo_se3_log_norm(const double* T16, double* out6);
 float efo_expf_spec(float x);
+void efo_covariance(const double* lastA36, double* cov36);   /* getCovariance: PartialPivLU inverse of lastA */
 
 /* ---- pre-processing + surfel map (Core/Shaders GLSL passes, IndexMap.cpp, GlobalModel.cpp) ---- */
 void efo_filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered);

@@ -196,5 +196,7 @@ void efo_rodrigues(const double* v, double* R) { M3d r = rodrigues(V3d{{v[0], v[
 void efo_se3_inverse(const double* T, double* out) { M4d m = se3_matrix(se3_inverse(se3_from_matrix(T))); std::memcpy(out, m.m, sizeof(m.m)); }
 double efo_se3_log_norm(const double* T, double* out6) { return se3_log_norm(se3_from_matrix(T), out6); }
 float efo_expf_spec(float x) { return efo_expf(x); }
+// RGBDOdometry::getCovariance (RGBDOdometry.cpp:573-575): lastA.cast<double>().lu().inverse()
+void efo_covariance(const double* lastA36, double* cov36) { lu_inverse<double, 6>(lastA36, cov36); }
 
 }  // extern "C"

@@ -370,4 +370,44 @@ inline double se3_log_norm(const SE3& T, double* out6 = nullptr) {
   return std::sqrt(up[0] * up[0] + up[1] * up[1] + up[2] * up[2] + om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
 }
 
+
+// Eigen::PartialPivLU<Matrix<double,6,6>>::inverse() as RGBDOdometry::getCovariance uses it (RGBDOdometry.cpp:573-575):
+// row-pivoted Doolittle LU (pivot = largest |entry| of the column at or below the diagonal, first one on ties), then
+// the inverse column by column from P, L (unit lower) and U by forward / back substitution.
+template <typename T, int N>
+inline void lu_inverse(const T* A_in, T* inv) {
+  T lu[N * N];
+  int perm[N];
+  for (int i = 0; i < N * N; ++i) lu[i] = A_in[i];
+  for (int i = 0; i < N; ++i) perm[i] = i;
+  for (int k = 0; k < N; ++k) {
+    int piv = k;
+    T best = lu[k * N + k] < 0 ? -lu[k * N + k] : lu[k * N + k];
+    for (int r = k + 1; r < N; ++r) {
+      const T a = lu[r * N + k] < 0 ? -lu[r * N + k] : lu[r * N + k];
+      if (a > best) { best = a; piv = r; }
+    }
+    if (piv != k) {
+      for (int c = 0; c < N; ++c) { const T tmp = lu[k * N + c]; lu[k * N + c] = lu[piv * N + c]; lu[piv * N + c] = tmp; }
+      const int ti = perm[k]; perm[k] = perm[piv]; perm[piv] = ti;
+    }
+    for (int r = k + 1; r < N; ++r) {
+      lu[r * N + k] = lu[r * N + k] / lu[k * N + k];
+      for (int c = k + 1; c < N; ++c) lu[r * N + c] = lu[r * N + c] - lu[r * N + k] * lu[k * N + c];
+    }
+  }
+  for (int col = 0; col < N; ++col) {
+    T y[N];
+    for (int r = 0; r < N; ++r) {        // L y = P e_col
+      T v = perm[r] == col ? T(1) : T(0);
+      for (int c = 0; c < r; ++c) v = v - lu[r * N + c] * y[c];
+      y[r] = v;
+    }
+    for (int r = N - 1; r >= 0; --r) {   // U x = y
+      T v = y[r];
+      for (int c = r + 1; c < N; ++c) v = v - lu[r * N + c] * inv[c * N + col];
+      inv[r * N + col] = v / lu[r * N + r];
+    }
+  }
+}
 }  // namespace efo

@@ -121,6 +121,12 @@ def lib():
     return _LIB
 
 
+def covariance(lastA):
+    c = np.zeros(36, np.float64)
+    lib().efo_covariance(ptr(np.ascontiguousarray(lastA, np.float64).reshape(36)), ptr(c))
+    return c.reshape(6, 6)
+
+
 def set_threads(n: int):
     """host threads for the parallel loops of the oracle (cpu_baseline "all cores" leg); results do not depend on it"""
     lib().efo_set_threads(c_i(int(n)))

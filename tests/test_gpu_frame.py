@@ -66,6 +66,8 @@ def test_tracking_and_fusion_sequence(hip, seq):
         so = o.stats()
         if k > 0:
             assert np.array_equal(np.asarray(st, np.float32).view(np.uint32), np.asarray(so, np.float32).view(np.uint32)), (k, st, so)
+        if k > 0:   # T18 getCovariance: the same LU inverse of the same lastA => the same bits
+            assert np.array_equal(ef.getCovariance(), efo.covariance(o.odometry().stats()[1])), k
         dt, da = pose_err(ef.get_T_wc(), o.pose())
         assert dt <= 1e-4 and da <= 1e-4, (k, dt, da)
         # the double-precision pose may differ in its last bits (libm sin/cos/atan2, test_gpu_ops_linalg.py); what the

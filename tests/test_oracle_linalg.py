@@ -93,3 +93,17 @@ def test_expf_spec_accuracy():
     assert np.max(np.abs(got - ref) / ref) < 2.5e-7   # ~2 ulp
     assert efo.lib().efo_expf_spec(C.c_float(-100.0)) == 0.0
     assert efo.lib().efo_expf_spec(C.c_float(0.0)) == 1.0
+
+
+def test_covariance_is_the_partial_pivot_lu_inverse():
+    """RGBDOdometry::getCovariance = lastA.lu().inverse() (RGBDOdometry.cpp:573-575): known-answer against numpy on SPD
+    normal matrices of the size and conditioning the tracker produces, and on a matrix that needs row pivoting."""
+    rng = np.random.RandomState(3)
+    for _ in range(20):
+        J = rng.randn(200, 6) * np.array([1, 1, 1, 0.3, 0.3, 0.3])
+        A = J.T @ J
+        C = efo.covariance(A)
+        assert np.allclose(C @ A, np.eye(6), atol=1e-9)
+        assert np.allclose(C, np.linalg.inv(A), rtol=1e-8, atol=1e-12)
+    P = np.eye(6)[[3, 0, 5, 1, 4, 2]] + 1e-3 * rng.randn(6, 6)
+    assert np.allclose(efo.covariance(P) @ P, np.eye(6), atol=1e-10)
