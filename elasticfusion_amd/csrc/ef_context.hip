@@ -138,11 +138,14 @@ int dev_alloc(ef_ctx* c, T** p, size_t n, int fill = 0) {
   } while (0)
 
 // scalar per-frame bookkeeping kernels -----------------------------------------------------------
-__global__ void k_init_state(eft::TrackState* st, int dense_samples) {
+__global__ void k_init_state(eft::TrackState* st, int dense_samples, int pixels) {
   if (threadIdx.x != 0) return;
   st->dense_count = 0;
   st->dense_samples = dense_samples;
   st->map_counts[0] = st->map_counts[1] = 0;
+  // RGBDOdometry's constructor (RGBDOdometry.cpp:31-36): errors 0, counts width * height until a step overwrites them
+  st->lastICPError = st->lastRGBError = st->lastSO3Error = 0.f;
+  st->lastICPCount = st->lastRGBCount = st->lastSO3Count = (float)pixels;
 }
 // API boundary: the frame tier's column-major index maps are handed out in the reference's row-major order
 template <typename T>
@@ -421,7 +424,7 @@ int ctx_init(ef_ctx* c) {
   c->traj_cap = 1 << 16;
   EF_ALLOC(c, c->traj, (size_t)c->traj_cap * 16);
   // T_wc = identity (ElasticFusion.h: T_wc_curr default) -> publish the float matrices
-  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->st, (W / 20) * (H / 20));
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->st, (W / 20) * (H / 20), W * H);
   const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   eft::pose_injected(c->st, I16, false, 1.0f, false, nullptr, 0, s);
   eft::pose_injected(c->st, I16, true, 1.0f, false, nullptr, 0, s);   // previous pose = identity too

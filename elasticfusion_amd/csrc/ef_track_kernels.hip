@@ -1277,6 +1277,11 @@ __device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sum
     if (icp) {
       st->lastICPError = sqrtf(sums[27]) / sums[28];
       st->lastICPCount = sums[28];
+    } else {
+      // RGBDOdometry.cpp:492-493 evaluates sqrt(residual[0]) / residual[1] on an UNINITIALISED residual[] when the ICP term is
+      // off; the specification (oracle) zero-initialises it: NaN error, zero count
+      st->lastICPError = __int_as_float(0x7fc00000);
+      st->lastICPCount = 0.f;
     }
   }
   EF_STAMP(st, 3);

@@ -114,6 +114,61 @@ def test_pipelined_frames_match_oracle(hip, seq):
         assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
 
 
+VARIANTS = {
+    "fastOdom": (dict(fastOdom=True), dict(fastOdom=1), None),
+    "no_so3": (dict(so3=False), dict(so3=0), None),
+    "no_pyramid": (dict(), dict(pyramid=0), lambda ef: ef.setPyramid(False)),
+    "icp_only": (dict(icpThresh=100.0), dict(icpWeight=100.0), None),
+    "rgb_only": (dict(), dict(rgbOnly=1), lambda ef: ef.setRgbOnly(True)),
+    "frame_to_frame_rgb": (dict(frameToFrameRGB=True), dict(frameToFrameRGB=1), None),
+    "low_icp_weight": (dict(icpThresh=2.5), dict(icpWeight=2.5), None),
+    "depth_cut_2m": (dict(depthCut=2.0), dict(depthCut=2.0), None),
+    "low_confidence_time_window": (dict(confidence=2.0, timeDelta=3), dict(confidence=2.0, timeDelta=3), None),
+}
+WEIGHTS = {"depth_cut_2m": 0.5}   # processFrame's weightMultiplier (ElasticFusion.h:70-75)
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_tracker_configurations_match_oracle(hip, seq, name):
+    """Every tracker knob of the reference's front-end (MainController flags -fo / -nso / -ftf / -i, setPyramid, setRgbOnly:
+    Core/ElasticFusion.h:135-183): 6 free-running frames, tracker statistics, float pose and the whole map identical to the
+    oracle run with the same knob (the rgbOnly variant exercises the per-level "break" bookkeeping)."""
+    hip_kw, oracle_kw, setter = VARIANTS[name]
+    ef = hip.ElasticFusion(**hip_kw)
+    if setter:
+        setter(ef)
+    o = efo.Fusion(**oracle_kw)
+    for k in range(6):
+        rgb, depth, _ = seq.frame(k)
+        wm = WEIGHTS.get(name, 1.0)
+        ef.processFrame(rgb, depth, k * 33333, weightMultiplier=wm)
+        o.process_frame(rgb, depth, k * 33333, weight=wm)
+        if k > 0:
+            st, _, _ = ef.trackingStats()
+            a, b = np.asarray(st, np.float32), np.asarray(o.stats(), np.float32)
+            nan = np.isnan(b)   # lastICPError with the ICP term off: sqrt(0)/0 (the NaN's sign bit differs between x86 and the GPU)
+            assert np.array_equal(np.isnan(a), nan) and np.array_equal(a[~nan].view(np.uint32), b[~nan].view(np.uint32)), (name, k, st, o.stats())
+        assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32)), (name, k)
+        assert ef.lastCount() == o.map_count(), (name, k)
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32)), name
+    ef.close()
+
+
+def test_noisy_depth_sequence_matches_oracle(hip):
+    """sensor-like depth noise (sigma 1.2 mm x z^2): holes, gate rejections and unstable surfels get exercised"""
+    from elasticfusion_amd import synth
+    s = synth.Sequence(0xEF0005, noise=True)
+    ef, o = hip.ElasticFusion(), efo.Fusion()
+    for k in range(8):
+        rgb, depth, _ = s.frame(k)
+        ef.processFrame(rgb, depth, k * 33333)
+        o.process_frame(rgb, depth, k * 33333)
+        assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32)), k
+        assert ef.lastCount() == o.map_count(), k
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    ef.close()
+
+
 def test_device_resident_frames_match_oracle(hip, seq):
     """ef_process_frame_dev (frames already in HBM, the bench path): the copies are folded into the first kernels that read
     the frame.  Same trajectory and map as the oracle, bit for bit, and the caller's buffers may be reused right after a
