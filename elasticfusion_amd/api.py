@@ -134,13 +134,23 @@ def default_config(**kw) -> ef_config:
     return cfg
 
 
+class LocalLoop(C.Structure):   # ef_local_loop
+    _fields_ = [("attempted", c_i), ("cov_ok", c_i), ("gates_ok", c_i), ("n_constraints", c_i), ("applied", c_i),
+                ("graph_nodes", c_i), ("stats", c_f * 6), ("cov_diag", C.c_double * 6), ("T_wc_curr", C.c_double * 16),
+                ("T_wc_est", C.c_double * 16)]
+
+
+LOOP_SOLVER = C.CFUNCTYPE(c_i, C.c_void_p, C.POINTER(LocalLoop), C.POINTER(C.c_double), c_i, C.POINTER(c_f), C.POINTER(c_i))
+
+
 class ElasticFusion:
     """Mirror of ``class ElasticFusion`` (Core/ElasticFusion.h) over the C ABI."""
 
     IMAGES = dict(depth_filtered=(0, np.uint16, 1), depth_metric=(1, np.float32, 1), depth_metric_filtered=(2, np.float32, 1),
                   image=(3, np.uint8, 4), vertex=(4, np.float32, 4), normal=(5, np.float32, 4), time=(6, np.uint16, 1),
                   fill_image=(7, np.uint8, 4), fill_vertex=(8, np.float32, 4), fill_normal=(9, np.float32, 4),
-                  index=(10, np.uint32, 1), vertConf=(11, np.float32, 4), colorTime=(12, np.float32, 4), normRad=(13, np.float32, 4))
+                  index=(10, np.uint32, 1), vertConf=(11, np.float32, 4), colorTime=(12, np.float32, 4), normRad=(13, np.float32, 4),
+                  old_image=(14, np.uint8, 4), old_vertex=(15, np.float32, 4), old_normal=(16, np.float32, 4), old_time=(17, np.uint16, 1))
     TRACKER = dict(vmap_curr=(0, np.float32, 3), nmap_curr=(1, np.float32, 3), vmap_g_prev=(2, np.float32, 3),
                    nmap_g_prev=(3, np.float32, 3), lastDepth=(4, np.float32, 1), nextDepth=(5, np.float32, 1),
                    lastImage=(6, np.uint8, 1), nextImage=(7, np.uint8, 1), lastNextImage=(8, np.uint8, 1),
@@ -148,7 +158,8 @@ class ElasticFusion:
 
     def __init__(self, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, timeDelta=2147483647 // 2,
                  confidence=10.0, depthCut=3.0, icpThresh=10.0, fastOdom=False, so3=True, frameToFrameRGB=False,
-                 closeLoops=False, maxSurfels=4 * 1024 * 1024, device=0, stream=None):
+                 closeLoops=False, maxSurfels=4 * 1024 * 1024, device=0, stream=None, countThresh=35000, errThresh=5e-05,
+                 covThresh=1e-05):
         cfg = default_config(width=width, height=height, fx=fx, fy=fy, cx=cx, cy=cy, time_delta=timeDelta,
                              confidence=confidence, depth_cut=depthCut, icp_weight=icpThresh, fast_odom=int(fastOdom),
                              so3=int(so3), frame_to_frame_rgb=int(frameToFrameRGB), close_loops=int(closeLoops),
@@ -156,6 +167,9 @@ class ElasticFusion:
         self.cfg = cfg
         self.h = P()
         _chk(lib().ef_create(C.byref(cfg), C.byref(self.h)))
+        self._solver = None
+        if closeLoops:
+            _chk(lib().ef_set_loop_thresholds(self.h, c_i(countThresh), c_f(errThresh), c_f(covThresh)), self.h)
 
     def close(self):
         if getattr(self, "h", None):
@@ -178,6 +192,35 @@ class ElasticFusion:
         T = None if in_T_wc is None else np.ascontiguousarray(in_T_wc, np.float64).reshape(16)
         _chk(lib().ef_process_frame_dev(self.h, P(int(rgb_dev)), P(int(depth_dev)), C.c_int64(timestamp), c_f(weightMultiplier),
                                         _ptr(T) if T is not None else None), self.h)
+
+    # --- local loop closure, front half (ElasticFusion.cpp:447-527; closeLoops=True contexts) ---
+    def setLoopSolver(self, fn):
+        """fn(info: LocalLoop, constraints [n, 8] float64) -> None (reject) | graph [nodes, 16] float32 (accept).
+        Stands where Deformation::constrain stands in the reference; called inside processFrame."""
+        if fn is None:
+            self._solver = None
+            _chk(lib().ef_set_loop_solver(self.h, None, None), self.h)
+            return
+
+        def tramp(user, info, cons, n, graph_out, nodes_out):
+            c = np.ctypeslib.as_array(cons, shape=(n, 8)).copy() if n > 0 else np.zeros((0, 8))
+            g = fn(info.contents, c)
+            if g is None:
+                return 0
+            g = np.ascontiguousarray(g, np.float32).reshape(-1, 16)
+            C.memmove(graph_out, g.ctypes.data, g.nbytes)
+            nodes_out[0] = len(g)
+            return 1
+        self._solver = LOOP_SOLVER(tramp)
+        _chk(lib().ef_set_loop_solver(self.h, self._solver, None), self.h)
+
+    def localLoop(self):
+        """(info, constraints [n, 8]) of the last processFrame."""
+        info = LocalLoop()
+        cons = np.zeros((4096, 8), np.float64)
+        n = c_i(0)
+        _chk(lib().ef_get_local_loop(self.h, C.byref(info), _ptr(cons), c_i(len(cons)), C.byref(n)), self.h)
+        return info, cons[:n.value].copy()
 
     def predict(self):
         _chk(lib().ef_predict(self.h), self.h)

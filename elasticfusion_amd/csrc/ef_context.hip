@@ -88,6 +88,22 @@ struct ef_ctx {
   float* graph_dev = nullptr;
   int graph_nodes = 0, graph_is_fern = 0;
   float* synth_depth = nullptr;
+  // local loop closure, front half (ElasticFusion.cpp:447-527): a second tracker instance registers the view of the INACTIVE
+  // part of the model against the ACTIVE one; buffers exist only when cfg.close_loops is set
+  int icp_count_thresh = 35000;            // ElasticFusion.h:44-46
+  float icp_err_thresh = 5e-05f, cov_thresh = 1e-05f;
+  int deforms = 0;
+  eft::Pyramid pyr2{};                     // RGBDOdometry modelToModel (ElasticFusion.h:280)
+  eft::TrackState* st2 = nullptr;
+  efm::PredictMaps old{};                  // IndexMap's oldImage/oldVertex/oldNormal/oldTime textures (IndexMap.h:114-128)
+  float* cons_dev = nullptr;               // (W/20) x (H/20) x {x, y, z, inactive time}
+  float* h_cons = nullptr;                 // pinned
+  eft::TrackState* h_states = nullptr;     // pinned: [0] frame-to-model, [1] model-to-model
+  ef_loop_solver solver = nullptr;
+  void* solver_user = nullptr;
+  ef_local_loop loop{};
+  std::vector<double> loop_constraints;    // n x 8
+  std::vector<float> loop_graph;
   // hipGraph replay of the tracker (BASELINE.json configs[4]): the ~70 launches of getIncrementalTransformation are
   // captured once per pyramid parity (the SO(3) reference / frame intensity buffers swap every frame) and replayed
   bool use_graph = false;
@@ -180,6 +196,98 @@ int do_predict(ef_ctx* c) {
   efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick,
                         c->cfg.time_delta, c->zbuf, c->pm, c->fm, c->depth_filtered, c->rgb, c->cfg.frame_to_frame_rgb != 0,
                         &c->st->dense_count, c->stream);
+  return EF_OK;
+}
+
+// ElasticFusion.cpp:447-527 (the fern branch :391-444 and Deformation::constrain itself are out of scope: the optimisation is
+// the registered solver's).  Synchronises once, where the reference reads the constraint buffers back (Resize.cpp:108,146).
+int local_loop_closure(ef_ctx* c, int log_slot) {
+  hipStream_t s = c->stream;
+  const int W = c->cam.cols, H = c->cam.rows, step = 20 /* consSample, ElasticFusion.cpp:62 */;
+  const int cw = W / step, ch = H / step;
+  const efm::FillMaps none{nullptr, nullptr, nullptr};
+  const unsigned* count = &c->st->map_counts[c->cur];
+  // predict() of :387: the ACTIVE view at the pose just estimated (its fill-in only feeds the fern database: skipped)
+  efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], count, c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick, c->cfg.time_delta,
+                        c->zbuf, c->pm, none, nullptr, nullptr, false, nullptr, s);
+  // :451-459, IndexMap::INACTIVE: surfels last seen at or before tick - timeDelta
+  efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], count, c->maxDepthProcessed, c->cfg.confidence, 0, c->tick - c->cfg.time_delta,
+                        c->cfg.time_delta, c->zbuf, c->old, none, nullptr, nullptr, false, nullptr, s);
+  eft::copy_pose(c->st2, c->st, s);                                                              // :469
+  const float maxDepthRGB = 6.0f;                                                                // RGBDOdometry.cpp:42
+  eft::init_icp_model(c->pyr2, (const float*)c->old.vertex, (const float*)c->old.normal, (const float*)c->old.vertex,
+                      (const float*)c->old.normal, c->st2, maxDepthRGB, s);                      // :463
+  eft::init_rgb_model(c->pyr2, (const uint8_t*)c->old.image, (const uint8_t*)c->old.image, false, c->st2, s);   // :464
+  eft::init_icp_maps(c->pyr2, (const float*)c->pm.vertex, (const float*)c->pm.normal, (const uint8_t*)c->pm.image, c->st2, maxDepthRGB, s);  // :466-467
+  eft::init_rgb_sobel(c->pyr2, s);
+  eft::TrackParams tp;
+  tp.rgbOnly = false; tp.pyramid = c->cfg.pyramid != 0; tp.fastOdom = c->cfg.fast_odom != 0; tp.so3 = false; tp.icpWeight = 10.f;   // :471
+  tp.distThres = 0.10f;
+  tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
+  eft::track(c->pyr2, c->st2, c->intr, tp, s, nullptr);
+  eft::track_end(c->st2, true, 1.0f, nullptr, -1, s);
+  eft::sample_constraints((const float*)c->pm.vertex, c->old.time, W, H, step, c->cons_dev, s);  // :485-486
+  EF_HIP(c, hipMemcpyAsync(&c->h_states[0], c->st, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
+  EF_HIP(c, hipMemcpyAsync(&c->h_states[1], c->st2, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
+  EF_HIP(c, hipMemcpyAsync(c->h_cons, c->cons_dev, (size_t)cw * ch * 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+  EF_HIP(c, hipStreamSynchronize(s));
+  ef_local_loop& L = c->loop;
+  memset(&L, 0, sizeof(L));
+  c->loop_constraints.clear();
+  L.attempted = 1;
+  const eft::TrackState& hc = c->h_states[0];
+  const eft::TrackState& he = c->h_states[1];
+  efl::SE3 Tc, Te;
+  for (int i = 0; i < 4; ++i) { Tc.q[i] = hc.q[i]; Te.q[i] = he.q[i]; }
+  for (int i = 0; i < 3; ++i) { Tc.t[i] = hc.t[i]; Te.t[i] = he.t[i]; }
+  efl::se3_matrix(Tc, L.T_wc_curr);
+  efl::se3_matrix(Te, L.T_wc_est);
+  L.stats[0] = he.lastICPError; L.stats[1] = he.lastICPCount; L.stats[2] = he.lastRGBError;
+  L.stats[3] = he.lastRGBCount; L.stats[4] = he.lastSO3Error; L.stats[5] = he.lastSO3Count;
+  double cov[36];
+  efl::lu_inverse<double, 6>(he.lastA, cov);                                                     // :473, getCovariance
+  bool covOk = true;
+  for (int i = 0; i < 6; ++i) {
+    L.cov_diag[i] = cov[i * 6 + i];
+    if (cov[i * 6 + i] > (double)c->cov_thresh) { covOk = false; break; }
+  }
+  L.cov_ok = covOk;
+  L.gates_ok = covOk && he.lastICPCount > (float)c->icp_count_thresh && he.lastICPError < c->icp_err_thresh;   // :483-484
+  if (!L.gates_ok) return EF_OK;
+  const double* M = L.T_wc_curr;
+  const double* E = L.T_wc_est;
+  for (int i = 0; i < cw; ++i)
+    for (int j = 0; j < ch; ++j) {
+      const float* v = c->h_cons + (size_t)(i * ch + j) * 4;
+      const unsigned tm = (unsigned)v[3];
+      if (v[2] > 0 && v[2] < c->maxDepthProcessed && tm > 0) {                                     // :490-492
+        double row[8];
+        for (int r = 0; r < 3; ++r) {   // T * Vector4d(x, y, z, 1), a 4x4 matrix product evaluated left to right
+          row[r] = ((M[r * 4] * (double)v[0] + M[r * 4 + 1] * (double)v[1]) + M[r * 4 + 2] * (double)v[2]) + M[r * 4 + 3] * 1.0;
+          row[3 + r] = ((E[r * 4] * (double)v[0] + E[r * 4 + 1] * (double)v[1]) + E[r * 4 + 2] * (double)v[2]) + E[r * 4 + 3] * 1.0;
+        }
+        row[6] = (double)tm;
+        row[7] = c->deforms == 0 ? 1.0 : 0.0;                                                      // :507-508 pinConstraints
+        c->loop_constraints.insert(c->loop_constraints.end(), row, row + 8);
+      }
+    }
+  L.n_constraints = (int)(c->loop_constraints.size() / 8);
+  if (!c->solver) return EF_OK;
+  c->loop_graph.assign((size_t)1024 * 16, 0.f);
+  int nodes = 0;
+  if (c->solver(c->solver_user, &L, c->loop_constraints.data(), L.n_constraints, c->loop_graph.data(), &nodes)) {   // :513-514
+    if (nodes < 0 || nodes >= 1024) { c->err = "loop solver: 0..1023 graph nodes (GlobalModel::MAX_NODES)"; return EF_EINVAL; }
+    L.applied = 1;
+    L.graph_nodes = nodes;
+    c->deforms += nodes > 0;                                                                       // :523
+    eft::adopt_pose(c->st, c->st2, log_slot >= 0 ? c->traj : nullptr, log_slot, s);                // :525
+    if (nodes > 0) {
+      EF_HIP(c, hipMemcpyAsync(c->graph_dev, c->loop_graph.data(), (size_t)nodes * 16 * sizeof(float), hipMemcpyHostToDevice, s));
+      EF_HIP(c, hipStreamSynchronize(s));
+    }
+    c->graph_nodes = nodes;
+    c->graph_is_fern = 0;
+  }
   return EF_OK;
 }
 
@@ -296,6 +404,12 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
     // from here on nothing of this frame reads the frame-side pyramids: the next frame's input stage may start
     EF_HIP(c, hipEventRecord(c->ev_track_done, s));
     // mid-frame predict() of ElasticFusion.cpp:387 is dead work without loop closure: skipped
+    if (c->cfg.close_loops) {
+      timer_begin(c, "localLoop");
+      const int r = local_loop_closure(c, log_slot);
+      timer_end(c, "localLoop");
+      if (r != EF_OK) return r;
+    }
     if (!rgbOnly) {  // ElasticFusion.cpp:536-585
       timer_begin(c, "indexMap");
       const bool sample_splat = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0 && c->probe_splat.start;
@@ -376,6 +490,7 @@ int ctx_init(ef_ctx* c) {
     EF_ALLOC(c, c->pyr.vmap_g_prev[i], 3 * n);
     EF_ALLOC(c, c->pyr.nmap_g_prev[i], 3 * n);
     EF_ALLOC(c, c->pyr.lastDepth[i], n);
+    c->pyr.nextDepth[i] = c->pyr.lastDepth[i];   // quirk Q1
     EF_ALLOC(c, c->pyr.lastImage[i], n);
     EF_ALLOC(c, c->pyr.nextImage[i], n);
     EF_ALLOC(c, c->pyr.lastNextImage[i], n);
@@ -421,6 +536,37 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->cs.chunk_count, c->cs.max_chunks);
   EF_ALLOC(c, c->cs.chunk_offset, c->cs.max_chunks);
   EF_ALLOC(c, c->cs.totals, 8);
+  if (g.close_loops) {
+    c->pyr2.width = W;
+    c->pyr2.height = H;
+    for (int i = 0; i < eft::NUM_PYRS; ++i) {
+      const size_t n = (size_t)(W >> i) * (H >> i);
+      EF_ALLOC(c, c->pyr2.depth_tmp[i], n);
+      EF_ALLOC(c, c->pyr2.vmap_curr[i], 3 * n);
+      EF_ALLOC(c, c->pyr2.nmap_curr[i], 3 * n);
+      EF_ALLOC(c, c->pyr2.vmap_g_prev[i], 3 * n);
+      EF_ALLOC(c, c->pyr2.nmap_g_prev[i], 3 * n);
+      EF_ALLOC(c, c->pyr2.lastDepth[i], n);
+      EF_ALLOC(c, c->pyr2.nextDepth[i], n);
+      EF_ALLOC(c, c->pyr2.lastImage[i], n);
+      EF_ALLOC(c, c->pyr2.nextImage[i], n);
+      EF_ALLOC(c, c->pyr2.lastNextImage[i], n);
+      EF_ALLOC(c, c->pyr2.dIdx[i], n);
+      EF_ALLOC(c, c->pyr2.dIdy[i], n);
+      EF_ALLOC(c, c->pyr2.corres[i], n);
+      EF_ALLOC(c, c->pyr2.rgbMask[i], n);
+    }
+    EF_ALLOC(c, c->pyr2.partials, (size_t)eft::PARTIAL_FLOATS);
+    EF_ALLOC(c, c->st2, 1);
+    EF_ALLOC(c, c->old.image, P);
+    EF_ALLOC(c, c->old.vertex, P);
+    EF_ALLOC(c, c->old.normal, P);
+    EF_ALLOC(c, c->old.time, P);
+    EF_ALLOC(c, c->cons_dev, (size_t)(W / 20) * (H / 20) * 4 + 4);
+    EF_HIP(c, hipHostMalloc((void**)&c->h_cons, ((size_t)(W / 20) * (H / 20) * 4 + 4) * sizeof(float)));
+    EF_HIP(c, hipHostMalloc((void**)&c->h_states, 2 * sizeof(eft::TrackState)));
+    hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->st2, (W / 20) * (H / 20), W * H);
+  }
   c->traj_cap = 1 << 16;
   EF_ALLOC(c, c->traj, (size_t)c->traj_cap * 16);
   // T_wc = identity (ElasticFusion.h: T_wc_curr default) -> publish the float matrices
@@ -441,6 +587,8 @@ void ctx_free(ef_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->h_rgb) (void)hipHostFree(c->h_rgb);
   if (c->h_depth) (void)hipHostFree(c->h_depth);
+  if (c->h_cons) (void)hipHostFree(c->h_cons);
+  if (c->h_states) (void)hipHostFree(c->h_states);
   for (auto& t : c->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : c->kt_start) (void)hipEventDestroy(e);
   for (auto e : c->kt_stop) (void)hipEventDestroy(e);
@@ -479,7 +627,6 @@ int ef_create(const ef_config* cfg, ef_ctx** out) {
     g_create_error = "width/height must be positive multiples of 4 and focal lengths positive";
     return EF_EINVAL;
   }
-  if (cfg->close_loops) { g_create_error = "close_loops=1: loop closure is out of scope of this engine (SURVEY.md §8f)"; return EF_EINVAL; }
   if ((size_t)cfg->max_surfels < (size_t)cfg->width * cfg->height) { g_create_error = "max_surfels must be >= width*height"; return EF_EINVAL; }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -546,6 +693,26 @@ int ef_set_deformation(ef_ctx* c, const float* graph, int nodes, int is_fern) {
   if (nodes > 0) EF_HIP(c, hipStreamSynchronize(c->stream));   // the caller's buffer is borrowed for the call only
   c->graph_nodes = nodes;
   c->graph_is_fern = is_fern != 0;
+  return EF_OK;
+}
+int ef_set_loop_thresholds(ef_ctx* c, int icp_count_thresh, float icp_err_thresh, float cov_thresh) {
+  if (!c) return EF_EINVAL;
+  c->icp_count_thresh = icp_count_thresh; c->icp_err_thresh = icp_err_thresh; c->cov_thresh = cov_thresh;
+  return EF_OK;
+}
+int ef_set_loop_solver(ef_ctx* c, ef_loop_solver fn, void* user) {
+  if (!c) return EF_EINVAL;
+  if (!c->cfg.close_loops) { c->err = "ef_set_loop_solver: the context was created with close_loops = 0"; return EF_ESTATE; }
+  c->solver = fn; c->solver_user = user;
+  return EF_OK;
+}
+int ef_get_local_loop(ef_ctx* c, ef_local_loop* info, double* constraints, int max_constraints, int* n_out) {
+  if (!c || !info) return EF_EINVAL;
+  *info = c->loop;
+  int n = c->loop.n_constraints < max_constraints ? c->loop.n_constraints : max_constraints;
+  if (!constraints) n = 0;
+  if (n > 0) memcpy(constraints, c->loop_constraints.data(), (size_t)n * 8 * sizeof(double));
+  if (n_out) *n_out = n;
   return EF_OK;
 }
 int ef_set_graph_replay(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->use_graph = on != 0; return EF_OK; }
@@ -722,8 +889,13 @@ int ef_get_image(ef_ctx* c, int which, void* dst, size_t bytes) {
     case EF_IMG_VERT_CONF: src = c->im.vert_conf; need = P * 16; break;
     case EF_IMG_COLOR_TIME: src = c->im.color_time; need = P * 16; break;
     case EF_IMG_NORM_RAD: src = c->im.norm_rad; need = P * 16; break;
+    case EF_IMG_OLD_IMAGE: src = c->old.image; need = P * 4; break;
+    case EF_IMG_OLD_VERTEX: src = c->old.vertex; need = P * 16; break;
+    case EF_IMG_OLD_NORMAL: src = c->old.normal; need = P * 16; break;
+    case EF_IMG_OLD_TIME: src = c->old.time; need = P * 2; break;
     default: c->err = "ef_get_image: unknown image"; return EF_EINVAL;
   }
+  if (!src) { c->err = "ef_get_image: this image only exists in a close_loops context"; return EF_ESTATE; }
   if (bytes < need) { c->err = "ef_get_image: destination too small"; return EF_EINVAL; }
   void* tmp = nullptr;
   if (c->im.colmajor && which >= EF_IMG_INDEX && which <= EF_IMG_NORM_RAD) {

@@ -84,7 +84,8 @@ struct Pyramid {               // one RGBDOdometry instance's device buffers (RG
   float* nmap_curr[NUM_PYRS];
   float* vmap_g_prev[NUM_PYRS];
   float* nmap_g_prev[NUM_PYRS];
-  float* lastDepth[NUM_PYRS];      // == nextDepth in frame-to-model tracking (quirk Q1): one buffer
+  float* lastDepth[NUM_PYRS];
+  float* nextDepth[NUM_PYRS];      // frame-to-model tracking: the SAME buffers as lastDepth (quirk Q1); model-to-model: its own
   uint8_t* lastImage[NUM_PYRS];
   uint8_t* nextImage[NUM_PYRS];
   uint8_t* lastNextImage[NUM_PYRS];
@@ -167,6 +168,10 @@ void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pre
 void init_rgb_model(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* fill_image_rgba, bool frameToFrameRGB,
                     const TrackState* st, hipStream_t s);
 void init_rgb_frame(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
+// initICP(predictedVertices, predictedNormals) + initRGB(predictedImage), RGBDOdometry.cpp:149-169,241-244: the "current" side of
+// model-to-model tracking from a model prediction (camera-frame maps, nextDepth from the same vertices, intensity of the image)
+void init_icp_maps(const Pyramid& p, const float* vertex4, const float* normal4, const uint8_t* image_rgba, const TrackState* st,
+                   float maxDepthRGB, hipStream_t s);
 void init_rgb_sobel(const Pyramid& p, hipStream_t s);
 // init_icp + init_rgb_model + init_rgb_frame in three launches (single-stream frame script; needs init_icp_model first)
 void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, const uint8_t* pred_image_rgba,
@@ -186,5 +191,10 @@ void track_end(TrackState* st, bool rgb, float weightMultiplier, double* traj, i
 void pose_injected(TrackState* st, const double* T_wc16, bool save_prev, float weightMultiplier, bool with_weighting, double* traj,
                    int slot, hipStream_t s);
 void log_pose(const TrackState* st, double* traj, int slot, hipStream_t s);
+// local loop closure plumbing (ElasticFusion.cpp:469-527): T_wc_est := T_wc_curr before the model-to-model tracker runs;
+// T_wc_curr := T_wc_est after an accepted deformation; the (W/20)x(H/20) constraint samples {x, y, z, inactive time}
+void copy_pose(TrackState* dst, const TrackState* src, hipStream_t s);
+void adopt_pose(TrackState* st, const TrackState* est, double* traj, int slot, hipStream_t s);
+void sample_constraints(const float* vertex4, const uint16_t* old_time, int cols, int rows, int step, float* out4, hipStream_t s);
 
 }  // namespace eft

@@ -399,6 +399,7 @@ struct ModelMapsArgs {
   float* depth0;
   int cols, rows;
   float maxDepthRGB;
+  bool camera_frame;   // initICP(predictedVertices, predictedNormals): copyMaps + resize only, no tranformMaps
 };
 // ALL_PLANES: level 0 (copyMaps NaNs x, y and z of an empty texel); the resized levels only get the
 // x-plane NaN that resizeMapKernel / tranformMapsKernel write (quirk Q3: y/z planes keep stale data).
@@ -425,6 +426,7 @@ __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const
   const float4* __restrict__ nsrc = fill ? A.fill_normal : A.pred_normal;
   const m33 R = m33_load(st->R_wc_f);
   const f3 t{st->t_wc_f[0], st->t_wc_f[1], st->t_wc_f[2]};
+  const bool cf = A.camera_frame;
   const int c1 = cols / 2, r1 = rows / 2, c2 = cols / 4, r2 = rows / 4;
   f3 v1[2][2], n1[2][2];
   bool v1ok[2][2], n1ok[2][2];
@@ -448,8 +450,13 @@ __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const
           A.depth0[y * cols + x] = (vs.z > A.maxDepthRGB || vs.z <= 0) ? qnan() : vs.z;
           // level 0: copyMaps NaNs all planes where z == 0, transform propagates NaN via the x-plane
           const bool nok = ok && !isnan(ns.x);
-          store_planar<true>(A.vmap[0], cols, rows, x, y, ok && !isnan(vs.x), mul(R, v0[sy][sx]) + t);
-          store_planar<true>(A.nmap[0], cols, rows, x, y, nok, mul(R, n0[sy][sx]));
+          if (cf) {   // copyMaps alone: the NaN test of tranformMaps is not applied, an empty texel NaNs all planes
+            store_planar<true>(A.vmap[0], cols, rows, x, y, ok, v0[sy][sx]);
+            store_planar<true>(A.nmap[0], cols, rows, x, y, ok, n0[sy][sx]);
+          } else {
+            store_planar<true>(A.vmap[0], cols, rows, x, y, ok && !isnan(vs.x), mul(R, v0[sy][sx]) + t);
+            store_planar<true>(A.nmap[0], cols, rows, x, y, nok, mul(R, n0[sy][sx]));
+          }
         }
       // level 1: 2x2 box of the camera-frame level-0 maps (x-plane NaN test only)
       const bool vok = ok0[0][0] && ok0[0][1] && ok0[1][0] && ok0[1][1] && !isnan(v0[0][0].x) && !isnan(v0[0][1].x) &&
@@ -465,8 +472,13 @@ __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const
       // a valid-flagged average can still be NaN in x (NaN y/z never matter: only x is tested downstream)
       v1ok[qy][qx] = vok; n1ok[qy][qx] = nok;
       const int x1 = bx * 2 + qx, y1 = by * 2 + qy;
-      store_planar<false>(A.vmap[1], c1, r1, x1, y1, vok && !isnan(va.x), mul(R, va) + t);
-      store_planar<false>(A.nmap[1], c1, r1, x1, y1, nok && !isnan(na.x), mul(R, na));
+      if (cf) {   // resizeMapKernel alone: x-plane NaN where a source x is NaN, else the three averages as they come
+        store_planar<false>(A.vmap[1], c1, r1, x1, y1, vok, va);
+        store_planar<false>(A.nmap[1], c1, r1, x1, y1, nok, na);
+      } else {
+        store_planar<false>(A.vmap[1], c1, r1, x1, y1, vok && !isnan(va.x), mul(R, va) + t);
+        store_planar<false>(A.nmap[1], c1, r1, x1, y1, nok && !isnan(na.x), mul(R, na));
+      }
     }
   // level 2
   const bool vok2 = v1ok[0][0] && v1ok[0][1] && v1ok[1][0] && v1ok[1][1] && !isnan(v1[0][0].x) && !isnan(v1[0][1].x) &&
@@ -478,8 +490,13 @@ __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const
   f3 na{(n1[0][0].x + n1[0][1].x + n1[1][0].x + n1[1][1].x) / 4, (n1[0][0].y + n1[0][1].y + n1[1][0].y + n1[1][1].y) / 4,
         (n1[0][0].z + n1[0][1].z + n1[1][0].z + n1[1][1].z) / 4};
   na = normalized(na);
-  store_planar<false>(A.vmap[2], c2, r2, bx, by, vok2 && !isnan(va.x), mul(R, va) + t);
-  store_planar<false>(A.nmap[2], c2, r2, bx, by, nok2 && !isnan(na.x), mul(R, na));
+  if (cf) {
+    store_planar<false>(A.vmap[2], c2, r2, bx, by, vok2, va);
+    store_planar<false>(A.nmap[2], c2, r2, bx, by, nok2, na);
+  } else {
+    store_planar<false>(A.vmap[2], c2, r2, bx, by, vok2 && !isnan(va.x), mul(R, va) + t);
+    store_planar<false>(A.nmap[2], c2, r2, bx, by, nok2 && !isnan(na.x), mul(R, na));
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -686,7 +703,8 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_residual_op(const Residual
 // do the warp + gathers and rewrite their 4-byte packed correspondence.
 struct ResidualPackedView {
   const uint8_t* mask;
-  const float* lastDepth;     // == nextDepth (quirk Q1)
+  const float* lastDepth;
+  const float* nextDepth;     // the same buffer as lastDepth in frame-to-model tracking (quirk Q1)
   const uint8_t* lastImage;
   const uint8_t* nextImage;
   uint32_t* corres;
@@ -709,7 +727,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_residual(const ResidualPac
   for (int j = 0; j < PPT; ++j) {
     const int k = base + j * REDUCE_BLOCK, q = k < N ? k : N - 1;
     m[j] = V.mask[q];
-    d1s[j] = V.lastDepth[q];  // mask guarantees !isnan(d1)
+    d1s[j] = V.nextDepth[q];  // mask guarantees !isnan(d1)
     ni[j] = V.nextImage[q];
     if (k >= N) m[j] = 0;
   }
@@ -1420,6 +1438,32 @@ __global__ void k_pose_injected(TrackState* st, efl::SE3 T, bool save_prev, floa
   st->dense_count = 0;
   log_pose(st, traj, slot);
 }
+// model-to-model tracking of the local loop closure (ElasticFusion.cpp:469-471): T_wc_est starts as a copy of T_wc_curr
+__global__ void k_copy_pose(TrackState* dst, const TrackState* src) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 4; ++i) dst->q[i] = src->q[i];
+  for (int i = 0; i < 3; ++i) dst->t[i] = src->t[i];
+  publish_pose(dst);
+}
+// T_wc_curr = T_wc_est (ElasticFusion.cpp:525) after an accepted deformation; the logged pose of this frame follows (:588)
+__global__ void k_adopt_pose(TrackState* st, const TrackState* est, double* traj, int slot) {
+  if (threadIdx.x != 0) return;
+  for (int i = 0; i < 4; ++i) st->q[i] = est->q[i];
+  for (int i = 0; i < 3; ++i) st->t[i] = est->t[i];
+  publish_pose(st);
+  log_pose(st, traj, slot);
+}
+// Resize::vertex + Resize::time (Resize.cpp:85-159) for the constraint grid: texel (20a+10, 20b+10) of the ACTIVE vertex map
+// and of the INACTIVE time map -> out[(a * ch + b)] = {x, y, z, time} in the order ElasticFusion.cpp:488-489 walks them
+__global__ void k_sample_constraints(const float4* __restrict__ vertex, const uint16_t* __restrict__ old_time, int cols, int cw, int ch,
+                                     int step, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cw * ch) return;
+  const int a = i / ch, b = i - a * ch;
+  const int texel = (b * step + step / 2) * cols + (a * step + step / 2);
+  const float4 v = vertex[texel];
+  out[i] = make_float4(v.x, v.y, v.z, (float)old_time[texel]);
+}
 __global__ void k_log_pose(const TrackState* st, double* traj, int slot) {
   if (threadIdx.x == 0) log_pose(st, traj, slot);
 }
@@ -1723,6 +1767,7 @@ void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pre
   A.depth0 = p.lastDepth[0];
   A.cols = p.W(0); A.rows = p.H(0);
   A.maxDepthRGB = maxDepthRGB;
+  A.camera_frame = false;
   dim3 block(64, 4);
   dim3 grid(ceil_div(p.W(0) / 4, 64), ceil_div(p.H(0) / 4, 4));
   hipLaunchKernelGGL(k_model_maps, grid, block, 0, s, A, st);
@@ -1748,6 +1793,22 @@ void init_rgb_model(const Pyramid& p, const uint8_t* pred_image_rgba, const uint
   hipLaunchKernelGGL(k_model_intensity, dim3(ceil_div(n, 256)), dim3(256), 0, s, pred_image_rgba, fill_image_rgba, frameToFrameRGB, st, n,
                      p.lastImage[0]);
   for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_uchar_gauss(p.lastImage[i], p.W(i), p.H(i), p.lastImage[i + 1], s);
+}
+void init_icp_maps(const Pyramid& p, const float* vertex, const float* normal, const uint8_t* image_rgba, const TrackState* st,
+                   float maxDepthRGB, hipStream_t s) {
+  ModelMapsArgs A;
+  A.pred_vertex = A.fill_vertex = (const float4*)vertex;
+  A.pred_normal = A.fill_normal = (const float4*)normal;
+  for (int i = 0; i < NUM_PYRS; ++i) { A.vmap[i] = p.vmap_curr[i]; A.nmap[i] = p.nmap_curr[i]; }
+  A.depth0 = p.nextDepth[0];
+  A.cols = p.W(0); A.rows = p.H(0);
+  A.maxDepthRGB = maxDepthRGB;
+  A.camera_frame = true;
+  hipLaunchKernelGGL(k_model_maps, dim3(ceil_div(p.W(0) / 4, 64), ceil_div(p.H(0) / 4, 4)), dim3(64, 4), 0, s, A, st);
+  const int n = p.W(0) * p.H(0);
+  for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_gauss_f(p.nextDepth[i], p.W(i), p.H(i), p.nextDepth[i + 1], s);
+  hipLaunchKernelGGL(k_model_intensity, dim3(ceil_div(n, 256)), dim3(256), 0, s, image_rgba, image_rgba, true, st, n, p.nextImage[0]);
+  for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_uchar_gauss(p.nextImage[i], p.W(i), p.H(i), p.nextImage[i + 1], s);
 }
 void init_rgb_frame(const Pyramid& p, const uint8_t* rgb3, hipStream_t s) {
   // populateRGBDData(frame): nextDepth == lastDepth (Q1), only the intensity pyramid is new
@@ -1813,7 +1874,7 @@ void init_rgb_sobel(const Pyramid& p, hipStream_t s) {
   const float sobelScale = 1.0f / 8.0f;       // RGBDOdometry.cpp:39-40
   for (int i = 0; i < NUM_PYRS; ++i) {
     L.src[i] = p.nextImage[i]; L.dx[i] = p.dIdx[i]; L.dy[i] = p.dIdy[i];
-    L.nextDepth[i] = p.lastDepth[i]; L.mask[i] = p.rgbMask[i]; L.corres[i] = p.corres[i];
+    L.nextDepth[i] = p.nextDepth[i]; L.mask[i] = p.rgbMask[i]; L.corres[i] = p.corres[i];
     L.minScale[i] = (float)(pow((double)minGrad[i], 2.0) / pow((double)sobelScale, 2.0));  // RGBDOdometry.cpp:425
     L.cols[i] = p.W(i); L.rows[i] = p.H(i);
   }
@@ -1831,7 +1892,7 @@ namespace {
 template <int PPT>
 void launch_residual(const Pyramid& p, TrackState* st, int level, hipStream_t s) {
   const int cols = p.W(level), rows = p.H(level), N = cols * rows;
-  ResidualPackedView RV{p.rgbMask[level], p.lastDepth[level], p.lastImage[level], p.nextImage[level], p.corres[level], cols, rows,
+  ResidualPackedView RV{p.rgbMask[level], p.lastDepth[level], p.nextDepth[level], p.lastImage[level], p.nextImage[level], p.corres[level], cols, rows,
                         0.07f /* maxDepthDeltaRGB, RGBDOdometry.cpp:41 */};
   hipLaunchKernelGGL(k_rgb_residual<PPT>, dim3(ceil_div(N, REDUCE_BLOCK * PPT)), dim3(REDUCE_BLOCK), 0, s, RV, (const float*)st->krkinv,
                      (const float*)st->kt, &st->rgb_slots[0][0], (const int*)&st->rgb_broken);
@@ -1905,6 +1966,15 @@ void pose_injected(TrackState* st, const double* T_wc16, bool save_prev, float w
                    hipStream_t s) {
   hipLaunchKernelGGL(k_pose_injected, dim3(1), dim3(64), 0, s, st, efl::se3_from_matrix(T_wc16), save_prev, weightMultiplier, with_weighting,
                      traj, slot);
+}
+void copy_pose(TrackState* dst, const TrackState* src, hipStream_t s) { hipLaunchKernelGGL(k_copy_pose, dim3(1), dim3(64), 0, s, dst, src); }
+void adopt_pose(TrackState* st, const TrackState* est, double* traj, int slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_adopt_pose, dim3(1), dim3(64), 0, s, st, est, traj, slot);
+}
+void sample_constraints(const float* vertex4, const uint16_t* old_time, int cols, int rows, int step, float* out4, hipStream_t s) {
+  const int cw = cols / step, ch = rows / step;
+  hipLaunchKernelGGL(k_sample_constraints, dim3(ceil_div(cw * ch, 256)), dim3(256), 0, s, (const float4*)vertex4, old_time, cols, cw, ch, step,
+                     (float4*)out4);
 }
 void log_pose(const TrackState* st, double* traj, int slot, hipStream_t s) { hipLaunchKernelGGL(k_log_pose, dim3(1), dim3(64), 0, s, st, traj, slot); }
 

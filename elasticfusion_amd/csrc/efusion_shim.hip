@@ -54,12 +54,12 @@ void SE3d::matrix(double* out16) const {
   efl::se3_matrix(T, out16);
 }
 
-ElasticFusion::ElasticFusion(const int timeDelta_, const int /*countThresh*/, const float /*errThresh*/, const float /*covThresh*/,
+ElasticFusion::ElasticFusion(const int timeDelta_, const int countThresh, const float errThresh, const float covThresh,
                              const bool closeLoops, const bool /*iclnuim*/, const bool /*reloc*/, const float /*photoThresh*/,
                              const float confidence, const float depthCut, const float icpThresh, const bool fastOdom,
                              const float /*fernThresh*/, const bool so3, const bool frameToFrameRGB, const std::string fileName,
                              const int device)
-    : saveFilename(fileName), timeDelta(timeDelta_), confidenceThreshold(confidence) {
+    : saveFilename(fileName), timeDelta(timeDelta_), confidenceThreshold(confidence), closeLoops(closeLoops) {
   ef_config cfg;
   ef_default_config(&cfg);
   cfg.width = Resolution::getInstance().width();
@@ -80,6 +80,7 @@ ElasticFusion::ElasticFusion(const int timeDelta_, const int /*countThresh*/, co
   ef_ctx* c = nullptr;
   chk(ef_create(&cfg, &c), nullptr, "ElasticFusion::ElasticFusion");
   ctx.reset(c);
+  if (closeLoops) chk(ef_set_loop_thresholds(c, countThresh, errThresh, covThresh), c, "ElasticFusion::ElasticFusion");
   indexMap.ctx = globalModel.ctx = c;
   indexMap.w = cfg.width;
   indexMap.h = cfg.height;
@@ -97,6 +98,10 @@ void ElasticFusion::processFrame(const uint8_t* rgb, const uint16_t* depth, cons
   double M[16];
   if (in_T_wc) in_T_wc->matrix(M);
   chk(ef_process_frame(C(ctx.get()), rgb, depth, timestamp, weightMultiplier, in_T_wc ? M : nullptr), ctx.get(), "processFrame");
+  if (closeLoops) {   // deforms += rawGraph.size() > 0, ElasticFusion.cpp:523
+    const ef_local_loop& L = getLocalLoop();
+    deforms += (L.applied && L.graph_nodes > 0) ? 1 : 0;
+  }
 }
 #ifdef EFUSION_USE_SOPHUS
 void ElasticFusion::processFrame(const uint8_t* rgb, const uint16_t* depth, const int64_t& timestamp, const float weightMultiplier,
@@ -115,8 +120,20 @@ Sophus::SE3d ElasticFusion::get_T_wc_sophus() {
 
 void ElasticFusion::predict() { chk(ef_predict(C(ctx.get())), ctx.get(), "predict"); }
 
+void ElasticFusion::setLoopSolver(ef_loop_solver fn, void* user) { chk(ef_set_loop_solver(C(ctx.get()), fn, user), ctx.get(), "setLoopSolver"); }
+const ef_local_loop& ElasticFusion::getLocalLoop() {
+  chk(ef_get_local_loop(C(ctx.get()), &localLoop, nullptr, 0, nullptr), ctx.get(), "getLocalLoop");
+  return localLoop;
+}
+
 const OdometryStats& ElasticFusion::getModelToModel() {
   float s[6];
+  if (closeLoops) {   // the model-to-model tracker of the local loop closure (ElasticFusion.h:280)
+    const ef_local_loop& L = getLocalLoop();
+    stats.lastICPError = L.stats[0]; stats.lastICPCount = L.stats[1]; stats.lastRGBError = L.stats[2];
+    stats.lastRGBCount = L.stats[3]; stats.lastSO3Error = L.stats[4]; stats.lastSO3Count = L.stats[5];
+    return stats;
+  }
   chk(ef_get_tracking_stats(C(ctx.get()), s, stats.lastA, stats.lastb), ctx.get(), "getModelToModel");
   stats.lastICPError = s[0]; stats.lastICPCount = s[1]; stats.lastRGBError = s[2];
   stats.lastRGBCount = s[3]; stats.lastSO3Error = s[4]; stats.lastSO3Count = s[5];

@@ -11,7 +11,9 @@
 //  * getIndexMap()/getGlobalModel()/getModelToModel() return small HBM-backed facades with the members the
 //    front-end actually reads (lastCount, lastICPError, lastICPCount, downloadMap, host copies of the predicted
 //    images); there is no GL texture or VBO behind them.
-//  * closeLoops must be false (open loop, -o): loop closure is out of scope for this build.
+//  * closeLoops = true runs the LOCAL loop closure's front half every frame (ElasticFusion.cpp:447-511: inactive-model
+//    prediction, model-to-model registration, gates, surface constraints); the deformation-graph optimiser on its far
+//    side is supplied by the caller (setLoopSolver / ef_set_loop_solver).  Fern-based global closure is not built.
 //  * errors throw std::runtime_error instead of assert()/exit(0).
 #ifndef EFUSION_ELASTICFUSION_H_
 #define EFUSION_ELASTICFUSION_H_
@@ -20,6 +22,8 @@
 #include <memory>
 #include <string>
 #include <vector>
+
+#include "ef_hip.h"   // ef_local_loop, ef_loop_solver
 
 #ifdef EFUSION_USE_SOPHUS
 #include <sophus/se3.hpp>
@@ -123,7 +127,12 @@ class ElasticFusion {
 
   IndexMapView& getIndexMap() { return indexMap; }
   GlobalModelView& getGlobalModel() { return globalModel; }
+  // closeLoops: the model-to-model tracker of the local loop closure; open loop: the frame-to-model tracker's statistics
   const OdometryStats& getModelToModel();   // refreshed from the device on each call
+  // local loop closure (closeLoops = true): the solver standing where Deformation::constrain stands (include/ef_hip.h), and
+  // the gates / statistics / poses of the last frame's attempt
+  void setLoopSolver(ef_loop_solver fn, void* user);
+  const ef_local_loop& getLocalLoop();
 
   const float& getConfidenceThreshold() { return confidenceThreshold; }
   void setRgbOnly(const bool& val);
@@ -162,6 +171,8 @@ class ElasticFusion {
   float maxDepthProcessed = 20.0f;
   bool lost = false;
   int deforms = 0, fernDeforms = 0;
+  bool closeLoops = false;
+  ef_local_loop localLoop{};
 };
 
 }  // namespace efusion

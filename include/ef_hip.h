@@ -47,7 +47,8 @@ typedef struct ef_config {
   int frame_to_frame_rgb;     /* frameToFrameRGB (0)                                */
   int pyramid;                /* setPyramid      (1)                                */
   int rgb_only;               /* setRgbOnly      (0)                                */
-  int close_loops;            /* must be 0: loop closure is out of scope */
+  int close_loops;            /* closeLoops (0 = -o): 1 runs the LOCAL loop closure's front half every frame (below);
+                                 fern-based global closure and the graph optimiser stay out of scope */
   uint32_t max_surfels;       /* surfel capacity; reference: 3072*3072 (GlobalModel.cpp:22-24) */
   int device;                 /* HIP device ordinal                                 */
   void* stream;               /* hipStream_t to run on, or NULL to create a private one */
@@ -86,6 +87,35 @@ int ef_set_graph_replay(ef_ctx* ctx, int on);
  * whole map exactly as ElasticFusion.cpp:558-585 does (synthesizeDepth first unless is_fern).  Finding the loop closure and
  * optimising the graph stay with the caller (Ferns / Deformation are out of scope). */
 int ef_set_deformation(ef_ctx* ctx, const float* graph_host, int nodes, int is_fern);
+/* ---- local loop closure, front half (ElasticFusion.cpp:447-527; contexts created with close_loops = 1) ----
+ * After tracking, every frame: the INACTIVE part of the model (surfels not seen for time_delta frames) is predicted into the
+ * camera (IndexMap::combinedPredict(..., INACTIVE), IndexMap.cpp:293-393), a second tracker (RGBDOdometry modelToModel) registers
+ * it against the ACTIVE prediction, and if the covariance / ICP-count / ICP-error gates hold (:473-484) the surface constraints
+ * of :485-509 are sampled every 20 pixels (Resize::vertex / Resize::time).  What the reference does next — Deformation::constrain,
+ * a sparse non-linear solve with CHOLMOD — is the registered solver's job: it receives the constraints and may return a
+ * deformation graph (same layout as ef_set_deformation); the engine then does what :514-527 and :558-585 do: T_wc := T_wc_est,
+ * synthesizeDepth, and this frame's clean pass applies the graph to the whole map.  Costs one stream synchronisation per frame,
+ * where the reference reads the constraint buffers back. */
+typedef struct ef_local_loop {
+  int attempted;            /* the front half ran in the last ef_process_frame (tick > 1) */
+  int cov_ok;               /* no diagonal entry of modelToModel's covariance above covThresh */
+  int gates_ok;             /* cov_ok && lastICPCount > icpCountThresh && lastICPError < icpErrThresh */
+  int n_constraints;        /* surface constraints sampled (0 unless gates_ok) */
+  int applied;              /* the solver accepted: pose replaced, graph (if any) applied by this frame's clean */
+  int graph_nodes;
+  float stats[6];           /* modelToModel: lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count */
+  double cov_diag[6];       /* diagonal of getCovariance() up to and including the first entry above covThresh */
+  double T_wc_curr[16];     /* pose after frame-to-model tracking, row-major */
+  double T_wc_est[16];      /* pose proposed by the model-to-model registration */
+} ef_local_loop;
+/* constraints: n rows of 8 doubles {vert_w_curr xyz (source), vert_w_est xyz (target), time the inactive surface was last seen,
+ * pin (1 while no deformation has been applied yet, ElasticFusion.cpp:507-508)}.  graph_out has room for 1023 x 16 floats.
+ * Return non-zero to accept (Deformation::constrain returning true); called on the thread inside ef_process_frame. */
+typedef int (*ef_loop_solver)(void* user, const ef_local_loop* info, const double* constraints, int n, float* graph_out, int* nodes_out);
+int ef_set_loop_solver(ef_ctx* ctx, ef_loop_solver fn, void* user);   /* NULL: gates and constraints are still evaluated */
+/* icpCountThresh, icpErrThresh, covThresh of the constructor (ElasticFusion.h:44-46; defaults 35000, 5e-05, 1e-05) */
+int ef_set_loop_thresholds(ef_ctx* ctx, int icp_count_thresh, float icp_err_thresh, float cov_thresh);
+int ef_get_local_loop(ef_ctx* ctx, ef_local_loop* info, double* constraints_or_null, int max_constraints, int* n_out_or_null);
 int ef_predict(ef_ctx* ctx);                                  /* ElasticFusion::predict() */
 int ef_get_pose(ef_ctx* ctx, double* T_wc16);                 /* get_T_wc(); synchronises */
 int ef_get_tick(ef_ctx* ctx, int* tick);                      /* getTick() */
@@ -125,7 +155,11 @@ enum ef_image {
   EF_IMG_INDEX,                   /* u32  IndexMap::indexTex   */
   EF_IMG_VERT_CONF,               /* f32x4 */
   EF_IMG_COLOR_TIME,              /* f32x4 */
-  EF_IMG_NORM_RAD                 /* f32x4 */
+  EF_IMG_NORM_RAD,                /* f32x4 */
+  EF_IMG_OLD_IMAGE,               /* u8x4 IndexMap::oldImageTex  (INACTIVE prediction; close_loops contexts only) */
+  EF_IMG_OLD_VERTEX,              /* f32x4 IndexMap::oldVertexTex */
+  EF_IMG_OLD_NORMAL,              /* f32x4 IndexMap::oldNormalTex */
+  EF_IMG_OLD_TIME                 /* u16  IndexMap::oldTimeTex   */
 };
 int ef_get_image(ef_ctx* ctx, int which, void* host_dst, size_t bytes);
 /* tracker pyramids (RGBDOdometry private state) for kernel-level parity tests:

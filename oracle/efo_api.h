@@ -40,6 +40,8 @@ efo_odometry* efo_odom_create(int w, int h, float cx, float cy, float fx, float 
 void efo_odom_destroy(efo_odometry*);
 void efo_odom_init_icp(efo_odometry*, const uint16_t* filteredDepth, float depthCutoff);
 void efo_odom_init_icp_model(efo_odometry*, const float* vtex, const float* ntex, const double* T_wc16);
+/* initICP(predictedVertices, predictedNormals), RGBDOdometry.cpp:149-169 */
+void efo_odom_init_icp_maps(efo_odometry*, const float* vtex, const float* ntex);
 void efo_odom_init_rgb_model(efo_odometry*, const uint8_t* rgba);
 void efo_odom_init_rgb(efo_odometry*, const uint8_t* rgba);
 void efo_odom_init_first_rgb(efo_odometry*, const uint8_t* rgba);
@@ -121,6 +123,24 @@ void efo_set_threads(int n);
 /* deformation graph (nodes x 16, sorted by time) applied by the next frame's clean, as after a loop closure */
 void efo_fusion_set_deformation(efo_fusion*, const float* graph, int nodes, int isFern);
 void efo_fusion_stats(const efo_fusion*, float* out6);
+/* ---- local loop closure, front half (ElasticFusion.cpp:447-511): INACTIVE prediction, model-to-model odometry, covariance and
+ * error gates, surface constraints sampled every consSample = 20 pixels.  The deformation-graph optimisation on their far side
+ * (Deformation::constrain) is the caller's: a solver callback receives the constraints and may return a graph, which is then
+ * applied by this frame's clean pass, with T_wc := T_wc_est, exactly as :514-527 / :558-585 do. */
+typedef struct efo_local_loop {
+  int attempted, cov_ok, gates_ok, n_constraints, applied, graph_nodes;
+  float stats[6];        /* modelToModel: lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count */
+  double cov_diag[6];
+  double T_wc_curr[16], T_wc_est[16];
+} efo_local_loop;
+/* constraints: n rows of 8 doubles {vert_w_curr xyz, vert_w_est xyz, time of the inactive surface, pin}; return non-zero to accept */
+typedef int (*efo_loop_solver)(void* user, const efo_local_loop* info, const double* constraints, int n, float* graph_out /* 1024 x 16 */,
+                               int* nodes_out);
+void efo_fusion_set_close_loops(efo_fusion*, int on, int icpCountThresh, float icpErrThresh, float covThresh);
+void efo_fusion_set_loop_solver(efo_fusion*, efo_loop_solver fn, void* user);
+int efo_fusion_local_loop(const efo_fusion*, efo_local_loop* info, double* constraints, int max_constraints);
+/* which: 0 image 1 vertex 2 normal 3 time of the INACTIVE prediction */
+const void* efo_fusion_old_buffer(const efo_fusion*, int which);
 /* which: 0 image_rgba(u8x4) 1 vertex(f4) 2 normal(f4) 3 time(u16) 4 fill_image 5 fill_vertex 6 fill_normal
  * 7 indexMap(u32) 8 vertConf 9 colorTime 10 normRad 11 depthFiltered(u16) 12 depthMetric 13 depthMetricFiltered */
 const void* efo_fusion_buffer(const efo_fusion*, int which);

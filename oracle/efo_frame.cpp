@@ -15,7 +15,19 @@ struct efo_fusion {
   efo_fusion_params p;
   efo_cam cam;
   efo_odometry* frameToModel;
+  efo_odometry* modelToModel;
   int tick = 1;
+  // local loop closure (ElasticFusion.h:288-305)
+  int closeLoops = 0, icpCountThresh = 35000, deforms = 0;
+  float icpErrThresh = 5e-05f, covThresh = 1e-05f;
+  const int consSample = 20;             // ElasticFusion.cpp:62
+  efo_loop_solver solver = nullptr;
+  void* solverUser = nullptr;
+  efo_local_loop loop{};
+  std::vector<double> loopConstraints;   // n x 8
+  std::vector<uint8_t> oldImage;
+  std::vector<float> oldVertex, oldNormal;
+  std::vector<uint16_t> oldTime;
   std::vector<float> pendingGraph;   // nodes x 16, applied by the next frame's clean (efo_fusion_set_deformation)
   int pendingFern = 0;
   SE3 T_wc = se3_identity();
@@ -42,18 +54,82 @@ struct efo_fusion {
   explicit efo_fusion(const efo_fusion_params& pp) : p(pp) {
     cam = efo_cam{p.width, p.height, p.fx, p.fy, p.cx, p.cy};
     frameToModel = efo_odom_create(p.width, p.height, p.cx, p.cy, p.fx, p.fy);
+    modelToModel = efo_odom_create(p.width, p.height, p.cx, p.cy, p.fx, p.fy);
     size_t P = (size_t)p.width * p.height;
     rgb.assign(P * 3, 0); rgba.assign(P * 4, 0);
     depthRaw.assign(P, 0); depthFiltered.assign(P, 0);
     depthMetric.assign(P, 0.f); depthMetricFiltered.assign(P, 0.f);
     indexMap.assign(P, 0); vertConf.assign(P * 4, 0.f); colorTime.assign(P * 4, 0.f); normRad.assign(P * 4, 0.f);
     image.assign(P * 4, 0); vertex.assign(P * 4, 0.f); normal.assign(P * 4, 0.f); timeMap.assign(P, 0);
+    oldImage.assign(P * 4, 0); oldVertex.assign(P * 4, 0.f); oldNormal.assign(P * 4, 0.f); oldTime.assign(P, 0);
     fimage.assign(P * 4, 0); fvertex.assign(P * 4, 0.f); fnormal.assign(P * 4, 0.f);
     surfels.assign((size_t)p.maxSurfels * 12, 0.f);
     surfelsTmp.assign((size_t)p.maxSurfels * 12, 0.f);
     newUnstable.assign(P * 12, 0.f);
   }
-  ~efo_fusion() { efo_odom_destroy(frameToModel); }
+  ~efo_fusion() { efo_odom_destroy(frameToModel); efo_odom_destroy(modelToModel); }
+
+  // ElasticFusion.cpp:447-527 without the fern branch (:391-444, out of scope): the view of the INACTIVE part of the model is
+  // registered against the ACTIVE prediction made by predict() at :387; returns true when a deformation was accepted
+  void localLoopClosure() {
+    loop = efo_local_loop{};
+    loopConstraints.clear();
+    loop.attempted = 1;
+    double M[16];
+    pose16(M);
+    std::memcpy(loop.T_wc_curr, M, sizeof(M));
+    efo_combined_predict(&cam, M, surfels.data(), count, maxDepthProcessed, p.confidence, 0, tick - p.timeDelta, p.timeDelta,
+                         oldImage.data(), oldVertex.data(), oldNormal.data(), oldTime.data());                 // :451-459, INACTIVE
+    efo_odom_init_icp_model(modelToModel, oldVertex.data(), oldNormal.data(), M);                              // :463
+    efo_odom_init_rgb_model(modelToModel, oldImage.data());                                                    // :464
+    efo_odom_init_icp_maps(modelToModel, vertex.data(), normal.data());                                        // :466
+    efo_odom_init_rgb(modelToModel, image.data());                                                             // :467
+    double E[16];
+    std::memcpy(E, M, sizeof(M));
+    efo_odom_track(modelToModel, E, 0, 10.0f, p.pyramid, p.fastOdom, 0);                                       // :471
+    std::memcpy(loop.T_wc_est, E, sizeof(E));
+    double lastA[36], cov[36];
+    efo_odom_stats(modelToModel, loop.stats, lastA, nullptr);
+    lu_inverse<double, 6>(lastA, cov);                                                                         // :473, getCovariance
+    bool covOk = true;
+    for (int i = 0; i < 6; ++i) {
+      loop.cov_diag[i] = cov[i * 6 + i];
+      if (cov[i * 6 + i] > (double)covThresh) { covOk = false; break; }
+    }
+    loop.cov_ok = covOk;
+    loop.gates_ok = covOk && loop.stats[1] > (float)icpCountThresh && loop.stats[0] < icpErrThresh;            // :483-484
+    if (!loop.gates_ok) return;
+    // Resize::vertex / Resize::time (Resize.cpp:85-159): NEAREST sample of texel (20a+10, 20b+10) like Resize::image (G8)
+    const int cw = p.width / consSample, ch = p.height / consSample;
+    for (int i = 0; i < cw; ++i)
+      for (int j = 0; j < ch; ++j) {
+        const size_t texel = (size_t)(j * consSample + consSample / 2) * p.width + (i * consSample + consSample / 2);
+        const float* v = &vertex[texel * 4];
+        const uint16_t tm = oldTime[texel];
+        if (v[2] > 0 && v[2] < maxDepthProcessed && tm > 0) {                                                   // :490-492
+          double row[8];
+          for (int r = 0; r < 3; ++r) {   // T * Vector4d(x, y, z, 1): 4x4 matrix product, left to right
+            row[r] = ((M[r * 4] * (double)v[0] + M[r * 4 + 1] * (double)v[1]) + M[r * 4 + 2] * (double)v[2]) + M[r * 4 + 3] * 1.0;
+            row[3 + r] = ((E[r * 4] * (double)v[0] + E[r * 4 + 1] * (double)v[1]) + E[r * 4 + 2] * (double)v[2]) + E[r * 4 + 3] * 1.0;
+          }
+          row[6] = (double)tm;
+          row[7] = deforms == 0 ? 1.0 : 0.0;                                                                    // :507-508
+          loopConstraints.insert(loopConstraints.end(), row, row + 8);
+        }
+      }
+    loop.n_constraints = (int)(loopConstraints.size() / 8);
+    if (!solver) return;
+    std::vector<float> graph((size_t)1024 * 16, 0.f);
+    int nodes = 0;
+    if (solver(solverUser, &loop, loopConstraints.data(), loop.n_constraints, graph.data(), &nodes)) {          // :513-514
+      loop.applied = 1;
+      loop.graph_nodes = nodes;
+      deforms += nodes > 0;                                                                                     // :523
+      T_wc = se3_from_matrix(E);                                                                                // :525
+      pendingGraph.assign(graph.begin(), graph.begin() + (size_t)nodes * 16);
+      pendingFern = 0;
+    }
+  }
 
   void pose16(double* M) const { M4d m = se3_matrix(T_wc); std::memcpy(M, m.m, sizeof(m.m)); }
 
@@ -105,6 +181,7 @@ struct efo_fusion {
       lastWeighting = weighting;
 
       predict();  // :387 (result unused when closeLoops == false; kept for fidelity)
+      if (closeLoops) localLoopClosure();
 
       if (!p.rgbOnly) {  // :536-585 (trackingOk && !lost always hold without reloc)
         double M[16];
@@ -163,6 +240,25 @@ void efo_set_threads(int n) { efo::threads() = n < 1 ? 1 : n; }
 void efo_fusion_set_deformation(efo_fusion* f, const float* graph, int nodes, int isFern) {
   f->pendingGraph.assign(graph, graph + (size_t)nodes * 16);
   f->pendingFern = isFern;
+}
+void efo_fusion_set_close_loops(efo_fusion* f, int on, int icpCountThresh, float icpErrThresh, float covThresh) {
+  f->closeLoops = on; f->icpCountThresh = icpCountThresh; f->icpErrThresh = icpErrThresh; f->covThresh = covThresh;
+}
+void efo_fusion_set_loop_solver(efo_fusion* f, efo_loop_solver fn, void* user) { f->solver = fn; f->solverUser = user; }
+int efo_fusion_local_loop(const efo_fusion* f, efo_local_loop* info, double* constraints, int max_constraints) {
+  *info = f->loop;
+  const int n = std::min(f->loop.n_constraints, max_constraints);
+  if (constraints && n > 0) std::memcpy(constraints, f->loopConstraints.data(), (size_t)n * 8 * sizeof(double));
+  return n;
+}
+const void* efo_fusion_old_buffer(const efo_fusion* f, int which) {
+  switch (which) {
+    case 0: return f->oldImage.data();
+    case 1: return f->oldVertex.data();
+    case 2: return f->oldNormal.data();
+    case 3: return f->oldTime.data();
+  }
+  return nullptr;
 }
 void efo_fusion_stats(const efo_fusion* f, float* out6) {
   efo_odom_stats(f->frameToModel, out6, nullptr, nullptr);

@@ -78,6 +78,16 @@ struct efo_odometry {
     }
   }
 
+  // RGBDOdometry::initICP(GPUTexture* predictedVertices, GPUTexture* predictedNormals), RGBDOdometry.cpp:149-169:
+  // the "current" side taken from a model prediction (model-to-model tracking of the local loop closure)
+  void initICP(const float* vtex, const float* ntex) {
+    efo_copy_maps(vtex, ntex, width, height, vmaps_tmp.data(), vmaps_curr[0].data(), nmaps_curr[0].data());
+    for (int i = 1; i < NUM_PYRS; ++i) {
+      efo_resize_map(vmaps_curr[i - 1].data(), W(i - 1), H(i - 1), vmaps_curr[i].data(), 0);
+      efo_resize_map(nmaps_curr[i - 1].data(), W(i - 1), H(i - 1), nmaps_curr[i].data(), 1);
+    }
+  }
+
   // RGBDOdometry::initICPModel, RGBDOdometry.cpp:171-210
   void initICPModel(const float* vtex, const float* ntex, const SE3& T_wc) {
     efo_copy_maps(vtex, ntex, width, height, vmaps_tmp.data(), vmaps_g_prev[0].data(), nmaps_g_prev[0].data());
@@ -294,6 +304,7 @@ efo_odometry* efo_odom_create(int w, int h, float cx, float cy, float fx, float 
 }
 void efo_odom_destroy(efo_odometry* o) { delete o; }
 void efo_odom_init_icp(efo_odometry* o, const uint16_t* filteredDepth, float depthCutoff) { o->initICP(filteredDepth, depthCutoff); }
+void efo_odom_init_icp_maps(efo_odometry* o, const float* vtex, const float* ntex) { o->initICP(vtex, ntex); }
 void efo_odom_init_icp_model(efo_odometry* o, const float* vtex, const float* ntex, const double* T_wc16) {
   o->initICPModel(vtex, ntex, se3_from_matrix(T_wc16));
 }

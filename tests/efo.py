@@ -447,6 +447,15 @@ class Odometry:
         return arr.view(dt).reshape(h * planes, w).copy()
 
 
+class LocalLoop(C.Structure):
+    _fields_ = [("attempted", c_i), ("cov_ok", c_i), ("gates_ok", c_i), ("n_constraints", c_i), ("applied", c_i),
+                ("graph_nodes", c_i), ("stats", c_f * 6), ("cov_diag", C.c_double * 6), ("T_wc_curr", C.c_double * 16),
+                ("T_wc_est", C.c_double * 16)]
+
+
+LOOP_SOLVER = C.CFUNCTYPE(c_i, C.c_void_p, C.POINTER(LocalLoop), C.POINTER(C.c_double), c_i, C.POINTER(c_f), C.POINTER(c_i))
+
+
 class Fusion:
     def __init__(self, **kw):
         self.p = FusionParams()
@@ -468,6 +477,45 @@ class Fusion:
     def set_deformation(self, graph, isFern=False):
         g = f32(graph).reshape(-1, 16)
         lib().efo_fusion_set_deformation(self.h_, ptr(g), c_i(len(g)), c_i(int(isFern)))
+
+    # ---- local loop closure, front half (ElasticFusion.cpp:447-511) ----
+    def set_close_loops(self, on=True, icpCountThresh=35000, icpErrThresh=5e-05, covThresh=1e-05):
+        lib().efo_fusion_set_close_loops(self.h_, c_i(int(on)), c_i(icpCountThresh), c_f(icpErrThresh), c_f(covThresh))
+
+    def set_loop_solver(self, fn):
+        """fn(info: LocalLoop, constraints [n, 8] float64) -> None | graph [nodes, 16] float32 (accepted)."""
+        if fn is None:
+            self._solver = None
+            lib().efo_fusion_set_loop_solver(self.h_, None, None)
+            return
+
+        def tramp(user, info, cons, n, graph_out, nodes_out):
+            c = np.ctypeslib.as_array(cons, shape=(n, 8)).copy() if n > 0 else np.zeros((0, 8))
+            g = fn(info.contents, c)
+            if g is None:
+                return 0
+            g = f32(g).reshape(-1, 16)
+            C.memmove(graph_out, g.ctypes.data, g.nbytes)
+            nodes_out[0] = len(g)
+            return 1
+        self._solver = LOOP_SOLVER(tramp)
+        lib().efo_fusion_set_loop_solver(self.h_, self._solver, None)
+
+    def local_loop(self):
+        info = LocalLoop()
+        cons = np.zeros((4096, 8), np.float64)
+        lib().efo_fusion_local_loop.restype = c_i
+        n = lib().efo_fusion_local_loop(self.h_, C.byref(info), ptr(cons), c_i(len(cons)))
+        return info, cons[:n].copy()
+
+    def old_buffer(self, name):
+        which = dict(image=0, vertex=1, normal=2, time=3)[name]
+        dt, ch = self._BUF[which]
+        lib().efo_fusion_old_buffer.restype = C.c_void_p
+        addr = lib().efo_fusion_old_buffer(self.h_, c_i(which))
+        n = self.p.width * self.p.height * ch
+        a = np.ctypeslib.as_array(C.cast(addr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy()
+        return a.reshape(self.p.height, self.p.width, ch) if ch > 1 else a.reshape(self.p.height, self.p.width)
 
     def pose(self):
         T = np.zeros(16, np.float64)

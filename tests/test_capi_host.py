@@ -39,10 +39,7 @@ def test_create_fails_loudly_without_gpu_or_with_bad_config(so):
     from elasticfusion_amd import api
     so.ef_last_error.restype = C.c_char_p
     so.ef_last_error.argtypes = [C.c_void_p]
-    cfg = api.default_config(close_loops=1)
     h = C.c_void_p()
-    assert so.ef_create(C.byref(cfg), C.byref(h)) == -1
-    assert b"loop closure" in so.ef_last_error(None)
     cfg = api.default_config(width=641)
     assert so.ef_create(C.byref(cfg), C.byref(h)) == -1
     if not os.path.exists("/dev/kfd"):

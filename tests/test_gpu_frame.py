@@ -255,8 +255,6 @@ def test_fusion_with_injected_poses(hip, seq):
 
 def test_api_errors(hip):
     with pytest.raises(hip.EFError):
-        hip.ElasticFusion(closeLoops=True)
-    with pytest.raises(hip.EFError):
         hip.ElasticFusion(width=642)
     with pytest.raises(hip.EFError):
         hip.ElasticFusion(maxSurfels=1000)
