@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--width", type=int, default=W, help="1280 (with --height 960) = BASELINE.json configs[2]: the first frame seeds "
                     "~1.2 M surfels, i.e. the 1 M-surfel HBM-bound map; NOT the headline metric")
     ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--close-loops", action="store_true", help="closeLoops = true with the reference's default time window of 200 "
+                    "frames: every frame also runs the local loop closure's front half (inactive-model prediction, second tracker, "
+                    "gates, one stream synchronisation).  NOT the headline metric, which is open loop (-o)")
     a = ap.parse_args()
     w, h = a.width, a.height
 
@@ -113,7 +116,7 @@ def main():
     stream = tstream.cuda_stream
     sc = w / 640.0
     ef = api.ElasticFusion(width=w, height=h, fx=528.0 * sc, fy=528.0 * sc, cx=320.0 * sc, cy=240.0 * sc, device=local_rank, stream=stream,
-                           maxSurfels=max(4 * 1024 * 1024, 6 * w * h))
+                           maxSurfels=max(4 * 1024 * 1024, 6 * w * h), **(dict(closeLoops=True, timeDelta=200) if a.close_loops else {}))
     dev = [(api.DevBuf.from_array(r), api.DevBuf.from_array(d)) for r, d, _ in frames]
 
     def step(k):
@@ -199,7 +202,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{w}x{h} synthetic RGB-D replay (box+spheres, Lissajous trajectory), open loop, "
+        "config": {"workload": f"{w}x{h} synthetic RGB-D replay (box+spheres, Lissajous trajectory), "
+                               + ("closeLoops (local loop closure front half every frame, timeDelta 200), " if a.close_loops else "open loop, ") +
                                "SO(3)+ICP+RGB 3-level tracking (10/5/4 its) + surfel fuse/clean/predict; "
                                + ("stand-in for configs[1] (dyson_lab.klg is not available offline)" if (w, h) == (W, H) else
                                   "configs[2]: 1280x960 stream, ~1.2 M-surfel map"),

@@ -88,6 +88,19 @@ def test_predict_indices(ops, cams, mature):
         assert bits_equal(a, b)
 
 
+def test_inactive_prediction(ops, cams, mature):
+    """IndexMap::INACTIVE (ElasticFusion.cpp:451-459): time = 0, maxTime = tick - timeDelta"""
+    cam, ocam = cams
+    f, fr = mature
+    surf = f.map()
+    T = fr[5][2]
+    ref = efo.combined_predict(ocam, T, surf, MAXD, 1.0, 0, f.tick() - 3, 3)
+    got = ops.combined_predict(cam, T, surf, MAXD, 1.0, 0, f.tick() - 3, 3)
+    assert (ref[1][..., 2] > 0).sum() > 1000
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[3], ref[3])
+    assert bits_equal(got[1], ref[1]) and bits_equal(got[2], ref[2])
+
+
 def test_combined_predict_fill_dense(ops, cams, mature):
     cam, ocam = cams
     f, fr = mature

@@ -73,6 +73,28 @@ def test_depth_buffer_rule_is_the_only_difference_in_the_splat(inputs):
     assert 0 < differing < 0.02, differing
 
 
+def test_inactive_prediction_against_compiled_shader(inputs):
+    """IndexMap::combinedPredict(..., INACTIVE) as the local loop closure calls it (ElasticFusion.cpp:451-459): time = 0,
+    maxTime = tick - timeDelta, so only surfels NOT seen inside the window are drawn.  No-FMA oracle vs splat.vert +
+    combo_splat.frag: bit for bit, and the view is a proper subset of the ACTIVE one."""
+    so = efo.reference_glsl_lib()
+    so.efg_use_specified_exp(1)
+    so.efg_set_depth_compare(1)
+    c = inputs["cam"]
+    cam = efo.make_cam(int(c[0]), int(c[1]), *[float(x) for x in c[2:]])
+    T, tick = inputs["T"].reshape(4, 4), int(inputs["tick"].reshape(-1)[0])
+    with efo.backend("reference_glsl"):
+        ref = efo.combined_predict(cam, T, inputs["surf"], mapops.MAXD, mapops.CONF, 0, tick - 2, 2)
+        act = efo.combined_predict(cam, T, inputs["surf"], mapops.MAXD, mapops.CONF, tick, tick, mapops.TD)
+    with efo.backend("nofma"):
+        got = efo.combined_predict(cam, T, inputs["surf"], mapops.MAXD, mapops.CONF, 0, tick - 2, 2)
+    for a, b in zip(got, ref):
+        assert trackops.bits_differ(a, b) == 0
+    n_old, n_act = int((ref[1][..., 2] > 0).sum()), int((act[1][..., 2] > 0).sum())
+    assert 1000 < n_old < n_act, (n_old, n_act)
+    assert ref[3][ref[1][..., 2] > 0].max() <= tick - 2
+
+
 def test_bilateral_with_libm_exp(inputs):
     """exp() through libm's expf instead of the specified polynomial: the filtered depth may differ by at most 1 mm, rarely"""
     so = efo.reference_glsl_lib()
