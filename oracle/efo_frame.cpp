@@ -1,9 +1,9 @@
 // TEST INFRASTRUCTURE — CPU oracle. Not part of the product path (see oracle/README.md).
 //
 // CPU restatement of ElasticFusion::processFrame (Core/ElasticFusion.cpp:270-607) and predict()
-// (:621-653) in open-loop mode (closeLoops = false, reloc = false): the loop-closure branches
-// (:391-534), Ferns::addFrame (:601-619) and the deformation-graph sampling (:593-595) have no effect
-// on pose or map in that mode and are omitted.
+// (:621-653) with reloc = false.  Open loop (closeLoops = false) by default; efo_fusion_set_close_loops adds the LOCAL loop
+// closure block (:447-527) with a solver callback where Deformation::constrain stands.  The fern branch (:391-444),
+// Ferns::addFrame (:601-619) and the deformation-graph sampling (:593-595) are omitted.
 #include "efo_common.h"
 #include "efo_linalg.h"
 #include "efo_api.h"
