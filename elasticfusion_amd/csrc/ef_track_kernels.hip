@@ -1008,12 +1008,17 @@ __device__ unsigned long long g_accum_stamps[2 * VWARPS];   // entry / exit of e
 #define EF_ASTAMP(i) do { } while (0)
 #define EF_ASTAMP_ALL(slot) do { } while (0)
 #endif
-template <int BLOCK, int KC, bool HAS_ICP, bool HAS_RGB, bool PACKED>
+// NW = virtual warps per workgroup (1 in the product).  NW = 2 with 640 threads (EF_ACCUM_NW=2: 256 workgroups, one per CU,
+// all resident in ONE dispatch round, two pixel-visits per thread in flight together) was built to remove the second dispatch
+// round of the 512 ten-wave workgroups and measured the same launch time (9.06 vs 9.30 us, same frames/s): a CU needs the same
+// time for its 1216 visits whether they arrive as one workgroup or as two in sequence, so the launch is bound by the memory
+// phase of the whole chip bursting at once, not by the number of rounds.
+template <int BLOCK, int KC, int NW, bool HAS_ICP, bool HAS_RGB, bool PACKED>
 __device__ __forceinline__ void se3_accum_body(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, float* __restrict__ partials_icp,
                                                float* __restrict__ partials_rgb) {
-  static_assert(BLOCK >= 256 && BLOCK % 64 == 0, "phase B needs 256 threads");
-  __shared__ float rows[2][KC * ROW_STRIDE];
-  const int t = threadIdx.x, W = blockIdx.x;
+  static_assert(BLOCK >= 256 * NW && BLOCK % 64 == 0, "phase B needs 256 threads per virtual warp");
+  __shared__ float rows[NW][2][KC * ROW_STRIDE];
+  const int t = threadIdx.x, W0 = blockIdx.x * NW;
   const int cols = HAS_ICP ? IV.cols : RV.cols, nrows = HAS_ICP ? IV.rows : RV.rows;
   const int N = cols * nrows;
   const int K = (N + VTHREADS - 1) / VTHREADS;
@@ -1033,14 +1038,16 @@ __device__ __forceinline__ void se3_accum_body(const IcpView& IV, const RgbView&
     P.tprev = {in.tprev[0], in.tprev[1], in.tprev[2]};
   }
   __builtin_amdgcn_sched_barrier(0);   // keep the (scalar) pose loads ahead of the vector loads below: they overlap
-  // every thread owns up to MAXT pixel-visits of a chunk (task s = t + j * BLOCK); their stage-1 loads all go out together
-  constexpr int MAXT = (KC * 32 + BLOCK - 1) / BLOCK;
+  // every thread owns up to MAXT pixel-visits of a chunk: task (w, s = t + jj * BLOCK) for j = w * MAXT1 + jj, i.e. the same
+  // slot of every virtual warp of the workgroup; their stage-1 loads all go out together
+  constexpr int MAXT1 = (KC * 32 + BLOCK - 1) / BLOCK;
+  constexpr int MAXT = NW * MAXT1;
   VisitLoads L0[MAXT];
   if (PACKED) {
 #pragma unroll
     for (int j = 0; j < MAXT; ++j) {
-      const int s0 = t + j * BLOCK;
-      L0[j] = visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, s0 < min(KC, K) * 32 ? (s0 >> 5) * VTHREADS + W * 32 + (s0 & 31) : N, N);
+      const int w = j / MAXT1, s0 = t + (j % MAXT1) * BLOCK;
+      L0[j] = visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, s0 < min(KC, K) * 32 ? (s0 >> 5) * VTHREADS + (W0 + w) * 32 + (s0 & 31) : N, N);
     }
   }
   if (broken) return;  // rgbOnly "break": the level is over (k_se3_finish does the bookkeeping)
@@ -1059,10 +1066,10 @@ __device__ __forceinline__ void se3_accum_body(const IcpView& IV, const RgbView&
     sigma = sigma_s;
   }
   EF_ASTAMP(1);
-  // phase-B identity of this thread
-  const int l = t & 31, term = (t >> 5) & 1, part = t >> 6;
-  const bool chain_thread = t < 256 && (term == 0 ? HAS_ICP : HAS_RGB);
-  const int g = W * 32 + l;
+  // phase-B identity of this thread: 256 threads per virtual warp
+  const int wB = t >> 8, l = t & 31, term = (t >> 5) & 1, part = (t >> 6) & 3;
+  const bool chain_thread = t < 256 * NW && (term == 0 ? HAS_ICP : HAS_RGB);
+  const int g = (W0 + wB) * 32 + l;
   const int nk = g < N ? (N - g + VTHREADS - 1) / VTHREADS : 0;   // passes virtual thread g really makes
   float acc[8];
 #pragma unroll
@@ -1074,27 +1081,29 @@ __device__ __forceinline__ void se3_accum_body(const IcpView& IV, const RgbView&
       VisitLoads L[MAXT];
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) {
-        const int s1 = t + j * BLOCK;
-        L[j] = k0 == 0 ? L0[j] : visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, s1 < kc * 32 ? (k0 + (s1 >> 5)) * VTHREADS + W * 32 + (s1 & 31) : N, N);
+        const int w = j / MAXT1, s1 = t + (j % MAXT1) * BLOCK;
+        L[j] = k0 == 0 ? L0[j]
+                       : visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, s1 < kc * 32 ? (k0 + (s1 >> 5)) * VTHREADS + (W0 + w) * 32 + (s1 & 31) : N, N);
       }
       VisitGathers G[MAXT];
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) G[j] = visit_stage2a<HAS_ICP, HAS_RGB>(IV, RV, P, L[j]);
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) {
-        const int s1 = t + j * BLOCK;
+        const int w = j / MAXT1, s1 = t + (j % MAXT1) * BLOCK;
         if (s1 < kc * 32) {
           float irow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, grow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           float ifound, gfound;
           visit_stage2b<HAS_ICP, HAS_RGB>(IV, RV, P, sigma, L[j], G[j], irow, ifound, grow, gfound);
-          if (HAS_ICP) store_row(rows[0], s1 >> 5, s1 & 31, irow, ifound);
-          if (HAS_RGB) store_row(rows[1], s1 >> 5, s1 & 31, grow, gfound);
+          if (HAS_ICP) store_row(rows[w][0], s1 >> 5, s1 & 31, irow, ifound);
+          if (HAS_RGB) store_row(rows[w][1], s1 >> 5, s1 & 31, grow, gfound);
         }
       }
     } else {
-      for (int s = t; s < kc * 32; s += BLOCK) {
+      for (int sw = t; sw < NW * kc * 32; sw += BLOCK) {
+        const int w = sw / (kc * 32), s = sw - w * (kc * 32);
         const int k = s >> 5, sl = s & 31;
-        const int p = (k0 + k) * VTHREADS + W * 32 + sl;
+        const int p = (k0 + k) * VTHREADS + (W0 + w) * 32 + sl;
         if (HAS_ICP) {
           float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           float found = 0.f;
@@ -1102,19 +1111,19 @@ __device__ __forceinline__ void se3_accum_body(const IcpView& IV, const RgbView&
             const int y = p / cols, x = p - y * cols;
             if (icp_row(IV, P, x, y, row)) found = 1.f;
           }
-          store_row(rows[0], k, sl, row, found);
+          store_row(rows[w][0], k, sl, row, found);
         }
         if (HAS_RGB) {
           float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           float found = 0.f;
           if (p < N && rgb_row<PACKED>(RV, sigma, p, row)) found = 1.f;
-          store_row(rows[1], k, sl, row, found);
+          store_row(rows[w][1], k, sl, row, found);
         }
       }
     }
     __syncthreads();
     EF_ASTAMP(2);
-    if (chain_thread) se3_chains(rows[term], l, part, min(kc, nk - k0), acc);
+    if (chain_thread) se3_chains(rows[wB][term], l, part, min(kc, nk - k0), acc);
     __syncthreads();
     EF_ASTAMP(3);
   }
@@ -1125,7 +1134,7 @@ __device__ __forceinline__ void se3_accum_body(const IcpView& IV, const RgbView&
 #pragma unroll
       for (int off = 16; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 32);
     if (l == 0) {
-      float* out = (term == 0 ? partials_icp : partials_rgb) + W;
+      float* out = (term == 0 ? partials_icp : partials_rgb) + W0 + wB;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int a = se3_member(part, i);
@@ -1136,10 +1145,10 @@ __device__ __forceinline__ void se3_accum_body(const IcpView& IV, const RgbView&
   EF_ASTAMP(4);
   EF_ASTAMP_ALL(1);
 }
-template <int BLOCK, int KC, bool HAS_ICP, bool HAS_RGB, bool PACKED>
+template <int BLOCK, int KC, int NW, bool HAS_ICP, bool HAS_RGB, bool PACKED>
 __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, float* __restrict__ partials_icp,
                                                      float* __restrict__ partials_rgb) {
-  se3_accum_body<BLOCK, KC, HAS_ICP, HAS_RGB, PACKED>(IV, RV, in, partials_icp, partials_rgb);
+  se3_accum_body<BLOCK, KC, NW, HAS_ICP, HAS_RGB, PACKED>(IV, RV, in, partials_icp, partials_rgb);
 }
 #ifdef EF_ACCUM_CLOCKS
 extern "C" int ef_debug_accum_stamps(unsigned long long* out) {
@@ -1684,11 +1693,16 @@ void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int
   // developer knob: EF_ACCUM_BLOCK=256 runs level 0 with 4-wave workgroups too (all 512 resident at once, three
   // pixel-visits per thread) instead of 10-wave ones (one visit per thread, two dispatch rounds): same end-to-end time
   static const int big = getenv("EF_ACCUM_BLOCK") ? atoi(getenv("EF_ACCUM_BLOCK")) : ACC_BLOCK_BIG;
-  if (N > 8 * VTHREADS && big != 256)
-    hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_BIG, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(ACC_BLOCK_BIG), 0, s, IV, RV, in,
+  // developer knob: EF_ACCUM_NW=2 runs level 0 as 256 ten-wave workgroups of two virtual warps each (one dispatch round)
+  static const int nw = getenv("EF_ACCUM_NW") ? atoi(getenv("EF_ACCUM_NW")) : 1;
+  if (N > 8 * VTHREADS && big != 256 && nw == 2)
+    hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_BIG, ACC_KC, 2, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS / 2), dim3(ACC_BLOCK_BIG), 0, s, IV, RV, in,
+                       partials_icp, partials_rgb);
+  else if (N > 8 * VTHREADS && big != 256)
+    hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_BIG, ACC_KC, 1, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(ACC_BLOCK_BIG), 0, s, IV, RV, in,
                        partials_icp, partials_rgb);
   else
-    hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_SMALL, ACC_KC, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(ACC_BLOCK_SMALL), 0, s, IV, RV, in,
+    hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_SMALL, ACC_KC, 1, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(ACC_BLOCK_SMALL), 0, s, IV, RV, in,
                        partials_icp, partials_rgb);
 }
 }  // namespace
