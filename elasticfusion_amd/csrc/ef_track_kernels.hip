@@ -869,6 +869,11 @@ struct Se3Inputs {            // device pointers: the Gauss-Newton state the acc
   const int* broken;          // rgbOnly early-exit flag, or null
   float sigma_fixed;
   bool rgbOnly;
+  // Workgroup b runs on XCD b % 8 and every XCD has its own L2.  With the swizzle on, the workgroups of one XCD own a
+  // CONTIGUOUS range of virtual warps (= of pixels in every pass), so the lines of the model maps that neighbouring virtual
+  // warps share through the projective association (shifted 128-byte segments) are fetched once per XCD instead of once per
+  // workgroup; where a virtual warp's partial sums land does not change.
+  bool xcd_swizzle = false;
 };
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sums, bool broken, bool icp, bool rgb, bool rgbOnly,
                                                 float icpWeight, Intr knext, bool level_changes, efs::SolveScratch& S,
@@ -1018,7 +1023,9 @@ __device__ __forceinline__ void se3_accum_body(const IcpView& IV, const RgbView&
                                                float* __restrict__ partials_rgb) {
   static_assert(BLOCK >= 256 * NW && BLOCK % 64 == 0, "phase B needs 256 threads per virtual warp");
   __shared__ float rows[NW][2][KC * ROW_STRIDE];
-  const int t = threadIdx.x, W0 = blockIdx.x * NW;
+  const int t = threadIdx.x;
+  const int wg = in.xcd_swizzle ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int W0 = wg * NW;
   const int cols = HAS_ICP ? IV.cols : RV.cols, nrows = HAS_ICP ? IV.rows : RV.rows;
   const int N = cols * nrows;
   const int K = (N + VTHREADS - 1) / VTHREADS;
@@ -1689,7 +1696,10 @@ namespace {
 constexpr int ACC_BLOCK_BIG = 640, ACC_BLOCK_SMALL = 256, ACC_KC = 19;
 // one normal-equation accumulation launch (either tier)
 template <bool HAS_ICP, bool HAS_RGB, bool PACKED>
-void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int N, float* partials_icp, float* partials_rgb, hipStream_t s) {
+void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in_, int N, float* partials_icp, float* partials_rgb, hipStream_t s) {
+  static const int swz = getenv("EF_ACCUM_XCD") ? atoi(getenv("EF_ACCUM_XCD")) : 1;   // developer knob: 0 = linear block -> virtual warp
+  Se3Inputs in = in_;
+  in.xcd_swizzle = swz != 0;
   // developer knob: EF_ACCUM_BLOCK=256 runs level 0 with 4-wave workgroups too (all 512 resident at once, three
   // pixel-visits per thread) instead of 10-wave ones (one visit per thread, two dispatch rounds): same end-to-end time
   static const int big = getenv("EF_ACCUM_BLOCK") ? atoi(getenv("EF_ACCUM_BLOCK")) : ACC_BLOCK_BIG;
