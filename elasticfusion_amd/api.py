@@ -222,6 +222,13 @@ class ElasticFusion:
         _chk(lib().ef_get_local_loop(self.h, C.byref(info), _ptr(cons), c_i(len(cons)), C.byref(n)), self.h)
         return info, cons[:n.value].copy()
 
+    def sampleGraph(self, max_nodes=1024):
+        """Deformation::sampleGraphModel: [n, 4] float32 {x, y, z, initTime} of every 5000th surfel."""
+        out = np.zeros((max_nodes, 4), np.float32)
+        n = c_i(0)
+        _chk(lib().ef_sample_graph(self.h, _ptr(out), c_i(max_nodes), C.byref(n)), self.h)
+        return out[:n.value].copy()
+
     def predict(self):
         _chk(lib().ef_predict(self.h), self.h)
 

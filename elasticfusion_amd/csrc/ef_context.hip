@@ -715,6 +715,21 @@ int ef_get_local_loop(ef_ctx* c, ef_local_loop* info, double* constraints, int m
   if (n_out) *n_out = n;
   return EF_OK;
 }
+int ef_sample_graph(ef_ctx* c, float* nodes4, int max_nodes, int* n_out) {
+  if (!c || !nodes4 || !n_out || max_nodes <= 0) return EF_EINVAL;
+  float* dev = nullptr;
+  EF_HIP(c, hipMalloc((void**)&dev, ((size_t)max_nodes * 4 + 4) * sizeof(float)));
+  unsigned* n_dev = (unsigned*)(dev + (size_t)max_nodes * 4);
+  efm::sample_graph(c->maps[c->cur], &c->st->map_counts[c->cur], 5000, max_nodes, dev, n_dev, c->stream);
+  unsigned n = 0;
+  hipError_t e = hipMemcpyAsync(&n, n_dev, sizeof(n), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && n > 0) e = hipMemcpy(nodes4, dev, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  EF_HIP(c, e);
+  *n_out = (int)n;
+  return EF_OK;
+}
 int ef_set_graph_replay(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->use_graph = on != 0; return EF_OK; }
 int ef_predict(ef_ctx* c) {
   if (!c) return EF_EINVAL;

@@ -120,6 +120,8 @@ struct Deformation {
 void clean(const Cam& cam, const float* T_cw16_dev, int time, IndexMaps im, float confThreshold, int timeDelta, SurfelSoA map,
            const unsigned* count_dev, Candidates cand, uint32_t* winner, SurfelSoA out, unsigned* count_out_dev, uint32_t capacity,
            const CompactScratch& cs, int* overflow_flag, hipStream_t s, const Deformation* deform = nullptr);
+// Deformation::sampleGraphModel: nodes {x, y, z, initTime} = every `stride`-th surfel (5000 in the reference); *n_out = node count
+void sample_graph(SurfelSoA map, const unsigned* count_dev, int stride, int max_nodes, float* out4, unsigned* n_out, hipStream_t s);
 // candidates -> AoS "newUnstable" list in draw order (operator tier / tests)
 void candidates_to_aos(Candidates cand, float* aos, unsigned* count_dev, const CompactScratch& cs, hipStream_t s);
 

@@ -1159,4 +1159,21 @@ void candidates_to_aos(Candidates cand, float* aos, unsigned* count_dev, const C
   hipLaunchKernelGGL(k_cand_scatter, dim3(nch), dim3(BLK), 0, s, cand, (const uint8_t*)cs.flags, (const uint32_t*)cs.chunk_offset, (float4*)aos);
 }
 
+// Deformation::sampleGraphModel (Deformation.cpp:232-306; sample.vert + sample.geom): every 5000th surfel of the model, in
+// map order, as {position, initTime}
+__global__ void k_sample_graph(SurfelSoA map, const unsigned* __restrict__ count_dev, int stride, int max_nodes, float4* __restrict__ out,
+                               unsigned* __restrict__ n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned count = *count_dev;
+  const unsigned n = count == 0 ? 0u : (count - 1u) / (unsigned)stride + 1u;
+  if (i == 0) *n_out = n < (unsigned)max_nodes ? n : (unsigned)max_nodes;
+  if (i >= max_nodes || (unsigned)i >= n) return;
+  const float4 p = map.pos_conf[(size_t)i * stride];
+  const float4 c = map.col_time[(size_t)i * stride];
+  out[i] = make_float4(p.x, p.y, p.z, c.z);
+}
+void sample_graph(SurfelSoA map, const unsigned* count_dev, int stride, int max_nodes, float* out4, unsigned* n_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_sample_graph, dim3(ceil_div(max_nodes, 256)), dim3(256), 0, s, map, count_dev, stride, max_nodes, (float4*)out4, n_out);
+}
+
 }  // namespace efm

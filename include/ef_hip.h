@@ -116,6 +116,10 @@ int ef_set_loop_solver(ef_ctx* ctx, ef_loop_solver fn, void* user);   /* NULL: g
 /* icpCountThresh, icpErrThresh, covThresh of the constructor (ElasticFusion.h:44-46; defaults 35000, 5e-05, 1e-05) */
 int ef_set_loop_thresholds(ef_ctx* ctx, int icp_count_thresh, float icp_err_thresh, float cov_thresh);
 int ef_get_local_loop(ef_ctx* ctx, ef_local_loop* info, double* constraints_or_null, int max_constraints, int* n_out_or_null);
+/* Deformation::sampleGraphModel (Deformation.cpp:232-306, sample.vert + sample.geom): the deformation graph's nodes, every 5000th
+ * surfel of the current model in map order as {x, y, z, initTime} (times ascend because the map keeps creation order); what the
+ * reference hands to DeformationGraph::initialiseGraph.  nodes4_host: max_nodes x 4 floats.  Synchronises. */
+int ef_sample_graph(ef_ctx* ctx, float* nodes4_host, int max_nodes, int* n_out);
 int ef_predict(ef_ctx* ctx);                                  /* ElasticFusion::predict() */
 int ef_get_pose(ef_ctx* ctx, double* T_wc16);                 /* get_T_wc(); synchronises */
 int ef_get_tick(ef_ctx* ctx, int* tick);                      /* getTick() */

@@ -139,6 +139,8 @@ typedef int (*efo_loop_solver)(void* user, const efo_local_loop* info, const dou
 void efo_fusion_set_close_loops(efo_fusion*, int on, int icpCountThresh, float icpErrThresh, float covThresh);
 void efo_fusion_set_loop_solver(efo_fusion*, efo_loop_solver fn, void* user);
 int efo_fusion_local_loop(const efo_fusion*, efo_local_loop* info, double* constraints, int max_constraints);
+/* Deformation::sampleGraphModel: every 5000th surfel -> {x, y, z, initTime}; returns the node count */
+int efo_sample_graph(const float* surfels, int count, float* out4);
 /* which: 0 image 1 vertex 2 normal 3 time of the INACTIVE prediction */
 const void* efo_fusion_old_buffer(const efo_fusion*, int which);
 /* which: 0 image_rgba(u8x4) 1 vertex(f4) 2 normal(f4) 3 time(u16) 4 fill_image 5 fill_vertex 6 fill_normal

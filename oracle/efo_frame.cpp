@@ -251,6 +251,17 @@ int efo_fusion_local_loop(const efo_fusion* f, efo_local_loop* info, double* con
   if (constraints && n > 0) std::memcpy(constraints, f->loopConstraints.data(), (size_t)n * 8 * sizeof(double));
   return n;
 }
+// Deformation::sampleGraphModel (Deformation.cpp:232-306, sample.vert + sample.geom): every 5000th surfel -> {position, initTime}
+int efo_sample_graph(const float* surfels, int count, float* out4) {
+  int n = 0;
+  for (int id = 0; id < count; ++id)
+    if (id % 5000 == 0) {
+      const float* s = surfels + (size_t)id * 12;
+      out4[n * 4] = s[0]; out4[n * 4 + 1] = s[1]; out4[n * 4 + 2] = s[2]; out4[n * 4 + 3] = s[6];
+      ++n;
+    }
+  return n;
+}
 const void* efo_fusion_old_buffer(const efo_fusion* f, int which) {
   switch (which) {
     case 0: return f->oldImage.data();

@@ -391,6 +391,25 @@ int efg_clean(const efo_cam* cam, const double* T_wc16, int time, const uint32_t
                           newUnstable, newCount, nullptr, 0, nullptr, 0, out);
 }
 
+// Deformation::sampleGraphModel (Deformation.cpp:232-306): sample.vert + sample.geom under transform feedback, every 5000th
+// surfel of the model -> {position, initTime}
+int efg_sample_graph(const float* surfels, int count, float* out4) {
+  namespace V = glsl::sh_sample_vert;
+  namespace G = glsl::sh_sample_geom;
+  int n = 0;
+  glsl::emit_hook = [&]() { put4(out4 + (size_t)n * 4, G::vData); ++n; };
+  for (int k = 0; k < count; ++k) {
+    const float* s = surfels + (size_t)k * 12;
+    V::vPosition = get4(s); V::vColorTime = get4(s + 4); V::vNormRad = get4(s + 8);
+    glsl::gl_VertexID = k;
+    V::shader_main();
+    G::vPosition0[0] = V::vPosition0; G::vColorTime0[0] = V::vColorTime0; G::vNormRad0[0] = V::vNormRad0; G::id[0] = V::id;
+    G::shader_main();
+  }
+  glsl::emit_hook = nullptr;
+  return n;
+}
+
 const char* efg_about() {
   return "reference Core/Shaders/*.{vert,geom,frag,glsl} compiled by g++ through oracle/glsl_on_cpu (-ffp-contract=off); "
          "fixed-function stages as specified in SURVEY.md 8a N1-N5";

@@ -38,7 +38,7 @@ class _Proxy:
                                 "derivative_images", "project_to_point_cloud", "icp_step", "rgb_residual", "rgb_step", "so3_step")}
 
     MAP_OPS = {"efo_" + n for n in ("filter_depth", "metricise_depth", "seed_map", "predict_indices", "combined_predict", "synthesize_depth", "fill_in", "fuse", "clean_deform",
-                                    "clean")}
+                                    "clean", "sample_graph")}
 
     def __init__(self, so, prefix, default, ops=None):
         self._so, self._prefix, self._default = so, prefix, default
@@ -445,6 +445,14 @@ class Odometry:
         n = w * h * planes
         arr = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,))
         return arr.view(dt).reshape(h * planes, w).copy()
+
+
+def sample_graph(surfels):
+    s = f32(surfels).reshape(-1, 12)
+    out = np.zeros((len(s) // 5000 + 1, 4), np.float32)
+    fn = getattr(lib(), "efo_sample_graph")
+    n = fn(ptr(s), c_i(len(s)), ptr(out))
+    return out[:n].copy()
 
 
 class LocalLoop(C.Structure):

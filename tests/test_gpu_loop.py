@@ -53,6 +53,10 @@ def run_pair(solver_factory):
             assert same_floats(ef.image("old_normal"), o.old_buffer("normal")), i
         assert np.array_equal(bits(ef.get_T_wc()), bits(o.pose())), i
         assert ef.lastCount() == o.map_count(), i
+        if i % 5 == 4:   # Deformation::sampleGraphModel of the map as it stands (ElasticFusion.cpp:593)
+            nodes = ef.sampleGraph()
+            assert np.array_equal(bits(nodes), bits(efo.sample_graph(o.map()))) and len(nodes) == (o.map_count() - 1) // 5000 + 1
+            assert (np.diff(nodes[:, 3]) >= 0).all()    # the assumption Deformation.cpp:295-297 asserts
         opened += a.gates_ok
         applied += a.applied
     assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))

@@ -95,6 +95,16 @@ def test_inactive_prediction_against_compiled_shader(inputs):
     assert ref[3][ref[1][..., 2] > 0].max() <= tick - 2
 
 
+def test_graph_sampling_against_compiled_shader(inputs):
+    """SURVEY §8f row 4, device part: Deformation::sampleGraphModel = sample.vert + sample.geom under transform feedback"""
+    surf = inputs["surf"]
+    with efo.backend("reference_glsl"):
+        ref = efo.sample_graph(surf)
+    got = efo.sample_graph(surf)
+    assert len(ref) == (len(surf) - 1) // 5000 + 1 and trackops.bits_differ(got, ref) == 0
+    assert np.array_equal(ref[:, :3], surf[::5000, :3]) and np.array_equal(ref[:, 3], surf[::5000, 6])
+
+
 def test_bilateral_with_libm_exp(inputs):
     """exp() through libm's expf instead of the specified polynomial: the filtered depth may differ by at most 1 mm, rarely"""
     so = efo.reference_glsl_lib()
