@@ -230,6 +230,31 @@ def test_frames_at_1280x960_match_oracle(hip):
     ef.close()
 
 
+@pytest.mark.parametrize("size", [(320, 240), (332, 252), (100, 76)])
+def test_small_and_odd_resolutions_match_oracle(hip, size):
+    """Sizes whose pyramid levels are smaller than one pass of the 16384 virtual threads (80x60, 25x19), whose pixel counts are not
+    multiples of it, and whose levels have odd dimensions (83x63): partial passes, idle virtual warps, ragged tiles."""
+    from elasticfusion_amd import synth
+    W, H = size
+    sq = synth.Sequence(seed=0xEF0003, width=W, height=H)
+    kw = dict(width=W, height=H, fx=sq.fx, fy=sq.fy, cx=sq.cx, cy=sq.cy)
+    ef = hip.ElasticFusion(maxSurfels=1 << 19, **kw)
+    o = efo.Fusion(maxSurfels=1 << 19, **kw)
+    for k in range(6):
+        rgb, depth, _ = sq.frame(k)
+        ef.processFrame(rgb, depth, k * 33333)
+        o.process_frame(rgb, depth, k * 33333)
+        if k > 0:
+            st, _, _ = ef.trackingStats()
+            assert np.array_equal(np.asarray(st, np.float32).view(np.uint32), np.asarray(o.stats(), np.float32).view(np.uint32)), (k, st, o.stats())
+        assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32)), k
+        assert ef.lastCount() == o.map_count(), k
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    for name, oname in (("image", "image"), ("time", "time"), ("fill_image", "fill_image"), ("index", "index")):
+        assert np.array_equal(ef.image(name), o.buffer(oname)), name
+    ef.close()
+
+
 def test_fusion_with_injected_poses(hip, seq):
     """Ground-truth poses injected (in_T_wc), the reference's own way of decoupling fusion from tracking
     (ElasticFusion.cpp:302,367-369): identical poses => the map must match surfel for surfel."""
