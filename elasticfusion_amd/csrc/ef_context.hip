@@ -666,10 +666,11 @@ void ef_destroy(ef_ctx* c) {
 }
 const char* ef_last_error(const ef_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 void* ef_stream(ef_ctx* c) { return c ? (void*)c->stream : nullptr; }
+static int check_capacity(ef_ctx* c);
 int ef_synchronize(ef_ctx* c) {
   if (!c) return EF_EINVAL;
   EF_HIP(c, hipStreamSynchronize(c->stream));
-  return EF_OK;
+  return check_capacity(c);
 }
 
 int ef_process_frame(ef_ctx* c, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, float wm, const double* T) {
@@ -788,11 +789,23 @@ int ef_get_trajectory(ef_ctx* c, double* T16s, int64_t* stamps, int max_frames, 
   *n_frames = n;
   return EF_OK;
 }
+// clean() clamps the new surfel count to the capacity and raises a device flag; the getters that synchronise report it
+// (the reference's fixed 3072 x 3072 vertex buffer simply overflows, GlobalModel.cpp:22-24)
+static int check_capacity(ef_ctx* c) {
+  int flag = 0;
+  EF_HIP(c, hipMemcpyAsync(&flag, c->overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  if (flag) {
+    c->err = "surfel capacity exceeded (ef_config.max_surfels = " + std::to_string(c->capacity) + "): the newest surfels were dropped";
+    return EF_ECAPACITY;
+  }
+  return EF_OK;
+}
 int ef_map_count(ef_ctx* c, uint32_t* count) {
   if (!c || !count) return EF_EINVAL;
   EF_HIP(c, hipMemcpyAsync(count, &c->st->map_counts[c->cur], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   EF_HIP(c, hipStreamSynchronize(c->stream));
-  return EF_OK;
+  return check_capacity(c);
 }
 int ef_map_download(ef_ctx* c, float* surfels, uint32_t max_surfels, uint32_t* count) {
   if (!c || !count) return EF_EINVAL;

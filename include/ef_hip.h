@@ -30,7 +30,7 @@ extern "C" {
 #define EF_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
 #define EF_ENOMEM (-3)
 #define EF_ESTATE (-4)   /* call not valid in the current state */
-#define EF_ECAPACITY (-5) /* surfel capacity exceeded */
+#define EF_ECAPACITY (-5) /* surfel capacity exceeded: the map was clamped to max_surfels (reported by ef_synchronize / ef_map_count) */
 
 typedef struct ef_ctx ef_ctx;
 

@@ -255,6 +255,39 @@ def test_small_and_odd_resolutions_match_oracle(hip, size):
     ef.close()
 
 
+def test_degenerate_frames_match_oracle(hip):
+    """An all-invalid depth image, a black colour image and a depth image entirely beyond the cut-off in the middle of a sequence:
+    empty vertex maps, zero correspondences (0 / 0 statistics), singular normal equations — the tracker must carry on exactly as
+    the oracle does, NaNs included."""
+    from elasticfusion_amd import synth
+    W, H = 320, 240
+    sq = synth.Sequence(seed=0xEF0003, width=W, height=H)
+    kw = dict(width=W, height=H, fx=sq.fx, fy=sq.fy, cx=sq.cx, cy=sq.cy)
+    ef = hip.ElasticFusion(maxSurfels=1 << 19, **kw)
+    o = efo.Fusion(maxSurfels=1 << 19, **kw)
+    nans = 0
+    for k in range(9):
+        rgb, depth, _ = sq.frame(k)
+        if k == 3:
+            depth = np.zeros_like(depth)
+        if k == 5:
+            rgb = np.zeros_like(rgb)
+        if k == 6:
+            depth = np.full_like(depth, 65535)
+        ef.processFrame(rgb, depth, k * 33333)
+        o.process_frame(rgb, depth, k * 33333)
+        if k > 0:
+            st, _, _ = ef.trackingStats()
+            a, b = np.asarray(st, np.float32), np.asarray(o.stats(), np.float32)
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32)), (k, a, b)
+            nans += int(np.isnan(b).any())
+        assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32)), k
+        assert ef.lastCount() == o.map_count(), k
+    assert nans >= 2 and np.isfinite(o.pose()).all()
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    ef.close()
+
+
 def test_fusion_with_injected_poses(hip, seq):
     """Ground-truth poses injected (in_T_wc), the reference's own way of decoupling fusion from tracking
     (ElasticFusion.cpp:302,367-369): identical poses => the map must match surfel for surfel."""
@@ -275,6 +308,27 @@ def test_fusion_with_injected_poses(hip, seq):
     assert exact > 0.999, exact
     for name in ("image", "time", "fill_image"):
         assert np.array_equal(ef.image(name), o.buffer(name)), name
+    ef.close()
+
+
+def test_capacity_overflow_is_reported(hip):
+    """max_surfels = width * height holds the first frame exactly; the surfels later frames add do not fit: the map is clamped,
+    nothing is written out of bounds, and the synchronising getters say so (EF_ECAPACITY) instead of staying silent."""
+    from elasticfusion_amd import synth
+    W, H = 320, 240
+    sq = synth.Sequence(seed=0xEF0003, width=W, height=H)
+    ef = hip.ElasticFusion(width=W, height=H, fx=sq.fx, fy=sq.fy, cx=sq.cx, cy=sq.cy, maxSurfels=W * H, confidence=1.0)
+    rgb, depth, _ = sq.frame(0)
+    depth = np.where(depth == 0, 1500, depth).astype(np.uint16)        # every pixel seeds a surfel: the map is full
+    ef.processFrame(rgb, depth, 0)
+    assert ef.lastCount() == W * H
+    for k in range(1, 4):
+        rgb, depth, _ = sq.frame(20 * k)
+        ef.processFrame(rgb, depth, k)
+    with pytest.raises(hip.EFError, match="capacity"):
+        ef.lastCount()
+    with pytest.raises(hip.EFError, match="capacity"):
+        ef.synchronize()
     ef.close()
 
 

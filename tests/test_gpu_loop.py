@@ -78,9 +78,9 @@ def test_accepted_deformation_matches_oracle():
         assert na == nb and np.array_equal(bits(ca), bits(cb))
 
 
-def test_cxx_class_runs_the_front_half(tmp_path):
-    """libefusion.so: the reference's constructor with closeLoops = true (its default) now builds a context that runs the front
-    half; getModelToModel() reports the second tracker."""
+def test_thresholds_and_state_errors():
+    """countThresh / errThresh / covThresh of the constructor reach the gates; a solver can only be registered on a context
+    created with closeLoops."""
     from elasticfusion_amd import api
     ef = api.ElasticFusion(timeDelta=loopscene.TIME_DELTA, confidence=loopscene.CONFIDENCE, closeLoops=True, countThresh=20000,
                            maxSurfels=1 << 21)

@@ -35,3 +35,30 @@ def test_klg_replay_through_cpp_shim(tmp_path, seq):
         # yet, the header must still be a valid binary PLY
         hdr = open(log + ".ply", "rb").read(400)
         assert hdr.startswith(b"ply\nformat binary_little_endian 1.0") and b"element vertex" in hdr and b"end_header" in hdr
+
+
+def test_klg_replay_with_close_loops(tmp_path, seq):
+    """-cl: the C++ class constructed with closeLoops = true runs the local loop closure's front half on every frame; with no
+    solver registered it only evaluates the gates, so the trajectory equals the oracle's run in the same configuration."""
+    from elasticfusion_amd import api, synth
+    n = 8
+    frames = [seq.frame(k) for k in range(n)]
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "efusion_replay")
+    o = efo.Fusion(timeDelta=3, confidence=2.0)
+    o.set_close_loops(True)
+    attempts = opened = 0
+    for k, (rgb, depth, _) in enumerate(frames):
+        o.process_frame(rgb, depth, k * 33333)
+        info, _ = o.local_loop()
+        attempts += info.attempted
+        opened += info.gates_ok
+    log = str(tmp_path / "loops.klg")
+    synth.write_klg(log, frames)
+    r = subprocess.run([exe, "-l", log, "-cl", "-t", "3", "-c", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("local loop closure")][0].split()
+    assert int(line[line.index("attempts") + 1]) == attempts == n - 1 and int(line[line.index("open") + 1]) == opened
+    words = r.stdout.split()
+    assert int(words[words.index("surfels") + 1]) == o.map_count(), r.stdout
+    traj = np.loadtxt(log + ".freiburg")
+    assert np.abs(traj[-1, 1:4] - o.pose()[:3, 3]).max() <= 1e-8

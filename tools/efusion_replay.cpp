@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
   std::string log;
   int w = 640, h = 480, timeDelta = 200, end = -1, dev = 0;
   float fx = 528, fy = 528, cx = 320, cy = 240, depthCut = 3, confidence = 10, icp = 10;
-  bool fastOdom = false, so3 = true, ftf = false, ply = false, quiet = false;
+  bool fastOdom = false, so3 = true, ftf = false, ply = false, quiet = false, closeLoops = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&](int n = 1) { if (i + n >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -85,7 +85,8 @@ int main(int argc, char** argv) {
     else if (a == "-ftf") ftf = true;
     else if (a == "-ply") ply = true;
     else if (a == "-q") quiet = true;
-    else if (a == "-o") {}
+    else if (a == "-o") closeLoops = false;   // the default here (the reference closes loops unless -o is given)
+    else if (a == "-cl") closeLoops = true;   // local loop closure front half every frame, time window from -t
     else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
   }
   if (log.empty()) { std::fprintf(stderr, "usage: efusion_replay -l file.klg [...]\n"); return 2; }
@@ -94,14 +95,15 @@ int main(int argc, char** argv) {
     Intrinsics::getInstance(fx, fy, cx, cy);
     KlgReader reader(log, w, h);
     // open loop: timeDelta = INT_MAX / 2 exactly as MainController does for -o (MainController.cpp:179-183)
-    ElasticFusion eFusion(2147483647 / 2, 35000, 5e-05f, 1e-05f, false, false, false, 115, confidence, depthCut, icp, fastOdom, 0.3095f,
-                          so3, ftf, log, dev);
-    (void)timeDelta;
+    ElasticFusion eFusion(closeLoops ? timeDelta : 2147483647 / 2, 35000, 5e-05f, 1e-05f, closeLoops, false, false, 115, confidence, depthCut,
+                          icp, fastOdom, 0.3095f, so3, ftf, log, dev);
+    int attempts = 0, opened = 0;
     const auto t0 = std::chrono::steady_clock::now();
     int n = 0;
     while (reader.hasMore() && (end < 0 || n < end)) {
       reader.getNext();
       eFusion.processFrame(reader.rgb.data(), (const uint16_t*)reader.depth.data(), reader.timestamp, 1.0f);
+      if (closeLoops) { const ef_local_loop& L = eFusion.getLocalLoop(); attempts += L.attempted; opened += L.gates_ok; }
       ++n;
     }
     eFusion.synchronize();
@@ -111,6 +113,7 @@ int main(int argc, char** argv) {
     if (!quiet)
       std::printf("frames %d  %.1f fps  surfels %u  icp %g/%g  t_wc %.9g %.9g %.9g\n", n, n / dt, eFusion.getGlobalModel().lastCount(),
                   (double)eFusion.getModelToModel().lastICPError, (double)eFusion.getModelToModel().lastICPCount, M[3], M[7], M[11]);
+    if (!quiet && closeLoops) std::printf("local loop closure: attempts %d  gates open %d  deformations %d\n", attempts, opened, eFusion.getDeforms());
     if (ply) eFusion.savePly();
   } catch (const std::exception& e) {
     std::fprintf(stderr, "efusion_replay: %s\n", e.what());
