@@ -34,8 +34,12 @@ def needs_build() -> bool:
     if not os.path.exists(LIB) or not os.path.exists(SHIM_LIB) or not os.path.exists(NOFMA_LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "ef_hip.h"), __file__]
-    return any(os.path.getmtime(d) > t for d in deps)
+    root = os.path.dirname(HERE)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".o")]
+    deps += [os.path.join(root, "include", "ef_hip.h"), os.path.join(root, "include", "ElasticFusion.h"),
+             os.path.join(root, "tools", "efusion_replay.cpp"), __file__]
+    replay = os.path.join(HERE, "efusion_replay")
+    return not os.path.exists(replay) or any(os.path.getmtime(d) > min(t, os.path.getmtime(replay)) for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
