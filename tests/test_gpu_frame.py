@@ -311,6 +311,34 @@ def test_fusion_with_injected_poses(hip, seq):
     ef.close()
 
 
+def test_two_contexts_interleaved(hip):
+    """Nothing in the engine is global (the reference's Resolution / Intrinsics singletons became ef_config fields): two contexts
+    of different resolutions in one process, fed alternately, each on its own stream, give what each gives alone."""
+    from elasticfusion_amd import synth
+    cfgs = [dict(width=320, height=240), dict(width=332, height=252)]
+    seqs = [synth.Sequence(seed=0xEF0004 + i, **c) for i, c in enumerate(cfgs)]
+    kws = [dict(fx=s.fx, fy=s.fy, cx=s.cx, cy=s.cy, maxSurfels=1 << 19, **c) for s, c in zip(seqs, cfgs)]
+    n = 6
+    solo = []
+    for s, kw in zip(seqs, kws):
+        ef = hip.ElasticFusion(**kw)
+        for k in range(n):
+            rgb, depth, _ = s.frame(k)
+            ef.processFrame(rgb, depth, k)
+        solo.append((ef.get_T_wc(), ef.downloadMap()))
+        ef.close()
+    efs = [hip.ElasticFusion(**kw) for kw in kws]
+    assert efs[0].stream() != efs[1].stream()
+    for k in range(n):
+        for s, ef in zip(seqs, efs):
+            rgb, depth, _ = s.frame(k)
+            ef.processFrame(rgb, depth, k)
+    for ef, (T, m) in zip(efs, solo):
+        assert np.array_equal(ef.get_T_wc(), T)
+        assert np.array_equal(ef.downloadMap().view(np.uint32), m.view(np.uint32))
+        ef.close()
+
+
 def test_capacity_overflow_is_reported(hip):
     """max_surfels = width * height holds the first frame exactly; the surfels later frames add do not fit: the map is clamped,
     nothing is written out of bounds, and the synchronising getters say so (EF_ECAPACITY) instead of staying silent."""
