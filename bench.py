@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--width", type=int, default=W, help="1280 (with --height 960) = BASELINE.json configs[2]: the first frame seeds "
                     "~1.2 M surfels, i.e. the 1 M-surfel HBM-bound map; NOT the headline metric")
     ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--host-frames", action="store_true", help="hand the frames over as HOST buffers (ef_process_frame: copy into pinned "
+                    "staging + PCIe upload inside the timed region) - the PCIe-inclusive rate of DESIGN.md, never the headline value")
     ap.add_argument("--close-loops", action="store_true", help="closeLoops = true with the reference's default time window of 200 "
                     "frames: every frame also runs the local loop closure's front half (inactive-model prediction, second tracker, "
                     "gates, one stream synchronisation).  NOT the headline metric, which is open loop (-o)")
@@ -120,7 +122,10 @@ def main():
     dev = [(api.DevBuf.from_array(r), api.DevBuf.from_array(d)) for r, d, _ in frames]
 
     def step(k):
-        ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
+        if a.host_frames:
+            ef.processFrame(frames[k][0], frames[k][1], k * 33333)
+        else:
+            ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
 
     step(0)
     for k in range(1, a.warmup + 1):
@@ -203,6 +208,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{w}x{h} synthetic RGB-D replay (box+spheres, Lissajous trajectory), "
+                               + ("HOST frames (pinned staging + PCIe upload timed), " if a.host_frames else "")
                                + ("closeLoops (local loop closure front half every frame, timeDelta 200), " if a.close_loops else "open loop, ") +
                                "SO(3)+ICP+RGB 3-level tracking (10/5/4 its) + surfel fuse/clean/predict; "
                                + ("stand-in for configs[1] (dyson_lab.klg is not available offline)" if (w, h) == (W, H) else

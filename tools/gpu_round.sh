@@ -17,6 +17,12 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${tag} --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $out/${tag}_prof_stdout.log 2>&1
 find /tmp/prof -name "${tag}_kernel_stats.csv" -exec cp {} $out/ \;
 head -12 $out/${tag}_kernel_stats.csv | cut -c1-200
+# side measurements (not the headline): frames handed over as host buffers (PCIe inclusive), and closeLoops
+cd $GRAFT_REPO_ROOT
+timeout 300 python bench.py --no-cpu-baseline --host-frames --steps 200 --warmup 20 > $out/${tag}_hostframes_bench.json 2>/dev/null
+cut -c1-220 $out/${tag}_hostframes_bench.json
+timeout 300 python bench.py --no-cpu-baseline --close-loops --steps 200 --warmup 20 > $out/${tag}_closeloops_bench.json 2>/dev/null
+cut -c1-220 $out/${tag}_closeloops_bench.json
 # configs[2]: 1280x960, ~1 M surfels
 cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py --no-cpu-baseline --width 1280 --height 960 --steps 100 --warmup 10 > $out/${tag}_1280x960_bench.json 2>/dev/null
