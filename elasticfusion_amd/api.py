@@ -222,6 +222,14 @@ class ElasticFusion:
         _chk(lib().ef_get_local_loop(self.h, C.byref(info), _ptr(cons), c_i(len(cons)), C.byref(n)), self.h)
         return info, cons[:n.value].copy()
 
+    def imageResized(self, name: str, factor: int) -> np.ndarray:
+        """Resize::{image,vertex,time}: the named predicted / fill-in / inactive image, NEAREST-downsampled on the device."""
+        which, dt, ch = self.IMAGES[name]
+        h, w = self.cfg.height // factor, self.cfg.width // factor
+        out = np.zeros((h, w, ch) if ch > 1 else (h, w), dt)
+        _chk(lib().ef_get_image_resized(self.h, c_i(which), c_i(factor), _ptr(out), C.c_size_t(out.nbytes)), self.h)
+        return out
+
     def sampleGraph(self, max_nodes=1024):
         """Deformation::sampleGraphModel: [n, 4] float32 {x, y, z, initTime} of every 5000th surfel."""
         out = np.zeros((max_nodes, 4), np.float32)

@@ -171,6 +171,14 @@ __global__ void k_to_rowmajor(const T* __restrict__ src, int cols, int rows, T* 
   const int y = i / cols, x = i - y * cols;
   dst[i] = src[x * rows + y];
 }
+// Resize::{image,vertex,time} (Resize.cpp:50-159): NEAREST downsample, destination (a, b) <- source texel (f a + f/2, f b + f/2)
+template <typename T>
+__global__ void k_resize_nearest(const T* __restrict__ src, int cols, int dw, int dh, int factor, T* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= dw * dh) return;
+  const int b = i / dw, a = i - b * dw;
+  dst[i] = src[(size_t)(b * factor + factor / 2) * cols + (a * factor + factor / 2)];
+}
 __global__ void k_set_count(unsigned* count_dev, unsigned v) {
   if (threadIdx.x == 0) *count_dev = v;
 }
@@ -937,6 +945,40 @@ int ef_get_image(ef_ctx* c, int which, void* dst, size_t bytes) {
   hipError_t e = hipMemcpyAsync(dst, src, need, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (tmp) (void)hipFree(tmp);
+  EF_HIP(c, e);
+  return EF_OK;
+}
+int ef_get_image_resized(ef_ctx* c, int which, int factor, void* dst, size_t bytes) {
+  if (!c || !dst || factor < 1) return EF_EINVAL;
+  const int W = c->cam.cols, H = c->cam.rows, dw = W / factor, dh = H / factor;
+  const void* src = nullptr;
+  int elem = 0;
+  switch (which) {
+    case EF_IMG_PREDICT_IMAGE: src = c->pm.image; elem = 4; break;
+    case EF_IMG_PREDICT_VERTEX: src = c->pm.vertex; elem = 16; break;
+    case EF_IMG_PREDICT_NORMAL: src = c->pm.normal; elem = 16; break;
+    case EF_IMG_PREDICT_TIME: src = c->pm.time; elem = 2; break;
+    case EF_IMG_FILL_IMAGE: src = c->fm.image; elem = 4; break;
+    case EF_IMG_FILL_VERTEX: src = c->fm.vertex; elem = 16; break;
+    case EF_IMG_FILL_NORMAL: src = c->fm.normal; elem = 16; break;
+    case EF_IMG_OLD_IMAGE: src = c->old.image; elem = 4; break;
+    case EF_IMG_OLD_VERTEX: src = c->old.vertex; elem = 16; break;
+    case EF_IMG_OLD_NORMAL: src = c->old.normal; elem = 16; break;
+    case EF_IMG_OLD_TIME: src = c->old.time; elem = 2; break;
+    default: c->err = "ef_get_image_resized: a predicted, fill-in or inactive-prediction image"; return EF_EINVAL;
+  }
+  if (!src) { c->err = "ef_get_image_resized: this image only exists in a close_loops context"; return EF_ESTATE; }
+  const size_t need = (size_t)dw * dh * elem;
+  if (dw == 0 || dh == 0 || bytes < need) { c->err = "ef_get_image_resized: destination too small"; return EF_EINVAL; }
+  void* tmp = nullptr;
+  EF_HIP(c, hipMalloc(&tmp, need));
+  const dim3 g((unsigned)((dw * dh + 255) / 256));
+  if (elem == 16) hipLaunchKernelGGL(k_resize_nearest<float4>, g, dim3(256), 0, c->stream, (const float4*)src, W, dw, dh, factor, (float4*)tmp);
+  else if (elem == 4) hipLaunchKernelGGL(k_resize_nearest<uint32_t>, g, dim3(256), 0, c->stream, (const uint32_t*)src, W, dw, dh, factor, (uint32_t*)tmp);
+  else hipLaunchKernelGGL(k_resize_nearest<uint16_t>, g, dim3(256), 0, c->stream, (const uint16_t*)src, W, dw, dh, factor, (uint16_t*)tmp);
+  hipError_t e = hipMemcpyAsync(dst, tmp, need, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(tmp);
   EF_HIP(c, e);
   return EF_OK;
 }

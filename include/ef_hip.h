@@ -166,6 +166,10 @@ enum ef_image {
   EF_IMG_OLD_TIME                 /* u16  IndexMap::oldTimeTex   */
 };
 int ef_get_image(ef_ctx* ctx, int which, void* host_dst, size_t bytes);
+/* Resize::image / vertex / time (Core/Shaders/Resize.cpp:50-159): the predicted, fill-in or inactive-prediction image `which`
+ * downsampled NEAREST by an integer factor on the device ((W/factor) x (H/factor) elements copied to the host): what the fern
+ * database encodes (factor 8, Ferns.cpp:31-36,78-116) and what the constraint sampling reads (factor 20).  Synchronises. */
+int ef_get_image_resized(ef_ctx* ctx, int which, int factor, void* host_dst, size_t bytes);
 /* tracker pyramids (RGBDOdometry private state) for kernel-level parity tests:
  * which: 0 vmap_curr 1 nmap_curr 2 vmap_g_prev 3 nmap_g_prev 4 lastDepth 5 nextDepth 6 lastImage
  *        7 nextImage 8 lastNextImage 9 dIdx 10 dIdy 11 depth_tmp */

@@ -320,6 +320,17 @@ void efo_fill_in(const efo_cam* cam, const uint8_t* image, const float* vertex, 
 }
 
 // Resize::image + ElasticFusion::denseEnough (G8), consSample = 20 (ElasticFusion.cpp:62-70,256-268)
+// Resize::{image,vertex,time} (Resize.cpp:50-159; empty.vert + quad.geom + resize.frag): NEAREST downsample, destination pixel
+// (a, b) <- source texel (f*a + f/2, f*b + f/2) (the sample point (a + 0.5) * f falls exactly on a texel boundary and belongs to
+// the upper texel, N4 / G8).  Used with f = 20 for the constraint grid and denseEnough, f = 8 by the fern database (Ferns.cpp:31-36).
+void efo_resize_nearest(const void* src, int cols, int rows, int elemBytes, int factor, void* dst) {
+  const int dw = cols / factor, dh = rows / factor;
+  for (int b = 0; b < dh; ++b)
+    for (int a = 0; a < dw; ++a)
+      std::memcpy((char*)dst + ((size_t)b * dw + a) * elemBytes,
+                  (const char*)src + ((size_t)(b * factor + factor / 2) * cols + (a * factor + factor / 2)) * elemBytes, elemBytes);
+}
+
 int efo_dense_enough(const efo_cam* cam, const uint8_t* image) {
   const int dc = cam->cols / 20, dr = cam->rows / 20;
   int sum = 0;

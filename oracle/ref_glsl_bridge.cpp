@@ -410,6 +410,28 @@ int efg_sample_graph(const float* surfels, int count, float* out4) {
   return n;
 }
 
+// Resize::vertex / Resize::image (Resize.cpp:50-121): one point expanded by quad.geom to a full-viewport quad whose texcoord runs
+// 0..1, so fragment (a, b) of the (cols/f x rows/f) target samples the source at its own centre, ((a + 0.5) / dw, (b + 0.5) / dh).
+// elemBytes 16 = RGBA32F texture, 4 = RGBA8 (read back through the normalised float path).
+void efg_resize_nearest(const void* src, int cols, int rows, int elemBytes, int factor, void* dst) {
+  namespace F = glsl::sh_resize_frag;
+  const int dw = cols / factor, dh = rows / factor;
+  const Texture t = elemBytes == 16 ? tex((const float*)src, cols, rows, 4, Texture::F32) : tex((const uint8_t*)src, cols, rows, 4, Texture::U8_NORM);
+  F::eSampler.t = &t;
+  for (int b = 0; b < dh; ++b)
+    for (int a = 0; a < dw; ++a) {
+      F::texcoord = vec2(((float)a + 0.5f) / (float)dw, ((float)b + 0.5f) / (float)dh);
+      F::shader_main();
+      if (elemBytes == 16) {
+        put4((float*)dst + ((size_t)b * dw + a) * 4, F::FragColor);
+      } else {
+        float c[4];
+        put4(c, F::FragColor);
+        for (int k = 0; k < 4; ++k) ((uint8_t*)dst)[((size_t)b * dw + a) * 4 + k] = (uint8_t)std::lround(c[k] * 255.0f);
+      }
+    }
+}
+
 const char* efg_about() {
   return "reference Core/Shaders/*.{vert,geom,frag,glsl} compiled by g++ through oracle/glsl_on_cpu (-ffp-contract=off); "
          "fixed-function stages as specified in SURVEY.md 8a N1-N5";

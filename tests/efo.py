@@ -38,7 +38,7 @@ class _Proxy:
                                 "derivative_images", "project_to_point_cloud", "icp_step", "rgb_residual", "rgb_step", "so3_step")}
 
     MAP_OPS = {"efo_" + n for n in ("filter_depth", "metricise_depth", "seed_map", "predict_indices", "combined_predict", "synthesize_depth", "fill_in", "fuse", "clean_deform",
-                                    "clean", "sample_graph")}
+                                    "clean", "sample_graph", "resize_nearest")}
 
     def __init__(self, so, prefix, default, ops=None):
         self._so, self._prefix, self._default = so, prefix, default
@@ -445,6 +445,16 @@ class Odometry:
         n = w * h * planes
         arr = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,))
         return arr.view(dt).reshape(h * planes, w).copy()
+
+
+def resize_nearest(img, factor):
+    """Resize::{image,vertex,time}: img [H, W] or [H, W, C] of any dtype -> [H // factor, W // factor(, C)]"""
+    a = np.ascontiguousarray(img)
+    h, w = a.shape[:2]
+    elem = a.dtype.itemsize * (a.shape[2] if a.ndim == 3 else 1)
+    out = np.zeros((h // factor, w // factor) + a.shape[2:], a.dtype)
+    lib().efo_resize_nearest(ptr(a), c_i(w), c_i(h), c_i(elem), c_i(factor), ptr(out))
+    return out
 
 
 def sample_graph(surfels):

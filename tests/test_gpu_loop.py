@@ -53,6 +53,11 @@ def run_pair(solver_factory):
             assert same_floats(ef.image("old_normal"), o.old_buffer("normal")), i
         assert np.array_equal(bits(ef.get_T_wc()), bits(o.pose())), i
         assert ef.lastCount() == o.map_count(), i
+        if i % 5 == 4:   # Resize::{image,vertex} at the fern database's factor 8 and the constraint grid's factor 20
+            for f in (8, 20):
+                assert np.array_equal(ef.imageResized("image", f), efo.resize_nearest(o.buffer("image"), f)), (i, f)
+                assert same_floats(ef.imageResized("vertex", f), efo.resize_nearest(o.buffer("vertex"), f)), (i, f)
+                assert np.array_equal(ef.imageResized("old_time", f), efo.resize_nearest(o.old_buffer("time"), f)), (i, f)
         if i % 5 == 4:   # Deformation::sampleGraphModel of the map as it stands (ElasticFusion.cpp:593)
             nodes = ef.sampleGraph()
             assert np.array_equal(bits(nodes), bits(efo.sample_graph(o.map()))) and len(nodes) == (o.map_count() - 1) // 5000 + 1

@@ -10,6 +10,8 @@ seeding, the surfel splat with its ray/disc intersection, fill-in, the 16-tap as
 and the clean pass with its float tap loops (copy_unstable.vert) — except for the index map, where index_map.vert's round
 trip through NDC moves a handful of points across a pixel edge (mapops.INDEX_PIXEL_TOLERANCE).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -103,6 +105,21 @@ def test_graph_sampling_against_compiled_shader(inputs):
     got = efo.sample_graph(surf)
     assert len(ref) == (len(surf) - 1) // 5000 + 1 and trackops.bits_differ(got, ref) == 0
     assert np.array_equal(ref[:, :3], surf[::5000, :3]) and np.array_equal(ref[:, 3], surf[::5000, 6])
+
+
+@pytest.mark.parametrize("factor", [20, 8])
+def test_resize_against_compiled_shader(inputs, factor):
+    """Resize::vertex / Resize::image = empty.vert + quad.geom + resize.frag: the constraint grid (factor 20) and the fern
+    database's inputs (factor 8) — the sample point falls exactly on a texel boundary and takes the upper texel (G8 / N4)."""
+    vt, img = inputs["vt"], inputs["img"]
+    for a in (vt, img):
+        with efo.backend("reference_glsl"):
+            ref = efo.resize_nearest(a, factor)
+        got = efo.resize_nearest(a, factor)
+        assert ref.shape == (a.shape[0] // factor, a.shape[1] // factor, 4)
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+        assert np.array_equal(got, a[factor // 2::factor, factor // 2::factor][:ref.shape[0], :ref.shape[1]])
+    assert (efo.resize_nearest(vt, factor)[..., 2] > 0).sum() > 10
 
 
 def test_bilateral_with_libm_exp(inputs):
