@@ -26,6 +26,8 @@ def init_process_group(backend: str, local_rank: int):
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # the host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails (hipIpcGetMemHandle)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_PORT", "29511")
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
