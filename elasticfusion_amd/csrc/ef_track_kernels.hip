@@ -1157,6 +1157,128 @@ __global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const Rgb
                                                      float* __restrict__ partials_rgb) {
   se3_accum_body<BLOCK, KC, NW, HAS_ICP, HAS_RGB, PACKED>(IV, RV, in, partials_icp, partials_rgb);
 }
+// EXPERIMENT, off by default (EF_ACCUM_BLOCKWISE=1).  Small levels (N <= 8 passes): one workgroup per REFERENCE BLOCK (256 virtual threads = 8 virtual warps, 1024 threads), 64
+// workgroups.  The block's 8-warp tree then runs inside the workgroup (LDS + width-8 shuffles: the second stage of the
+// reference's blockReduceSum, whose other 24 lanes hold exact zeros), the kernel leaves the 64 block partials directly and
+// the finishing kernel needs neither its first stage nor the ticket hand-over between workgroups.  Per pass the workgroup
+// reads 256 consecutive pixels of every planar map.  Same chains, same trees, same bits.
+constexpr int ACCB_BLOCK = 1024, ACCB_KC = 5;
+template <int KC, bool HAS_ICP, bool HAS_RGB>
+__global__ void __launch_bounds__(ACCB_BLOCK) k_se3_accum_block(const IcpView IV, const RgbView RV, const Se3Inputs in,
+                                                                float* __restrict__ block_partials) {
+  constexpr int BLOCK = ACCB_BLOCK;
+  __shared__ float rows[8][2][KC * ROW_STRIDE];
+  __shared__ float wsum[2 * SE3_ACCS][8];
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int cols = HAS_ICP ? IV.cols : RV.cols, nrows = HAS_ICP ? IV.rows : RV.rows;
+  const int N = cols * nrows;
+  const int K = (N + VTHREADS - 1) / VTHREADS;
+  const int broken = in.broken ? *in.broken : 0;
+  int slot_a = 0, slot_b = 0;
+  const bool with_slots = HAS_RGB && in.rgb_slots;
+  if (with_slots && t < 64) { slot_a = in.rgb_slots[t * 16]; slot_b = in.rgb_slots[t * 16 + 1]; }
+  IcpPose P;
+  if (HAS_ICP) {
+    P.Rcurr = m33_load(in.Rcurr);
+    P.tcurr = {in.tcurr[0], in.tcurr[1], in.tcurr[2]};
+    P.Rprev_inv = m33_load(in.Rprev_inv);
+    P.tprev = {in.tprev[0], in.tprev[1], in.tprev[2]};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // task id = t + j * BLOCK of a chunk: pass id >> 8, virtual thread id & 255 of this reference block
+  constexpr int MAXT = (KC * 256 + BLOCK - 1) / BLOCK;
+  VisitLoads L0[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int id = t + j * BLOCK;
+    L0[j] = visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, id < min(KC, K) * 256 ? (id >> 8) * VTHREADS + b * 256 + (id & 255) : N, N);
+  }
+  if (broken) return;
+  float sigma = in.sigma_fixed;
+  if (with_slots) {
+    __shared__ float sigma_s;
+    if (t < 64) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        slot_a += __shfl_down(slot_a, off, 64);
+        slot_b += __shfl_down(slot_b, off, 64);
+      }
+      if (t == 0) sigma_s = sigma_from_sums(slot_b, slot_a, in.rgbOnly);
+    }
+    __syncthreads();
+    sigma = sigma_s;
+  }
+  // phase-B roles: 8 virtual warps x 256 (lane, term, part) = 2048 roles, two per thread (virtual warps t >> 8 and (t >> 8) + 4)
+  const int l = t & 31, term = (t >> 5) & 1, part = (t >> 6) & 3;
+  const bool chain_thread = term == 0 ? HAS_ICP : HAS_RGB;
+  float acc[2][8];
+  int nk[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int g = (b * 8 + (t >> 8) + 4 * q) * 32 + l;
+    nk[q] = g < N ? (N - g + VTHREADS - 1) / VTHREADS : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[q][i] = 0.f;
+  }
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    const int kc = min(KC, K - k0);
+    VisitLoads L[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int id = t + j * BLOCK;
+      L[j] = k0 == 0 ? L0[j] : visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, id < kc * 256 ? (k0 + (id >> 8)) * VTHREADS + b * 256 + (id & 255) : N, N);
+    }
+    VisitGathers G[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) G[j] = visit_stage2a<HAS_ICP, HAS_RGB>(IV, RV, P, L[j]);
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int id = t + j * BLOCK;
+      if (id < kc * 256) {
+        float irow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, grow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float ifound, gfound;
+        visit_stage2b<HAS_ICP, HAS_RGB>(IV, RV, P, sigma, L[j], G[j], irow, ifound, grow, gfound);
+        const int vt = id & 255;
+        if (HAS_ICP) store_row(rows[vt >> 5][0], id >> 8, vt & 31, irow, ifound);
+        if (HAS_RGB) store_row(rows[vt >> 5][1], id >> 8, vt & 31, grow, gfound);
+      }
+    }
+    __syncthreads();
+    if (chain_thread) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) se3_chains(rows[(t >> 8) + 4 * q][term], l, part, min(kc, nk[q] - k0), acc[q]);
+    }
+    __syncthreads();
+  }
+  if (chain_thread) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      // warpReduceSum, reduce.cu:57-95
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) acc[q][i] += __shfl_down(acc[q][i], off, 32);
+      if (l == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int a = se3_member(part, i);
+          if (a >= 0) wsum[term * SE3_ACCS + a][(t >> 8) + 4 * q] = acc[q][i];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // blockReduceSum's second stage (reduce.cu:97-117): lanes 0..7 of warp 0 hold the 8 warp sums, the rest exact zeros
+  if (t < 2 * SE3_ACCS * 8) {
+    const int a = t >> 3, w = t & 7, tm = a / SE3_ACCS;
+    const bool present = tm == 0 ? HAS_ICP : HAS_RGB;
+    float v = present ? wsum[a][w] : 0.f;
+    v += __shfl_down(v, 4, 8);
+    v += __shfl_down(v, 2, 8);
+    v += __shfl_down(v, 1, 8);
+    if (present && w == 0) block_partials[(a - ((HAS_ICP || tm == 0) ? 0 : SE3_ACCS)) * 64 + b] = v;
+  }
+}
 #ifdef EF_ACCUM_CLOCKS
 extern "C" int ef_debug_accum_stamps(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_accum_stamps), sizeof(unsigned long long) * 2 * VWARPS) == hipSuccess ? 0 : -1;
@@ -1334,6 +1456,7 @@ struct FinishArgs {
   float icpWeight;
   Intr knext;
   bool level_changes;
+  bool blocks_ready;   // the 64 block partials were left by k_se3_accum_block: one workgroup, no first stage, no hand-over
 };
 __global__ void __launch_bounds__(FINISH_BLOCK) k_se3_finish(TrackState* st, const float* __restrict__ partials_icp,
                                                              const float* __restrict__ partials_rgb, float* block_partials,
@@ -1349,6 +1472,7 @@ __global__ void __launch_bounds__(FINISH_BLOCK) k_se3_finish(TrackState* st, con
     return;
   }
   const int na = (A.icp ? SE3_ACCS : 0) + (A.rgb ? SE3_ACCS : 0);
+  if (!A.blocks_ready) {
   if (t < na * 8) {   // na * 8 <= 464: whole 8-lane groups
     const int a = t >> 3, w = t & 7;
     const float* src = (A.icp && a < SE3_ACCS) ? partials_icp + (size_t)a * VWARPS : partials_rgb + (size_t)(a - (A.icp ? SE3_ACCS : 0)) * VWARPS;
@@ -1362,13 +1486,14 @@ __global__ void __launch_bounds__(FINISH_BLOCK) k_se3_finish(TrackState* st, con
   if (t == 0) last_s = (take_ticket(&st->acc_ticket_final) == 63u);
   __syncthreads();
   if (!last_s) return;
+  }
   {
     constexpr int PASSES = (2 * SE3_ACCS * 64 + FINISH_BLOCK - 1) / FINISH_BLOCK;
     float v[PASSES];
 #pragma unroll
     for (int q = 0; q < PASSES; ++q) {
       const int idx = t + q * FINISH_BLOCK;
-      v[q] = idx < na * 64 ? coherent_load(block_partials + idx) : 0.f;
+      v[q] = idx < na * 64 ? (A.blocks_ready ? block_partials[idx] : coherent_load(block_partials + idx)) : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < PASSES; ++q) {
@@ -1380,7 +1505,7 @@ __global__ void __launch_bounds__(FINISH_BLOCK) k_se3_finish(TrackState* st, con
       if (idx < na * 64 && (idx & 63) == 0) sums_s[(A.icp ? 0 : SE3_ACCS) + (idx >> 6)] = x + w1;
     }
   }
-  if (t == 0) st->acc_ticket_final = 0;
+  if (t == 0 && !A.blocks_ready) st->acc_ticket_final = 0;
   __syncthreads();
   if (t < 64) solve_step_wave(st, sums_s, false, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S, PF);
 }
@@ -1934,13 +2059,21 @@ void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, cons
   Se3Inputs in{st->Rcurr, st->tcurr, st->Rprev_inv, st->tprev, &st->rgb_slots[0][0], &st->rgb_broken, 0.f, tp.rgbOnly};
   float* prgb = p.partials + SE3_ACCS * VWARPS;
   float* pblk = p.partials + 2 * SE3_ACCS * VWARPS;
+  // developer knob: EF_ACCUM_BLOCKWISE=1 runs the small levels as 64 reference-block workgroups + a single-workgroup finishing
+  // kernel (bit-identical; measured 2 % slower end to end than 512 virtual-warp workgroups + the two-stage finish)
+  static const int blockwise_knob = getenv("EF_ACCUM_BLOCKWISE") ? atoi(getenv("EF_ACCUM_BLOCKWISE")) : 0;
+  const bool blockwise = blockwise_knob != 0 && N <= 8 * VTHREADS;
   if (sample) (void)hipEventRecord(probe->start[probe->used], s);
-  if (icp && rgb) launch_accum<true, true, true>(IV, GV, in, N, p.partials, prgb, s);
+  if (blockwise) {
+    if (icp && rgb) hipLaunchKernelGGL((k_se3_accum_block<ACCB_KC, true, true>), dim3(64), dim3(ACCB_BLOCK), 0, s, IV, GV, in, pblk);
+    else if (icp) hipLaunchKernelGGL((k_se3_accum_block<ACCB_KC, true, false>), dim3(64), dim3(ACCB_BLOCK), 0, s, IV, GV, in, pblk);
+    else hipLaunchKernelGGL((k_se3_accum_block<ACCB_KC, false, true>), dim3(64), dim3(ACCB_BLOCK), 0, s, IV, GV, in, pblk);
+  } else if (icp && rgb) launch_accum<true, true, true>(IV, GV, in, N, p.partials, prgb, s);
   else if (icp) launch_accum<true, false, true>(IV, GV, in, N, p.partials, prgb, s);
   else launch_accum<false, true, true>(IV, GV, in, N, p.partials, prgb, s);
   if (sample) (void)hipEventRecord(probe->stop[probe->used++], s);
-  const FinishArgs fa{icp, rgb, tp.rgbOnly, tp.icpWeight, knext, level_changes};
-  hipLaunchKernelGGL(k_se3_finish, dim3(64), dim3(FINISH_BLOCK), 0, s, st, (const float*)p.partials, (const float*)prgb, pblk, fa);
+  const FinishArgs fa{icp, rgb, tp.rgbOnly, tp.icpWeight, knext, level_changes, blockwise};
+  hipLaunchKernelGGL(k_se3_finish, dim3(blockwise ? 1 : 64), dim3(FINISH_BLOCK), 0, s, st, (const float*)p.partials, (const float*)prgb, pblk, fa);
 }
 }  // namespace
 
