@@ -311,6 +311,53 @@ def test_fusion_with_injected_poses(hip, seq):
     ef.close()
 
 
+def test_map_upload_tick_trajectory_timings_and_dumps(hip, seq, tmp_path):
+    """The state API around processFrame: a map downloaded from one context and uploaded into a fresh one (ef_map_upload +
+    ef_set_tick) continues exactly like the original; the device-resident trajectory log; the per-stage timers; the dumps."""
+    frames = [seq.frame(k) for k in range(9)]
+
+    def feed(ef, k):
+        rgb, depth, T = frames[k]
+        ef.processFrame(rgb, depth, k * 33333, in_T_wc=None if k == 0 else T)
+
+    a = hip.ElasticFusion(confidence=1.0)
+    for k in range(6):
+        feed(a, k)
+    m, tick = a.downloadMap(), a.getTick()
+    assert tick == 7 and len(m) == a.lastCount()
+    b = hip.ElasticFusion(confidence=1.0)
+    b.uploadMap(m)
+    b.setTick(tick)
+    assert b.getTick() == tick and np.array_equal(b.downloadMap().view(np.uint32), m.view(np.uint32))
+    for k in (6, 7):
+        feed(a, k)
+        feed(b, k)
+    assert np.array_equal(a.downloadMap().view(np.uint32), b.downloadMap().view(np.uint32))
+    assert np.array_equal(a.image("image"), b.image("image")) and np.array_equal(a.image("time"), b.image("time"))
+    b.predict()                                                   # ElasticFusion::predict(): idempotent on an unchanged map and pose
+    assert np.array_equal(a.image("image"), b.image("image"))
+    b.close()
+    Ts, ts = a.trajectory()
+    assert len(Ts) == 8 and np.array_equal(ts, np.arange(8) * 33333)
+    assert np.array_equal(Ts[-1], a.get_T_wc()) and np.array_equal(Ts[0], np.eye(4))
+    for k in range(1, 8):
+        assert np.allclose(Ts[k], frames[k][2], atol=1e-12), k
+    a.enableTiming(True)
+    feed(a, 8)
+    a.synchronize()
+    t = a.timings()
+    for stage in ("Preprocess", "indexMap", "Fuse::Data+Update", "Fuse::Copy", "IndexMap::ACTIVE"):
+        assert stage in t and 0 < t[stage] < 50, (stage, t)
+    a.enableTiming(False)
+    a.saveFreiburg(str(tmp_path / "t.freiburg"))
+    a.savePly(str(tmp_path / "m.ply"))
+    assert len(open(tmp_path / "t.freiburg").read().splitlines()) == 9
+    hdr = open(tmp_path / "m.ply", "rb").read(300)
+    n_stable = int((a.downloadMap()[:, 3] > 1.0).sum())
+    assert hdr.startswith(b"ply") and (b"element vertex %d" % n_stable) in hdr and n_stable > 10000
+    a.close()
+
+
 def test_two_contexts_interleaved(hip):
     """Nothing in the engine is global (the reference's Resolution / Intrinsics singletons became ef_config fields): two contexts
     of different resolutions in one process, fed alternately, each on its own stream, give what each gives alone."""
