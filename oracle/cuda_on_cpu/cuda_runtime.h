@@ -22,9 +22,9 @@
 #include <cstring>
 #include <functional>
 
-#ifndef __CUDACC__
-#define __CUDACC__ 1   // the reference's headers hide their Eigen-dependent host helpers behind this (types.cuh:58)
-#endif
+#if !defined(__CUDACC__) && !defined(EFR_HOST_TU)
+#define __CUDACC__ 1   // the reference's headers hide their Eigen-dependent host helpers behind this (types.cuh:58);
+#endif                 // EFR_HOST_TU: a HOST translation unit of the reference (RGBDOdometry.cpp), compiled against host_on_cpu/
 #define __host__
 #define __device__
 #define __global__
@@ -110,7 +110,9 @@ static inline cudaError_t cudaGetLastError() { return cudaSuccess; }
 static inline cudaError_t cudaDeviceSynchronize() { return cudaSuccess; }
 static inline cudaError_t cudaMalloc(void** p, size_t n) {
   *p = nullptr;
-  return posix_memalign(p, 512, n ? n : 1) == 0 ? cudaSuccess : cudaErrorMemoryAllocation;
+  if (posix_memalign(p, 512, n ? n : 1) != 0) return cudaErrorMemoryAllocation;
+  std::memset(*p, 0, n ? n : 1);   // real device memory is uninitialised; zeros make the stale planes of quirk Q3 deterministic
+  return cudaSuccess;
 }
 template <typename T>
 static inline cudaError_t cudaMalloc(T** p, size_t n) { return cudaMalloc((void**)p, n); }

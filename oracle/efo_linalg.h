@@ -181,7 +181,8 @@ inline M3d rodrigues(const V3d& src) {
 
 // Orthogonal polar factor U*V^T of a 3x3 (what JacobiSVD U*V^T yields), by one-sided Jacobi
 // (Hestenes) sweeps: A*V = U*S  =>  U V^T = (A V) S^-1 V^T.
-inline M3d polar3(const M3d& Ain) {
+// one-sided Jacobi SVD of a 3x3 matrix: U (the rotated, column-normalised input) and V; singular values are not needed
+inline void svd3_uv(const M3d& Ain, M3d& Uout, M3d& Vout) {
   double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   std::memcpy(A, Ain.m, sizeof(A));
   for (int sweep = 0; sweep < 30; ++sweep) {
@@ -217,6 +218,14 @@ inline M3d polar3(const M3d& Ain) {
     n = std::sqrt(n);
     for (int i = 0; i < 3; ++i) A[i * 3 + j] /= n;
   }
+  std::memcpy(Uout.m, A, sizeof(A));
+  std::memcpy(Vout.m, V, sizeof(V));
+}
+inline M3d polar3(const M3d& Ain) {
+  M3d Um, Vm;
+  svd3_uv(Ain, Um, Vm);
+  const double* A = Um.m;
+  const double* V = Vm.m;
   M3d R;
   for (int i = 0; i < 3; ++i)
     for (int j = 0; j < 3; ++j) {

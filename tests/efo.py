@@ -40,6 +40,10 @@ class _Proxy:
     MAP_OPS = {"efo_" + n for n in ("filter_depth", "metricise_depth", "seed_map", "predict_indices", "combined_predict", "synthesize_depth", "fill_in", "fuse", "clean_deform",
                                     "clean", "sample_graph", "resize_nearest")}
 
+    # the tracking DRIVER (RGBDOdometry): handle-based, so an Odometry must be created and used under the same backend
+    ODOM_OPS = {"efo_odom_" + n for n in ("create", "destroy", "init_icp", "init_icp_model", "init_icp_maps", "init_rgb_model", "init_rgb",
+                                          "init_first_rgb", "track", "stats")}
+
     def __init__(self, so, prefix, default, ops=None):
         self._so, self._prefix, self._default = so, prefix, default
         self.OPS = ops if ops is not None else _Proxy.OPS
@@ -52,6 +56,8 @@ class _Proxy:
 
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libefr_cuda.so")
 REF_GLSL_SO = os.path.join(ORACLE_DIR, "_ref", "libefr_glsl.so")
+REF_DRIVER_SO = os.path.join(ORACLE_DIR, "_ref", "libefr_driver.so")
+REF_DRIVER_DSQRT_SO = os.path.join(ORACLE_DIR, "_ref", "libefr_driver_dsqrt.so")   # unqualified sqrt(float) read as ::sqrt(double)
 NOFMA_SO = os.path.join(ORACLE_DIR, "libefo_oracle_nofma.so")
 
 
@@ -68,6 +74,14 @@ def have_reference_glsl() -> bool:
     if not os.path.exists(REF_GLSL_SO) and os.path.isdir("/root/reference/Core/Shaders"):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "refglsl"])
     return os.path.exists(REF_GLSL_SO)
+
+
+def have_reference_driver() -> bool:
+    """oracle/_ref/libefr_driver.so = the reference's own Core/Utils/RGBDOdometry.cpp compiled for the CPU against
+    oracle/host_on_cpu (Eigen / Sophus / Pangolin in miniature) over its own CUDA operators (oracle/Makefile `refdriver`)."""
+    if not (os.path.exists(REF_DRIVER_SO) and os.path.exists(REF_DRIVER_DSQRT_SO)) and os.path.isdir("/root/reference/Core/Utils"):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "refdriver"])
+    return os.path.exists(REF_DRIVER_SO)
 
 
 def reference_glsl_lib():
@@ -95,6 +109,21 @@ class backend:
         elif self.which == "nofma":
             subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libefo_oracle_nofma.so"])
             _BACKEND = _Proxy(C.CDLL(NOFMA_SO), "efo_", default, _Proxy.OPS | _Proxy.MAP_OPS)
+        elif self.which == "nofma_driver":      # the oracle's tracking driver in the no-FMA build (its operators are then no-FMA too)
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libefo_oracle_nofma.so"])
+            so = C.CDLL(NOFMA_SO)
+            so.efo_odom_create.restype = P
+            _BACKEND = _Proxy(so, "efo_", default, _Proxy.ODOM_OPS)
+        elif self.which == "reference_driver":  # the reference's own RGBDOdometry.cpp, compiled
+            assert have_reference_driver(), "oracle/_ref/libefr_driver.so is missing and cannot be built here"
+            so = C.CDLL(REF_DRIVER_SO)
+            so.efd_odom_create.restype = P
+            _BACKEND = _Proxy(so, "efd_", default, _Proxy.ODOM_OPS)
+        elif self.which == "reference_driver_dsqrt":
+            assert have_reference_driver()
+            so = C.CDLL(REF_DRIVER_DSQRT_SO)
+            so.efd_odom_create.restype = P
+            _BACKEND = _Proxy(so, "efd_", default, _Proxy.ODOM_OPS)
         else:
             raise ValueError(self.which)
         return self
@@ -404,44 +433,48 @@ class Odometry:
     def __init__(self, w, h, cx, cy, fx, fy, handle=None):
         self.w, self.h = w, h
         self.own = handle is None
-        self.h_ = P(lib().efo_odom_create(c_i(w), c_i(h), c_f(cx), c_f(cy), c_f(fx), c_f(fy))) if handle is None else P(handle)
+        self._l = lib()   # the backend this object lives on (an Odometry is created and used on ONE library)
+        self.h_ = P(self._l.efo_odom_create(c_i(w), c_i(h), c_f(cx), c_f(cy), c_f(fx), c_f(fy))) if handle is None else P(handle)
 
     def __del__(self):
         if getattr(self, "own", False) and self.h_:
-            lib().efo_odom_destroy(self.h_)
+            self._l.efo_odom_destroy(self.h_)
             self.h_ = None
 
     def init_icp(self, depth_filtered, cutoff):
-        lib().efo_odom_init_icp(self.h_, ptr(depth_filtered), c_f(cutoff))
+        self._l.efo_odom_init_icp(self.h_, ptr(depth_filtered), c_f(cutoff))
 
     def init_icp_model(self, vtex, ntex, T_wc):
-        lib().efo_odom_init_icp_model(self.h_, ptr(f32(vtex)), ptr(f32(ntex)), ptr(_T(T_wc)))
+        self._l.efo_odom_init_icp_model(self.h_, ptr(f32(vtex)), ptr(f32(ntex)), ptr(_T(T_wc)))
+
+    def init_icp_maps(self, vtex, ntex):
+        self._l.efo_odom_init_icp_maps(self.h_, ptr(f32(vtex)), ptr(f32(ntex)))
 
     def init_rgb_model(self, rgba):
-        lib().efo_odom_init_rgb_model(self.h_, ptr(rgba))
+        self._l.efo_odom_init_rgb_model(self.h_, ptr(rgba))
 
     def init_rgb(self, rgba):
-        lib().efo_odom_init_rgb(self.h_, ptr(rgba))
+        self._l.efo_odom_init_rgb(self.h_, ptr(rgba))
 
     def init_first_rgb(self, rgba):
-        lib().efo_odom_init_first_rgb(self.h_, ptr(rgba))
+        self._l.efo_odom_init_first_rgb(self.h_, ptr(rgba))
 
     def track(self, T_wc, rgbOnly=False, icpWeight=10.0, pyramid=True, fastOdom=False, so3=True):
         T = _T(T_wc).copy()
-        lib().efo_odom_track(self.h_, ptr(T), c_i(int(rgbOnly)), c_f(icpWeight), c_i(int(pyramid)), c_i(int(fastOdom)), c_i(int(so3)))
+        self._l.efo_odom_track(self.h_, ptr(T), c_i(int(rgbOnly)), c_f(icpWeight), c_i(int(pyramid)), c_i(int(fastOdom)), c_i(int(so3)))
         return T.reshape(4, 4)
 
     def stats(self):
         out = np.zeros(6, np.float32)
         A = np.zeros((6, 6), np.float64)
         b = np.zeros(6, np.float64)
-        lib().efo_odom_stats(self.h_, ptr(out), ptr(A), ptr(b))
+        self._l.efo_odom_stats(self.h_, ptr(out), ptr(A), ptr(b))
         return out, A, b
 
     def buffer(self, name, level=0):
         which, dt, planes = self.BUF[name]
         w, h = self.w >> level, self.h >> level
-        addr = lib().efo_odom_buffer(self.h_, c_i(which), c_i(level))
+        addr = self._l.efo_odom_buffer(self.h_, c_i(which), c_i(level))
         n = w * h * planes
         arr = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,))
         return arr.view(dt).reshape(h * planes, w).copy()
