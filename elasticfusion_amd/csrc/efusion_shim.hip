@@ -8,6 +8,7 @@
 #include <stdexcept>
 
 #include "../../include/ef_hip.h"
+#include "../../include/efusion_klg.hpp"
 #include "ef_linalg_dev.hpp"
 
 // ---- singletons (Core/Utils/Resolution.h, Intrinsics.h): first call fixes the values for the process ----
@@ -205,3 +206,28 @@ std::vector<uint16_t> IndexMapView::time() {
 }
 
 }  // namespace efusion
+
+// ---- C API of the .klg reader (include/efusion_klg.hpp) ----
+namespace { thread_local std::string g_klg_error; }
+extern "C" {
+void* efk_open(const char* file, int width, int height, int deliver_last_frame, int flip_colors) {
+  try {
+    auto* r = new efusion::KlgReader(file, width, height);
+    r->deliverLastFrame = deliver_last_frame != 0;
+    r->flipColors = flip_colors != 0;
+    return r;
+  } catch (const std::exception& e) { g_klg_error = e.what(); return nullptr; }
+}
+void efk_close(void* reader) { delete (efusion::KlgReader*)reader; }
+int efk_num_frames(void* reader) { return ((efusion::KlgReader*)reader)->getNumFrames(); }
+int efk_has_more(void* reader) { return ((efusion::KlgReader*)reader)->hasMore() ? 1 : 0; }
+int efk_next(void* reader, int64_t* timestamp, uint16_t* depth, uint8_t* rgb) {
+  auto* r = (efusion::KlgReader*)reader;
+  try { r->getNext(); } catch (const std::exception& e) { g_klg_error = e.what(); return 0; }
+  if (timestamp) *timestamp = r->timestamp;
+  if (depth) std::memcpy(depth, r->depth.data(), r->depth.size());
+  if (rgb) std::memcpy(rgb, r->rgb.data(), r->rgb.size());
+  return 1;
+}
+const char* efk_last_error(void) { return g_klg_error.c_str(); }
+}

@@ -7,9 +7,8 @@
 //   efusion_replay -l seq.klg [-w 640 -h 480] [-cal fx fy cx cy] [-d depthCut] [-c confidence] [-t timeDelta]
 //                  [-fo] [-nso] [-ftf] [-i icpWeight] [-e endFrame] [-ply] [-dev N] [-q]
 //
-// Always open loop (the reference's -o): loop closure is out of scope of this build.
-#include <zlib.h>
-
+// Open loop (the reference's -o) unless -cl is given.  Like the reference's run loop, the last frame of a log is not
+// processed (RawLogReader::hasMore, see include/efusion_klg.hpp); -all processes every frame.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,54 +18,15 @@
 #include <vector>
 
 #include "../include/ElasticFusion.h"
+#include "../include/efusion_klg.hpp"
 
-namespace {
-struct KlgReader {
-  FILE* fp = nullptr;
-  int32_t numFrames = 0;
-  int numPixels;
-  std::vector<uint8_t> depthRead, imageRead, depth, rgb;
-  int64_t timestamp = 0;
-  int current = 0;
-  KlgReader(const std::string& file, int w, int h) : numPixels(w * h) {
-    fp = std::fopen(file.c_str(), "rb");
-    if (!fp) throw std::runtime_error("cannot open " + file);
-    if (std::fread(&numFrames, sizeof(int32_t), 1, fp) != 1) throw std::runtime_error("empty log");
-    depthRead.resize((size_t)numPixels * 2 + 65536);
-    imageRead.resize((size_t)numPixels * 3 + 65536);
-    depth.resize((size_t)numPixels * 2);
-    rgb.resize((size_t)numPixels * 3);
-  }
-  ~KlgReader() { if (fp) std::fclose(fp); }
-  bool hasMore() const { return current < numFrames; }
-  void getNext() {
-    int32_t depthSize = 0, imageSize = 0;
-    if (std::fread(&timestamp, sizeof(int64_t), 1, fp) != 1 || std::fread(&depthSize, sizeof(int32_t), 1, fp) != 1 ||
-        std::fread(&imageSize, sizeof(int32_t), 1, fp) != 1)
-      throw std::runtime_error("truncated log header");
-    if (depthSize < 0 || (size_t)depthSize > depthRead.size() || imageSize < 0 || (size_t)imageSize > imageRead.size())
-      throw std::runtime_error("frame larger than the configured resolution");
-    if (depthSize && std::fread(depthRead.data(), depthSize, 1, fp) != 1) throw std::runtime_error("truncated depth");
-    if (imageSize && std::fread(imageRead.data(), imageSize, 1, fp) != 1) throw std::runtime_error("truncated image");
-    if (depthSize == numPixels * 2) {
-      std::memcpy(depth.data(), depthRead.data(), depth.size());
-    } else {
-      unsigned long len = depth.size();
-      if (uncompress(depth.data(), &len, depthRead.data(), depthSize) != Z_OK) throw std::runtime_error("zlib depth frame corrupt");
-    }
-    if (imageSize == numPixels * 3) std::memcpy(rgb.data(), imageRead.data(), rgb.size());
-    else if (imageSize == 0) std::memset(rgb.data(), 0, rgb.size());
-    else throw std::runtime_error("JPEG-compressed colour frames are not supported in this build (no libjpeg)");
-    ++current;
-  }
-};
-}  // namespace
+using efusion::KlgReader;
 
 int main(int argc, char** argv) {
   std::string log;
   int w = 640, h = 480, timeDelta = 200, end = -1, dev = 0;
   float fx = 528, fy = 528, cx = 320, cy = 240, depthCut = 3, confidence = 10, icp = 10;
-  bool fastOdom = false, so3 = true, ftf = false, ply = false, quiet = false, closeLoops = false;
+  bool fastOdom = false, so3 = true, ftf = false, ply = false, quiet = false, closeLoops = false, allFrames = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&](int n = 1) { if (i + n >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -85,6 +45,7 @@ int main(int argc, char** argv) {
     else if (a == "-ftf") ftf = true;
     else if (a == "-ply") ply = true;
     else if (a == "-q") quiet = true;
+    else if (a == "-all") allFrames = true;
     else if (a == "-o") closeLoops = false;   // the default here (the reference closes loops unless -o is given)
     else if (a == "-cl") closeLoops = true;   // local loop closure front half every frame, time window from -t
     else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
@@ -94,6 +55,7 @@ int main(int argc, char** argv) {
     Resolution::getInstance(w, h);
     Intrinsics::getInstance(fx, fy, cx, cy);
     KlgReader reader(log, w, h);
+    reader.deliverLastFrame = allFrames;
     // open loop: timeDelta = INT_MAX / 2 exactly as MainController does for -o (MainController.cpp:179-183)
     ElasticFusion eFusion(closeLoops ? timeDelta : 2147483647 / 2, 35000, 5e-05f, 1e-05f, closeLoops, false, false, 115, confidence, depthCut,
                           icp, fastOdom, 0.3095f, so3, ftf, log, dev);
