@@ -116,3 +116,46 @@ def test_hip_nofma_deformation_equals_compiled_shader(nofma_map_ops):
     cols = [c for c in range(12) if c != 7]
     assert got.shape == ref.shape and trackops.bits_differ(got[:, cols], ref[:, cols]) == 0
     assert (got[:, 7] != ref[:, 7]).sum() <= 1e-5 * len(got)
+
+
+# ---- the frame tier's tracker (no-FMA build) against the reference's own tracking driver ----
+def test_hip_nofma_tracker_equals_compiled_reference_driver():
+    """ef_process_frame's tracker — pyramids, SO(3) pre-alignment, 19 Gauss-Newton iterations with the device-side solve — against
+    the reference's own Core/Utils/RGBDOdometry.cpp compiled where it lies (oracle/_ref/libefr_driver.so, over its own CUDA operators):
+    fed with the model images and the filtered depth the engine itself produced, the compiled driver must land on the same pose
+    and the same six statistics, bit for bit, frame after frame."""
+    if not efo.have_reference_driver():
+        pytest.skip("oracle/_ref/libefr_driver.so did not travel with the snapshot")
+    from elasticfusion_amd import api, build, synth
+    W, H = 320, 240
+    sq = synth.Sequence(seed=0xEF0005, width=W, height=H)
+    api.use_library(build.NOFMA_LIB)
+    try:
+        ef = api.ElasticFusion(width=W, height=H, fx=sq.fx, fy=sq.fy, cx=sq.cx, cy=sq.cy, maxSurfels=1 << 19)
+        frames = [sq.frame(k) for k in range(4)]
+        rgba = []
+        for rgb, _, _ in frames:
+            a = np.full((H, W, 4), 255, np.uint8)
+            a[..., :3] = rgb
+            rgba.append(a)
+        ef.processFrame(frames[0][0], frames[0][1], 0)
+        with efo.backend("reference_driver"):
+            od = efo.Odometry(W, H, sq.cx, sq.cy, sq.fx, sq.fy)
+            od.init_first_rgb(rgba[0])
+            for k in (1, 2, 3):
+                T_prev = ef.get_T_wc()
+                model = [ef.image(n) for n in ("fill_vertex", "fill_normal", "fill_image")]   # young map: the tracker uses the fill-in maps
+                ef.processFrame(frames[k][0], frames[k][1], k * 33333)
+                st, A, b = ef.trackingStats()
+                od.init_icp_model(model[0], model[1], T_prev)
+                od.init_rgb_model(model[2])
+                od.init_icp(ef.image("depth_filtered"), 20.0)
+                od.init_rgb(rgba[k])
+                T_ref = od.track(T_prev)
+                st_ref, A_ref, b_ref = od.stats()
+                assert np.array_equal(np.asarray(st, np.float32).view(np.uint32), st_ref.view(np.uint32)), (k, st, st_ref)
+                assert np.array_equal(np.asarray(A).view(np.uint64), A_ref.view(np.uint64)) and np.array_equal(np.asarray(b).view(np.uint64), b_ref.view(np.uint64)), k
+                assert np.array_equal(ef.get_T_wc().astype(np.float32), T_ref.astype(np.float32)), (k, np.abs(ef.get_T_wc() - T_ref).max())
+        ef.close()
+    finally:
+        api.use_library(None)
