@@ -70,9 +70,17 @@ class Matrix {
     for (int i = 0; i < R; ++i)
       for (int j = 0; j < C; ++j) (*this)(i, j) = b(i, j);
   }
+  Matrix(T x, T y) {
+    static_assert(R * C == 2, "two-coefficient constructor");
+    m[0] = x; m[1] = y;
+  }
   Matrix(T x, T y, T z) {
     static_assert(R * C == 3, "three-coefficient constructor");
     m[0] = x; m[1] = y; m[2] = z;
+  }
+  Matrix(T x, T y, T z, T w) {
+    static_assert(R * C == 4, "four-coefficient constructor");
+    m[0] = x; m[1] = y; m[2] = z; m[3] = w;
   }
   template <typename U, int O2>
   Matrix& operator=(const Matrix<U, R, C, O2>& o) {
@@ -228,6 +236,7 @@ Matrix<T, N, N, O> PartialPivLU<T, N, O>::inverse() const {
   return r;
 }
 
+typedef Matrix<float, 2, 1> Vector2f;
 typedef Matrix<float, 3, 1> Vector3f;
 typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<float, 4, 1> Vector4f;

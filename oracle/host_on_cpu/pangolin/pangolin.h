@@ -1,8 +1,7 @@
-// TEST INFRASTRUCTURE — what Core/GPUTexture.h needs from Pangolin / OpenGL to be parsed: two type names.
+// TEST INFRASTRUCTURE — what the reference's headers need from <pangolin/pangolin.h>: the GL type names and wrapper classes
 #pragma once
 #include <string>
-typedef unsigned int GLenum;
-typedef unsigned int GLuint;
-namespace pangolin {
-struct GlTexture { GLuint tid = 0; };
-}
+#include "gl/gl.h"
+#include "gl/glsl.h"
+#include "display/opengl_render_state.h"
+#include "utils/file_utils.h"

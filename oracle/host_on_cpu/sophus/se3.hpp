@@ -2,8 +2,23 @@
 // own SE(3) arithmetic (efo_linalg.h: unit quaternion x,y,z,w + translation; rotationMatrix / setRotationMatrix as restated there).
 #pragma once
 #include "../mini_eigen.h"
+#include "../../efo_pose.h"
 
 namespace Sophus {
+// T.cast<float>(): only its matrix() is used (GlobalModel.cpp:403): quaternion cast to float, renormalised, rotation in float
+class SE3f {
+ public:
+  explicit SE3f(const efo::Mat4f& m) : M(m) {}
+  Eigen::Matrix4f matrix() const {
+    Eigen::Matrix4f r;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) r(i, j) = M.m[i * 4 + j];
+    return r;
+  }
+
+ private:
+  efo::Mat4f M;
+};
 class SE3d {
  public:
   SE3d() : T(efo::se3_identity()) { sync_t(); }
@@ -23,6 +38,19 @@ class SE3d {
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) m.m[i * 3 + j] = R(i, j);
     efo::se3_set_rotation(T, m);
+  }
+  SE3d inverse() const { return SE3d(efo::se3_inverse(value())); }
+  Eigen::Matrix4d matrix() const {
+    const efo::M4d M = efo::se3_matrix(value());
+    Eigen::Matrix4d r;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) r(i, j) = M.m[i * 4 + j];
+    return r;
+  }
+  template <typename U>
+  SE3f cast() const {
+    const efo::M4d M = efo::se3_matrix(value());
+    return SE3f(efo::pose_castf(M.m));
   }
   efo::SE3 value() const {
     efo::SE3 r = T;
