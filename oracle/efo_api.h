@@ -139,6 +139,8 @@ typedef int (*efo_loop_solver)(void* user, const efo_local_loop* info, const dou
 void efo_fusion_set_close_loops(efo_fusion*, int on, int icpCountThresh, float icpErrThresh, float covThresh);
 void efo_fusion_set_loop_solver(efo_fusion*, efo_loop_solver fn, void* user);
 int efo_fusion_local_loop(const efo_fusion*, efo_local_loop* info, double* constraints, int max_constraints);
+/* T_cw = float(T_wc^-1) and pose = T_wc cast to float, row-major 4x4: the matrices the map passes hand to their shaders */
+void efo_pose_matrices(const double* T_wc16, float* T_cw16, float* pose16);
 /* Resize::{image,vertex,time} (Resize.cpp:50-159): NEAREST downsample by an integer factor, any element size */
 void efo_resize_nearest(const void* src, int cols, int rows, int elemBytes, int factor, void* dst);
 /* Deformation::sampleGraphModel: every 5000th surfel -> {x, y, z, initTime}; returns the node count */

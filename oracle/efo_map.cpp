@@ -320,6 +320,14 @@ void efo_fill_in(const efo_cam* cam, const uint8_t* image, const float* vertex, 
 }
 
 // Resize::image + ElasticFusion::denseEnough (G8), consSample = 20 (ElasticFusion.cpp:62-70,256-268)
+// the two float pose matrices every map pass derives from T_wc (efo_pose.h), row-major: T_cw = T_wc.inverse().matrix().cast<float>()
+// (IndexMap.cpp:208, GlobalModel.cpp:567) and pose = T_wc.cast<float>().matrix() (GlobalModel.cpp:403)
+void efo_pose_matrices(const double* T_wc16, float* T_cw16, float* pose16) {
+  const Mat4f a = T_cw_float(T_wc16), b = pose_castf(T_wc16);
+  std::memcpy(T_cw16, a.m, sizeof(a.m));
+  std::memcpy(pose16, b.m, sizeof(b.m));
+}
+
 // Resize::{image,vertex,time} (Resize.cpp:50-159; empty.vert + quad.geom + resize.frag): NEAREST downsample, destination pixel
 // (a, b) <- source texel (f*a + f/2, f*b + f/2) (the sample point (a + 0.5) * f falls exactly on a texel boundary and belongs to
 // the upper texel, N4 / G8).  Used with f = 20 for the constraint grid and denseEnough, f = 8 by the fern database (Ferns.cpp:31-36).

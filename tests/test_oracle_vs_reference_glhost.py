@@ -108,11 +108,21 @@ def pose():
     return T
 
 
-def T_cw_colmajor(T):
+def oracle_mats(T):
+    """the oracle's own float matrices (efo_pose.h), as glUniformMatrix4fv receives Eigen's column-major data()"""
     import efo
-    m = np.zeros(16, np.float32)
-    # the matrix the oracle's map passes use (efo_pose.h T_cw_float), as glUniformMatrix4fv receives Eigen's column-major data()
-    return np.linalg.inv(T).astype(np.float32).T.reshape(16)
+    a, b = np.zeros(16, np.float32), np.zeros(16, np.float32)
+    efo.lib().efo_pose_matrices(np.ascontiguousarray(T, np.float64).ctypes.data_as(P), a.ctypes.data_as(P), b.ctypes.data_as(P))
+    return a.reshape(4, 4).T.reshape(16), b.reshape(4, 4).T.reshape(16)
+
+
+def same32(vals, want):
+    """%.9g round-trips binary32: the recorded values must equal the oracle's floats exactly"""
+    return np.array_equal(np.asarray(vals, np.float64).astype(np.float32), np.asarray(want, np.float32))
+
+
+def T_cw_colmajor(T):
+    return oracle_mats(T)[0]
 
 
 def bound_fbo(p):
@@ -129,7 +139,7 @@ def test_predict_indices(host):
     _, (p,) = parse(host["so"].efh_predict_indices(host["h"], T.ctypes.data, 7, 20.0, 200).decode())
     t = host["tid"]
     assert p.program == ("index_map.vert", "index_map.frag")
-    assert np.allclose(p.uniforms["t_inv"], T_cw_colmajor(T), atol=1e-6) and "transpose=0" in [l for l in p.lines if "t_inv" in l][0]
+    assert same32(p.uniforms["t_inv"], T_cw_colmajor(T)) and "transpose=0" in [l for l in p.lines if "t_inv" in l][0]
     assert p.uniforms["cam"] == [CX, CY, FX, FY]
     assert (p.uniforms["maxDepth"], p.uniforms["cols"], p.uniforms["rows"], p.uniforms["time"], p.uniforms["timeDelta"]) == (20.0, W, H, 7, 200)
     assert host["attach"][bound_fbo(p)] == [t["index"], t["vertConf"], t["colorTime"], t["normalRad"]]
@@ -144,7 +154,7 @@ def test_combined_predict(host, inactive):
     _, (p,) = parse(txt)
     t = host["tid"]
     assert p.program == ("splat.vert", "combo_splat.frag")
-    assert np.allclose(p.uniforms["t_inv"], T_cw_colmajor(T), atol=1e-6) and p.uniforms["cam"] == [CX, CY, FX, FY]
+    assert same32(p.uniforms["t_inv"], T_cw_colmajor(T)) and p.uniforms["cam"] == [CX, CY, FX, FY]
     u = p.uniforms
     assert (u["maxDepth"], u["confThreshold"], u["cols"], u["rows"], u["timeDelta"]) == (20.0, 10.0, W, H, 4)
     assert (u["time"], u["maxTime"]) == ((0, 5) if inactive else (9, 9))
@@ -173,10 +183,10 @@ def test_fuse(host):
     assert {n: data.units[k] for n, k in sam.items()} == dict(cSampler=t["rgb"], drSampler=t["depthMetric"], drfSampler=t["depthMetricFiltered"],
                                                                indexSampler=t["index"], vertConfSampler=t["vertConf"], colorTimeSampler=t["colorTime"],
                                                                normRadSampler=t["normalRad"])
-    assert np.allclose(u["cam"], [CX, CY, np.float32(1.0 / FX), np.float32(1.0 / FY)], rtol=1e-7)       # inverse focal lengths here
+    assert same32(u["cam"], [CX, CY, np.float32(1.0 / FX), np.float32(1.0 / FY)])       # inverse focal lengths here
     assert (u["cols"], u["rows"], u["scale"], u["texDim"], u["maxDepth"], u["time"]) == (W, H, 1.0, 3072.0, 20.0, 7.0)
     assert abs(u["weighting"] - np.float32(0.8)) < 1e-9
-    assert np.allclose(u["pose"], T.astype(np.float32).T.reshape(16), atol=1e-6)                           # T_wc.cast<float>().matrix(), not its inverse
+    assert same32(u["pose"], oracle_mats(T)[1])                           # T_wc.cast<float>().matrix(), not its inverse
     assert "glViewport 0 0 3072 3072" in data.pre                                                           # the update map is TEXTURE_DIMENSION square
     assert data.attribs == ["glVertexAttribPointer 0 size=2 type=0x1406 norm=0 stride=0 offset=0"]         # one vec2 per pixel: the uv buffer
     assert data.draws == [["glDrawArrays", "0", "0", str(W * H)]]
@@ -194,7 +204,7 @@ def test_clean(host):
     assert p.program == ("copy_unstable.vert", "copy_unstable.geom")
     u = p.uniforms
     assert (u["time"], u["confThreshold"], u["scale"], u["nodes"], u["nodeCols"], u["timeDelta"], u["maxDepth"], u["isFern"]) == (7, 10.0, 1.0, 3.0, 16384.0, 200, 20.0, 0)
-    assert np.allclose(u["t_inv"], T_cw_colmajor(T), atol=1e-6) and u["cam"] == [CX, CY, FX, FY] and (u["cols"], u["rows"]) == (W, H)
+    assert same32(u["t_inv"], T_cw_colmajor(T)) and u["cam"] == [CX, CY, FX, FY] and (u["cols"], u["rows"]) == (W, H)
     want = dict(indexSampler="index", vertConfSampler="vertConf", colorTimeSampler="colorTime", normRadSampler="normalRad", depthSampler="depth")
     assert {n: p.units[int(u[n])] for n in want} == {n: t[v] for n, v in want.items()}
     assert any(l.startswith("glTexSubImage2D") and " 48 1 " in l for l in p.pre)          # the graph: nodes x 16 floats in one row of the node texture
@@ -208,7 +218,7 @@ def test_first_frame_seeding(host):
     for p, depth in ((raw, "depthMetric"), (flt, "depthMetricFiltered")):
         assert p.program == ("vertex_feedback.vert", "vertex_feedback.geom")
         u = p.uniforms
-        assert np.allclose(u["cam"], [CX, CY, np.float32(1.0 / FX), np.float32(1.0 / FY)], rtol=1e-7)
+        assert same32(u["cam"], [CX, CY, np.float32(1.0 / FX), np.float32(1.0 / FY)])
         assert (u["cols"], u["rows"], u["time"], u["maxDepth"], u["threshold"]) == (W, H, 1, 20.0, 0.0)
         assert p.units[int(u["gSampler"])] == t[depth] and p.units[int(u["cSampler"])] == t["rgb"]
         assert p.draws == [["glDrawArrays", "0", "0", str(W * H)]]
@@ -232,7 +242,7 @@ def test_fill_in_resize_and_compute_packs(host):
         assert p.program == ("empty.vert", "quad.geom", frag) and p.uniforms["passthrough"] == 0
         assert p.units[int(p.uniforms["eSampler"])] == t[e] and p.units[int(p.uniforms["rSampler"])] == t[r]
         assert p.draws == [["glDrawArrays", "0", "0", "1"]]
-    assert np.allclose(fv.uniforms["cam"], [CX, CY, np.float32(1.0 / FX), np.float32(1.0 / FY)], rtol=1e-7) and "cam" not in fc.uniforms
+    assert same32(fv.uniforms["cam"], [CX, CY, np.float32(1.0 / FX), np.float32(1.0 / FY)]) and "cam" not in fc.uniforms
     assert [host["attach"][bound_fbo(p)] for p in (fv, fn, fc)] == [[t["fillVertex"]], [t["fillNormal"]], [t["fillImage"]]]
     _, rs = parse(host["so"].efh_resize(host["h"]).decode())
     assert [p.units[0] for p in rs] == [t["image"], t["vertex"], t["oldTime"]] and all(f"glViewport 0 0 {W // 20} {H // 20}" in p.pre for p in rs)
