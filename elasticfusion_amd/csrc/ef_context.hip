@@ -850,6 +850,44 @@ int ef_map_upload(ef_ctx* c, const float* surfels, uint32_t count) {
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, c->stream, &c->st->map_counts[c->cur], count);
   return EF_OK;
 }
+// Host-only writers (no context, no GPU): the two dumps of the reference, byte for byte.
+//   trajectory: ~ElasticFusion, ElasticFusion.cpp:112-139 — "timestamp tx ty tz qx qy qz qw" per pose, the timestamp as microseconds / 1e6
+//     with six decimals, the seven numbers as an ostream prints a double by default (six significant digits, %g);
+//   map: ElasticFusion::savePly, :684-781 — binary little-endian PLY of the surfels with confidence above the threshold:
+//     x y z, r g b unpacked from the colour float, the NEGATED normal (:741-743), the radius.
+int ef_write_freiburg(const char* path, const double* T_wc16_array, const int64_t* timestamps, int n) {
+  if (!path || (n > 0 && (!T_wc16_array || !timestamps))) return EF_EINVAL;
+  FILE* f = fopen(path, "w");
+  if (!f) return EF_EINVAL;
+  for (int i = 0; i < n; ++i) {
+    const efl::SE3 S = efl::se3_from_matrix(T_wc16_array + (size_t)i * 16);
+    fprintf(f, "%.6f %g %g %g %g %g %g %g\n", (double)timestamps[i] / 1000000.0, S.t[0], S.t[1], S.t[2], S.q[0], S.q[1], S.q[2], S.q[3]);
+  }
+  fclose(f);
+  return EF_OK;
+}
+int ef_write_ply(const char* path, const float* surfels, uint32_t count, float confidence_threshold) {
+  if (!path || (count > 0 && !surfels)) return EF_EINVAL;
+  uint32_t valid = 0;
+  for (uint32_t i = 0; i < count; ++i) valid += surfels[(size_t)i * 12 + 3] > confidence_threshold;
+  FILE* f = fopen(path, "wb");
+  if (!f) return EF_EINVAL;
+  fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %u\nproperty float x\nproperty float y\nproperty float z\n"
+             "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty float nx\nproperty float ny\nproperty float nz\n"
+             "property float radius\nend_header\n", valid);
+  for (uint32_t i = 0; i < count; ++i) {
+    const float* s = surfels + (size_t)i * 12;
+    if (!(s[3] > confidence_threshold)) continue;
+    const int col = (int)s[4];
+    const unsigned char rgbc[3] = {(unsigned char)((col >> 16) & 0xFF), (unsigned char)((col >> 8) & 0xFF), (unsigned char)(col & 0xFF)};
+    const float nr[4] = {s[8] * -1, s[9] * -1, s[10] * -1, s[11]};
+    fwrite(s, sizeof(float), 3, f);
+    fwrite(rgbc, 1, 3, f);
+    fwrite(nr, sizeof(float), 4, f);
+  }
+  fclose(f);
+  return EF_OK;
+}
 int ef_save_freiburg(ef_ctx* c, const char* path) {
   if (!c || !path) return EF_EINVAL;
   const int n = (int)c->stamps.size();
@@ -857,15 +895,9 @@ int ef_save_freiburg(ef_ctx* c, const char* path) {
   int got = 0;
   int r = ef_get_trajectory(c, T.data(), nullptr, n, &got);
   if (r != EF_OK) return r;
-  FILE* f = fopen(path, "w");
-  if (!f) { c->err = std::string("cannot open ") + path; return EF_EINVAL; }
-  // "timestamp tx ty tz qx qy qz qw", timestamp = microseconds / 1e6 (ElasticFusion.cpp:112-139)
-  for (int i = 0; i < got; ++i) {
-    const efl::SE3 S = efl::se3_from_matrix(&T[(size_t)i * 16]);
-    fprintf(f, "%.6f %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", (double)c->stamps[i] / 1000000.0, S.t[0], S.t[1], S.t[2], S.q[0], S.q[1], S.q[2], S.q[3]);
-  }
-  fclose(f);
-  return EF_OK;
+  r = ef_write_freiburg(path, T.data(), c->stamps.data(), got);
+  if (r != EF_OK) c->err = std::string("cannot open ") + path;
+  return r;
 }
 int ef_save_ply(ef_ctx* c, const char* path) {
   if (!c || !path) return EF_EINVAL;
@@ -875,27 +907,10 @@ int ef_save_ply(ef_ctx* c, const char* path) {
   std::vector<float> m((size_t)n * 12);
   r = ef_map_download(c, m.data(), n, &n);
   if (r != EF_OK) return r;
-  uint32_t valid = 0;
-  for (uint32_t i = 0; i < n; ++i) valid += m[(size_t)i * 12 + 3] > c->cfg.confidence;
-  FILE* f = fopen(path, "wb");
-  if (!f) { c->err = std::string("cannot open ") + path; return EF_EINVAL; }
-  // header + binary little-endian records of ElasticFusion::savePly (ElasticFusion.cpp:684-781)
-  fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %u\nproperty float x\nproperty float y\nproperty float z\n"
-             "property uchar red\nproperty uchar green\nproperty uchar blue\nproperty float nx\nproperty float ny\nproperty float nz\n"
-             "property float radius\nend_header\n", valid);
-  for (uint32_t i = 0; i < n; ++i) {
-    const float* s = &m[(size_t)i * 12];
-    if (!(s[3] > c->cfg.confidence)) continue;
-    const int col = (int)s[4];
-    const unsigned char rgbc[3] = {(unsigned char)((col >> 16) & 0xFF), (unsigned char)((col >> 8) & 0xFF), (unsigned char)(col & 0xFF)};
-    fwrite(s, sizeof(float), 3, f);
-    fwrite(rgbc, 1, 3, f);
-    fwrite(s + 8, sizeof(float), 4, f);
-  }
-  fclose(f);
-  return EF_OK;
+  r = ef_write_ply(path, m.data(), n, c->cfg.confidence);
+  if (r != EF_OK) c->err = std::string("cannot open ") + path;
+  return r;
 }
-
 int ef_set_rgb_only(ef_ctx* c, int v) { if (!c) return EF_EINVAL; c->cfg.rgb_only = v; return EF_OK; }
 int ef_set_icp_weight(ef_ctx* c, float v) { if (!c) return EF_EINVAL; c->cfg.icp_weight = v; return EF_OK; }
 int ef_set_pyramid(ef_ctx* c, int v) { if (!c) return EF_EINVAL; c->cfg.pyramid = v; return EF_OK; }

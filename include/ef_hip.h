@@ -134,6 +134,10 @@ int ef_map_download(ef_ctx* ctx, float* surfels, uint32_t max_surfels, uint32_t*
 int ef_map_upload(ef_ctx* ctx, const float* surfels, uint32_t count);  /* test/bench seeding */
 int ef_save_freiburg(ef_ctx* ctx, const char* path);          /* trajectory dump of ~ElasticFusion, :112-139 */
 int ef_save_ply(ef_ctx* ctx, const char* path);               /* ElasticFusion::savePly, :684-781 */
+/* the same two writers on HOST arrays (no context, no GPU): byte for byte the reference's files — the trajectory with six
+ * significant digits per number as its ostream prints them, the PLY with the normals negated as savePly does (:741-743) */
+int ef_write_freiburg(const char* path, const double* T_wc16_array, const int64_t* timestamps, int n);
+int ef_write_ply(const char* path, const float* surfels12, uint32_t count, float confidence_threshold);
 /* setters (Core/ElasticFusion.h:135-183) */
 int ef_set_rgb_only(ef_ctx*, int v);
 int ef_set_icp_weight(ef_ctx*, float v);

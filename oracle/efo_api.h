@@ -123,6 +123,9 @@ void efo_set_threads(int n);
 /* deformation graph (nodes x 16, sorted by time) applied by the next frame's clean, as after a loop closure */
 void efo_fusion_set_deformation(efo_fusion*, const float* graph, int nodes, int isFern);
 void efo_fusion_stats(const efo_fusion*, float* out6);
+/* trace of the frame loop: one line per step with its parameters (tests/test_oracle_vs_reference_frame.py) */
+void efo_fusion_trace(efo_fusion*, int on);
+const char* efo_fusion_take_trace(efo_fusion*);
 /* ---- local loop closure, front half (ElasticFusion.cpp:447-511): INACTIVE prediction, model-to-model odometry, covariance and
  * error gates, surface constraints sampled every consSample = 20 pixels.  The deformation-graph optimisation on their far side
  * (Deformation::constrain) is the caller's: a solver callback receives the constraints and may return a graph, which is then

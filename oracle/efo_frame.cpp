@@ -7,6 +7,9 @@
 #include "efo_common.h"
 #include "efo_linalg.h"
 #include "efo_api.h"
+#include <cstdarg>
+#include <cstdio>
+#include <string>
 #include <vector>
 
 using namespace efo;
@@ -24,6 +27,27 @@ struct efo_fusion {
   efo_loop_solver solver = nullptr;
   void* solverUser = nullptr;
   efo_local_loop loop{};
+  // optional trace of the frame loop (efo_fusion_trace): one line per step with its parameters, in the vocabulary
+  // tests/test_oracle_vs_reference_frame.py also derives from the compiled reference's transcript
+  bool tracing = false;
+  std::string trace;
+  void tr(const char* fmt, ...) {
+    if (!tracing) return;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    trace += buf;
+    trace += '\n';
+  }
+  void tr_pose(const char* what, const double* M) {
+    if (!tracing) return;
+    std::string t;
+    char b[40];
+    for (int i = 0; i < 12; ++i) { snprintf(b, sizeof(b), " %.17g", M[i]); t += b; }
+    tr("%s%s", what, t.c_str());
+  }
   std::vector<double> loopConstraints;   // n x 8
   std::vector<uint8_t> oldImage;
   std::vector<float> oldVertex, oldNormal;
@@ -78,6 +102,15 @@ struct efo_fusion {
     double M[16];
     pose16(M);
     std::memcpy(loop.T_wc_curr, M, sizeof(M));
+    tr("combinedPredict INACTIVE maxDepth=%g conf=%g time=%d maxTime=%d timeDelta=%d", maxDepthProcessed, p.confidence, 0, tick - p.timeDelta, p.timeDelta);
+    tr_pose("  pose", M);
+    tr("modelToModel.initICPModel vertices=old normals=old");
+    tr_pose("  pose", M);
+    tr("modelToModel.initRGBModel image=old");
+    tr("modelToModel.initICP vertices=pred normals=pred");
+    tr("modelToModel.initRGB image=pred");
+    tr("modelToModel.track rgbOnly=0 icpWeight=10 pyramid=%d fastOdom=%d so3=0", p.pyramid, p.fastOdom);
+    tr("modelToModel.getCovariance");
     efo_combined_predict(&cam, M, surfels.data(), count, maxDepthProcessed, p.confidence, 0, tick - p.timeDelta, p.timeDelta,
                          oldImage.data(), oldVertex.data(), oldNormal.data(), oldTime.data());                 // :451-459, INACTIVE
     efo_odom_init_icp_model(modelToModel, oldVertex.data(), oldNormal.data(), M);                              // :463
@@ -137,6 +170,9 @@ struct efo_fusion {
   void predict() {
     double M[16];
     pose16(M);
+    tr("combinedPredict ACTIVE maxDepth=%g conf=%g time=%d maxTime=%d timeDelta=%d", maxDepthProcessed, p.confidence, tick, tick, p.timeDelta);
+    tr_pose("  pose", M);
+    tr("fillIn vertex passthrough=0; normal passthrough=0; image passthrough=%d", p.frameToFrameRGB ? 1 : 0);
     efo_combined_predict(&cam, M, surfels.data(), count, maxDepthProcessed, p.confidence, tick, tick, p.timeDelta,
                          image.data(), vertex.data(), normal.data(), timeMap.data());
     efo_fill_in(&cam, image.data(), vertex.data(), normal.data(), depthFiltered.data(), rgb.data(), 0,
@@ -148,11 +184,15 @@ struct efo_fusion {
     std::memcpy(depthRaw.data(), depth_in, P * 2);       // :278-280
     std::memcpy(rgb.data(), rgb_in, P * 3);
     for (size_t i = 0; i < P; ++i) { rgba[i * 4] = rgb[i * 3]; rgba[i * 4 + 1] = rgb[i * 3 + 1]; rgba[i * 4 + 2] = rgb[i * 3 + 2]; rgba[i * 4 + 3] = 255; }
+    tr("filterDepth cols=%d rows=%d maxD=%g", p.width, p.height, p.depthCut);
+    tr("metriciseDepth raw maxD=%g; filtered maxD=%g", p.depthCut, p.depthCut);
     efo_filter_depth(depthRaw.data(), p.width, p.height, p.depthCut, depthFiltered.data());                 // :284
     efo_metricise_depth(depthRaw.data(), p.width, p.height, p.depthCut, depthMetric.data());                // :285
     efo_metricise_depth(depthFiltered.data(), p.width, p.height, p.depthCut, depthMetricFiltered.data());
 
     if (tick == 1) {  // :290-296
+      tr("feedback raw+filtered time=%d maxDepth=%g; initialise", tick, maxDepthProcessed);
+      tr("frameToModel.initFirstRGB image=rgb");
       count = efo_seed_map(&cam, rgb.data(), depthMetric.data(), depthMetricFiltered.data(), tick, maxDepthProcessed, surfels.data());
       efo_odom_init_first_rgb(frameToModel, rgba.data());
     } else {
@@ -161,6 +201,13 @@ struct efo_fusion {
         bool shouldFillIn = !efo_dense_enough(&cam, image.data());  // :304-305
         double M[16];
         pose16(M);
+        tr("denseEnough -> %s", shouldFillIn ? "fill" : "model");
+        tr("frameToModel.initICPModel vertices=%s normals=%s", shouldFillIn ? "fill" : "pred", shouldFillIn ? "fill" : "pred");
+        tr_pose("  pose", M);
+        tr("frameToModel.initRGBModel image=%s", (shouldFillIn || p.frameToFrameRGB) ? "fill" : "pred");
+        tr("frameToModel.initICP depth=filtered cutoff=%g", maxDepthProcessed);
+        tr("frameToModel.initRGB image=rgb");
+        tr("frameToModel.track rgbOnly=%d icpWeight=%g pyramid=%d fastOdom=%d so3=%d", p.rgbOnly, p.icpWeight, p.pyramid, p.fastOdom, p.so3);
         efo_odom_init_icp_model(frameToModel, shouldFillIn ? fvertex.data() : vertex.data(),
                                 shouldFillIn ? fnormal.data() : normal.data(), M);                           // :310-313
         efo_odom_init_rgb_model(frameToModel, (shouldFillIn || p.frameToFrameRGB) ? fimage.data() : image.data());
@@ -182,6 +229,18 @@ struct efo_fusion {
 
       predict();  // :387 (result unused when closeLoops == false; kept for fidelity)
       if (closeLoops) localLoopClosure();
+      if (!p.rgbOnly) {
+        double Mt[16];
+        pose16(Mt);
+        tr("predictIndices time=%d maxDepth=%g timeDelta=%d", tick, maxDepthProcessed, p.timeDelta);
+        tr("fuse time=%d maxDepth=%g weighting=%.9g", tick, maxDepthProcessed, weighting);
+        tr_pose("  pose", Mt);
+        tr("predictIndices time=%d maxDepth=%g timeDelta=%d", tick, maxDepthProcessed, p.timeDelta);
+        if (!pendingGraph.empty() && !pendingFern)
+          tr("synthesizeDepth maxDepth=%g conf=%g time=%d maxTime=%d timeDelta=%d", maxDepthProcessed, p.confidence, tick, tick - p.timeDelta, 65535);
+        tr("clean time=%d conf=%g nodes=%d timeDelta=%d maxDepth=%g isFern=%d", tick, p.confidence, (int)(pendingGraph.size() / 16), p.timeDelta,
+           maxDepthProcessed, pendingFern);
+      }
 
       if (!p.rgbOnly) {  // :536-585 (trackingOk && !lost always hold without reloc)
         double M[16];
@@ -240,6 +299,13 @@ void efo_set_threads(int n) { efo::threads() = n < 1 ? 1 : n; }
 void efo_fusion_set_deformation(efo_fusion* f, const float* graph, int nodes, int isFern) {
   f->pendingGraph.assign(graph, graph + (size_t)nodes * 16);
   f->pendingFern = isFern;
+}
+void efo_fusion_trace(efo_fusion* f, int on) { f->tracing = on != 0; f->trace.clear(); }
+const char* efo_fusion_take_trace(efo_fusion* f) {
+  static thread_local std::string out;
+  out.swap(f->trace);
+  f->trace.clear();
+  return out.c_str();
 }
 void efo_fusion_set_close_loops(efo_fusion* f, int on, int icpCountThresh, float icpErrThresh, float covThresh) {
   f->closeLoops = on; f->icpCountThresh = icpCountThresh; f->icpErrThresh = icpErrThresh; f->covThresh = covThresh;

@@ -10,7 +10,9 @@
 #include <cstdarg>
 #include <cstddef>
 #include <cstdint>
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -34,6 +36,9 @@ struct State {
   std::map<GLint, std::pair<GLuint, std::string>> uniform_loc;  // location -> (program, name)
   GLuint next_id = 1;
   GLuint query_result = 0;                                      // what glGetQueryObjectuiv hands back (set by the bridge)
+  int query_once = -1;                                          // >= 0: handed back by the NEXT query only, then query_result again
+  int readpixels_fill = -1;                                     // >= 0: glReadPixels fills its destination with this byte
+  std::vector<unsigned char> buffer_data;                       // what glGetBufferSubData copies out (e.g. the surfel map)
 };
 inline State& S() { static State s; return s; }
 inline void rec(const char* fmt, ...) {
@@ -111,9 +116,23 @@ inline void glGenQueries(GLsizei n, GLuint* ids) { for (int i = 0; i < n; ++i) i
 inline void glDeleteQueries(GLsizei, const GLuint*) {}
 inline void glBeginQuery(GLenum target, GLuint id) { rec("glBeginQuery %#x %u", target, id); }
 inline void glEndQuery(GLenum target) { rec("glEndQuery %#x", target); }
-inline void glGetQueryObjectuiv(GLuint id, GLenum pname, GLuint* out) { *out = glrec::S().query_result; rec("glGetQueryObjectuiv %u %#x -> %u", id, pname, *out); }
-inline void glReadPixels(GLint x, GLint y, GLsizei w, GLsizei h, GLenum fmt, GLenum type, void*) { rec("glReadPixels %d %d %d %d fmt=%#x type=%#x", x, y, w, h, fmt, type); }
-inline void glGetBufferSubData(GLenum target, GLintptr off, GLsizeiptr size, void*) { rec("glGetBufferSubData %#x %ld %ld", target, (long)off, (long)size); }
+inline void glGetQueryObjectuiv(GLuint id, GLenum pname, GLuint* out) {
+  *out = glrec::S().query_once >= 0 ? (GLuint)glrec::S().query_once : glrec::S().query_result;
+  glrec::S().query_once = -1; rec("glGetQueryObjectuiv %u %#x -> %u", id, pname, *out);
+}
+inline void glReadPixels(GLint x, GLint y, GLsizei w, GLsizei h, GLenum fmt, GLenum type, void* dst) {
+  rec("glReadPixels %d %d %d %d fmt=%#x type=%#x", x, y, w, h, fmt, type);
+  if (glrec::S().readpixels_fill >= 0 && dst) {
+    const int ch = fmt == GL_RGB ? 3 : fmt == GL_RGBA ? 4 : 1;
+    const int bytes = type == GL_FLOAT || type == GL_UNSIGNED_INT ? 4 : type == GL_UNSIGNED_SHORT ? 2 : 1;
+    memset(dst, glrec::S().readpixels_fill, (size_t)w * h * ch * bytes);
+  }
+}
+inline void glGetBufferSubData(GLenum target, GLintptr off, GLsizeiptr size, void* dst) {
+  rec("glGetBufferSubData %#x %ld %ld", target, (long)off, (long)size);
+  const std::vector<unsigned char>& b = glrec::S().buffer_data;
+  if (dst && !b.empty() && (size_t)off < b.size()) memcpy(dst, b.data() + off, std::min((size_t)size, b.size() - (size_t)off));
+}
 inline void glCopyBufferSubData(GLenum r, GLenum w, GLintptr ro, GLintptr wo, GLsizeiptr size) { rec("glCopyBufferSubData %#x %#x %ld %ld %ld", r, w, (long)ro, (long)wo, (long)size); }
 inline void glTexSubImage2D(GLenum target, GLint level, GLint x, GLint y, GLsizei w, GLsizei h, GLenum fmt, GLenum type, const void*) {
   rec("glTexSubImage2D %#x %d %d %d %d %d fmt=%#x type=%#x", target, level, x, y, w, h, fmt, type);

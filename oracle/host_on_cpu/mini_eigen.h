@@ -13,7 +13,10 @@
 #include <cassert>
 #include <cmath>
 #include <cstring>
+#include <fstream>
+#include <iostream>
 #include <limits>
+#include <vector>
 #include "../efo_linalg.h"
 
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -115,6 +118,8 @@ class Matrix {
   const T& operator()(int i, int j) const { return m[idx(i, j)]; }
   T& operator()(int i) { return m[i]; }
   const T& operator()(int i) const { return m[i]; }
+  T& operator[](int i) { return m[i]; }
+  const T& operator[](int i) const { return m[i]; }
   T* data() { return m; }
   const T* data() const { return m; }
   int rows() const { return R; }
@@ -138,6 +143,13 @@ class Matrix {
     for (int i = 1; i < R * C; ++i) s += m[i] * m[i];
     return std::sqrt(s);
   }
+  template <int N>
+  Matrix<T, N, 1> head() const {
+    Matrix<T, N, 1> r;
+    for (int i = 0; i < N; ++i) r.m[i] = m[i];
+    return r;
+  }
+  Matrix<T, 3, 1> head(int n) const { assert(n == 3); return head<3>(); }
   Block<Matrix> topLeftCorner(int nr, int nc) { return Block<Matrix>{*this, 0, 0, nr, nc}; }
   Block<Matrix> topRightCorner(int nr, int nc) { return Block<Matrix>{*this, 0, C - nc, nr, nc}; }
 
@@ -236,6 +248,8 @@ Matrix<T, N, N, O> PartialPivLU<T, N, O>::inverse() const {
   return r;
 }
 
+typedef Matrix<int, 2, 1> Vector2i;
+typedef Matrix<int, 4, 1> Vector4i;
 typedef Matrix<float, 2, 1> Vector2f;
 typedef Matrix<float, 3, 1> Vector3f;
 typedef Matrix<double, 3, 1> Vector3d;
@@ -245,6 +259,35 @@ typedef Matrix<float, 3, 3> Matrix3f;
 typedef Matrix<double, 3, 3> Matrix3d;
 typedef Matrix<float, 4, 4> Matrix4f;
 typedef Matrix<double, 4, 4> Matrix4d;
+
+// Quaternion<double>(rotation matrix): the branchy trace method, as restated in efo_linalg.h (mat_to_quat)
+class Quaterniond {
+ public:
+  template <int O>
+  explicit Quaterniond(const Matrix<double, 3, 3, O>& R) {
+    efo::M3d m;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) m.m[i * 3 + j] = R(i, j);
+    efo::mat_to_quat(m, q);
+  }
+  double x() const { return q[0]; }
+  double y() const { return q[1]; }
+  double z() const { return q[2]; }
+  double w() const { return q[3]; }
+
+ private:
+  double q[4];
+};
+// run-time sized vector (only declared by the reference's deformation-graph headers here)
+class VectorXd {
+ public:
+  std::vector<double> v;
+  VectorXd() {}
+  explicit VectorXd(int n) : v((size_t)n, 0.0) {}
+  double& operator()(int i) { return v[(size_t)i]; }
+  const double& operator()(int i) const { return v[(size_t)i]; }
+  int rows() const { return (int)v.size(); }
+};
 
 // what getCovariance() returns: a run-time sized copy of a fixed-size result
 class MatrixXd {

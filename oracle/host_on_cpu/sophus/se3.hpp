@@ -15,6 +15,7 @@ class SE3f {
       for (int j = 0; j < 4; ++j) r(i, j) = M.m[i * 4 + j];
     return r;
   }
+  Eigen::Vector4f operator*(const Eigen::Vector4f& p) const { return matrix() * p; }
 
  private:
   efo::Mat4f M;
@@ -40,6 +41,19 @@ class SE3d {
     efo::se3_set_rotation(T, m);
   }
   SE3d inverse() const { return SE3d(efo::se3_inverse(value())); }
+  SE3d operator*(const SE3d& o) const { return SE3d(efo::se3_mul(value(), o.value())); }
+  // homogeneous point: 4x4 matrix product evaluated left to right (the specification of ElasticFusion.cpp:493-503)
+  Eigen::Vector4d operator*(const Eigen::Vector4d& p) const {
+    const efo::M4d M = efo::se3_matrix(value());
+    Eigen::Vector4d r;
+    for (int i = 0; i < 4; ++i) r(i) = ((M.m[i * 4] * p(0) + M.m[i * 4 + 1] * p(1)) + M.m[i * 4 + 2] * p(2)) + M.m[i * 4 + 3] * p(3);
+    return r;
+  }
+  Eigen::Matrix<double, 6, 1> log() const {
+    Eigen::Matrix<double, 6, 1> r;
+    efo::se3_log_norm(value(), r.data());
+    return r;
+  }
   Eigen::Matrix4d matrix() const {
     const efo::M4d M = efo::se3_matrix(value());
     Eigen::Matrix4d r;

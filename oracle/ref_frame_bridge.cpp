@@ -1,0 +1,160 @@
+// TEST INFRASTRUCTURE — runs the REFERENCE's own per-frame orchestration, Core/ElasticFusion.cpp (constructor, processFrame, predict,
+// savePly, the destructor's trajectory dump), compiled from /root/reference where it lies and linked with its own IndexMap /
+// GlobalModel / FillIn / ComputePack / FeedbackBuffer / Resize / Ferns / Deformation sources, over
+//   * OpenGL + Pangolin as a tape recorder (host_on_cpu/gl_record.h), and
+//   * recording doubles (below, ours) for the two things that would need real pixels: the tracker (RGBDOdometry) and the graph
+//     optimiser (DeformationGraph).
+// processFrame then leaves a transcript of the whole frame: which passes run in which order with which parameters, what the tracker
+// is initialised from and asked to do, how the pose flows.  The transcript is what tests compare with the oracle's frame loop
+// (oracle/efo_frame.cpp); savePly and the .freiburg dump are compared byte for byte with the product's writers.
+// oracle/Makefile, target `refframe` -> _ref/libefr_frame.so.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ElasticFusion.h"
+#include "efo_linalg.h"
+
+const std::string GPUTexture::RGB = "RGB";
+const std::string GPUTexture::DEPTH_RAW = "DEPTH";
+const std::string GPUTexture::DEPTH_FILTERED = "DEPTH_FILTERED";
+const std::string GPUTexture::DEPTH_METRIC = "DEPTH_METRIC";
+const std::string GPUTexture::DEPTH_METRIC_FILTERED = "DEPTH_METRIC_FILTERED";
+const std::string GPUTexture::DEPTH_NORM = "DEPTH_NORM";
+GPUTexture::GPUTexture(const int w, const int h, const GLenum internalFormat_, const GLenum format_, const GLenum dataType_, const bool draw_)
+    : texture(new pangolin::GlTexture(w, h, internalFormat_, draw_, 0, format_, dataType_)), cudaRes(nullptr), draw(draw_), width(w), height(h),
+      internalFormat(internalFormat_), format(format_), dataType(dataType_) {}
+GPUTexture::~GPUTexture() { delete texture; }
+
+namespace {
+struct TrackerScript {   // what the recording tracker answers
+  double delta[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};   // T_wc := T_wc * delta
+  float icpError = 1e-6f, icpCount = 100000.f;
+  double covDiag = 1e-7;
+  int constrainResult = 0;   // what DeformationGraph::optimiseGraphSparse / Deformation::constrain see
+} g_script;
+int tex_id(GPUTexture* t) { return t && t->texture ? (int)t->texture->tid : 0; }
+void rec_pose(const char* what, const Sophus::SE3d& T) {
+  const Eigen::Matrix4d M = T.matrix();
+  std::string s;
+  char b[40];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) { snprintf(b, sizeof(b), " %.17g", M(i, j)); s += b; }
+  rec("%s T_wc:%s", what, s.c_str());
+}
+}  // namespace
+
+// ---- recording double of Core/Utils/RGBDOdometry.cpp ----
+RGBDOdometry::RGBDOdometry(int width_, int height_, float cx_, float cy_, float fx_, float fy_, float distThresh, float angleThresh)
+    : lastICPError(0), lastICPCount(width_ * height_), lastRGBError(0), lastRGBCount(width_ * height_), lastSO3Error(0), lastSO3Count(width_ * height_),
+      lastA(Eigen::Matrix<double, 6, 6, Eigen::RowMajor>::Zero()), lastb(Eigen::Matrix<double, 6, 1>::Zero()), sobelSize(3), sobelScale(1.0f / 8.0f),
+      maxDepthDeltaRGB(0.07f), maxDepthRGB(6.0f), distThres_(distThresh), angleThres_(angleThresh), width(width_), height(height_), cx(cx_), cy(cy_),
+      fx(fx_), fy(fy_) {
+  rec("RGBDOdometry[%dx%d] created at %p", width, height, (void*)this);
+}
+RGBDOdometry::~RGBDOdometry() {}
+void RGBDOdometry::initICP(GPUTexture* filteredDepth, const float depthCutoff) { rec("RGBDOdometry@%p[%dx%d]::initICP depth=tex%d cutoff=%.9g", (void*)this, width, height, tex_id(filteredDepth), depthCutoff); }
+void RGBDOdometry::initICP(GPUTexture* v, GPUTexture* n) { rec("RGBDOdometry@%p[%dx%d]::initICP vertices=tex%d normals=tex%d", (void*)this, width, height, tex_id(v), tex_id(n)); }
+void RGBDOdometry::initICPModel(GPUTexture* v, GPUTexture* n, const Sophus::SE3d& T_wc) {
+  rec("RGBDOdometry@%p[%dx%d]::initICPModel vertices=tex%d normals=tex%d", (void*)this, width, height, tex_id(v), tex_id(n));
+  rec_pose("  initICPModel", T_wc);
+}
+void RGBDOdometry::initRGB(GPUTexture* rgb) { rec("RGBDOdometry@%p[%dx%d]::initRGB image=tex%d", (void*)this, width, height, tex_id(rgb)); }
+void RGBDOdometry::initRGBModel(GPUTexture* rgb) { rec("RGBDOdometry@%p[%dx%d]::initRGBModel image=tex%d", (void*)this, width, height, tex_id(rgb)); }
+void RGBDOdometry::initFirstRGB(GPUTexture* rgb) { rec("RGBDOdometry@%p[%dx%d]::initFirstRGB image=tex%d", (void*)this, width, height, tex_id(rgb)); }
+void RGBDOdometry::getIncrementalTransformation(Sophus::SE3d& T_wc, const bool& rgbOnly, const float& icpWeight, const bool& pyramid,
+                                                const bool& fastOdom, const bool& so3) {
+  rec("RGBDOdometry@%p[%dx%d]::getIncrementalTransformation rgbOnly=%d icpWeight=%.9g pyramid=%d fastOdom=%d so3=%d", (void*)this, width, height, (int)rgbOnly,
+      icpWeight, (int)pyramid, (int)fastOdom, (int)so3);
+  rec_pose("  track in ", T_wc);
+  T_wc = T_wc * Sophus::SE3d(efo::se3_from_matrix(g_script.delta));
+  rec_pose("  track out", T_wc);
+  lastICPError = g_script.icpError;
+  lastICPCount = g_script.icpCount;
+}
+Eigen::MatrixXd RGBDOdometry::getCovariance() {
+  rec("RGBDOdometry@%p[%dx%d]::getCovariance", (void*)this, width, height);
+  Eigen::Matrix<double, 6, 6, Eigen::RowMajor> c = Eigen::Matrix<double, 6, 6, Eigen::RowMajor>::Zero();
+  for (int i = 0; i < 6; ++i) c(i, i) = g_script.covDiag;
+  return Eigen::MatrixXd(c);
+}
+
+// ---- recording double of Core/Utils/DeformationGraph.cpp (the CHOLMOD-based optimiser) ----
+DeformationGraph::DeformationGraph(int k_, std::vector<Eigen::Vector3d>* sv) : k(k_), initialised(false), wRot(1), wReg(10), wCon(100), sourceVertices(sv) {}
+DeformationGraph::~DeformationGraph() {}
+void DeformationGraph::initialiseGraph(std::vector<Eigen::Vector3d>* g, std::vector<uint64_t>* t) { rec("DeformationGraph::initialiseGraph nodes=%d", (int)g->size()); initialised = true; }
+void DeformationGraph::appendVertices(std::vector<uint64_t>* t, uint32_t originalPointEnd) { rec("DeformationGraph::appendVertices %d from %u", (int)t->size(), originalPointEnd); }
+void DeformationGraph::setPosesSeq(std::vector<uint64_t>* t, const std::vector<Sophus::SE3d>& T) { rec("DeformationGraph::setPosesSeq %d", (int)T.size()); }
+std::vector<GraphNode*>& DeformationGraph::getGraph() { return graph; }
+std::vector<uint64_t>& DeformationGraph::getGraphTimes() { static std::vector<uint64_t> none; return none; }
+void DeformationGraph::addConstraint(int vertexId, Eigen::Vector3d& target) { rec("DeformationGraph::addConstraint vertex=%d target=%.9g %.9g %.9g", vertexId, target(0), target(1), target(2)); }
+void DeformationGraph::addRelativeConstraint(int a, int b) { rec("DeformationGraph::addRelativeConstraint %d %d", a, b); }
+void DeformationGraph::clearConstraints() { rec("DeformationGraph::clearConstraints"); }
+void DeformationGraph::applyGraphToVertices() { rec("DeformationGraph::applyGraphToVertices"); }
+void DeformationGraph::applyGraphToPoses(std::vector<Sophus::SE3d*> p) { rec("DeformationGraph::applyGraphToPoses %d", (int)p.size()); }
+bool DeformationGraph::optimiseGraphSparse(float& error, float& meanConsErr, const bool fernMatch, const uint64_t lastDeformTime) {
+  rec("DeformationGraph::optimiseGraphSparse fernMatch=%d lastDeformTime=%lu -> %d", (int)fernMatch, (unsigned long)lastDeformTime, g_script.constrainResult);
+  error = 0; meanConsErr = 0;
+  return g_script.constrainResult != 0;
+}
+
+namespace {
+struct Frame {
+  ElasticFusion* ef;
+  std::string out;
+};
+const char* take(Frame* f) { f->out.swap(glrec::S().log); glrec::S().log.clear(); return f->out.c_str(); }
+}  // namespace
+
+extern "C" {
+void* efe_create(int w, int h, float fx, float fy, float cx, float cy, int timeDelta, int countThresh, float errThresh, float covThresh, int closeLoops,
+                 float confidence, float depthCut, float icpThresh, int fastOdom, int so3, int frameToFrameRGB, const char* fileName) {
+  Resolution::getInstance(w, h);
+  Intrinsics::getInstance(fx, fy, cx, cy);
+  Frame* f = new Frame();
+  f->ef = new ElasticFusion(timeDelta, countThresh, errThresh, covThresh, closeLoops != 0, false, false, 115, confidence, depthCut, icpThresh,
+                            fastOdom != 0, 0.3095f, so3 != 0, frameToFrameRGB != 0, fileName);
+  return f;
+}
+const char* efe_take_log(void* p) { return take((Frame*)p); }
+void efe_destroy(void* p) { Frame* f = (Frame*)p; delete f->ef; delete f; }   // the destructor writes <fileName>.freiburg
+const char* efe_process_frame(void* p, const unsigned char* rgb, const unsigned short* depth, long long timestamp, float weightMultiplier, const double* T16) {
+  Frame* f = (Frame*)p;
+  if (T16) {
+    const Sophus::SE3d T(efo::se3_from_matrix(T16));
+    f->ef->processFrame(rgb, depth, timestamp, weightMultiplier, &T);
+  } else {
+    f->ef->processFrame(rgb, depth, timestamp, weightMultiplier, nullptr);
+  }
+  return take(f);
+}
+void efe_save_ply(void* p) { ((Frame*)p)->ef->savePly(); }
+void efe_get_pose(void* p, double* T16) {
+  const Eigen::Matrix4d M = ((Frame*)p)->ef->get_T_wc().matrix();
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) T16[i * 4 + j] = M(i, j);
+}
+int efe_tick(void* p) { return ((Frame*)p)->ef->getTick(); }
+// scripting the doubles and the recorder's readbacks
+void efe_script_tracker(const double* delta16, float icpError, float icpCount, double covDiag, int constrainResult) {
+  std::memcpy(g_script.delta, delta16, sizeof(g_script.delta));
+  g_script.icpError = icpError; g_script.icpCount = icpCount; g_script.covDiag = covDiag; g_script.constrainResult = constrainResult;
+}
+void efe_script_readbacks(int readpixels_fill, unsigned query_result, const unsigned char* buffer, long buffer_bytes) {
+  glrec::S().readpixels_fill = readpixels_fill;
+  glrec::S().query_result = query_result;
+  glrec::S().buffer_data.assign(buffer, buffer + (buffer ? buffer_bytes : 0));
+}
+void efe_script_next_query(int n) { glrec::S().query_once = n; }   // the next "primitives written" query only (e.g. the clean pass's count)
+unsigned efe_tid(void* p, const char* name) {
+  ElasticFusion* e = ((Frame*)p)->ef;
+  const std::string n = name;
+  IndexMap& im = e->getIndexMap();
+  GPUTexture* t = n == "index" ? im.indexTex() : n == "vertConf" ? im.vertConfTex() : n == "colorTime" ? im.colorTimeTex() : n == "normalRad" ? im.normalRadTex()
+                : n == "image" ? im.imageTex() : n == "vertex" ? im.vertexTex() : n == "normal" ? im.normalTex() : n == "time" ? im.timeTex()
+                : n == "oldImage" ? im.oldImageTex() : n == "oldVertex" ? im.oldVertexTex() : n == "oldNormal" ? im.oldNormalTex() : n == "oldTime" ? im.oldTimeTex()
+                : n == "depth" ? im.depthTex() : nullptr;
+  if (!t && e->getTextures().count(n)) t = e->getTextures()[n];
+  return t ? t->texture->tid : 0;
+}
+}  // extern "C"

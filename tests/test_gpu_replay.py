@@ -31,7 +31,7 @@ def test_klg_replay_through_cpp_shim(tmp_path, seq):
         traj = np.loadtxt(log + ".freiburg")
         assert traj.shape == (n - 1, 8)
         assert np.allclose(traj[:, 0], np.arange(n - 1) * 33333 / 1e6, atol=1e-6)
-        assert np.abs(traj[-1, 1:4] - Tr[:3, 3]).max() <= 1e-8     # %.9g text round trip of an identical pose
+        assert np.abs(traj[-1, 1:4] - Tr[:3, 3]).max() <= 1e-6     # six significant digits, as the reference writes them
         # savePly keeps surfels above the confidence threshold only (ElasticFusion.cpp:703-712): a 6-frame map has none
         # yet, the header must still be a valid binary PLY
         hdr = open(log + ".ply", "rb").read(400)
@@ -62,4 +62,4 @@ def test_klg_replay_with_close_loops(tmp_path, seq):
     words = r.stdout.split()
     assert int(words[words.index("surfels") + 1]) == o.map_count(), r.stdout
     traj = np.loadtxt(log + ".freiburg")
-    assert np.abs(traj[-1, 1:4] - o.pose()[:3, 3]).max() <= 1e-8
+    assert np.abs(traj[-1, 1:4] - o.pose()[:3, 3]).max() <= 1e-6

@@ -1,0 +1,307 @@
+"""The oracle's frame loop against the reference's own: Core/ElasticFusion.cpp (constructor, processFrame, predict, savePly, the
+destructor's trajectory dump) compiled from /root/reference where it lies, together with its IndexMap / GlobalModel / FillIn /
+ComputePack / FeedbackBuffer / Resize / Ferns / Deformation sources, over OpenGL-as-a-tape-recorder and recording doubles of the
+tracker and the graph optimiser (oracle/Makefile `refframe`, oracle/ref_frame_bridge.cpp).  Running it leaves a transcript of every
+frame: which passes run, in which order, with which parameters, what the tracker is initialised from.  That transcript, translated
+into the vocabulary of the oracle's own trace (efo_fusion_trace), must equal the oracle's, step by step — open loop and with the
+local loop closure — and the two file writers of the product must reproduce the reference's files byte for byte."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import efo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "_ref", "libefr_frame.so")
+W, H = 640, 480
+P = C.c_void_p
+
+
+def have():
+    if not os.path.exists(SO) and os.path.isdir("/root/reference/Core"):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "refframe"])
+    return os.path.exists(SO)
+
+
+pytestmark = pytest.mark.skipif(not have(), reason="oracle/_ref/libefr_frame.so can only be built where /root/reference exists")
+
+
+def lib():
+    so = C.CDLL(SO)
+    so.efe_create.restype = P
+    so.efe_create.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
+                              C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    so.efe_take_log.restype = C.c_char_p
+    so.efe_take_log.argtypes = [P]
+    so.efe_process_frame.restype = C.c_char_p
+    so.efe_process_frame.argtypes = [P, P, P, C.c_longlong, C.c_float, P]
+    so.efe_destroy.argtypes = [P]
+    so.efe_save_ply.argtypes = [P]
+    so.efe_get_pose.argtypes = [P, P]
+    so.efe_tick.argtypes = [P]
+    so.efe_tid.argtypes = [P, C.c_char_p]
+    so.efe_script_tracker.argtypes = [P, C.c_float, C.c_float, C.c_double, C.c_int]
+    so.efe_script_readbacks.argtypes = [C.c_int, C.c_uint, P, C.c_long]
+    return so
+
+
+class Ref:
+    """one compiled-reference ElasticFusion; `tid` maps the reference's own texture names to the recorder's ids"""
+
+    def __init__(self, so, path, timeDelta=200, closeLoops=0, confidence=10.0, depthCut=3.0, icpThresh=10.0, fastOdom=0, so3=1, ftf=0):
+        self.so = so
+        so.efe_script_readbacks(-1, 0, None, 0)
+        self.h = P(so.efe_create(W, H, 528.0, 528.0, 320.0, 240.0, timeDelta, 35000, 5e-5, 1e-5, closeLoops, confidence, depthCut, icpThresh, fastOdom, so3,
+                                 ftf, path.encode()))
+        self.built = so.efe_take_log(self.h).decode()
+        names = ["index", "vertConf", "colorTime", "normalRad", "image", "vertex", "normal", "time", "oldImage", "oldVertex", "oldNormal", "oldTime", "depth",
+                 "RGB", "DEPTH", "DEPTH_FILTERED", "DEPTH_METRIC", "DEPTH_METRIC_FILTERED"]
+        self.tid = {n: so.efe_tid(self.h, n.encode()) for n in names}
+        # fill-in textures: created by FillIn() in the order image, vertex, normal (FillIn.cpp:22-47): find them as the attachments
+        # of the three framebuffers whose programs are fill_*.frag — simpler: they are what predict() renders into, see frames below
+        self.trackers = [ln.split()[-1] for ln in self.built.splitlines() if ln.startswith("RGBDOdometry[640x480] created")]
+        self.fill_tex = {}     # texture id -> "fill": learnt from the attachments of the fill_*.frag passes as they are seen
+
+    def frame(self, rgb, depth, ts, T=None, weight=1.0):
+        Tp = None if T is None else np.ascontiguousarray(T, np.float64).ctypes.data
+        return self.so.efe_process_frame(self.h, rgb.ctypes.data, depth.ctypes.data, ts, weight, Tp).decode()
+
+    def pose(self):
+        T = np.zeros(16)
+        self.so.efe_get_pose(self.h, T.ctypes.data)
+        return T.reshape(4, 4)
+
+    def close(self):
+        self.so.efe_destroy(self.h)
+
+
+def translate(ref, text):
+    """the reference's transcript of one frame -> the vocabulary of efo_fusion_trace (poses dropped except the tracker's)"""
+    t = ref.tid
+    out, prog, uni, unit, units, fb_attach, pending_metric, pending_fill, seeded = [], None, {}, 0, {}, None, [], [], []
+    attach = {}
+    for ln in ref.built.splitlines():
+        if "AttachColour" in ln:
+            a = ln.split()
+            attach.setdefault(int(a[1]), []).append(int(a[-1]))
+    fill_tex = ref.fill_tex
+    fbo = None
+    f2m, m2m = ref.trackers[0], ref.trackers[1]
+    bound_before_program = None
+    for ln in text.splitlines():
+        a = ln.split()
+        if a[0] == "GlFramebuffer" and a[2] == "Bind":
+            fbo = int(a[1])
+        elif a[0] == "glBindTexture" and prog is None and int(a[2]):
+            bound_before_program = int(a[2])
+        elif ln.startswith("program Bind:"):
+            prog, uni, units, unit = tuple(ln.split(":", 1)[1].split()), {}, {}, 0
+        elif a[0] == "uniform" and prog:
+            uni[a[1]] = float(a[3]) if a[2] in ("int", "float") else [float(x) for x in a[3:]] if a[2] != "mat4" else None
+        elif a[0] == "glActiveTexture":
+            unit = int(a[1])
+        elif a[0] == "glBindTexture" and int(a[2]) and prog:
+            units[unit] = int(a[2])
+        elif a[0] in ("glDrawArrays", "glDrawTransformFeedback") and prog:
+            frag = prog[-1]
+            if frag == "depth_bilateral.frag":
+                out.append("filterDepth cols=%d rows=%d maxD=%g" % (uni["cols"], uni["rows"], uni["maxD"]))
+            elif frag == "depth_metric.frag":
+                pending_metric.append(("raw" if bound_before_program == t["DEPTH"] else "filtered" if bound_before_program == t["DEPTH_FILTERED"] else "?", uni["maxD"]))
+                if len(pending_metric) == 2:
+                    out.append("metriciseDepth %s maxD=%g; %s maxD=%g" % (pending_metric[0] + pending_metric[1]))
+                    pending_metric = []
+            elif prog == ("vertex_feedback.vert", "vertex_feedback.geom"):
+                seeded.append(("raw" if units[int(uni["gSampler"])] == t["DEPTH_METRIC"] else "filtered", uni["time"], uni["maxDepth"]))
+            elif prog == ("init_unstable.vert",):
+                assert [s[0] for s in seeded] == ["raw", "filtered"]
+                out.append("feedback raw+filtered time=%d maxDepth=%g; initialise" % (seeded[0][1], seeded[0][2]))
+                seeded = []
+            elif frag == "combo_splat.frag":
+                kind = "ACTIVE" if attach[fbo][0] == t["image"] else "INACTIVE" if attach[fbo][0] == t["oldImage"] else "?"
+                out.append("combinedPredict %s maxDepth=%g conf=%g time=%d maxTime=%d timeDelta=%d" % (kind, uni["maxDepth"], uni["confThreshold"], uni["time"],
+                                                                                                   uni["maxTime"], uni["timeDelta"]))
+            elif frag in ("fill_vertex.frag", "fill_normal.frag", "fill_rgb.frag"):
+                fill_tex[attach[fbo][0]] = "fill"
+                pending_fill.append((frag[5:-5].replace("rgb", "image"), int(uni["passthrough"])))
+                if len(pending_fill) == 3:
+                    out.append("fillIn " + "; ".join("%s passthrough=%d" % pf for pf in pending_fill))
+                    pending_fill = []
+            elif frag == "index_map.frag":
+                out.append("predictIndices time=%d maxDepth=%g timeDelta=%d" % (uni["time"], uni["maxDepth"], uni["timeDelta"]))
+            elif prog == ("data.vert", "data.geom", "data.frag"):
+                out.append("fuse time=%d maxDepth=%g weighting=%.9g" % (uni["time"], uni["maxDepth"], uni["weighting"]))
+            elif frag == "depth_splat.frag":
+                out.append("synthesizeDepth maxDepth=%g conf=%g time=%d maxTime=%d timeDelta=%d" % (uni["maxDepth"], uni["confThreshold"], uni["time"],
+                                                                                              uni["maxTime"], uni["timeDelta"]))
+            elif prog == ("copy_unstable.vert", "copy_unstable.geom"):
+                line = "clean time=%d conf=%g nodes=%d timeDelta=%d maxDepth=%g isFern=%d" % (uni["time"], uni["confThreshold"], uni["nodes"], uni["timeDelta"],
+                                                                                             uni["maxDepth"], uni["isFern"])
+                if not out or out[-1] != line:     # two draws (old map, new surfels) are one clean
+                    out.append(line)
+        elif ln.startswith("program Unbind"):
+            prog = None
+            bound_before_program = None
+        elif a[0].startswith("RGBDOdometry@"):
+            who = "frameToModel" if a[0].startswith("RGBDOdometry@" + f2m) else "modelToModel" if a[0].startswith("RGBDOdometry@" + m2m) else None
+            if who is None:
+                continue       # the fern database's own tracker (out of scope)
+            call = a[0].split("::")[1]
+            role = {t["image"]: "pred", t["vertex"]: "pred", t["normal"]: "pred", t["oldImage"]: "old", t["oldVertex"]: "old", t["oldNormal"]: "old",
+                    t["RGB"]: "rgb", t["DEPTH_FILTERED"]: "filtered"}
+            role.update(fill_tex)
+            args = []
+            for kv in a[1:]:
+                k, v = kv.split("=")
+                args.append("%s=%s" % (k, role.get(int(v[3:]), "tex?") if v.startswith("tex") else ("%g" % float(v))))
+            name = {"getIncrementalTransformation": "track"}.get(call, call)
+            out.append("%s.%s%s" % (who, name, (" " + " ".join(args)) if args else ""))
+        elif ln.startswith("  initICPModel T_wc:") :
+            out.append("  pose " + " ".join(ln.split()[2:]))
+    return out
+
+
+def oracle_lines(text, keep_pose_after=("initICPModel",)):
+    out = []
+    for ln in text.splitlines():
+        if ln.startswith("  pose"):
+            if out and any(k in out[-1] for k in keep_pose_after):
+                out.append("  pose " + " ".join("%s" % x for x in ln.split()[1:]))
+            continue
+        if ln.startswith("denseEnough"):
+            continue
+        out.append(ln)
+    return out
+
+
+def norm_pose(lines):
+    """numeric comparison of pose lines: both print %.17g of the same doubles"""
+    return [" ".join("%.12g" % float(x) if i else x for i, x in enumerate(l.split())) if l.startswith("  pose") else l for l in lines]
+
+
+def synth_poses(n):
+    from elasticfusion_amd import synth
+    seq = synth.Sequence(seed=0xEF0001)
+    return [seq.pose(k) for k in range(n)]
+
+
+@pytest.mark.parametrize("mode", ["open_loop", "close_loops"])
+def test_frame_loop_matches_the_compiled_reference(tmp_path, mode):
+    """injected poses on both sides (so that the velocity weighting is comparable); frame 1 is tracked on the reference side by the
+    scripted tracker and its initialisation sequence is compared with the oracle's trace of a tracked frame"""
+    so = lib()
+    close = mode == "close_loops"
+    kw = dict(timeDelta=3 if close else 200, closeLoops=int(close), confidence=2.0)
+    ref = Ref(so, str(tmp_path / "ref"), **kw)
+    o = efo.Fusion(timeDelta=kw["timeDelta"], confidence=kw["confidence"])
+    if close:
+        o.set_close_loops(True)
+    efo.lib().efo_fusion_trace(o.h_, 1)
+    efo.lib().efo_fusion_take_trace.restype = C.c_char_p
+    rgb = np.full((H, W, 3), 90, np.uint8)
+    depth = np.full((H, W), 1500, np.uint16)
+    poses = synth_poses(6)
+    so.efe_script_tracker(np.eye(4).ctypes.data, 1e-6, 0.0, 1e-7, 0)      # modelToModel: ICP count 0 -> the gates stay shut, like the oracle's on flat input
+    for k in range(6):
+        T = None if k == 0 else poses[k]
+        txt = ref.frame(rgb, depth, k * 33333, T)
+        o.process_frame(rgb, depth, k * 33333, T_wc=T)
+        got = oracle_lines(efo.lib().efo_fusion_take_trace(o.h_).decode())
+        want = translate(ref, txt)
+        assert norm_pose(got) == norm_pose(want), (k, "\n".join(got), "\n".join(want))
+        assert np.array_equal(ref.pose(), o.pose()), k
+        assert so.efe_tick(ref.h) == o.tick()
+    ref.close()
+
+
+def test_tracked_frame_initialisation_sequence(tmp_path):
+    """a frame WITHOUT an injected pose: what the tracker is initialised from, in which order, and with which flags — with the
+    predicted image empty (fill-in maps) and with it full (model maps)"""
+    so = lib()
+    ref = Ref(so, str(tmp_path / "ref"))
+    rgb = np.full((H, W, 3), 90, np.uint8)
+    depth = np.full((H, W), 1500, np.uint16)
+    translate(ref, ref.frame(rgb, depth, 0))          # (learns which textures the fill-in passes render into)
+    so.efe_script_tracker(np.eye(4).ctypes.data, 1e-6, 100000.0, 1e-7, 0)
+    first = [l for l in translate(ref, ref.frame(rgb, depth, 33333)) if l.startswith("frameToModel")]
+    assert first == ["frameToModel.initICPModel vertices=fill normals=fill", "frameToModel.initRGBModel image=fill", "frameToModel.initICP depth=filtered cutoff=20",
+                     "frameToModel.initRGB image=rgb", "frameToModel.track rgbOnly=0 icpWeight=10 pyramid=1 fastOdom=0 so3=1"]
+    so.efe_script_readbacks(255, 0, None, 0)          # Resize::image reads back a full image: denseEnough
+    dense = [l for l in translate(ref, ref.frame(rgb, depth, 66666)) if l.startswith("frameToModel")]
+    assert dense[:2] == ["frameToModel.initICPModel vertices=pred normals=pred", "frameToModel.initRGBModel image=pred"] and dense[2:] == first[2:]
+    # the oracle's trace of a tracked frame lists the same five calls with the same flags
+    o = efo.Fusion()
+    efo.lib().efo_fusion_trace(o.h_, 1)
+    efo.lib().efo_fusion_take_trace.restype = C.c_char_p
+    from elasticfusion_amd import synth
+    seq = synth.Sequence(seed=0xEF0001)
+    for k in range(2):
+        r, d, _ = seq.frame(k)
+        o.process_frame(r, d, k)
+        tr = efo.lib().efo_fusion_take_trace(o.h_).decode()
+    mine = [l for l in oracle_lines(tr) if l.startswith("frameToModel")]
+    assert mine == first
+    so.efe_script_readbacks(-1, 0, None, 0)
+    ref.close()
+
+
+def test_local_loop_block_continues_past_open_gates(tmp_path):
+    """with the scripted second tracker reporting a confident registration the reference goes on to Resize::vertex(vertexTex) and
+    Resize::time(oldTimeTex) at consSample = 20 (ElasticFusion.cpp:485-486) — the two read-backs the product's k_sample_constraints replaces"""
+    so = lib()
+    ref = Ref(so, str(tmp_path / "ref"), timeDelta=3, closeLoops=1, confidence=2.0)
+    rgb = np.full((H, W, 3), 90, np.uint8)
+    depth = np.full((H, W), 1500, np.uint16)
+    so.efe_script_tracker(np.eye(4).ctypes.data, 1e-6, 100000.0, 1e-7, 0)
+    ref.frame(rgb, depth, 0)
+    txt = ref.frame(rgb, depth, 33333, synth_poses(2)[1])
+    lines = txt.splitlines()
+    i = max(k for k, l in enumerate(lines) if "getCovariance" in l)
+    tail = [l for l in lines[i:] if l.startswith("glReadPixels") or (l.startswith("glBindTexture") and not l.endswith(" 0"))]
+    want_v, want_t = ref.tid["vertex"], ref.tid["oldTime"]
+    reads = [l for l in tail if l.startswith("glReadPixels 0 0 32 24")]
+    assert len(reads) >= 2 and any(l == "glBindTexture 0xde1 %d" % want_v for l in tail) and any(l == "glBindTexture 0xde1 %d" % want_t for l in tail)
+    ref.close()
+
+
+def test_writers_reproduce_the_reference_files_byte_for_byte(tmp_path):
+    """ElasticFusion::savePly and the destructor's .freiburg dump (compiled reference) against ef_write_ply / ef_write_freiburg"""
+    so = lib()
+    from elasticfusion_amd import build
+    hip = C.CDLL(build.build())
+    hip.ef_write_freiburg.argtypes = [C.c_char_p, P, P, C.c_int]
+    hip.ef_write_ply.argtypes = [C.c_char_p, P, C.c_uint, C.c_float]
+    rng = np.random.RandomState(5)
+    n = 5000
+    surf = np.zeros((n, 12), np.float32)
+    surf[:, 0:3] = rng.uniform(-2, 2, (n, 3))
+    surf[:, 3] = rng.uniform(0, 20, n)                                          # confidence: about half above the threshold
+    surf[:, 4] = (rng.randint(0, 256, n) << 16 | rng.randint(0, 256, n) << 8 | rng.randint(0, 256, n)).astype(np.float32)
+    surf[:, 6:8] = rng.randint(1, 50, (n, 2))
+    nrm = rng.normal(size=(n, 3))
+    surf[:, 8:11] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    surf[:, 11] = rng.uniform(0.001, 0.02, n)
+    ref = Ref(so, str(tmp_path / "ref"), confidence=10.0)
+    rgb = np.full((H, W, 3), 90, np.uint8)
+    depth = np.full((H, W), 1500, np.uint16)
+    poses = synth_poses(7)
+    stamps = [1311868164 * 1000000 + 33367 * k for k in range(7)]              # realistic microsecond stamps
+    for k in range(7):
+        if k == 6:
+            so.efe_script_next_query(n)                                         # the last clean pass reports n surfels written: lastCount()
+        ref.frame(rgb, depth, stamps[k], None if k == 0 else poses[k])
+    so.efe_script_readbacks(-1, 0, surf.ctypes.data, surf.nbytes)               # downloadMap() reads this map back
+    so.efe_save_ply(ref.h)
+    so.efe_script_readbacks(-1, 0, None, 0)
+    ref.close()                                                                 # ~ElasticFusion writes ref.freiburg
+    T = np.ascontiguousarray(np.stack([np.eye(4)] + poses[1:]), np.float64)
+    ts = np.asarray(stamps, np.int64)
+    assert hip.ef_write_freiburg(str(tmp_path / "mine.freiburg").encode(), T.ctypes.data, ts.ctypes.data, 7) == 0
+    assert hip.ef_write_ply(str(tmp_path / "mine.ply").encode(), surf.ctypes.data, n, 10.0) == 0
+    a, b = open(tmp_path / "ref.freiburg", "rb").read(), open(tmp_path / "mine.freiburg", "rb").read()
+    assert a == b and len(a.splitlines()) == 7
+    a, b = open(tmp_path / "ref.ply", "rb").read(), open(tmp_path / "mine.ply", "rb").read()
+    assert a == b and (b"element vertex %d" % int((surf[:, 3] > 10.0).sum())) in a and 2000 < int((surf[:, 3] > 10.0).sum()) < 3000
