@@ -145,6 +145,19 @@ void efe_script_readbacks(int readpixels_fill, unsigned query_result, const unsi
   glrec::S().query_result = query_result;
   glrec::S().buffer_data.assign(buffer, buffer + (buffer ? buffer_bytes : 0));
 }
+// the reference's own setters (ElasticFusion.h:135-183)
+void efe_set(void* p, const char* what, float v) {
+  ElasticFusion* e = ((Frame*)p)->ef;
+  const std::string n = what;
+  if (n == "rgbOnly") e->setRgbOnly(v != 0);
+  else if (n == "icpWeight") e->setIcpWeight(v);
+  else if (n == "pyramid") e->setPyramid(v != 0);
+  else if (n == "fastOdom") e->setFastOdom(v != 0);
+  else if (n == "so3") e->setSo3(v != 0);
+  else if (n == "frameToFrameRGB") e->setFrameToFrameRGB(v != 0);
+  else if (n == "confidence") e->setConfidenceThreshold(v);
+  else if (n == "depthCutoff") e->setDepthCutoff(v);
+}
 void efe_script_next_query(int n) { glrec::S().query_once = n; }   // the next "primitives written" query only (e.g. the clean pass's count)
 unsigned efe_tid(void* p, const char* name) {
   ElasticFusion* e = ((Frame*)p)->ef;

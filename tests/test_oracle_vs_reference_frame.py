@@ -44,6 +44,7 @@ def lib():
     so.efe_tick.argtypes = [P]
     so.efe_tid.argtypes = [P, C.c_char_p]
     so.efe_script_tracker.argtypes = [P, C.c_float, C.c_float, C.c_double, C.c_int]
+    so.efe_set.argtypes = [P, C.c_char_p, C.c_float]
     so.efe_script_readbacks.argtypes = [C.c_int, C.c_uint, P, C.c_long]
     return so
 
@@ -214,6 +215,40 @@ def test_frame_loop_matches_the_compiled_reference(tmp_path, mode):
         assert norm_pose(got) == norm_pose(want), (k, "\n".join(got), "\n".join(want))
         assert np.array_equal(ref.pose(), o.pose()), k
         assert so.efe_tick(ref.h) == o.tick()
+    ref.close()
+
+
+SETTERS = {   # reference setter -> the oracle's parameter
+    "rgb_only": (dict(rgbOnly=1), dict(rgbOnly=1)),
+    "frame_to_frame_rgb": (dict(frameToFrameRGB=1), dict(frameToFrameRGB=1)),
+    "confidence_and_depth_cut": (dict(confidence=4.0, depthCutoff=2.0), dict(confidence=4.0, depthCut=2.0)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SETTERS))
+def test_setters_change_the_frame_loop_the_same_way(tmp_path, name):
+    """setRgbOnly (no fusion block at all), setFrameToFrameRGB (the image fill-in passes the camera frame through),
+    setConfidenceThreshold / setDepthCutoff: the compiled reference's frame after its own setters vs the oracle configured alike"""
+    so = lib()
+    ref_set, ora = SETTERS[name]
+    ref = Ref(so, str(tmp_path / "ref"))
+    for k, v in ref_set.items():
+        so.efe_set(ref.h, k.encode(), float(v))
+    o = efo.Fusion(timeDelta=200, **ora)
+    efo.lib().efo_fusion_trace(o.h_, 1)
+    efo.lib().efo_fusion_take_trace.restype = C.c_char_p
+    rgb = np.full((H, W, 3), 90, np.uint8)
+    depth = np.full((H, W), 1500, np.uint16)
+    poses = synth_poses(4)
+    for k in range(4):
+        T = None if k == 0 else poses[k]
+        txt = ref.frame(rgb, depth, k * 33333, T)
+        o.process_frame(rgb, depth, k * 33333, T_wc=T)
+        got = oracle_lines(efo.lib().efo_fusion_take_trace(o.h_).decode())
+        want = translate(ref, txt)
+        assert norm_pose(got) == norm_pose(want), (k, "\n".join(got), "\n".join(want))
+    if name == "rgb_only":
+        assert not any(l.startswith(("fuse", "clean", "predictIndices")) for l in want)
     ref.close()
 
 
