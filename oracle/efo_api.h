@@ -139,6 +139,9 @@ typedef struct efo_local_loop {
 /* constraints: n rows of 8 doubles {vert_w_curr xyz, vert_w_est xyz, time of the inactive surface, pin}; return non-zero to accept */
 typedef int (*efo_loop_solver)(void* user, const efo_local_loop* info, const double* constraints, int n, float* graph_out /* 1024 x 16 */,
                                int* nodes_out);
+/* the constraint sampling + arithmetic of ElasticFusion.cpp:485-509 on explicit inputs (what efo_fusion's local loop closure runs) */
+int efo_loop_constraints(const float* vertex4, const uint16_t* oldTime, int width, int height, int consSample, const double* T_wc_curr16,
+                         const double* T_wc_est16, float maxDepth, int pin, double* rows8);
 void efo_fusion_set_close_loops(efo_fusion*, int on, int icpCountThresh, float icpErrThresh, float covThresh);
 void efo_fusion_set_loop_solver(efo_fusion*, efo_loop_solver fn, void* user);
 int efo_fusion_local_loop(const efo_fusion*, efo_local_loop* info, double* constraints, int max_constraints);

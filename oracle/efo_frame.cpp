@@ -14,6 +14,33 @@
 
 using namespace efo;
 
+// The surface constraints of the local loop closure, ElasticFusion.cpp:485-509: Resize::vertex / Resize::time (Resize.cpp:85-159) =
+// NEAREST sample of texel (20a+10, 20b+10) like Resize::image (G8), walked column by column (:488-489); a sample counts when
+// 0 < z < maxDepth and the inactive surface has a time there; both world points are T * Vector4d(x, y, z, 1), a 4x4 matrix product
+// evaluated left to right.  rows: n x {vert_w_curr xyz, vert_w_est xyz, inactive time, pin}
+extern "C" int efo_loop_constraints(const float* vertex4, const uint16_t* oldTime, int width, int height, int consSample, const double* M,
+                                    const double* E, float maxDepth, int pin, double* rows) {
+  const int cw = width / consSample, ch = height / consSample;
+  int n = 0;
+  for (int i = 0; i < cw; ++i)
+    for (int j = 0; j < ch; ++j) {
+      const size_t texel = (size_t)(j * consSample + consSample / 2) * width + (i * consSample + consSample / 2);
+      const float* v = &vertex4[texel * 4];
+      const uint16_t tm = oldTime[texel];
+      if (v[2] > 0 && v[2] < maxDepth && tm > 0) {                                                           // :490-492
+        double* row = rows + (size_t)n * 8;
+        for (int r = 0; r < 3; ++r) {
+          row[r] = ((M[r * 4] * (double)v[0] + M[r * 4 + 1] * (double)v[1]) + M[r * 4 + 2] * (double)v[2]) + M[r * 4 + 3] * 1.0;
+          row[3 + r] = ((E[r * 4] * (double)v[0] + E[r * 4 + 1] * (double)v[1]) + E[r * 4 + 2] * (double)v[2]) + E[r * 4 + 3] * 1.0;
+        }
+        row[6] = (double)tm;
+        row[7] = pin ? 1.0 : 0.0;                                                                             // :507-508
+        ++n;
+      }
+    }
+  return n;
+}
+
 struct efo_fusion {
   efo_fusion_params p;
   efo_cam cam;
@@ -133,24 +160,10 @@ struct efo_fusion {
     loop.gates_ok = covOk && loop.stats[1] > (float)icpCountThresh && loop.stats[0] < icpErrThresh;            // :483-484
     if (!loop.gates_ok) return;
     // Resize::vertex / Resize::time (Resize.cpp:85-159): NEAREST sample of texel (20a+10, 20b+10) like Resize::image (G8)
-    const int cw = p.width / consSample, ch = p.height / consSample;
-    for (int i = 0; i < cw; ++i)
-      for (int j = 0; j < ch; ++j) {
-        const size_t texel = (size_t)(j * consSample + consSample / 2) * p.width + (i * consSample + consSample / 2);
-        const float* v = &vertex[texel * 4];
-        const uint16_t tm = oldTime[texel];
-        if (v[2] > 0 && v[2] < maxDepthProcessed && tm > 0) {                                                   // :490-492
-          double row[8];
-          for (int r = 0; r < 3; ++r) {   // T * Vector4d(x, y, z, 1): 4x4 matrix product, left to right
-            row[r] = ((M[r * 4] * (double)v[0] + M[r * 4 + 1] * (double)v[1]) + M[r * 4 + 2] * (double)v[2]) + M[r * 4 + 3] * 1.0;
-            row[3 + r] = ((E[r * 4] * (double)v[0] + E[r * 4 + 1] * (double)v[1]) + E[r * 4 + 2] * (double)v[2]) + E[r * 4 + 3] * 1.0;
-          }
-          row[6] = (double)tm;
-          row[7] = deforms == 0 ? 1.0 : 0.0;                                                                    // :507-508
-          loopConstraints.insert(loopConstraints.end(), row, row + 8);
-        }
-      }
-    loop.n_constraints = (int)(loopConstraints.size() / 8);
+    loopConstraints.resize((size_t)(p.width / consSample) * (p.height / consSample) * 8);
+    loop.n_constraints = efo_loop_constraints(vertex.data(), oldTime.data(), p.width, p.height, consSample, M, E, maxDepthProcessed, deforms == 0,
+                                              loopConstraints.data());
+    loopConstraints.resize((size_t)loop.n_constraints * 8);
     if (!solver) return;
     std::vector<float> graph((size_t)1024 * 16, 0.f);
     int nodes = 0;

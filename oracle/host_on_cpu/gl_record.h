@@ -38,6 +38,8 @@ struct State {
   GLuint query_result = 0;                                      // what glGetQueryObjectuiv hands back (set by the bridge)
   int query_once = -1;                                          // >= 0: handed back by the NEXT query only, then query_result again
   int readpixels_fill = -1;                                     // >= 0: glReadPixels fills its destination with this byte
+  std::vector<std::vector<unsigned char>> readpixels_queue;     // if not empty: successive glReadPixels calls copy these out, in order
+  std::vector<int> query_queue;                                 // if not empty: successive queries hand these back, in order
   std::vector<unsigned char> buffer_data;                       // what glGetBufferSubData copies out (e.g. the surfel map)
 };
 inline State& S() { static State s; return s; }
@@ -117,12 +119,21 @@ inline void glDeleteQueries(GLsizei, const GLuint*) {}
 inline void glBeginQuery(GLenum target, GLuint id) { rec("glBeginQuery %#x %u", target, id); }
 inline void glEndQuery(GLenum target) { rec("glEndQuery %#x", target); }
 inline void glGetQueryObjectuiv(GLuint id, GLenum pname, GLuint* out) {
-  *out = glrec::S().query_once >= 0 ? (GLuint)glrec::S().query_once : glrec::S().query_result;
+  if (!glrec::S().query_queue.empty()) {
+    *out = (GLuint)glrec::S().query_queue.front();
+    glrec::S().query_queue.erase(glrec::S().query_queue.begin());
+  } else {
+    *out = glrec::S().query_once >= 0 ? (GLuint)glrec::S().query_once : glrec::S().query_result;
+  }
   glrec::S().query_once = -1; rec("glGetQueryObjectuiv %u %#x -> %u", id, pname, *out);
 }
 inline void glReadPixels(GLint x, GLint y, GLsizei w, GLsizei h, GLenum fmt, GLenum type, void* dst) {
   rec("glReadPixels %d %d %d %d fmt=%#x type=%#x", x, y, w, h, fmt, type);
-  if (glrec::S().readpixels_fill >= 0 && dst) {
+  if (!glrec::S().readpixels_queue.empty() && dst) {
+    const std::vector<unsigned char>& b = glrec::S().readpixels_queue.front();
+    memcpy(dst, b.data(), b.size());
+    glrec::S().readpixels_queue.erase(glrec::S().readpixels_queue.begin());
+  } else if (glrec::S().readpixels_fill >= 0 && dst) {
     const int ch = fmt == GL_RGB ? 3 : fmt == GL_RGBA ? 4 : 1;
     const int bytes = type == GL_FLOAT || type == GL_UNSIGNED_INT ? 4 : type == GL_UNSIGNED_SHORT ? 2 : 1;
     memset(dst, glrec::S().readpixels_fill, (size_t)w * h * ch * bytes);

@@ -83,11 +83,15 @@ Eigen::MatrixXd RGBDOdometry::getCovariance() {
 DeformationGraph::DeformationGraph(int k_, std::vector<Eigen::Vector3d>* sv) : k(k_), initialised(false), wRot(1), wReg(10), wCon(100), sourceVertices(sv) {}
 DeformationGraph::~DeformationGraph() {}
 void DeformationGraph::initialiseGraph(std::vector<Eigen::Vector3d>* g, std::vector<uint64_t>* t) { rec("DeformationGraph::initialiseGraph nodes=%d", (int)g->size()); initialised = true; }
-void DeformationGraph::appendVertices(std::vector<uint64_t>* t, uint32_t originalPointEnd) { rec("DeformationGraph::appendVertices %d from %u", (int)t->size(), originalPointEnd); }
+void DeformationGraph::appendVertices(std::vector<uint64_t>* t, uint32_t originalPointEnd) {
+  rec("DeformationGraph::appendVertices %d from %u", (int)t->size(), originalPointEnd);
+  for (size_t i = originalPointEnd; i < sourceVertices->size(); ++i)      // the constraint sources (Deformation::constrain, Deformation.cpp:120-131)
+    rec("  vertex %d time=%lu %.17g %.17g %.17g", (int)i, (unsigned long)t->at(i), (*sourceVertices)[i](0), (*sourceVertices)[i](1), (*sourceVertices)[i](2));
+}
 void DeformationGraph::setPosesSeq(std::vector<uint64_t>* t, const std::vector<Sophus::SE3d>& T) { rec("DeformationGraph::setPosesSeq %d", (int)T.size()); }
 std::vector<GraphNode*>& DeformationGraph::getGraph() { return graph; }
 std::vector<uint64_t>& DeformationGraph::getGraphTimes() { static std::vector<uint64_t> none; return none; }
-void DeformationGraph::addConstraint(int vertexId, Eigen::Vector3d& target) { rec("DeformationGraph::addConstraint vertex=%d target=%.9g %.9g %.9g", vertexId, target(0), target(1), target(2)); }
+void DeformationGraph::addConstraint(int vertexId, Eigen::Vector3d& target) { rec("DeformationGraph::addConstraint vertex=%d target=%.17g %.17g %.17g", vertexId, target(0), target(1), target(2)); }
 void DeformationGraph::addRelativeConstraint(int a, int b) { rec("DeformationGraph::addRelativeConstraint %d %d", a, b); }
 void DeformationGraph::clearConstraints() { rec("DeformationGraph::clearConstraints"); }
 void DeformationGraph::applyGraphToVertices() { rec("DeformationGraph::applyGraphToVertices"); }
@@ -158,6 +162,9 @@ void efe_set(void* p, const char* what, float v) {
   else if (n == "confidence") e->setConfidenceThreshold(v);
   else if (n == "depthCutoff") e->setDepthCutoff(v);
 }
+void efe_queue_readpixels(const unsigned char* data, long bytes) { glrec::S().readpixels_queue.emplace_back(data, data + bytes); }
+void efe_queue_query(int n) { glrec::S().query_queue.push_back(n); }
+void efe_clear_queues() { glrec::S().readpixels_queue.clear(); glrec::S().query_queue.clear(); }
 void efe_script_next_query(int n) { glrec::S().query_once = n; }   // the next "primitives written" query only (e.g. the clean pass's count)
 unsigned efe_tid(void* p, const char* name) {
   ElasticFusion* e = ((Frame*)p)->ef;

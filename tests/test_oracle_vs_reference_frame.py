@@ -340,3 +340,68 @@ def test_writers_reproduce_the_reference_files_byte_for_byte(tmp_path):
     assert a == b and len(a.splitlines()) == 7
     a, b = open(tmp_path / "ref.ply", "rb").read(), open(tmp_path / "mine.ply", "rb").read()
     assert a == b and (b"element vertex %d" % int((surf[:, 3] > 10.0).sum())) in a and 2000 < int((surf[:, 3] > 10.0).sum()) < 3000
+
+
+def test_surface_constraints_match_the_compiled_reference(tmp_path):
+    """ElasticFusion.cpp:485-509 in the compiled reference — fed, through the recorder, a 32x24 vertex read-back with holes and a time
+    read-back — against the oracle's efo_loop_constraints on full-resolution maps holding the same values at the sampled texels:
+    which samples count, in which order they are walked, both world points of every constraint to the last bit, the time and the
+    pin flag, as they reach Deformation::constrain (whose graph is a recording double initialised through a scripted sample pass)."""
+    so = lib()
+    so.efe_queue_readpixels.argtypes = [P, C.c_long]
+    so.efe_queue_query.argtypes = [C.c_int]
+    ref = Ref(so, str(tmp_path / "ref"), timeDelta=3, closeLoops=1, confidence=2.0)
+    rgb = np.full((H, W, 3), 90, np.uint8)
+    depth = np.full((H, W), 1500, np.uint16)
+    rng = np.random.RandomState(11)
+    nodes = np.zeros((8, 4), np.float32)
+    nodes[:, :3] = rng.uniform(-1, 1, (8, 3))
+    nodes[:, 3] = np.arange(8)
+    so.efe_script_readbacks(-1, 0, nodes.ctypes.data, nodes.nbytes)            # Deformation::sampleGraphModel reads 8 graph nodes back
+    so.efe_queue_query(1000)                                                    # frame 0: the seeded map's count, then the sampled node count
+    so.efe_queue_query(8)
+    ref.frame(rgb, depth, 0)
+    cons = np.zeros((H // 20, W // 20, 4), np.float32)
+    cons[..., :2] = rng.uniform(-1, 1, cons.shape[:2] + (2,))
+    cons[..., 2] = rng.uniform(0.5, 3.0, cons.shape[:2])
+    cons[rng.uniform(size=cons.shape[:2]) < 0.2, 2] = 0.0                       # holes
+    cons[3, 5, 2] = 25.0                                                        # beyond maxDepthProcessed
+    times = rng.randint(0, 3, cons.shape[:2]).astype(np.uint16)                 # 0 = nothing inactive there
+    for shape in ((60, 80, 3, np.uint8), (60, 80, 4, np.float32), (60, 80, 4, np.float32)):    # Ferns::findFrame reads three 80x60 images first
+        z = np.zeros(shape[:3], shape[3])
+        so.efe_queue_readpixels(z.ctypes.data, z.nbytes)
+    so.efe_queue_readpixels(cons.ctypes.data, cons.nbytes)
+    so.efe_queue_readpixels(times.ctypes.data, times.nbytes)
+    so.efe_queue_query(1000)
+    so.efe_queue_query(8)
+    D = np.eye(4)
+    D[:3, 3] = [0.004, -0.002, 0.003]
+    so.efe_script_tracker(D.ctypes.data, 1e-6, 100000.0, 1e-7, 0)
+    T1 = synth_poses(2)[1]
+    txt = ref.frame(rgb, depth, 33333, T1)
+    so.efe_clear_queues()
+    lines = txt.splitlines()
+    m2m = [l for l in lines if l.startswith("  track ")]
+    M = np.eye(4)
+    M[:3] = np.array([float(x) for x in m2m[0].split()[3:]]).reshape(3, 4)
+    E = np.eye(4)
+    E[:3] = np.array([float(x) for x in m2m[1].split()[3:]]).reshape(3, 4)
+    verts = [(int(l.split()[2].split("=")[1]), [float(x) for x in l.split()[3:]]) for l in lines if l.startswith("  vertex ")]
+    targets = [[float(x.replace("target=", "")) for x in l.split()[2:]] for l in lines if l.startswith("DeformationGraph::addConstraint")]
+    assert len(verts) == len(targets) and len(verts) % 2 == 0 and len(verts) > 200
+    # the oracle on full-resolution maps carrying the same values at texel (20a + 10, 20b + 10)
+    vmap = np.zeros((H, W, 4), np.float32)
+    tmap = np.zeros((H, W), np.uint16)
+    vmap[10::20, 10::20] = cons
+    tmap[10::20, 10::20] = times
+    rows = np.zeros((cons.shape[0] * cons.shape[1], 8))
+    fn = efo.lib().efo_loop_constraints
+    n = fn(efo.ptr(vmap), efo.ptr(tmap), W, H, 20, efo.ptr(M.reshape(16)), efo.ptr(E.reshape(16)), C.c_float(20.0), 1, efo.ptr(rows))
+    rows = rows[:n]
+    assert n == len(verts) // 2 == int(((cons[..., 2] > 0) & (cons[..., 2] < 20) & (times > 0)).sum())
+    for i in range(n):
+        (t_src, src), (t_pin, pin_src) = verts[2 * i], verts[2 * i + 1]
+        assert src == list(rows[i, 0:3]) and targets[2 * i] == list(rows[i, 3:6])           # the constraint: surface under T_wc_curr -> under T_wc_est
+        assert pin_src == list(rows[i, 3:6]) and targets[2 * i + 1] == list(rows[i, 3:6])   # its pin (first deformation): target held in place
+        assert t_src == 2 and t_pin == int(rows[i, 6]) and rows[i, 7] == 1                  # source time = tick, pin time = the inactive surface's
+    ref.close()
