@@ -143,6 +143,17 @@ class LocalLoop(C.Structure):   # ef_local_loop
 LOOP_SOLVER = C.CFUNCTYPE(c_i, C.c_void_p, C.POINTER(LocalLoop), C.POINTER(C.c_double), c_i, C.POINTER(c_f), C.POINTER(c_i))
 
 
+def solve_local_deformation(nodes4, constraints, src_time, last_deform_time=0):
+    """ef_solve_local_deformation on host arrays (no GPU): -> (graph [n, 16] float32, error, mean constraint error) or None"""
+    nodes4 = np.ascontiguousarray(nodes4, np.float32).reshape(-1, 4)
+    cons = np.ascontiguousarray(constraints, np.float64).reshape(-1, 8)
+    g = np.zeros((max(len(nodes4), 1), 16), np.float32)
+    e, m = c_f(0), c_f(0)
+    rc = lib().ef_solve_local_deformation(_ptr(nodes4), c_i(len(nodes4)), _ptr(cons), c_i(len(cons)), C.c_int64(int(src_time)),
+                                          C.c_int64(int(last_deform_time)), _ptr(g), C.byref(e), C.byref(m))
+    return (g[:len(nodes4)], e.value, m.value) if rc == 0 else None
+
+
 class ElasticFusion:
     """Mirror of ``class ElasticFusion`` (Core/ElasticFusion.h) over the C ABI."""
 
@@ -213,6 +224,10 @@ class ElasticFusion:
             return 1
         self._solver = LOOP_SOLVER(tramp)
         _chk(lib().ef_set_loop_solver(self.h, self._solver, None), self.h)
+
+    def useBuiltinLoopSolver(self, on=True):
+        """the built-in deformation-graph optimiser where Deformation::constrain stands (ef_use_builtin_loop_solver)"""
+        _chk(lib().ef_use_builtin_loop_solver(self.h, c_i(int(on))), self.h)
 
     def localLoop(self):
         """(info, constraints [n, 8]) of the last processFrame."""

@@ -14,6 +14,7 @@
 #include "ef_linalg_dev.hpp"
 #include "ef_solve_dev.hpp"
 #include "ef_map.hpp"
+#include "ef_deform_solver.hpp"
 #include "ef_track.hpp"
 
 namespace {
@@ -101,6 +102,10 @@ struct ef_ctx {
   eft::TrackState* h_states = nullptr;     // pinned: [0] frame-to-model, [1] model-to-model
   ef_loop_solver solver = nullptr;
   void* solver_user = nullptr;
+  bool builtin_solver = false;             // ef_use_builtin_loop_solver: efd::solve_local where Deformation::constrain stands
+  int64_t last_deform_time = 0;            // Deformation::lastDeformTime (Deformation.cpp:31,199-201)
+  float* nodes_dev = nullptr;              // sampled graph nodes (Deformation::sampleGraphModel), 1024 x 4 + count
+  std::vector<float> h_nodes;
   ef_local_loop loop{};
   std::vector<double> loop_constraints;    // n x 8
   std::vector<float> loop_graph;
@@ -280,10 +285,30 @@ int local_loop_closure(ef_ctx* c, int log_slot) {
       }
     }
   L.n_constraints = (int)(c->loop_constraints.size() / 8);
-  if (!c->solver) return EF_OK;
+  if (!c->solver && !c->builtin_solver) return EF_OK;
   c->loop_graph.assign((size_t)1024 * 16, 0.f);
   int nodes = 0;
-  if (c->solver(c->solver_user, &L, c->loop_constraints.data(), L.n_constraints, c->loop_graph.data(), &nodes)) {   // :513-514
+  bool accepted = false;
+  if (c->solver) {
+    accepted = c->solver(c->solver_user, &L, c->loop_constraints.data(), L.n_constraints, c->loop_graph.data(), &nodes) != 0;   // :513-514
+  } else {
+    // the built-in optimiser on the graph Deformation::sampleGraphModel would have sampled at the end of the previous frame
+    // (ElasticFusion.cpp:593): every 5000th surfel of the map as it stands now
+    const int max_nodes = 1023;
+    unsigned* n_dev = (unsigned*)(c->nodes_dev + (size_t)1024 * 4);
+    efm::sample_graph(c->maps[c->cur], count, 5000, max_nodes, c->nodes_dev, n_dev, s);
+    c->h_nodes.resize((size_t)1024 * 4 + 4);
+    EF_HIP(c, hipMemcpyAsync(c->h_nodes.data(), c->nodes_dev, ((size_t)1024 * 4 + 1) * sizeof(float), hipMemcpyDeviceToHost, s));
+    EF_HIP(c, hipStreamSynchronize(s));
+    unsigned n_nodes = 0;
+    memcpy(&n_nodes, &c->h_nodes[(size_t)1024 * 4], sizeof(unsigned));
+    const efd::Result r = efd::solve_local(c->h_nodes.data(), (int)n_nodes, c->loop_constraints.data(), L.n_constraints, (uint64_t)c->tick,
+                                           (uint64_t)c->last_deform_time, c->loop_graph.data());
+    accepted = r.ok;
+    nodes = r.ok ? (int)n_nodes : 0;
+    if (r.ok) c->last_deform_time = c->tick;   // Deformation.cpp:199-201
+  }
+  if (accepted) {
     if (nodes < 0 || nodes >= 1024) { c->err = "loop solver: 0..1023 graph nodes (GlobalModel::MAX_NODES)"; return EF_EINVAL; }
     L.applied = 1;
     L.graph_nodes = nodes;
@@ -571,6 +596,7 @@ int ctx_init(ef_ctx* c) {
     EF_ALLOC(c, c->old.normal, P);
     EF_ALLOC(c, c->old.time, P);
     EF_ALLOC(c, c->cons_dev, (size_t)(W / 20) * (H / 20) * 4 + 4);
+    EF_ALLOC(c, c->nodes_dev, (size_t)1024 * 4 + 4);
     EF_HIP(c, hipHostMalloc((void**)&c->h_cons, ((size_t)(W / 20) * (H / 20) * 4 + 4) * sizeof(float)));
     EF_HIP(c, hipHostMalloc((void**)&c->h_states, 2 * sizeof(eft::TrackState)));
     hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->st2, (W / 20) * (H / 20), W * H);
@@ -714,6 +740,20 @@ int ef_set_loop_solver(ef_ctx* c, ef_loop_solver fn, void* user) {
   if (!c->cfg.close_loops) { c->err = "ef_set_loop_solver: the context was created with close_loops = 0"; return EF_ESTATE; }
   c->solver = fn; c->solver_user = user;
   return EF_OK;
+}
+int ef_use_builtin_loop_solver(ef_ctx* c, int on) {
+  if (!c) return EF_EINVAL;
+  if (!c->cfg.close_loops) { c->err = "ef_use_builtin_loop_solver: the context was created with close_loops = 0"; return EF_ESTATE; }
+  c->builtin_solver = on != 0;
+  return EF_OK;
+}
+int ef_solve_local_deformation(const float* nodes4, int n_nodes, const double* constraints8, int n_constraints, int64_t src_time,
+                               int64_t last_deform_time, float* graph16_out, float* error_out, float* mean_constraint_error_out) {
+  if (!nodes4 || !constraints8 || !graph16_out || n_nodes < 0 || n_nodes > 1023 || n_constraints < 0) return EF_EINVAL;
+  const efd::Result r = efd::solve_local(nodes4, n_nodes, constraints8, n_constraints, (uint64_t)src_time, (uint64_t)last_deform_time, graph16_out);
+  if (error_out) *error_out = r.error;
+  if (mean_constraint_error_out) *mean_constraint_error_out = r.meanConsErr;
+  return r.ok ? EF_OK : EF_ESTATE;
 }
 int ef_get_local_loop(ef_ctx* c, ef_local_loop* info, double* constraints, int max_constraints, int* n_out) {
   if (!c || !info) return EF_EINVAL;

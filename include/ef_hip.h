@@ -113,6 +113,16 @@ typedef struct ef_local_loop {
  * Return non-zero to accept (Deformation::constrain returning true); called on the thread inside ef_process_frame. */
 typedef int (*ef_loop_solver)(void* user, const ef_local_loop* info, const double* constraints, int n, float* graph_out, int* nodes_out);
 int ef_set_loop_solver(ef_ctx* ctx, ef_loop_solver fn, void* user);   /* NULL: gates and constraints are still evaluated */
+/* The built-in solver in that place: Deformation::constrain(..., fernMatch = false) re-implemented as a host-side banded Gauss-Newton
+ * optimiser of the embedded deformation graph (Deformation.cpp:88-215, DeformationGraph.cpp; no CHOLMOD), run on the graph nodes
+ * ef_sample_graph yields for the current map.  With it a closeLoops context closes LOCAL loops end to end.  A registered
+ * ef_loop_solver takes precedence. */
+int ef_use_builtin_loop_solver(ef_ctx* ctx, int on);
+/* the same optimiser on explicit inputs (host arrays, no context, no GPU): nodes4 = n_nodes x {x, y, z, time} ascending in time,
+ * constraints8 as ef_get_local_loop returns them (all sourced at src_time), nodes no younger than last_deform_time stay fixed;
+ * graph16_out = n_nodes x 16 floats in the layout ef_set_deformation takes.  EF_ESTATE when there are not more than 4 nodes. */
+int ef_solve_local_deformation(const float* nodes4, int n_nodes, const double* constraints8, int n_constraints, int64_t src_time,
+                               int64_t last_deform_time, float* graph16_out, float* error_out, float* mean_constraint_error_out);
 /* icpCountThresh, icpErrThresh, covThresh of the constructor (ElasticFusion.h:44-46; defaults 35000, 5e-05, 1e-05) */
 int ef_set_loop_thresholds(ef_ctx* ctx, int icp_count_thresh, float icp_err_thresh, float cov_thresh);
 int ef_get_local_loop(ef_ctx* ctx, ef_local_loop* info, double* constraints_or_null, int max_constraints, int* n_out_or_null);

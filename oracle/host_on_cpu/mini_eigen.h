@@ -132,6 +132,30 @@ class Matrix {
     return r;
   }
   Matrix eval() const { return *this; }
+  void setIdentity() { *this = Identity(); }
+  void setZero() { *this = Zero(); }
+  template <int O2>
+  Matrix& operator+=(const Matrix<T, R, C, O2>& o) {
+    for (int i = 0; i < R; ++i)
+      for (int j = 0; j < C; ++j) (*this)(i, j) += o(i, j);
+    return *this;
+  }
+  Matrix<T, R, 1> col(int j) const {
+    Matrix<T, R, 1> r;
+    for (int i = 0; i < R; ++i) r.m[i] = (*this)(i, j);
+    return r;
+  }
+  template <int O2>
+  T dot(const Matrix<T, R, C, O2>& o) const {   // coefficient products summed in storage order
+    T s = m[0] * o.m[0];
+    for (int i = 1; i < R * C; ++i) s += m[i] * o.m[i];
+    return s;
+  }
+  T squaredNorm() const {
+    T s = m[0] * m[0];
+    for (int i = 1; i < R * C; ++i) s += m[i] * m[i];
+    return s;
+  }
   Matrix<T, C, R, O> transpose() const {
     Matrix<T, C, R, O> r;
     for (int i = 0; i < R; ++i)
@@ -185,6 +209,12 @@ template <typename T, int R, int C, int O>
 Matrix<T, R, C, O> operator*(T s, const Matrix<T, R, C, O>& a) {
   Matrix<T, R, C, O> r;
   for (int i = 0; i < R * C; ++i) r.m[i] = s * a.m[i];
+  return r;
+}
+template <typename T, int R, int C, int O>
+Matrix<T, R, C, O> operator*(const Matrix<T, R, C, O>& a, T s) {
+  Matrix<T, R, C, O> r;
+  for (int i = 0; i < R * C; ++i) r.m[i] = a.m[i] * s;
   return r;
 }
 template <typename T, int R, int C, int O, int O2>
@@ -287,6 +317,19 @@ class VectorXd {
   double& operator()(int i) { return v[(size_t)i]; }
   const double& operator()(int i) const { return v[(size_t)i]; }
   int rows() const { return (int)v.size(); }
+  double* data() { return v.data(); }
+  const double* data() const { return v.data(); }
+  double squaredNorm() const { double s = 0; for (double x : v) s += x * x; return s; }
+  double norm() const { return std::sqrt(squaredNorm()); }
+  VectorXd operator-() const { VectorXd r((int)v.size()); for (size_t i = 0; i < v.size(); ++i) r.v[i] = -v[i]; return r; }
+  void conservativeResize(int n) { v.resize((size_t)n, 0.0); }
+  struct Segment {
+    VectorXd& o;
+    int start, len;
+    template <int R, int C, int O>
+    Segment& operator=(const Matrix<double, R, C, O>& m) { for (int i = 0; i < len; ++i) o.v[(size_t)(start + i)] = m.m[i]; return *this; }
+  };
+  Segment segment(int start, int len) { return Segment{*this, start, len}; }
 };
 
 // what getCovariance() returns: a run-time sized copy of a fixed-size result
