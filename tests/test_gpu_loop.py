@@ -64,7 +64,8 @@ def run_pair(solver_factory, builtin=False):
             assert np.array_equal(ef.image("old_image"), o.old_buffer("image")), i
             assert same_floats(ef.image("old_vertex"), o.old_buffer("vertex")), i
             assert same_floats(ef.image("old_normal"), o.old_buffer("normal")), i
-        assert np.array_equal(bits(ef.get_T_wc()), bits(o.pose())), i
+        # identical as floats; the double matrices may differ in the last bit of a small element (two libms' sin / cos)
+        assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32)) and np.abs(ef.get_T_wc() - o.pose()).max() < 1e-15, i
         assert ef.lastCount() == o.map_count(), i
         if i % 5 == 4:   # Resize::{image,vertex} at the fern database's factor 8 and the constraint grid's factor 20
             for f in (8, 20):
