@@ -82,7 +82,22 @@ Eigen::MatrixXd RGBDOdometry::getCovariance() {
 // ---- recording double of Core/Utils/DeformationGraph.cpp (the CHOLMOD-based optimiser) ----
 DeformationGraph::DeformationGraph(int k_, std::vector<Eigen::Vector3d>* sv) : k(k_), initialised(false), wRot(1), wReg(10), wCon(100), sourceVertices(sv) {}
 DeformationGraph::~DeformationGraph() {}
-void DeformationGraph::initialiseGraph(std::vector<Eigen::Vector3d>* g, std::vector<uint64_t>* t) { rec("DeformationGraph::initialiseGraph nodes=%d", (int)g->size()); initialised = true; }
+void DeformationGraph::initialiseGraph(std::vector<Eigen::Vector3d>* g, std::vector<uint64_t>* t) {
+  rec("DeformationGraph::initialiseGraph nodes=%d", (int)g->size());
+  graphNodes.clear();   // the double keeps the nodes (identity transforms), so that an accepted deformation hands a graph on
+  graph.clear();
+  graphNodes.resize(g->size());
+  sampledGraphTimes = *t;
+  for (size_t i = 0; i < g->size(); ++i) {
+    graphNodes[i].id = (int)i;
+    graphNodes[i].enabled = true;
+    graphNodes[i].position = g->at(i);
+    graphNodes[i].translation = Eigen::Vector3d::Zero();
+    graphNodes[i].rotation.setIdentity();
+    graph.push_back(&graphNodes[i]);
+  }
+  initialised = true;
+}
 void DeformationGraph::appendVertices(std::vector<uint64_t>* t, uint32_t originalPointEnd) {
   rec("DeformationGraph::appendVertices %d from %u", (int)t->size(), originalPointEnd);
   for (size_t i = originalPointEnd; i < sourceVertices->size(); ++i)      // the constraint sources (Deformation::constrain, Deformation.cpp:120-131)
@@ -90,7 +105,7 @@ void DeformationGraph::appendVertices(std::vector<uint64_t>* t, uint32_t origina
 }
 void DeformationGraph::setPosesSeq(std::vector<uint64_t>* t, const std::vector<Sophus::SE3d>& T) { rec("DeformationGraph::setPosesSeq %d", (int)T.size()); }
 std::vector<GraphNode*>& DeformationGraph::getGraph() { return graph; }
-std::vector<uint64_t>& DeformationGraph::getGraphTimes() { static std::vector<uint64_t> none; return none; }
+std::vector<uint64_t>& DeformationGraph::getGraphTimes() { return sampledGraphTimes; }
 void DeformationGraph::addConstraint(int vertexId, Eigen::Vector3d& target) { rec("DeformationGraph::addConstraint vertex=%d target=%.17g %.17g %.17g", vertexId, target(0), target(1), target(2)); }
 void DeformationGraph::addRelativeConstraint(int a, int b) { rec("DeformationGraph::addRelativeConstraint %d %d", a, b); }
 void DeformationGraph::clearConstraints() { rec("DeformationGraph::clearConstraints"); }

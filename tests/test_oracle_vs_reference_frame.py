@@ -405,3 +405,69 @@ def test_surface_constraints_match_the_compiled_reference(tmp_path):
         assert pin_src == list(rows[i, 3:6]) and targets[2 * i + 1] == list(rows[i, 3:6])   # its pin (first deformation): target held in place
         assert t_src == 2 and t_pin == int(rows[i, 6]) and rows[i, 7] == 1                  # source time = tick, pin time = the inactive surface's
     ref.close()
+
+
+def test_accepted_local_deformation_flow(tmp_path):
+    """ElasticFusion.cpp:513-527 and :558-585 in the compiled reference, with the optimiser's recording double accepting: the pose becomes
+    T_wc_est, the depth of the inactive surface is re-synthesised (maxTime = tick - timeDelta, timeDelta = 65535) and the clean pass
+    gets the graph (8 nodes, not a fern match); from then on constraints are no longer pinned.  The same steps, with the same
+    parameters, are what the oracle's frame loop traces when its solver accepts."""
+    so = lib()
+    so.efe_queue_readpixels.argtypes = [P, C.c_long]
+    so.efe_queue_query.argtypes = [C.c_int]
+    TD, CONF = 3, 2.0
+    ref = Ref(so, str(tmp_path / "ref"), timeDelta=TD, closeLoops=1, confidence=CONF)
+    rgb = np.full((H, W, 3), 90, np.uint8)
+    depth = np.full((H, W), 1500, np.uint16)
+    nodes = np.zeros((8, 4), np.float32)
+    nodes[:, 0] = np.linspace(-1, 1, 8)
+    nodes[:, 2] = 1.5
+    nodes[:, 3] = np.arange(8)
+    so.efe_script_readbacks(-1, 0, nodes.ctypes.data, nodes.nbytes)
+    so.efe_queue_query(1000)
+    so.efe_queue_query(8)                                        # frame 0 samples 8 graph nodes: the optimiser's graph is initialised
+    translate(ref, ref.frame(rgb, depth, 0))
+    cons = np.zeros((H // 20, W // 20, 4), np.float32)
+    cons[..., 2] = 1.5
+    times = np.ones(cons.shape[:2], np.uint16)
+    for shape in ((60, 80, 3, np.uint8), (60, 80, 4, np.float32), (60, 80, 4, np.float32)):
+        z = np.zeros(shape[:3], shape[3])
+        so.efe_queue_readpixels(z.ctypes.data, z.nbytes)
+    so.efe_queue_readpixels(cons.ctypes.data, cons.nbytes)
+    so.efe_queue_readpixels(times.ctypes.data, times.nbytes)
+    so.efe_queue_query(1000)
+    so.efe_queue_query(8)
+    D = np.eye(4)
+    D[:3, 3] = [0.004, -0.002, 0.003]
+    so.efe_script_tracker(D.ctypes.data, 1e-6, 100000.0, 1e-7, 1)     # gates open, the optimiser accepts
+    T1 = synth_poses(2)[1]
+    txt = ref.frame(rgb, depth, 33333, T1)
+    so.efe_clear_queues()
+    got = translate(ref, txt)
+    tick = 2
+    i_track = max(k for k, l in enumerate(got) if l.startswith("modelToModel.track"))
+    tail = got[i_track + 1:]
+    # what the oracle's frame loop traces after an accepting solver (efo_frame.cpp): the same lines with the same parameters
+    assert tail[:6] == ["modelToModel.getCovariance",
+                        "predictIndices time=%d maxDepth=20 timeDelta=%d" % (tick, TD),
+                        "fuse time=%d maxDepth=20 weighting=%s" % (tick, tail[2].split("=")[-1]),
+                        "predictIndices time=%d maxDepth=20 timeDelta=%d" % (tick, TD),
+                        "synthesizeDepth maxDepth=20 conf=%g time=%d maxTime=%d timeDelta=65535" % (CONF, tick, tick - TD),
+                        "clean time=%d conf=%g nodes=8 timeDelta=%d maxDepth=20 isFern=0" % (tick, CONF, TD)], "\n".join(tail)
+    assert np.allclose(ref.pose(), T1 @ D, atol=1e-12)               # T_wc_curr = T_wc_est
+    assert "DeformationGraph::optimiseGraphSparse fernMatch=0 lastDeformTime=0 -> 1" in txt
+    # the next attempt: deforms > 0, so the constraints come without pins (one vertex per constraint instead of two)
+    for shape in ((60, 80, 3, np.uint8), (60, 80, 4, np.float32), (60, 80, 4, np.float32)):
+        z = np.zeros(shape[:3], shape[3])
+        so.efe_queue_readpixels(z.ctypes.data, z.nbytes)
+    so.efe_queue_readpixels(cons.ctypes.data, cons.nbytes)
+    so.efe_queue_readpixels(times.ctypes.data, times.nbytes)
+    so.efe_queue_query(1000)
+    so.efe_queue_query(8)
+    txt2 = ref.frame(rgb, depth, 66666, synth_poses(3)[2])
+    so.efe_clear_queues()
+    n_vert = sum(1 for l in txt2.splitlines() if l.startswith("  vertex "))
+    n_cons = sum(1 for l in txt2.splitlines() if l.startswith("DeformationGraph::addConstraint"))
+    assert n_vert == n_cons == cons.shape[0] * cons.shape[1]
+    assert "lastDeformTime=2 -> 1" in txt2                            # Deformation::lastDeformTime = the tick of the accepted one
+    ref.close()
