@@ -122,6 +122,7 @@ Sophus::SE3d ElasticFusion::get_T_wc_sophus() {
 void ElasticFusion::predict() { chk(ef_predict(C(ctx.get())), ctx.get(), "predict"); }
 
 void ElasticFusion::setLoopSolver(ef_loop_solver fn, void* user) { chk(ef_set_loop_solver(C(ctx.get()), fn, user), ctx.get(), "setLoopSolver"); }
+void ElasticFusion::useBuiltinLoopSolver(bool on) { chk(ef_use_builtin_loop_solver(C(ctx.get()), on), ctx.get(), "useBuiltinLoopSolver"); }
 const ef_local_loop& ElasticFusion::getLocalLoop() {
   chk(ef_get_local_loop(C(ctx.get()), &localLoop, nullptr, 0, nullptr), ctx.get(), "getLocalLoop");
   return localLoop;

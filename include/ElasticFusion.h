@@ -132,6 +132,7 @@ class ElasticFusion {
   // local loop closure (closeLoops = true): the solver standing where Deformation::constrain stands (include/ef_hip.h), and
   // the gates / statistics / poses of the last frame's attempt
   void setLoopSolver(ef_loop_solver fn, void* user);
+  void useBuiltinLoopSolver(bool on = true);   // the built-in deformation-graph optimiser where Deformation::constrain stands
   const ef_local_loop& getLocalLoop();
 
   const float& getConfidenceThreshold() { return confidenceThreshold; }

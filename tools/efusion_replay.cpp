@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
   std::string log;
   int w = 640, h = 480, timeDelta = 200, end = -1, dev = 0;
   float fx = 528, fy = 528, cx = 320, cy = 240, depthCut = 3, confidence = 10, icp = 10;
-  bool fastOdom = false, so3 = true, ftf = false, ply = false, quiet = false, closeLoops = false, allFrames = false;
+  bool fastOdom = false, so3 = true, ftf = false, ply = false, quiet = false, closeLoops = false, allFrames = false, solve = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&](int n = 1) { if (i + n >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -46,6 +46,7 @@ int main(int argc, char** argv) {
     else if (a == "-ply") ply = true;
     else if (a == "-q") quiet = true;
     else if (a == "-all") allFrames = true;
+    else if (a == "-solve") solve = true;     // with -cl: close local loops with the built-in deformation-graph optimiser
     else if (a == "-o") closeLoops = false;   // the default here (the reference closes loops unless -o is given)
     else if (a == "-cl") closeLoops = true;   // local loop closure front half every frame, time window from -t
     else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
@@ -59,6 +60,7 @@ int main(int argc, char** argv) {
     // open loop: timeDelta = INT_MAX / 2 exactly as MainController does for -o (MainController.cpp:179-183)
     ElasticFusion eFusion(closeLoops ? timeDelta : 2147483647 / 2, 35000, 5e-05f, 1e-05f, closeLoops, false, false, 115, confidence, depthCut,
                           icp, fastOdom, 0.3095f, so3, ftf, log, dev);
+    if (closeLoops && solve) eFusion.useBuiltinLoopSolver(true);
     int attempts = 0, opened = 0;
     const auto t0 = std::chrono::steady_clock::now();
     int n = 0;
