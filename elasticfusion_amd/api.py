@@ -154,6 +154,126 @@ def solve_local_deformation(nodes4, constraints, src_time, last_deform_time=0):
     return (g[:len(nodes4)], e.value, m.value) if rc == 0 else None
 
 
+FERN_TRACKER = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(c_f), C.POINTER(c_f), C.POINTER(C.c_double), C.POINTER(c_f), C.POINTER(c_f),
+                           C.POINTER(C.c_double), C.POINTER(c_f), C.POINTER(c_f))
+
+
+class Ferns:
+    """The reference's fern database (Core/Ferns.h:35-184) over ef_ferns_* — host-side, no GPU.  Same members where they make
+    sense on arrays: addFrame, findFrame (-> T_wc_est, constraints [n, 6]), lastClosest, frames (count), conservatory (table).
+    Views are the 1/8-resolution images ``ElasticFusion.imageResized(..., 8)`` returns: rgb [h, w, 3|4] uint8, verts / norms
+    [h, w, 4] float32.  ``tracker(fern_verts, fern_norms, T_wc_fern, verts, norms, T_wc) -> (T_wc_est, icp_error, icp_count)``
+    stands where the reference runs its 80x60 RGBDOdometry (Ferns.cpp:243-258)."""
+
+    def __init__(self, n=500, maxDepth=3000, photoThresh=115.0, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, seed=0):
+        L = lib()
+        L.ef_ferns_create.restype = P
+        L.ef_ferns_create.argtypes = [c_i, c_i, c_f, c_i, c_i, c_f, c_f, c_f, c_f, C.c_uint]
+        for name in ("ef_ferns_block_hd_aware", "ef_ferns_photometric_check"):
+            getattr(L, name).restype = c_f
+        L.ef_ferns_destroy.argtypes = [P]
+        L.ef_ferns_get_table.argtypes = L.ef_ferns_set_table.argtypes = [P, P]
+        L.ef_ferns_add_frame.argtypes = [P, P, c_i, P, P, P, c_i, c_f]
+        L.ef_ferns_find_frame.argtypes = [P, P, c_i, P, P, P, c_i, c_i, FERN_TRACKER, P, P, P, c_i, P]
+        L.ef_ferns_count.argtypes = L.ef_ferns_last_closest.argtypes = [P]
+        L.ef_ferns_get_frame.argtypes = [P, c_i, P, P, P, P, P, P, P]
+        L.ef_ferns_set_frame_pose.argtypes = [P, c_i, P]
+        L.ef_ferns_block_hd_aware.argtypes = [P, c_i, c_i]
+        L.ef_ferns_photometric_check.argtypes = [P, P, c_i, P, P, c_i]
+        self.num, self.w, self.h = int(n), width // 8, height // 8
+        self._h = L.ef_ferns_create(int(n), int(maxDepth), float(photoThresh), int(width), int(height), fx, fy, cx, cy, int(seed))
+        if not self._h:
+            raise EFError("ef_ferns_create: bad arguments")
+
+    def close(self):
+        if self._h:
+            lib().ef_ferns_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _view(self, rgb, verts, norms):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        assert rgb.shape[:2] == (self.h, self.w) and rgb.shape[2] in (3, 4), rgb.shape
+        verts = np.ascontiguousarray(verts, np.float32).reshape(self.h, self.w, 4)
+        norms = np.ascontiguousarray(norms, np.float32).reshape(self.h, self.w, 4)
+        return rgb, verts, norms
+
+    @property
+    def conservatory(self):
+        t = np.zeros((self.num, 6), np.int32)
+        _chk(lib().ef_ferns_get_table(self._h, _ptr(t)))
+        return t
+
+    @conservatory.setter
+    def conservatory(self, table):
+        t = np.ascontiguousarray(table, np.int32).reshape(self.num, 6)
+        _chk(lib().ef_ferns_set_table(self._h, _ptr(t)))
+
+    def addFrame(self, rgb, verts, norms, T_wc, srcTime, threshold) -> bool:
+        rgb, verts, norms = self._view(rgb, verts, norms)
+        T = np.ascontiguousarray(T_wc, np.float64).reshape(4, 4)
+        rc = lib().ef_ferns_add_frame(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(norms), _ptr(T), int(srcTime), float(threshold))
+        if rc < 0:
+            _chk(rc)
+        return rc == 1
+
+    def findFrame(self, rgb, verts, norms, T_wc, time, lost, tracker):
+        rgb, verts, norms = self._view(rgb, verts, norms)
+        T = np.ascontiguousarray(T_wc, np.float64).reshape(4, 4)
+        px = self.w * self.h * 4
+
+        def tramp(_user, fv, fn, Tf, cv, cn, Tio, err, cnt):
+            A = lambda p, n, dt: np.ctypeslib.as_array(p, shape=(n,)).astype(dt).copy()
+            Te, e, k = tracker(A(fv, px, np.float32).reshape(self.h, self.w, 4), A(fn, px, np.float32).reshape(self.h, self.w, 4),
+                               A(Tf, 16, np.float64).reshape(4, 4), A(cv, px, np.float32).reshape(self.h, self.w, 4),
+                               A(cn, px, np.float32).reshape(self.h, self.w, 4), A(Tio, 16, np.float64).reshape(4, 4))
+            Te = np.ascontiguousarray(Te, np.float64).reshape(16)
+            for i in range(16):
+                Tio[i] = Te[i]
+            err[0], cnt[0] = float(e), float(k)
+
+        cb = FERN_TRACKER(tramp)
+        T_est = np.zeros((4, 4), np.float64)
+        cons = np.zeros((self.num, 6), np.float64)
+        n = c_i(0)
+        rc = lib().ef_ferns_find_frame(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(norms), _ptr(T), int(time), int(bool(lost)), cb, None,
+                                       _ptr(T_est), _ptr(cons), self.num, C.byref(n))
+        if rc < -1:
+            _chk(rc)
+        return T_est, cons[:n.value].copy()
+
+    @property
+    def lastClosest(self) -> int:
+        return lib().ef_ferns_last_closest(self._h)
+
+    def __len__(self):
+        return lib().ef_ferns_count(self._h)
+
+    def frame(self, i):
+        """-> dict(codes, goodCodes, srcTime, T_wc, rgb, verts, norms) of stored frame i"""
+        codes = np.zeros(self.num, np.uint8)
+        good, src = c_i(0), c_i(0)
+        T = np.zeros((4, 4), np.float64)
+        rgb = np.zeros((self.h, self.w, 3), np.uint8)
+        verts = np.zeros((self.h, self.w, 4), np.float32)
+        norms = np.zeros((self.h, self.w, 4), np.float32)
+        _chk(lib().ef_ferns_get_frame(self._h, int(i), _ptr(codes), C.byref(good), C.byref(src), _ptr(T), _ptr(rgb), _ptr(verts), _ptr(norms)))
+        return dict(codes=codes, goodCodes=good.value, srcTime=src.value, T_wc=T, rgb=rgb, verts=verts, norms=norms)
+
+    def setFramePose(self, i, T_wc):
+        T = np.ascontiguousarray(T_wc, np.float64).reshape(4, 4)
+        _chk(lib().ef_ferns_set_frame_pose(self._h, int(i), _ptr(T)))
+
+    def blockHDAware(self, a, b) -> float:
+        return lib().ef_ferns_block_hd_aware(self._h, int(a), int(b))
+
+    def photometricCheck(self, rgb, verts, T_wc_est, i) -> float:
+        rgb, verts, _ = self._view(rgb, verts, verts)
+        T = np.ascontiguousarray(T_wc_est, np.float64).reshape(4, 4)
+        return lib().ef_ferns_photometric_check(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(T), int(i))
+
+
 class ElasticFusion:
     """Mirror of ``class ElasticFusion`` (Core/ElasticFusion.h) over the C ABI."""
 

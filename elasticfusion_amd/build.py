@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libefusion_hip.so")
 NOFMA_LIB = os.path.join(HERE, "libefusion_hip_nofma.so")   # TEST-ONLY variant (-DEF_NO_FMA, see csrc/ef_device.hpp): compared bit
                                                               # for bit with the compiled reference in tests/test_gpu_vs_reference.py
 SHIM_LIB = os.path.join(HERE, "libefusion.so")          # class ElasticFusion (include/ElasticFusion.h) over the C ABI
-SOURCES = ["ef_track_kernels.hip", "ef_map_kernels.hip", "ef_context.hip"]
+SOURCES = ["ef_track_kernels.hip", "ef_map_kernels.hip", "ef_context.hip", "ef_ferns.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 

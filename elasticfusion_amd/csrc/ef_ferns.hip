@@ -1,0 +1,293 @@
+// Fern database: the keyframe store behind the reference's GLOBAL loop closure and relocalisation (Core/Ferns.h:35-184,
+// Core/Ferns.cpp:22-420).  Everything in here is host-side bookkeeping on 1/8-resolution images the device already produced
+// (ef_get_image_resized): `num` random ferns each make four binary tests on one pixel (r, g, b against a byte threshold, depth in
+// mm against a threshold), a frame is the vector of those 4-bit codes, two frames are compared through the inverted lists the
+// ferns keep per code value.  The one piece of per-pixel arithmetic the reference does between a stored frame and a new view — an
+// 80x60 ICP — is not done here: ef_ferns_find_frame calls the caller's ef_fern_tracker for it.
+//
+// Layout choices (not the reference's): frames own flat std::vector storage instead of new[]'d Eigen arrays; a fern's inverted
+// lists are 16 vectors of frame ids as in the reference because the co-occurrence count walks exactly those.
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <random>
+#include <vector>
+
+#include "../../include/ef_hip.h"
+#include "ef_linalg_dev.hpp"
+
+namespace {
+constexpr uint8_t BAD_CODE = 255;   // Ferns.cpp:35 badCode
+
+struct Fern {
+  int x, y;              // Fern::pos
+  int rgbd[4];           // thresholds: r, g, b (0..255), depth in mm (400..maxDepth)
+  std::vector<int> ids[16];
+};
+struct StoredFrame {
+  std::vector<uint8_t> codes;
+  int goodCodes = 0;
+  int id = 0;
+  efl::SE3 T_wc;
+  int srcTime = 0;
+  std::vector<uint8_t> rgb;     // 3 bytes per pixel
+  std::vector<float> verts, norms;
+};
+// one view as the caller hands it over
+struct View {
+  const uint8_t* rgb;
+  int ch;
+  const float* verts;
+  int w;
+  float z(int x, int y) const { return verts[((size_t)y * w + x) * 4 + 2]; }
+  const float* v(int x, int y) const { return verts + ((size_t)y * w + x) * 4; }
+  const uint8_t* px(int x, int y) const { return rgb + ((size_t)y * w + x) * ch; }
+};
+void identity16(double* M) {
+  for (int i = 0; i < 16; ++i) M[i] = (i % 5 == 0) ? 1.0 : 0.0;
+}
+}  // namespace
+
+struct ef_ferns {
+  int num, factor, width, height, maxDepth;
+  float photoThresh;
+  float fx, fy, cx, cy;   // full-resolution intrinsics
+  int lastClosest = -1;
+  std::vector<Fern> conservatory;
+  std::vector<std::unique_ptr<StoredFrame>> frames;
+
+  // Ferns.cpp:97-118 / :186-208: the codes of one view and, through the inverted lists, how many codes it shares with each stored frame
+  void encode(const View& v, std::vector<uint8_t>& codes, int& good, std::vector<int>& coOccurrences) const {
+    codes.assign(num, BAD_CODE);
+    good = 0;
+    coOccurrences.assign(frames.size(), 0);
+    for (int i = 0; i < num; ++i) {
+      const Fern& f = conservatory[i];
+      const float z = v.z(f.x, f.y);
+      if (z > 0) {
+        const uint8_t* p = v.px(f.x, f.y);
+        const uint8_t code = (uint8_t)((p[0] > f.rgbd[0]) << 3 | (p[1] > f.rgbd[1]) << 2 | (p[2] > f.rgbd[2]) << 1 | (int(z * 1000.0f) > f.rgbd[3]));
+        ++good;
+        for (int id : f.ids[code]) ++coOccurrences[id];
+        codes[i] = code;
+      }
+    }
+  }
+  float dissimilarity(int good, const StoredFrame& s, int co) const {
+    const float maxCo = (float)(good < s.goodCodes ? good : s.goodCodes);
+    return (maxCo - (float)co) / maxCo;
+  }
+  // Ferns.cpp:396-412
+  float blockHDAware(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b) const {
+    int count = 0;
+    float val = 0;
+    for (int i = 0; i < num; ++i)
+      if (a[i] != BAD_CODE && b[i] != BAD_CODE) {
+        ++count;
+        if (a[i] == b[i]) val += 1.0f;
+      }
+    return val / (float)count;
+  }
+  bool usable(const View& v, const Fern& f) const {   // the depth test shared by the photometric check and the constraints
+    const float z = v.z(f.x, f.y);
+    return z > 0 && int(z * 1000.0f) < maxDepth;
+  }
+  // Ferns.cpp:301-383: mean absolute colour difference between the view and the stored frame it was registered to
+  float photometricCheck(const View& v, const efl::SE3& T_wc_est, const StoredFrame& s) const {
+    const float cxs = cx / factor, cys = cy / factor;
+    const float invfx = 1.0f / float(fx / factor), invfy = 1.0f / float(fy / factor);
+    float M[16];
+    efl::se3_castf_matrix(efl::se3_mul(efl::se3_inverse(s.T_wc), T_wc_est), M);
+    float photoSum = 0;
+    int photoCount = 0;
+    for (int i = 0; i < num; ++i) {
+      const Fern& f = conservatory[i];
+      if (!usable(v, f)) continue;
+      const float* p = v.v(f.x, f.y);
+      float q[3];
+      for (int r = 0; r < 3; ++r) q[r] = ((M[r * 4] * p[0] + M[r * 4 + 1] * p[1]) + M[r * 4 + 2] * p[2]) + M[r * 4 + 3] * 1.0f;
+      const int u = (int)(q[0] * (1 / invfx) / q[2] + cxs);
+      const int w = (int)(q[1] * (1 / invfy) / q[2] + cys);
+      if (u >= 0 && w >= 0 && u < width && w < height) {
+        const uint8_t* a = s.rgb.data() + ((size_t)w * width + u) * 3;
+        if (a[0] > 0 || a[1] > 0 || a[2] > 0) {
+          const uint8_t* b = v.px(f.x, f.y);
+          photoSum += std::abs((int)a[0] - (int)b[0]);
+          photoSum += std::abs((int)a[1] - (int)b[1]);
+          photoSum += std::abs((int)a[2] - (int)b[2]);
+          ++photoCount;
+        }
+      }
+    }
+    return photoSum / float(photoCount);
+  }
+};
+
+extern "C" {
+
+ef_ferns* ef_ferns_create(int num, int max_depth_mm, float photo_thresh, int width, int height, float fx, float fy, float cx, float cy,
+                          unsigned seed) {
+  if (num <= 0 || width < 8 || height < 8 || max_depth_mm < 400) return nullptr;
+  ef_ferns* f = new ef_ferns();
+  f->num = num;
+  f->factor = 8;                       // Ferns.cpp:25
+  f->width = width / f->factor;
+  f->height = height / f->factor;
+  f->maxDepth = max_depth_mm;
+  f->photoThresh = photo_thresh;
+  f->fx = fx; f->fy = fy; f->cx = cx; f->cy = cy;
+  // Ferns::generateFerns (Ferns.cpp:62-77): position, then the three colour thresholds, then the depth threshold, fern by fern
+  std::mt19937 random(seed);
+  std::uniform_int_distribution<int32_t> widthDist(0, f->width - 1), heightDist(0, f->height - 1), rgbDist(0, 255), dDist(400, max_depth_mm);
+  f->conservatory.resize(num);
+  for (Fern& e : f->conservatory) {
+    e.x = widthDist(random);
+    e.y = heightDist(random);
+    e.rgbd[0] = rgbDist(random);
+    e.rgbd[1] = rgbDist(random);
+    e.rgbd[2] = rgbDist(random);
+    e.rgbd[3] = dDist(random);
+  }
+  return f;
+}
+void ef_ferns_destroy(ef_ferns* f) { delete f; }
+
+int ef_ferns_get_table(const ef_ferns* f, int* t) {
+  if (!f || !t) return EF_EINVAL;
+  for (int i = 0; i < f->num; ++i) {
+    const Fern& e = f->conservatory[i];
+    t[i * 6] = e.x; t[i * 6 + 1] = e.y;
+    for (int k = 0; k < 4; ++k) t[i * 6 + 2 + k] = e.rgbd[k];
+  }
+  return EF_OK;
+}
+int ef_ferns_set_table(ef_ferns* f, const int* t) {
+  if (!f || !t) return EF_EINVAL;
+  if (!f->frames.empty()) return EF_ESTATE;
+  for (int i = 0; i < f->num; ++i)
+    if (t[i * 6] < 0 || t[i * 6] >= f->width || t[i * 6 + 1] < 0 || t[i * 6 + 1] >= f->height) return EF_EINVAL;
+  for (int i = 0; i < f->num; ++i) {
+    Fern& e = f->conservatory[i];
+    e.x = t[i * 6]; e.y = t[i * 6 + 1];
+    for (int k = 0; k < 4; ++k) e.rgbd[k] = t[i * 6 + 2 + k];
+  }
+  return EF_OK;
+}
+
+int ef_ferns_add_frame(ef_ferns* f, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int src_time,
+                       float threshold) {
+  if (!f || !rgb || !verts4 || !norms4 || !T_wc16 || (ch != 3 && ch != 4)) return EF_EINVAL;
+  const View v{rgb, ch, verts4, f->width};
+  std::unique_ptr<StoredFrame> frame(new StoredFrame());
+  std::vector<int> co;
+  f->encode(v, frame->codes, frame->goodCodes, co);
+  float minimum = std::numeric_limits<float>::max();
+  if (frame->goodCodes > 0)
+    for (size_t i = 0; i < f->frames.size(); ++i) {
+      const float d = f->dissimilarity(frame->goodCodes, *f->frames[i], co[i]);
+      if (d < minimum) minimum = d;
+    }
+  if (!((minimum > threshold || f->frames.empty()) && frame->goodCodes > 0)) return 0;
+  const size_t px = (size_t)f->width * f->height;
+  frame->id = (int)f->frames.size();
+  frame->T_wc = efl::se3_from_matrix(T_wc16);
+  frame->srcTime = src_time;
+  frame->rgb.resize(px * 3);
+  for (size_t i = 0; i < px; ++i)
+    for (int k = 0; k < 3; ++k) frame->rgb[i * 3 + k] = rgb[i * ch + k];
+  frame->verts.assign(verts4, verts4 + px * 4);
+  frame->norms.assign(norms4, norms4 + px * 4);
+  for (int i = 0; i < f->num; ++i)
+    if (frame->codes[i] != BAD_CODE) f->conservatory[i].ids[frame->codes[i]].push_back(frame->id);
+  f->frames.push_back(std::move(frame));
+  return 1;
+}
+
+int ef_ferns_find_frame(ef_ferns* f, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int time, int lost,
+                        ef_fern_tracker tracker, void* user, double* T_est16_out, double* cons, int max_cons, int* n_out) {
+  if (!f || !rgb || !verts4 || !norms4 || !T_wc16 || !T_est16_out || (ch != 3 && ch != 4)) return EF_EINVAL;
+  f->lastClosest = -1;
+  if (n_out) *n_out = 0;
+  identity16(T_est16_out);                       // Sophus::SE3d T_wc_est; (Ferns.cpp:236)
+  const View v{rgb, ch, verts4, f->width};
+  std::vector<uint8_t> codes;
+  std::vector<int> co;
+  int good = 0;
+  f->encode(v, codes, good, co);
+  float minimum = std::numeric_limits<float>::max();
+  int minId = -1;
+  for (size_t i = 0; i < f->frames.size(); ++i) {
+    const float d = f->dissimilarity(good, *f->frames[i], co[i]);
+    if (d < minimum && time - f->frames[i]->srcTime > 300) {   // Ferns.cpp:225: only frames seen a while ago can close a loop
+      minimum = d;
+      minId = (int)i;
+    }
+  }
+  if (minId == -1 || !(f->blockHDAware(codes, f->frames[minId]->codes) > 0.3)) return -1;
+  if (!tracker) return EF_EINVAL;
+  const StoredFrame& s = *f->frames[minId];
+  double T_fern[16];
+  efl::se3_matrix(s.T_wc, T_fern);
+  std::memcpy(T_est16_out, T_fern, sizeof(T_fern));
+  float icpError = 0, icpCount = 0;
+  // rgbd.initICPModel(fern) / initICP(current) / getIncrementalTransformation(T, false, 100, false, false, false) (Ferns.cpp:243-258)
+  tracker(user, s.verts.data(), s.norms.data(), T_fern, verts4, norms4, T_est16_out, &icpError, &icpCount);
+  const efl::SE3 T_est = efl::se3_from_matrix(T_est16_out);
+  const float photoError = f->photometricCheck(v, T_est, s);
+  const int icpCountThresh = lost ? 1400 : 2400;
+  if (icpError < 0.0003 && icpCount > icpCountThresh && photoError < f->photoThresh) {
+    f->lastClosest = minId;
+    int n = 0;
+    const int step = f->num / 50;
+    for (int i = 0; step > 0 && i < f->num; i += step) {
+      const Fern& e = f->conservatory[i];
+      if (!f->usable(v, e)) continue;
+      if (cons && n < max_cons) {
+        const float* p = v.v(e.x, e.y);
+        const double h[4] = {p[0], p[1], p[2], 1.0};
+        for (int r = 0; r < 3; ++r) {
+          cons[n * 6 + r] = ((T_wc16[r * 4] * h[0] + T_wc16[r * 4 + 1] * h[1]) + T_wc16[r * 4 + 2] * h[2]) + T_wc16[r * 4 + 3] * h[3];
+          cons[n * 6 + 3 + r] = ((T_est16_out[r * 4] * h[0] + T_est16_out[r * 4 + 1] * h[1]) + T_est16_out[r * 4 + 2] * h[2]) + T_est16_out[r * 4 + 3] * h[3];
+        }
+      }
+      ++n;
+    }
+    if (n_out) *n_out = n;
+  }
+  return f->lastClosest;
+}
+
+int ef_ferns_count(const ef_ferns* f) { return f ? (int)f->frames.size() : EF_EINVAL; }
+int ef_ferns_last_closest(const ef_ferns* f) { return f ? f->lastClosest : EF_EINVAL; }
+
+int ef_ferns_get_frame(const ef_ferns* f, int id, uint8_t* codes, int* good, int* src_time, double* T_wc16, uint8_t* rgb3, float* verts4, float* norms4) {
+  if (!f || id < 0 || id >= (int)f->frames.size()) return EF_EINVAL;
+  const StoredFrame& s = *f->frames[id];
+  if (codes) std::memcpy(codes, s.codes.data(), s.codes.size());
+  if (good) *good = s.goodCodes;
+  if (src_time) *src_time = s.srcTime;
+  if (T_wc16) efl::se3_matrix(s.T_wc, T_wc16);
+  if (rgb3) std::memcpy(rgb3, s.rgb.data(), s.rgb.size());
+  if (verts4) std::memcpy(verts4, s.verts.data(), s.verts.size() * sizeof(float));
+  if (norms4) std::memcpy(norms4, s.norms.data(), s.norms.size() * sizeof(float));
+  return EF_OK;
+}
+int ef_ferns_set_frame_pose(ef_ferns* f, int id, const double* T_wc16) {
+  if (!f || !T_wc16 || id < 0 || id >= (int)f->frames.size()) return EF_EINVAL;
+  f->frames[id]->T_wc = efl::se3_from_matrix(T_wc16);
+  return EF_OK;
+}
+float ef_ferns_block_hd_aware(const ef_ferns* f, int a, int b) {
+  if (!f || a < 0 || b < 0 || a >= (int)f->frames.size() || b >= (int)f->frames.size()) return -1.f;
+  return f->blockHDAware(f->frames[a]->codes, f->frames[b]->codes);
+}
+float ef_ferns_photometric_check(const ef_ferns* f, const uint8_t* rgb, int ch, const float* verts4, const double* T_est16, int id) {
+  if (!f || !rgb || !verts4 || !T_est16 || id < 0 || id >= (int)f->frames.size() || (ch != 3 && ch != 4)) return -1.f;
+  const View v{rgb, ch, verts4, f->width};
+  return f->photometricCheck(v, efl::se3_from_matrix(T_est16), *f->frames[id]);
+}
+
+}  // extern "C"

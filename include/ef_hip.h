@@ -130,6 +130,44 @@ int ef_get_local_loop(ef_ctx* ctx, ef_local_loop* info, double* constraints_or_n
  * surfel of the current model in map order as {x, y, z, initTime} (times ascend because the map keeps creation order); what the
  * reference hands to DeformationGraph::initialiseGraph.  nodes4_host: max_nodes x 4 floats.  Synchronises. */
 int ef_sample_graph(ef_ctx* ctx, float* nodes4_host, int max_nodes, int* n_out);
+/* ---- fern database (Core/Ferns.h:35-184, Core/Ferns.cpp:22-420): the keyframe store of the GLOBAL loop closure and of
+ * relocalisation.  Host-side object with no GPU state of its own: it encodes the 1/8-resolution predicted views
+ * (ef_get_image_resized(EF_IMG_FILL_*, 8, ...)) with `num` random ferns (4 binary tests each: r, g, b
+ * against 0..255, depth in mm against 400..max_depth_mm), keeps a frame when it differs enough from all stored ones, and proposes
+ * the most similar stored frame for a new view.  The fern-to-view registration (an 80x60 ICP, Ferns.cpp:243-258) is the caller's:
+ * ef_fern_tracker gets both vertex / normal images and the stored pose, refines T_inout16 and reports the ICP statistics.
+ * Images: rgb = rows of `rgb_channels` (3 or 4) bytes per pixel, verts4 / norms4 = f32x4 per pixel, (W/8) x (H/8) pixels. */
+typedef struct ef_ferns ef_ferns;
+/* Ferns::Ferns(n, maxDepth, photoThresh) with Resolution / Intrinsics spelled out; the table is drawn from std::mt19937(seed) in the
+ * reference's order (Ferns.cpp:62-77; the reference seeds with time(0)). */
+ef_ferns* ef_ferns_create(int num, int max_depth_mm, float photo_thresh, int width, int height, float fx, float fy, float cx, float cy,
+                          unsigned seed);
+void ef_ferns_destroy(ef_ferns* f);
+/* the fern table, num rows of {x, y, r, g, b, d}; setting it is only allowed while no frame is stored */
+int ef_ferns_get_table(const ef_ferns* f, int* table6);
+int ef_ferns_set_table(ef_ferns* f, const int* table6);
+/* Ferns::addFrame (Ferns.cpp:79-159): returns 1 when the frame was stored, 0 when it was too similar (or had no valid code),
+ * a negative EF_E* on bad arguments */
+int ef_ferns_add_frame(ef_ferns* f, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16,
+                       int src_time, float threshold);
+typedef void (*ef_fern_tracker)(void* user, const float* fern_verts4, const float* fern_norms4, const double* T_wc_fern16,
+                                const float* cur_verts4, const float* cur_norms4, double* T_inout16, float* icp_error, float* icp_count);
+/* Ferns::findFrame (Ferns.cpp:161-299).  T_est16_out: the recovered pose (identity when no candidate passed the code gates);
+ * constraints6_out: up to max_constraints rows {T_wc * p (source), T_est * p (target)} (Ferns.cpp:268-293).  Returns lastClosest
+ * (the matched frame's id) or -1. */
+int ef_ferns_find_frame(ef_ferns* f, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16,
+                        int time, int lost, ef_fern_tracker tracker, void* user, double* T_est16_out, double* constraints6_out,
+                        int max_constraints, int* n_constraints_out);
+int ef_ferns_count(const ef_ferns* f);          /* frames.size() */
+int ef_ferns_last_closest(const ef_ferns* f);   /* lastClosest */
+/* one stored frame: any output may be NULL.  codes_out: num bytes (255 = no valid depth under that fern). */
+int ef_ferns_get_frame(const ef_ferns* f, int id, uint8_t* codes_out, int* good_codes_out, int* src_time_out, double* T_wc16_out,
+                       uint8_t* rgb3_out, float* verts4_out, float* norms4_out);
+/* Deformation::constrain's applyGraphToPoses (Deformation.cpp:196-203) hands the deformed poses back to the stored frames */
+int ef_ferns_set_frame_pose(ef_ferns* f, int id, const double* T_wc16);
+/* the two private measures, for tests: Ferns::blockHDAware of two stored frames; Ferns::photometricCheck of a view against frame id */
+float ef_ferns_block_hd_aware(const ef_ferns* f, int id_a, int id_b);
+float ef_ferns_photometric_check(const ef_ferns* f, const uint8_t* rgb, int rgb_channels, const float* verts4, const double* T_est16, int id);
 int ef_predict(ef_ctx* ctx);                                  /* ElasticFusion::predict() */
 int ef_get_pose(ef_ctx* ctx, double* T_wc16);                 /* get_T_wc(); synchronises */
 int ef_get_tick(ef_ctx* ctx, int* tick);                      /* getTick() */

@@ -8,10 +8,24 @@
 // is initialised from and asked to do, how the pose flows.  The transcript is what tests compare with the oracle's frame loop
 // (oracle/efo_frame.cpp); savePly and the .freiburg dump are compared byte for byte with the product's writers.
 // oracle/Makefile, target `refframe` -> _ref/libefr_frame.so.
+#include <algorithm>
 #include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <memory>
+#include <random>
+#include <sstream>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
+// the fern database's generator and its two measures are private members (Ferns.h:157-168); the tests call them directly
+#define private public
+#include "Ferns.h"
+#undef private
 #include "ElasticFusion.h"
 #include "efo_linalg.h"
 
@@ -191,5 +205,76 @@ unsigned efe_tid(void* p, const char* name) {
                 : n == "depth" ? im.depthTex() : nullptr;
   if (!t && e->getTextures().count(n)) t = e->getTextures()[n];
   return t ? t->texture->tid : 0;
+}
+
+// ---- the instance's fern database (the compiled Core/Ferns.cpp) driven directly: the three Resize read-backs of every call are queued
+// from the caller's arrays, the 80x60 tracker inside findFrame is the scripted double above
+static void queue_view(Ferns& f, const unsigned char* rgb3, const float* verts4, const float* norms4) {
+  const size_t px = (size_t)f.width * f.height;
+  glrec::S().readpixels_queue.clear();
+  glrec::S().readpixels_queue.emplace_back(rgb3, rgb3 + px * 3);
+  glrec::S().readpixels_queue.emplace_back((const unsigned char*)verts4, (const unsigned char*)verts4 + px * 16);
+  glrec::S().readpixels_queue.emplace_back((const unsigned char*)norms4, (const unsigned char*)norms4 + px * 16);
+}
+static void table_out(Ferns& f, int* t) {
+  for (int i = 0; i < f.num; ++i) {
+    t[i * 6] = f.conservatory[i].pos(0); t[i * 6 + 1] = f.conservatory[i].pos(1);
+    for (int k = 0; k < 4; ++k) t[i * 6 + 2 + k] = f.conservatory[i].rgbd(k);
+  }
+}
+int efe_ferns_num(void* p) { return ((Frame*)p)->ef->getFerns().num; }
+void efe_ferns_reseed(void* p, unsigned seed, int* table6) {   // Ferns::generateFerns itself, from a known seed instead of time(0)
+  Ferns& f = ((Frame*)p)->ef->getFerns();
+  f.conservatory.clear();
+  f.random.seed(seed);
+  f.generateFerns();
+  table_out(f, table6);
+}
+int efe_ferns_add_frame(void* p, const unsigned char* rgb3, const float* verts4, const float* norms4, const double* T16, int srcTime, float threshold) {
+  ElasticFusion* e = ((Frame*)p)->ef;
+  Ferns& f = e->getFerns();
+  queue_view(f, rgb3, verts4, norms4);
+  GPUTexture* t = e->getIndexMap().imageTex();
+  const bool r = f.addFrame(t, t, t, Sophus::SE3d(efo::se3_from_matrix(T16)), srcTime, threshold);
+  glrec::S().readpixels_queue.clear(); glrec::S().log.clear();
+  return r ? 1 : 0;
+}
+int efe_ferns_find_frame(void* p, const unsigned char* rgb3, const float* verts4, const float* norms4, const double* T16, int time, int lost,
+                         double* T_est16, double* cons6, int max_cons, int* n_out) {
+  ElasticFusion* e = ((Frame*)p)->ef;
+  Ferns& f = e->getFerns();
+  queue_view(f, rgb3, verts4, norms4);
+  GPUTexture* t = e->getIndexMap().imageTex();
+  std::vector<Ferns::SurfaceConstraint> cons;
+  const Sophus::SE3d T_est = f.findFrame(cons, Sophus::SE3d(efo::se3_from_matrix(T16)), t, t, t, time, lost != 0);
+  glrec::S().readpixels_queue.clear(); glrec::S().log.clear();
+  const Eigen::Matrix4d M = T_est.matrix();
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) T_est16[i * 4 + j] = M(i, j);
+  *n_out = (int)cons.size();
+  for (int i = 0; i < (int)cons.size() && i < max_cons; ++i)
+    for (int k = 0; k < 3; ++k) { cons6[i * 6 + k] = cons[i].sourcePoint(k); cons6[i * 6 + 3 + k] = cons[i].targetPoint(k); }
+  return f.lastClosest;
+}
+int efe_ferns_count(void* p) { return (int)((Frame*)p)->ef->getFerns().frames.size(); }
+void efe_ferns_frame(void* p, int i, unsigned char* codes, int* good, int* srcTime, double* T16) {
+  Ferns& f = ((Frame*)p)->ef->getFerns();
+  const Ferns::Frame* s = f.frames.at(i);
+  std::memcpy(codes, s->codes, f.num);
+  *good = s->goodCodes; *srcTime = s->srcTime;
+  const Eigen::Matrix4d M = s->T_wc.matrix();
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) T16[r * 4 + c] = M(r, c);
+}
+float efe_ferns_block_hd_aware(void* p, int a, int b) {
+  Ferns& f = ((Frame*)p)->ef->getFerns();
+  return f.blockHDAware(f.frames.at(a), f.frames.at(b));
+}
+float efe_ferns_photometric_check(void* p, const unsigned char* rgb3, const float* verts4, const double* T_est16, int id) {
+  Ferns& f = ((Frame*)p)->ef->getFerns();
+  Img<Eigen::Vector4f> verts(f.height, f.width, (Eigen::Vector4f*)verts4);
+  Img<Eigen::Matrix<uint8_t, 3, 1>> img(f.height, f.width, (Eigen::Matrix<uint8_t, 3, 1>*)rgb3);
+  const Ferns::Frame* s = f.frames.at(id);
+  return f.photometricCheck(verts, img, Sophus::SE3d(efo::se3_from_matrix(T_est16)), s->T_wc, s->initRgb);
 }
 }  // extern "C"
