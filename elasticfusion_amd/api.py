@@ -154,6 +154,40 @@ def solve_local_deformation(nodes4, constraints, src_time, last_deform_time=0):
     return (g[:len(nodes4)], e.value, m.value) if rc == 0 else None
 
 
+class GraphConstraint(C.Structure):   # ef_graph_constraint
+    _fields_ = [("src", C.c_double * 3), ("target", C.c_double * 3), ("src_time", C.c_int64), ("target_time", C.c_int64), ("relative", c_i), ("pin", c_i)]
+
+
+def graph_constraints(rows):
+    """rows of (src xyz, target xyz, src_time, target_time, relative, pin) -> ef_graph_constraint array"""
+    arr = (GraphConstraint * max(len(rows), 1))()
+    for a, (src, target, st, tt, rel, pin) in zip(arr, rows):
+        a.src[:] = [float(x) for x in src]
+        a.target[:] = [float(x) for x in target]
+        a.src_time, a.target_time, a.relative, a.pin = int(st), int(tt), int(bool(rel)), int(bool(pin))
+    return arr
+
+
+def solve_deformation(nodes4, rows, fernMatch=False, last_deform_time=0, poses=None, pose_times=None):
+    """ef_solve_deformation (Deformation::constrain in general form, host only).  rows as graph_constraints takes them.
+    -> dict(accepted, graph [n, 16], error, meanConsErr, poses [k, 4, 4] deformed along, new_relative rows)"""
+    nodes4 = np.ascontiguousarray(nodes4, np.float32).reshape(-1, 4)
+    cons = graph_constraints(rows)
+    g = np.zeros((max(len(nodes4), 1), 16), np.float32)
+    P16 = np.ascontiguousarray(np.zeros((0, 4, 4)) if poses is None else poses, np.float64).reshape(-1, 4, 4).copy()
+    times = np.ascontiguousarray([] if pose_times is None else pose_times, np.int64)
+    assert len(times) == len(P16)
+    rel = (GraphConstraint * max(len(rows), 1))()
+    n_rel, e, m = c_i(0), c_f(0), c_f(0)
+    rc = lib().ef_solve_deformation(_ptr(nodes4), c_i(len(nodes4)), cons, c_i(len(rows)), c_i(int(bool(fernMatch))), C.c_int64(int(last_deform_time)),
+                                    _ptr(P16) if len(P16) else None, _ptr(times) if len(P16) else None, c_i(len(P16)), _ptr(g), C.byref(e), C.byref(m),
+                                    rel, C.byref(n_rel))
+    if rc not in (0, -4):
+        _chk(rc)
+    new_rel = [(list(r.src), list(r.target), r.src_time, r.target_time, True, False) for r in rel[:n_rel.value]]
+    return dict(accepted=rc == 0, graph=g[:len(nodes4)], error=e.value, meanConsErr=m.value, poses=P16, new_relative=new_rel)
+
+
 FERN_TRACKER = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(c_f), C.POINTER(c_f), C.POINTER(C.c_double), C.POINTER(c_f), C.POINTER(c_f),
                            C.POINTER(C.c_double), C.POINTER(c_f), C.POINTER(c_f))
 

@@ -755,6 +755,31 @@ int ef_solve_local_deformation(const float* nodes4, int n_nodes, const double* c
   if (mean_constraint_error_out) *mean_constraint_error_out = r.meanConsErr;
   return r.ok ? EF_OK : EF_ESTATE;
 }
+int ef_solve_deformation(const float* nodes4, int n_nodes, const ef_graph_constraint* constraints, int n_constraints, int fern_match,
+                         int64_t last_deform_time, double* poses16, const int64_t* pose_times, int n_poses, float* graph16_out, float* error_out,
+                         float* mean_constraint_error_out, ef_graph_constraint* new_relative_out, int* n_new_relative_out) {
+  if (!nodes4 || !constraints || !graph16_out || n_nodes < 0 || n_nodes > 1023 || n_constraints < 0 || n_poses < 0 || (n_poses > 0 && (!poses16 || !pose_times)))
+    return EF_EINVAL;
+  std::vector<efd::Constraint> cons((size_t)n_constraints);
+  for (int i = 0; i < n_constraints; ++i) {
+    const ef_graph_constraint& c = constraints[i];
+    cons[i] = efd::Constraint{{c.src[0], c.src[1], c.src[2]}, {c.target[0], c.target[1], c.target[2]}, (uint64_t)c.src_time, (uint64_t)c.target_time,
+                              c.relative != 0, c.pin != 0};
+  }
+  efd::Result r{false, 0, 0.f, 0.f};
+  std::vector<efd::Constraint> rel;
+  const bool updated = efd::constrain(nodes4, n_nodes, cons.data(), n_constraints, fern_match != 0, (uint64_t)last_deform_time, poses16, pose_times, n_poses,
+                                      graph16_out, &r, new_relative_out ? &rel : nullptr);
+  if (n_new_relative_out) *n_new_relative_out = (int)rel.size();
+  for (size_t i = 0; new_relative_out && i < rel.size(); ++i) {
+    ef_graph_constraint& o = new_relative_out[i];
+    for (int k = 0; k < 3; ++k) { o.src[k] = rel[i].src[k]; o.target[k] = rel[i].target[k]; }
+    o.src_time = (int64_t)rel[i].srcTime; o.target_time = (int64_t)rel[i].targetTime; o.relative = 1; o.pin = 0;
+  }
+  if (error_out) *error_out = r.error;
+  if (mean_constraint_error_out) *mean_constraint_error_out = r.meanConsErr;
+  return updated ? EF_OK : EF_ESTATE;
+}
 int ef_get_local_loop(ef_ctx* c, ef_local_loop* info, double* constraints, int max_constraints, int* n_out) {
   if (!c || !info) return EF_EINVAL;
   *info = c->loop;

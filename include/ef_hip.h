@@ -123,6 +123,25 @@ int ef_use_builtin_loop_solver(ef_ctx* ctx, int on);
  * graph16_out = n_nodes x 16 floats in the layout ef_set_deformation takes.  EF_ESTATE when there are not more than 4 nodes. */
 int ef_solve_local_deformation(const float* nodes4, int n_nodes, const double* constraints8, int n_constraints, int64_t src_time,
                                int64_t last_deform_time, float* graph16_out, float* error_out, float* mean_constraint_error_out);
+/* Deformation::constrain in its general form (Deformation.cpp:88-215), the GLOBAL deformation included: constraints are the entries of
+ * Deformation::constraints — `relative`: the source has to land wherever the graph carries the target (the constraints a local closure
+ * leaves behind, Deformation.cpp:160-173); `pin`: a target held in place (src == target) —, fern_match selects the global closure's
+ * rules (nothing to do below 0.06 m mean constraint error; accepted only when the optimised mean error is below 3e-4 and the energy
+ * below 0.12; pass last_deform_time = 0 as Deformation.cpp:143 does).  poses16 (n_poses x 16, in/out) with pose_times: the keyframe
+ * poses (and with fern_match the trajectory) carried along by DeformationGraph::applyGraphToPoses — translation only, as observed in
+ * the reference.  For the global graph nodes4 is every 5th node of ef_sample_graph (Deformation::sampleGraphFrom, :217-237).
+ * new_relative_out (room for n_constraints entries, optional): after an accepted LOCAL solve, the relative constraints to hand to
+ * later global ones (newRelativeCons: the deformed source of every plain constraint against its target).
+ * EF_OK: accepted, graph16_out / poses16 written; EF_ESTATE: rejected (or not more than 4 nodes). */
+typedef struct ef_graph_constraint {
+  double src[3], target[3];
+  int64_t src_time, target_time;
+  int relative, pin;
+} ef_graph_constraint;
+int ef_solve_deformation(const float* nodes4, int n_nodes, const ef_graph_constraint* constraints, int n_constraints, int fern_match,
+                         int64_t last_deform_time, double* poses16_inout, const int64_t* pose_times, int n_poses, float* graph16_out,
+                         float* error_out, float* mean_constraint_error_out, ef_graph_constraint* new_relative_out_or_null,
+                         int* n_new_relative_out_or_null);
 /* icpCountThresh, icpErrThresh, covThresh of the constructor (ElasticFusion.h:44-46; defaults 35000, 5e-05, 1e-05) */
 int ef_set_loop_thresholds(ef_ctx* ctx, int icp_count_thresh, float icp_err_thresh, float cov_thresh);
 int ef_get_local_loop(ef_ctx* ctx, ef_local_loop* info, double* constraints_or_null, int max_constraints, int* n_out_or_null);
