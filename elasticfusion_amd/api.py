@@ -199,29 +199,38 @@ class Ferns:
     [h, w, 4] float32.  ``tracker(fern_verts, fern_norms, T_wc_fern, verts, norms, T_wc) -> (T_wc_est, icp_error, icp_count)``
     stands where the reference runs its 80x60 RGBDOdometry (Ferns.cpp:243-258)."""
 
+    _prefix = "ef_ferns_"      # tests/efo.py binds the same class to the oracle's restatement (efo_ferns_*)
+
+    def _library(self):
+        return lib()
+
+    def _f(self, name):
+        return getattr(self._L, self._prefix + name)
+
     def __init__(self, n=500, maxDepth=3000, photoThresh=115.0, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, seed=0):
-        L = lib()
-        L.ef_ferns_create.restype = P
-        L.ef_ferns_create.argtypes = [c_i, c_i, c_f, c_i, c_i, c_f, c_f, c_f, c_f, C.c_uint]
-        for name in ("ef_ferns_block_hd_aware", "ef_ferns_photometric_check"):
-            getattr(L, name).restype = c_f
-        L.ef_ferns_destroy.argtypes = [P]
-        L.ef_ferns_get_table.argtypes = L.ef_ferns_set_table.argtypes = [P, P]
-        L.ef_ferns_add_frame.argtypes = [P, P, c_i, P, P, P, c_i, c_f]
-        L.ef_ferns_find_frame.argtypes = [P, P, c_i, P, P, P, c_i, c_i, FERN_TRACKER, P, P, P, c_i, P]
-        L.ef_ferns_count.argtypes = L.ef_ferns_last_closest.argtypes = [P]
-        L.ef_ferns_get_frame.argtypes = [P, c_i, P, P, P, P, P, P, P]
-        L.ef_ferns_set_frame_pose.argtypes = [P, c_i, P]
-        L.ef_ferns_block_hd_aware.argtypes = [P, c_i, c_i]
-        L.ef_ferns_photometric_check.argtypes = [P, P, c_i, P, P, c_i]
+        self._h = None
+        self._L = self._library()
+        f = self._f
+        f("create").restype = P
+        f("create").argtypes = [c_i, c_i, c_f, c_i, c_i, c_f, c_f, c_f, c_f, C.c_uint]
+        f("block_hd_aware").restype = f("photometric_check").restype = c_f
+        f("destroy").argtypes = [P]
+        f("get_table").argtypes = f("set_table").argtypes = [P, P]
+        f("add_frame").argtypes = [P, P, c_i, P, P, P, c_i, c_f]
+        f("find_frame").argtypes = [P, P, c_i, P, P, P, c_i, c_i, FERN_TRACKER, P, P, P, c_i, P]
+        f("count").argtypes = f("last_closest").argtypes = [P]
+        f("get_frame").argtypes = [P, c_i, P, P, P, P, P, P, P]
+        f("set_frame_pose").argtypes = [P, c_i, P]
+        f("block_hd_aware").argtypes = [P, c_i, c_i]
+        f("photometric_check").argtypes = [P, P, c_i, P, P, c_i]
         self.num, self.w, self.h = int(n), width // 8, height // 8
-        self._h = L.ef_ferns_create(int(n), int(maxDepth), float(photoThresh), int(width), int(height), fx, fy, cx, cy, int(seed))
+        self._h = f("create")(int(n), int(maxDepth), float(photoThresh), int(width), int(height), fx, fy, cx, cy, int(seed))
         if not self._h:
             raise EFError("ef_ferns_create: bad arguments")
 
     def close(self):
         if self._h:
-            lib().ef_ferns_destroy(self._h)
+            self._f("destroy")(self._h)
             self._h = None
 
     __del__ = close
@@ -236,18 +245,18 @@ class Ferns:
     @property
     def conservatory(self):
         t = np.zeros((self.num, 6), np.int32)
-        _chk(lib().ef_ferns_get_table(self._h, _ptr(t)))
+        _chk(self._f("get_table")(self._h, _ptr(t)))
         return t
 
     @conservatory.setter
     def conservatory(self, table):
         t = np.ascontiguousarray(table, np.int32).reshape(self.num, 6)
-        _chk(lib().ef_ferns_set_table(self._h, _ptr(t)))
+        _chk(self._f("set_table")(self._h, _ptr(t)))
 
     def addFrame(self, rgb, verts, norms, T_wc, srcTime, threshold) -> bool:
         rgb, verts, norms = self._view(rgb, verts, norms)
         T = np.ascontiguousarray(T_wc, np.float64).reshape(4, 4)
-        rc = lib().ef_ferns_add_frame(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(norms), _ptr(T), int(srcTime), float(threshold))
+        rc = self._f("add_frame")(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(norms), _ptr(T), int(srcTime), float(threshold))
         if rc < 0:
             _chk(rc)
         return rc == 1
@@ -271,7 +280,7 @@ class Ferns:
         T_est = np.zeros((4, 4), np.float64)
         cons = np.zeros((self.num, 6), np.float64)
         n = c_i(0)
-        rc = lib().ef_ferns_find_frame(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(norms), _ptr(T), int(time), int(bool(lost)), cb, None,
+        rc = self._f("find_frame")(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(norms), _ptr(T), int(time), int(bool(lost)), cb, None,
                                        _ptr(T_est), _ptr(cons), self.num, C.byref(n))
         if rc < -1:
             _chk(rc)
@@ -279,10 +288,10 @@ class Ferns:
 
     @property
     def lastClosest(self) -> int:
-        return lib().ef_ferns_last_closest(self._h)
+        return self._f("last_closest")(self._h)
 
     def __len__(self):
-        return lib().ef_ferns_count(self._h)
+        return self._f("count")(self._h)
 
     def frame(self, i):
         """-> dict(codes, goodCodes, srcTime, T_wc, rgb, verts, norms) of stored frame i"""
@@ -292,20 +301,20 @@ class Ferns:
         rgb = np.zeros((self.h, self.w, 3), np.uint8)
         verts = np.zeros((self.h, self.w, 4), np.float32)
         norms = np.zeros((self.h, self.w, 4), np.float32)
-        _chk(lib().ef_ferns_get_frame(self._h, int(i), _ptr(codes), C.byref(good), C.byref(src), _ptr(T), _ptr(rgb), _ptr(verts), _ptr(norms)))
+        _chk(self._f("get_frame")(self._h, int(i), _ptr(codes), C.byref(good), C.byref(src), _ptr(T), _ptr(rgb), _ptr(verts), _ptr(norms)))
         return dict(codes=codes, goodCodes=good.value, srcTime=src.value, T_wc=T, rgb=rgb, verts=verts, norms=norms)
 
     def setFramePose(self, i, T_wc):
         T = np.ascontiguousarray(T_wc, np.float64).reshape(4, 4)
-        _chk(lib().ef_ferns_set_frame_pose(self._h, int(i), _ptr(T)))
+        _chk(self._f("set_frame_pose")(self._h, int(i), _ptr(T)))
 
     def blockHDAware(self, a, b) -> float:
-        return lib().ef_ferns_block_hd_aware(self._h, int(a), int(b))
+        return self._f("block_hd_aware")(self._h, int(a), int(b))
 
     def photometricCheck(self, rgb, verts, T_wc_est, i) -> float:
         rgb, verts, _ = self._view(rgb, verts, verts)
         T = np.ascontiguousarray(T_wc_est, np.float64).reshape(4, 4)
-        return lib().ef_ferns_photometric_check(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(T), int(i))
+        return self._f("photometric_check")(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(T), int(i))
 
 
 class ElasticFusion:

@@ -159,6 +159,25 @@ const void* efo_fusion_buffer(const efo_fusion*, int which);
 efo_odometry* efo_fusion_odometry(efo_fusion*);
 /* tracking-only timing hook for bench.py cpu_baseline: runs initICP/initRGB/track on the current state */
 
+/* ---- fern keyframe database (Core/Ferns.cpp), efo_ferns.cpp; signatures as include/ef_hip.h ef_ferns_* ---- */
+typedef struct efo_ferns efo_ferns;
+typedef void (*efo_fern_tracker)(void* user, const float* fern_verts4, const float* fern_norms4, const double* T_wc_fern16, const float* cur_verts4,
+                                 const float* cur_norms4, double* T_inout16, float* icp_error, float* icp_count);
+efo_ferns* efo_ferns_create(int num, int max_depth_mm, float photo_thresh, int width, int height, float fx, float fy, float cx, float cy, unsigned seed);
+void efo_ferns_destroy(efo_ferns*);
+int efo_ferns_get_table(const efo_ferns*, int* table6);
+int efo_ferns_set_table(efo_ferns*, const int* table6);
+int efo_ferns_add_frame(efo_ferns*, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16, int src_time,
+                        float threshold);
+int efo_ferns_find_frame(efo_ferns*, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16, int time, int lost,
+                         efo_fern_tracker tracker, void* user, double* T_est16_out, double* constraints6_out, int max_constraints, int* n_constraints_out);
+int efo_ferns_count(const efo_ferns*);
+int efo_ferns_last_closest(const efo_ferns*);
+int efo_ferns_get_frame(const efo_ferns*, int id, uint8_t* codes, int* good_codes, int* src_time, double* T_wc16, uint8_t* rgb3, float* verts4, float* norms4);
+int efo_ferns_set_frame_pose(efo_ferns*, int id, const double* T_wc16);
+float efo_ferns_block_hd_aware(const efo_ferns*, int a, int b);
+float efo_ferns_photometric_check(const efo_ferns*, const uint8_t* rgb, int rgb_channels, const float* verts4, const double* T_est16, int id);
+
 #ifdef __cplusplus
 }
 #endif

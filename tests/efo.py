@@ -608,3 +608,16 @@ class Fusion:
         arr = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,))
         a = arr.view(dt).copy()
         return a.reshape(self.p.height, self.p.width, ch) if ch > 1 else a.reshape(self.p.height, self.p.width)
+
+
+def Ferns(*a, **kw):
+    """the oracle's restatement of the fern database (oracle/efo_ferns.cpp) behind the interface of elasticfusion_amd.api.Ferns"""
+    from elasticfusion_amd import api
+
+    class OracleFerns(api.Ferns):
+        _prefix = "efo_ferns_"
+
+        def _library(self):
+            return lib()
+
+    return OracleFerns(*a, **kw)

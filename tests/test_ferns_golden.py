@@ -6,14 +6,22 @@ import os
 import numpy as np
 
 from elasticfusion_amd import build
-from elasticfusion_amd.api import Ferns
+from elasticfusion_amd import api
+import efo
+
+BACKENDS = {"product": api.Ferns, "oracle": efo.Ferns}
 from fernscene import CX, CY, FX, FY, H, W, geometry
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ferns_reference.npz")
 
 
-def test_session_answers_match_the_compiled_reference():
+import pytest
+
+
+@pytest.mark.parametrize("backend", list(BACKENDS))
+def test_session_answers_match_the_compiled_reference(backend):
     build.build()
+    Ferns = BACKENDS[backend]
     g = np.load(GOLDEN)
     f = Ferns(500, 3000, 115.0, W, H, FX, FY, CX, CY, seed=int(g["seed"]))
     assert np.array_equal(f.conservatory, g["table"])            # std::mt19937 + uniform_int_distribution in generateFerns' order

@@ -1,5 +1,5 @@
-"""The product's fern database (include/ef_hip.h ef_ferns_*, elasticfusion_amd/csrc/ef_ferns.hip) against the reference's own
-Core/Ferns.cpp, compiled from /root/reference where it lies inside oracle/_ref/libefr_frame.so (oracle/Makefile `refframe`): the
+"""The product's fern database (include/ef_hip.h ef_ferns_*, elasticfusion_amd/csrc/ef_ferns.hip) and the oracle's restatement
+(oracle/efo_ferns.cpp) against the reference's own Core/Ferns.cpp, compiled from /root/reference where it lies inside oracle/_ref/libefr_frame.so (oracle/Makefile `refframe`): the
 bridge queues the three Resize read-backs of every addFrame / findFrame from the same arrays the product gets, and the 80x60
 tracker inside findFrame is a scripted double on both sides (same pose increment, same ICP statistics).  Compared: the fern table
 drawn from a seed (generateFerns itself), which frames are kept, their codes, which stored frame a view is matched to, the
@@ -12,7 +12,10 @@ import numpy as np
 import pytest
 
 from elasticfusion_amd import build
-from elasticfusion_amd.api import Ferns
+from elasticfusion_amd import api
+import efo
+
+BACKENDS = {"product": api.Ferns, "oracle": efo.Ferns}
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "oracle", "_ref", "libefr_frame.so")
@@ -100,7 +103,9 @@ def both_find(so, hd, f, view, T, t, lost, delta, err, cnt):
     return closest, Tp, cp, seen
 
 
-def test_fern_table_from_seed_is_the_references(ref, tmp_path):
+@pytest.mark.parametrize("backend", list(BACKENDS))
+def test_fern_table_from_seed_is_the_references(ref, tmp_path, backend):
+    Ferns = BACKENDS[backend]
     hd = ref.make(str(tmp_path))
     num = ref.efe_ferns_num(hd)
     assert num == 500
@@ -113,7 +118,9 @@ def test_fern_table_from_seed_is_the_references(ref, tmp_path):
         f.close()
 
 
-def test_keyframe_selection_matching_and_constraints(ref, tmp_path):
+@pytest.mark.parametrize("backend", list(BACKENDS))
+def test_keyframe_selection_matching_and_constraints(ref, tmp_path, backend):
+    Ferns = BACKENDS[backend]
     hd = ref.make(str(tmp_path))
     num = ref.efe_ferns_num(hd)
     table = np.zeros((num, 6), np.int32)
@@ -193,6 +200,7 @@ def test_keyframe_selection_matching_and_constraints(ref, tmp_path):
 
 def test_arguments_and_state():
     build.build()
+    Ferns = api.Ferns
     f = Ferns(500, 3000, 115.0, W, H, FX, FY, CX, CY, seed=3)
     rgb, verts, norms = place(0)
     t = f.conservatory
