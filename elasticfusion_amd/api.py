@@ -228,10 +228,12 @@ class Ferns:
         if not self._h:
             raise EFError("ef_ferns_create: bad arguments")
 
+    _owned = True
+
     def close(self):
-        if self._h:
+        if self._h and self._owned:
             self._f("destroy")(self._h)
-            self._h = None
+        self._h = None
 
     __del__ = close
 

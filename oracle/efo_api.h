@@ -178,6 +178,26 @@ int efo_ferns_set_frame_pose(efo_ferns*, int id, const double* T_wc16);
 float efo_ferns_block_hd_aware(const efo_ferns*, int a, int b);
 float efo_ferns_photometric_check(const efo_ferns*, const uint8_t* rgb, int rgb_channels, const float* verts4, const double* T_est16, int id);
 
+/* ---- global loop closure (ElasticFusion.cpp:392-445,609-618) in the frame loop: efo_fusion_enable_ferns gives the instance its fern
+ * database (Ferns(num, depthCut * 1000, photoThresh), seed instead of time(0)) and 1/8-resolution tracker; a general solver callback
+ * stands where Deformation::constrain does, for the global AND (when registered) the local closure.
+ * rows10: {src xyz, target xyz, srcTime, targetTime, relative, pin}; poses16 in/out: keyframe poses, then (fernMatch) the trajectory;
+ * new_relative_rows10 / n_new_relative: newRelativeCons of a local closure (NULL for a global one).  Non-zero return = accepted. */
+typedef int (*efo_deform_solver)(void* user, int fernMatch, const double* rows10, int n_rows, double* poses16_inout, const int64_t* pose_times, int n_poses,
+                                 float* graph_out /* 1024 x 16 */, int* nodes_out, double* new_relative_rows10, int* n_new_relative);
+typedef struct efo_global_loop {
+  int attempted, closest, n_constraints, accepted, graph_nodes;
+  float icp_error, icp_count;          /* of the fern tracker, when it ran */
+  double T_wc_recovery[16];
+} efo_global_loop;
+void efo_fusion_set_tick(efo_fusion*, int tick);
+void efo_fusion_enable_ferns(efo_fusion*, int num, float photoThresh, float fernThresh, unsigned seed);
+efo_ferns* efo_fusion_ferns(efo_fusion*);
+void efo_fusion_set_deform_solver(efo_fusion*, efo_deform_solver fn, void* user);
+void efo_fusion_global_loop(const efo_fusion*, efo_global_loop* info);
+int efo_fusion_relative_constraints(const efo_fusion*, double* rows10, int max_rows);
+int efo_fusion_trajectory(const efo_fusion*, double* poses16, int max_poses);
+
 #ifdef __cplusplus
 }
 #endif

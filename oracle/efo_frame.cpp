@@ -2,8 +2,10 @@
 //
 // CPU restatement of ElasticFusion::processFrame (Core/ElasticFusion.cpp:270-607) and predict()
 // (:621-653) with reloc = false.  Open loop (closeLoops = false) by default; efo_fusion_set_close_loops adds the LOCAL loop
-// closure block (:447-527) with a solver callback where Deformation::constrain stands.  The fern branch (:391-444),
-// Ferns::addFrame (:601-619) and the deformation-graph sampling (:593-595) are omitted.
+// closure block (:447-527) with a solver callback where Deformation::constrain stands; efo_fusion_enable_ferns adds the GLOBAL one:
+// the fern branch (:391-444: Ferns::findFrame on the mid-frame fill-in, the global deformation with the relative constraints kept from
+// local closures) and Ferns::addFrame at the end of the frame (:601-619), over efo_ferns.cpp.  The deformation-graph sampling
+// (:593-595) is the solver callback's business (efo_sample_graph).
 #include "efo_common.h"
 #include "efo_linalg.h"
 #include "efo_api.h"
@@ -54,6 +56,17 @@ struct efo_fusion {
   efo_loop_solver solver = nullptr;
   void* solverUser = nullptr;
   efo_local_loop loop{};
+  // global loop closure (ElasticFusion.h:262-266,292-300)
+  efo_ferns* ferns = nullptr;
+  efo_odometry* fernOdom = nullptr;          // Ferns::rgbd, the 1/8-resolution tracker (Ferns.cpp:36-42)
+  float fernThresh = 0.3095f;
+  int fernDeforms = 0;
+  efo_deform_solver deformSolver = nullptr;
+  void* deformUser = nullptr;
+  efo_global_loop gloop{};
+  std::vector<double> relativeCons;          // rows of 10, Deformation::Constraint with relative = true
+  std::vector<double> trajectory;            // t_T_wc: 16 doubles per processed frame
+  std::vector<int64_t> trajectoryTimes;
   // optional trace of the frame loop (efo_fusion_trace): one line per step with its parameters, in the vocabulary
   // tests/test_oracle_vs_reference_frame.py also derives from the compiled reference's transcript
   bool tracing = false;
@@ -118,7 +131,109 @@ struct efo_fusion {
     surfelsTmp.assign((size_t)p.maxSurfels * 12, 0.f);
     newUnstable.assign(P * 12, 0.f);
   }
-  ~efo_fusion() { efo_odom_destroy(frameToModel); efo_odom_destroy(modelToModel); }
+  ~efo_fusion() {
+    efo_odom_destroy(frameToModel);
+    efo_odom_destroy(modelToModel);
+    if (fernOdom) efo_odom_destroy(fernOdom);
+    if (ferns) efo_ferns_destroy(ferns);
+  }
+
+  // the 1/8-resolution views of the fill-in the fern database works on (Ferns.cpp:91-93,178-180: Resize::image / vertex)
+  struct FernView { std::vector<uint8_t> img; std::vector<float> verts, norms; };
+  FernView fernView() const {
+    FernView v;
+    const size_t px = (size_t)(p.width / 8) * (p.height / 8);
+    v.img.resize(px * 4); v.verts.resize(px * 4); v.norms.resize(px * 4);
+    efo_resize_nearest(fimage.data(), p.width, p.height, 4, 8, v.img.data());
+    efo_resize_nearest(fvertex.data(), p.width, p.height, 16, 8, v.verts.data());
+    efo_resize_nearest(fnormal.data(), p.width, p.height, 16, 8, v.norms.data());
+    return v;
+  }
+  // Ferns.cpp:243-258: the stored keyframe is the model, the current view the frame; ICP only in effect (no colour is initialised)
+  static void fernTrack(void* user, const float* fv, const float* fn, const double* Tf, const float* cv, const float* cn, double* T, float* err, float* cnt) {
+    efo_fusion* f = (efo_fusion*)user;
+    f->tr("fernOdom.initICPModel vertices=fern normals=fern");
+    f->tr_pose("  pose", Tf);
+    f->tr("fernOdom.initICP vertices=view normals=view");
+    f->tr("fernOdom.track rgbOnly=0 icpWeight=100 pyramid=0 fastOdom=0 so3=0");
+    efo_odom_init_icp_model(f->fernOdom, fv, fn, Tf);
+    efo_odom_init_icp_maps(f->fernOdom, cv, cn);
+    efo_odom_track(f->fernOdom, T, 0, 100.0f, 0, 0, 0);
+    float st[6];
+    efo_odom_stats(f->fernOdom, st, nullptr, nullptr);
+    *err = st[0];
+    *cnt = st[1];
+    f->gloop.icp_error = st[0];
+    f->gloop.icp_count = st[1];
+  }
+  // every pose Deformation::constrain deforms along: the keyframes, and for a fern match the trajectory (Deformation.cpp:97-115)
+  void gatherPoses(bool withTrajectory, std::vector<double>& poses, std::vector<int64_t>& times) const {
+    const int nf = ferns ? efo_ferns_count(ferns) : 0;
+    poses.resize((size_t)nf * 16);
+    times.resize((size_t)nf);
+    for (int i = 0; i < nf; ++i) {
+      int t = 0;
+      efo_ferns_get_frame(ferns, i, nullptr, nullptr, &t, &poses[(size_t)i * 16], nullptr, nullptr, nullptr);
+      times[i] = t;
+    }
+    if (withTrajectory) {
+      poses.insert(poses.end(), trajectory.begin(), trajectory.end());
+      times.insert(times.end(), trajectoryTimes.begin(), trajectoryTimes.end());
+    }
+  }
+  void scatterPoses(bool withTrajectory, const std::vector<double>& poses) {
+    const int nf = ferns ? efo_ferns_count(ferns) : 0;
+    for (int i = 0; i < nf; ++i) efo_ferns_set_frame_pose(ferns, i, &poses[(size_t)i * 16]);
+    if (withTrajectory) std::copy(poses.begin() + (size_t)nf * 16, poses.end(), trajectory.begin());
+  }
+  static void push_row(std::vector<double>& rows, const double* src, const double* target, double srcTime, double targetTime, int relative, int pin) {
+    const double r[10] = {src[0], src[1], src[2], target[0], target[1], target[2], srcTime, targetTime, (double)relative, (double)pin};
+    rows.insert(rows.end(), r, r + 10);
+  }
+
+  // ElasticFusion.cpp:392-445 with lost == false: returns true when a fern was matched AND the global deformation accepted
+  bool fernClosure() {
+    gloop = efo_global_loop{};
+    gloop.attempted = 1;
+    gloop.closest = -1;
+    double M[16], E[16];
+    pose16(M);
+    const FernView v = fernView();
+    std::vector<double> cons((size_t)64 * 6);
+    int n = 0;
+    tr("ferns.findFrame time=%d lost=0", tick);
+    const int closest = efo_ferns_find_frame(ferns, v.img.data(), 4, v.verts.data(), v.norms.data(), M, tick, 0, &fernTrack, this, E, cons.data(), 64, &n);   // :395-402
+    tr("ferns.findFrame -> closest=%d constraints=%d", closest, n);
+    gloop.closest = closest;
+    gloop.n_constraints = n;
+    std::memcpy(gloop.T_wc_recovery, E, sizeof(E));
+    if (closest == -1) return false;                                                                          // :410
+    int fernTime = 0;
+    efo_ferns_get_frame(ferns, closest, nullptr, nullptr, &fernTime, nullptr, nullptr, nullptr, nullptr);
+    std::vector<double> rows;
+    for (int i = 0; i < n; ++i) {                                                                             // :415-422, pinConstraints = true
+      push_row(rows, &cons[(size_t)i * 6], &cons[(size_t)i * 6 + 3], tick, fernTime, 0, 0);
+      push_row(rows, &cons[(size_t)i * 6 + 3], &cons[(size_t)i * 6 + 3], fernTime, fernTime, 0, 1);
+    }
+    rows.insert(rows.end(), relativeCons.begin(), relativeCons.end());                                        // :424-426
+    tr("global.constrain fernMatch=1 constraints=%d relative=%d", 2 * n, (int)(relativeCons.size() / 10));
+    if (!deformSolver) return false;
+    std::vector<double> poses;
+    std::vector<int64_t> times;
+    gatherPoses(true, poses, times);
+    std::vector<float> graph((size_t)1024 * 16, 0.f);
+    int nodes = 0;
+    if (!deformSolver(deformUser, 1, rows.data(), (int)(rows.size() / 10), poses.data(), times.data(), (int)times.size(), graph.data(), &nodes, nullptr, nullptr))
+      return false;                                                                                           // :428
+    scatterPoses(true, poses);
+    T_wc = se3_from_matrix(E);                                                                                // :429
+    fernDeforms += nodes > 0;                                                                                 // :439
+    gloop.accepted = 1;
+    gloop.graph_nodes = nodes;
+    pendingGraph.assign(graph.begin(), graph.begin() + (size_t)nodes * 16);
+    pendingFern = 1;                                                                                          // fernAccepted, :441,584
+    return true;
+  }
 
   // ElasticFusion.cpp:447-527 without the fern branch (:391-444, out of scope): the view of the INACTIVE part of the model is
   // registered against the ACTIVE prediction made by predict() at :387; returns true when a deformation was accepted
@@ -164,9 +279,32 @@ struct efo_fusion {
     loop.n_constraints = efo_loop_constraints(vertex.data(), oldTime.data(), p.width, p.height, consSample, M, E, maxDepthProcessed, deforms == 0,
                                               loopConstraints.data());
     loopConstraints.resize((size_t)loop.n_constraints * 8);
-    if (!solver) return;
     std::vector<float> graph((size_t)1024 * 16, 0.f);
     int nodes = 0;
+    if (deformSolver) {   // Deformation::constrain in full: the keyframe poses follow, relative constraints are left behind (:511-526)
+      std::vector<double> rows, poses, rel((size_t)loop.n_constraints * 10);
+      for (int i = 0; i < loop.n_constraints; ++i) {                                                           // Deformation.cpp:73-86
+        const double* c = &loopConstraints[(size_t)i * 8];
+        push_row(rows, c, c + 3, tick, c[6], 0, 0);
+        if (c[7] != 0) push_row(rows, c + 3, c + 3, c[6], c[6], 0, 1);
+      }
+      std::vector<int64_t> times;
+      gatherPoses(false, poses, times);
+      int nrel = 0;
+      tr("local.constrain fernMatch=0 constraints=%d", (int)(rows.size() / 10));
+      if (deformSolver(deformUser, 0, rows.data(), (int)(rows.size() / 10), poses.data(), times.data(), (int)times.size(), graph.data(), &nodes, rel.data(), &nrel)) {
+        scatterPoses(false, poses);
+        loop.applied = 1;
+        loop.graph_nodes = nodes;
+        deforms += nodes > 0;
+        T_wc = se3_from_matrix(E);
+        for (int i = 0; i < nrel && nrel >= 3; i += nrel / 3) relativeCons.insert(relativeCons.end(), &rel[(size_t)i * 10], &rel[(size_t)i * 10] + 10);   // :522-524
+        pendingGraph.assign(graph.begin(), graph.begin() + (size_t)nodes * 16);
+        pendingFern = 0;
+      }
+      return;
+    }
+    if (!solver) return;
     if (solver(solverUser, &loop, loopConstraints.data(), loop.n_constraints, graph.data(), &nodes)) {          // :513-514
       loop.applied = 1;
       loop.graph_nodes = nodes;
@@ -241,7 +379,9 @@ struct efo_fusion {
       lastWeighting = weighting;
 
       predict();  // :387 (result unused when closeLoops == false; kept for fidelity)
-      if (closeLoops) localLoopClosure();
+      bool fernAccepted = false;
+      if (closeLoops && ferns) fernAccepted = fernClosure();                                                 // :392-445
+      if (closeLoops && !(fernAccepted && !pendingGraph.empty())) localLoopClosure();                        // :447: rawGraph.size() == 0
       if (!p.rgbOnly) {
         double Mt[16];
         pose16(Mt);
@@ -283,7 +423,20 @@ struct efo_fusion {
         surfels.swap(surfelsTmp);
       }
     }
+    {           // :588-589
+      double Mt[16];
+      pose16(Mt);
+      trajectory.insert(trajectory.end(), Mt, Mt + 16);
+      trajectoryTimes.push_back(tick);
+    }
     predict();  // :599
+    if (ferns) {   // processFerns, :609-618
+      double Mt[16];
+      pose16(Mt);
+      const FernView v = fernView();
+      const int kept = efo_ferns_add_frame(ferns, v.img.data(), 4, v.verts.data(), v.norms.data(), Mt, tick, fernThresh);
+      tr("ferns.addFrame time=%d -> %d", tick, kept);
+    }
     tick++;     // :603 (lost is never set without reloc)
   }
 };
@@ -324,6 +477,26 @@ void efo_fusion_set_close_loops(efo_fusion* f, int on, int icpCountThresh, float
   f->closeLoops = on; f->icpCountThresh = icpCountThresh; f->icpErrThresh = icpErrThresh; f->covThresh = covThresh;
 }
 void efo_fusion_set_loop_solver(efo_fusion* f, efo_loop_solver fn, void* user) { f->solver = fn; f->solverUser = user; }
+void efo_fusion_set_tick(efo_fusion* f, int tick) { f->tick = tick; }
+void efo_fusion_enable_ferns(efo_fusion* f, int num, float photoThresh, float fernThresh, unsigned seed) {
+  const efo_fusion_params& p = f->p;
+  f->ferns = efo_ferns_create(num, (int)(p.depthCut * 1000), photoThresh, p.width, p.height, p.fx, p.fy, p.cx, p.cy, seed);   // ElasticFusion.cpp:53
+  f->fernOdom = efo_odom_create(p.width / 8, p.height / 8, p.cx / 8, p.cy / 8, p.fx / 8, p.fy / 8);                          // Ferns.cpp:36-42
+  f->fernThresh = fernThresh;
+}
+efo_ferns* efo_fusion_ferns(efo_fusion* f) { return f->ferns; }
+void efo_fusion_set_deform_solver(efo_fusion* f, efo_deform_solver fn, void* user) { f->deformSolver = fn; f->deformUser = user; }
+void efo_fusion_global_loop(const efo_fusion* f, efo_global_loop* info) { *info = f->gloop; }
+int efo_fusion_relative_constraints(const efo_fusion* f, double* rows10, int max_rows) {
+  const int n = std::min((int)(f->relativeCons.size() / 10), max_rows);
+  if (rows10 && n > 0) std::memcpy(rows10, f->relativeCons.data(), (size_t)n * 10 * sizeof(double));
+  return (int)(f->relativeCons.size() / 10);
+}
+int efo_fusion_trajectory(const efo_fusion* f, double* poses16, int max_poses) {
+  const int n = std::min((int)f->trajectoryTimes.size(), max_poses);
+  if (poses16 && n > 0) std::memcpy(poses16, f->trajectory.data(), (size_t)n * 16 * sizeof(double));
+  return (int)f->trajectoryTimes.size();
+}
 int efo_fusion_local_loop(const efo_fusion* f, efo_local_loop* info, double* constraints, int max_constraints) {
   *info = f->loop;
   const int n = std::min(f->loop.n_constraints, max_constraints);

@@ -256,6 +256,9 @@ int efe_ferns_find_frame(void* p, const unsigned char* rgb3, const float* verts4
     for (int k = 0; k < 3; ++k) { cons6[i * 6 + k] = cons[i].sourcePoint(k); cons6[i * 6 + 3 + k] = cons[i].targetPoint(k); }
   return f.lastClosest;
 }
+void efe_set_tick(void* p, int tick) { ((Frame*)p)->ef->setTick(tick); }
+int efe_ferns_last_closest(void* p) { return ((Frame*)p)->ef->getFerns().lastClosest; }
+int efe_fern_deforms(void* p) { return ((Frame*)p)->ef->getFernDeforms(); }
 int efe_ferns_count(void* p) { return (int)((Frame*)p)->ef->getFerns().frames.size(); }
 void efe_ferns_frame(void* p, int i, unsigned char* codes, int* good, int* srcTime, double* T16) {
   Ferns& f = ((Frame*)p)->ef->getFerns();

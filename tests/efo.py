@@ -507,6 +507,15 @@ class LocalLoop(C.Structure):
 LOOP_SOLVER = C.CFUNCTYPE(c_i, C.c_void_p, C.POINTER(LocalLoop), C.POINTER(C.c_double), c_i, C.POINTER(c_f), C.POINTER(c_i))
 
 
+class GlobalLoop(C.Structure):
+    _fields_ = [("attempted", c_i), ("closest", c_i), ("n_constraints", c_i), ("accepted", c_i), ("graph_nodes", c_i), ("icp_error", c_f),
+                ("icp_count", c_f), ("T_wc_recovery", C.c_double * 16)]
+
+
+DEFORM_SOLVER = C.CFUNCTYPE(c_i, C.c_void_p, c_i, C.POINTER(C.c_double), c_i, C.POINTER(C.c_double), C.POINTER(C.c_int64), c_i, C.POINTER(c_f),
+                            C.POINTER(c_i), C.POINTER(C.c_double), C.POINTER(c_i))
+
+
 class Fusion:
     def __init__(self, **kw):
         self.p = FusionParams()
@@ -551,6 +560,67 @@ class Fusion:
             return 1
         self._solver = LOOP_SOLVER(tramp)
         lib().efo_fusion_set_loop_solver(self.h_, self._solver, None)
+
+    # ---- global loop closure (ElasticFusion.cpp:392-445,609-618) ----
+    def set_tick(self, tick):
+        lib().efo_fusion_set_tick(self.h_, c_i(int(tick)))
+
+    def enable_ferns(self, num=500, photoThresh=115.0, fernThresh=0.3095, seed=0):
+        lib().efo_fusion_enable_ferns(self.h_, c_i(num), c_f(photoThresh), c_f(fernThresh), C.c_uint(seed))
+
+    def ferns(self):
+        """the instance's fern database behind the interface of elasticfusion_amd.api.Ferns (not owned)"""
+        lib().efo_fusion_ferns.restype = C.c_void_p
+        f = Ferns.__new__(_oracle_ferns_class())
+        f._L, f._h = lib(), P(lib().efo_fusion_ferns(self.h_))
+        f.num, f.w, f.h = 500, self.p.width // 8, self.p.height // 8
+        for name, res in (("count", c_i), ("last_closest", c_i), ("block_hd_aware", c_f), ("photometric_check", c_f)):
+            f._f(name).restype = res
+        f._f("count").argtypes = f._f("last_closest").argtypes = [P]
+        f._f("get_frame").argtypes = [P, c_i, P, P, P, P, P, P, P]
+        f._f("get_table").argtypes = [P, P]
+        f._owned = False
+        return f
+
+    def set_deform_solver(self, fn):
+        """fn(fernMatch, rows [n, 10], poses [k, 4, 4], pose_times [k]) -> None | dict(graph [nodes, 16], poses [k, 4, 4], new_relative rows [m, 10])"""
+        def tramp(user, fernMatch, rows, n, poses, times, k, graph_out, nodes_out, rel_out, n_rel):
+            r = np.ctypeslib.as_array(rows, shape=(n, 10)).copy() if n > 0 else np.zeros((0, 10))
+            Pz = np.ctypeslib.as_array(poses, shape=(k, 4, 4)).copy() if k > 0 else np.zeros((0, 4, 4))
+            tz = np.ctypeslib.as_array(times, shape=(k,)).copy() if k > 0 else np.zeros(0, np.int64)
+            out = fn(bool(fernMatch), r, Pz, tz)
+            if out is None:
+                return 0
+            g = f32(out["graph"]).reshape(-1, 16)
+            C.memmove(graph_out, g.ctypes.data, g.nbytes)
+            nodes_out[0] = len(g)
+            if k > 0:
+                q = np.ascontiguousarray(out["poses"], np.float64).reshape(k, 16)
+                C.memmove(poses, q.ctypes.data, q.nbytes)
+            if rel_out:
+                rel = np.ascontiguousarray(out.get("new_relative", np.zeros((0, 10))), np.float64).reshape(-1, 10)
+                if len(rel):
+                    C.memmove(rel_out, rel.ctypes.data, rel.nbytes)
+                n_rel[0] = len(rel)
+            return 1
+        self._deform = DEFORM_SOLVER(tramp)
+        lib().efo_fusion_set_deform_solver(self.h_, self._deform, None)
+
+    def global_loop(self):
+        info = GlobalLoop()
+        lib().efo_fusion_global_loop(self.h_, C.byref(info))
+        return info
+
+    def relative_constraints(self):
+        rows = np.zeros((4096, 10), np.float64)
+        n = lib().efo_fusion_relative_constraints(self.h_, ptr(rows), c_i(len(rows)))
+        return rows[:n].copy()
+
+    def trajectory(self):
+        n = lib().efo_fusion_trajectory(self.h_, None, c_i(0))
+        T = np.zeros((max(n, 1), 4, 4), np.float64)
+        lib().efo_fusion_trajectory(self.h_, ptr(T), c_i(n))
+        return T[:n]
 
     def local_loop(self):
         info = LocalLoop()
@@ -610,14 +680,28 @@ class Fusion:
         return a.reshape(self.p.height, self.p.width, ch) if ch > 1 else a.reshape(self.p.height, self.p.width)
 
 
-def Ferns(*a, **kw):
+_ORACLE_FERNS = None
+
+
+def _oracle_ferns_class():
+    global _ORACLE_FERNS
+    if _ORACLE_FERNS is None:
+        from elasticfusion_amd import api
+
+        class OracleFerns(api.Ferns):
+            _prefix = "efo_ferns_"
+
+            def _library(self):
+                return lib()
+
+        _ORACLE_FERNS = OracleFerns
+    return _ORACLE_FERNS
+
+
+class Ferns:
     """the oracle's restatement of the fern database (oracle/efo_ferns.cpp) behind the interface of elasticfusion_amd.api.Ferns"""
-    from elasticfusion_amd import api
 
-    class OracleFerns(api.Ferns):
-        _prefix = "efo_ferns_"
-
-        def _library(self):
-            return lib()
-
-    return OracleFerns(*a, **kw)
+    def __new__(cls, *a, **kw):
+        if cls is Ferns:
+            return _oracle_ferns_class()(*a, **kw)
+        return object.__new__(cls)

@@ -1,21 +1,17 @@
-"""The product's fern database (ef_ferns_*, host side of libefusion_hip.so) replaying the session the REFERENCE's own Core/Ferns.cpp
+"""The product's fern database (ef_ferns_*, host side of libefusion_hip.so) and the oracle's restatement (efo_ferns_*) replaying the session the REFERENCE's own Core/Ferns.cpp
 answered in tests/golden/ferns_reference.npz (tools/make_ferns_golden.py): same fern table from the seed, same frames kept, same
 codes, same matches, same recovered poses and constraints.  Needs neither /root/reference nor a GPU."""
 import os
 
 import numpy as np
+import pytest
 
-from elasticfusion_amd import build
-from elasticfusion_amd import api
 import efo
-
-BACKENDS = {"product": api.Ferns, "oracle": efo.Ferns}
+from elasticfusion_amd import api, build
 from fernscene import CX, CY, FX, FY, H, W, geometry
 
+BACKENDS = {"product": api.Ferns, "oracle": efo.Ferns}
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ferns_reference.npz")
-
-
-import pytest
 
 
 @pytest.mark.parametrize("backend", list(BACKENDS))

@@ -64,6 +64,7 @@ class Ref:
         # fill-in textures: created by FillIn() in the order image, vertex, normal (FillIn.cpp:22-47): find them as the attachments
         # of the three framebuffers whose programs are fill_*.frag — simpler: they are what predict() renders into, see frames below
         self.trackers = [ln.split()[-1] for ln in self.built.splitlines() if ln.startswith("RGBDOdometry[640x480] created")]
+        self.fern_tracker = [ln.split()[-1] for ln in self.built.splitlines() if ln.startswith("RGBDOdometry[80x60] created")][0]
         self.fill_tex = {}     # texture id -> "fill": learnt from the attachments of the fill_*.frag passes as they are seen
 
     def frame(self, rgb, depth, ts, T=None, weight=1.0):
@@ -90,6 +91,7 @@ def translate(ref, text):
             attach.setdefault(int(a[1]), []).append(int(a[-1]))
     fill_tex = ref.fill_tex
     fbo = None
+    n_plain = n_rel = 0
     f2m, m2m = ref.trackers[0], ref.trackers[1]
     bound_before_program = None
     for ln in text.splitlines():
@@ -148,9 +150,12 @@ def translate(ref, text):
             bound_before_program = None
         elif a[0].startswith("RGBDOdometry@"):
             who = "frameToModel" if a[0].startswith("RGBDOdometry@" + f2m) else "modelToModel" if a[0].startswith("RGBDOdometry@" + m2m) else None
-            if who is None:
-                continue       # the fern database's own tracker (out of scope)
             call = a[0].split("::")[1]
+            if who is None:    # the fern database's own 80x60 tracker (Ferns.cpp:243-258): its textures are the database's private uploads
+                assert a[0].startswith("RGBDOdometry@" + ref.fern_tracker)
+                fixed = {"initICPModel": "fernOdom.initICPModel vertices=fern normals=fern", "initICP": "fernOdom.initICP vertices=view normals=view"}
+                out.append(fixed[call] if call in fixed else "fernOdom.track " + " ".join("%s=%g" % (kv.split("=")[0], float(kv.split("=")[1])) for kv in a[1:]))
+                continue
             role = {t["image"]: "pred", t["vertex"]: "pred", t["normal"]: "pred", t["oldImage"]: "old", t["oldVertex"]: "old", t["oldNormal"]: "old",
                     t["RGB"]: "rgb", t["DEPTH_FILTERED"]: "filtered"}
             role.update(fill_tex)
@@ -160,6 +165,14 @@ def translate(ref, text):
                 args.append("%s=%s" % (k, role.get(int(v[3:]), "tex?") if v.startswith("tex") else ("%g" % float(v))))
             name = {"getIncrementalTransformation": "track"}.get(call, call)
             out.append("%s.%s%s" % (who, name, (" " + " ".join(args)) if args else ""))
+        elif ln.startswith("DeformationGraph::clearConstraints"):
+            n_plain = n_rel = 0
+        elif ln.startswith("DeformationGraph::addConstraint"):
+            n_plain += 1
+        elif ln.startswith("DeformationGraph::addRelativeConstraint"):
+            n_rel += 1
+        elif ln.startswith("DeformationGraph::optimiseGraphSparse fernMatch=1"):
+            out.append("global.constrain fernMatch=1 constraints=%d relative=%d" % (n_plain, n_rel))
         elif ln.startswith("  initICPModel T_wc:") :
             out.append("  pose " + " ".join(ln.split()[2:]))
     return out
@@ -471,3 +484,117 @@ def test_accepted_local_deformation_flow(tmp_path):
     assert n_vert == n_cons == cons.shape[0] * cons.shape[1]
     assert "lastDeformTime=2 -> 1" in txt2                            # Deformation::lastDeformTime = the tick of the accepted one
     ref.close()
+
+
+def test_accepted_global_closure_flow(tmp_path):
+    """ElasticFusion.cpp:392-445 and :558-585,609-618 in the compiled reference — with its own Ferns.cpp at work on views handed to the
+    Resize read-backs, the fern tracker and the optimiser scripted to succeed: a keyframe stored at tick 1 is matched 401 ticks later,
+    the global deformation gets the fern constraints with their pins, the pose becomes the recovered one, the local closure is skipped
+    and the clean pass applies the graph as a fern match (no depth re-synthesis).  The oracle's frame loop (efo_frame.cpp fernClosure),
+    run on a rendered revisit with an accepting solver, traces the same steps."""
+    import re
+    import fernscene
+    so = lib()
+    so.efe_queue_readpixels.argtypes = [P, C.c_long]
+    so.efe_queue_query.argtypes = [C.c_int]
+    so.efe_set_tick.argtypes = [P, C.c_int]
+    for f in (so.efe_ferns_last_closest, so.efe_ferns_count, so.efe_fern_deforms):
+        f.argtypes = [P]
+    TD, CONF = 200, 2.0
+    ref = Ref(so, str(tmp_path / "ref"), timeDelta=TD, closeLoops=1, confidence=CONF)
+    rgb = np.full((H, W, 3), 90, np.uint8)
+    depth = np.full((H, W), 1500, np.uint16)
+    nodes = np.zeros((30, 4), np.float32)                         # 30 local samples -> 6 global nodes (sampleGraphFrom, every 5th): both graphs exist
+    nodes[:, 0] = np.linspace(-1, 1, 30)
+    nodes[:, 2] = 1.5
+    nodes[:, 3] = 1
+    view = fernscene.place(2)
+
+    def queue_view():
+        for a in view:
+            so.efe_queue_readpixels(a.ctypes.data, a.nbytes)
+
+    so.efe_script_readbacks(-1, 0, nodes.ctypes.data, nodes.nbytes)
+    so.efe_queue_query(1000)
+    so.efe_queue_query(30)
+    queue_view()                                                  # frame 0: Ferns::addFrame at the end of the frame
+    T0 = synth_poses(1)[0]
+    translate(ref, ref.frame(rgb, depth, 0, T0))
+    assert so.efe_ferns_count(ref.h) == 1
+    so.efe_set_tick(ref.h, 402)
+    queue_view()                                                  # findFrame ...
+    queue_view()                                                  # ... and addFrame of the revisit
+    so.efe_queue_query(1000)
+    so.efe_queue_query(30)
+    D = np.eye(4)
+    D[:3, 3] = [0.004, -0.002, 0.003]
+    so.efe_script_tracker(D.ctypes.data, 1e-5, 3000.0, 1e-7, 1)      # the fern tracker converges, the optimiser accepts
+    drift = np.eye(4)
+    drift[:3, 3] = [0.15, 0.0, 0.08]
+    txt = ref.frame(rgb, depth, 33333, T0 @ drift)
+    so.efe_clear_queues()
+    assert so.efe_ferns_last_closest(ref.h) == 0 and so.efe_fern_deforms(ref.h) == 1
+    assert np.allclose(ref.pose(), T0 @ D, atol=1e-12)               # T_wc_curr = T_wc_recovery = the keyframe's pose refined by the tracker
+    got = [l for l in translate(ref, txt) if not l.startswith("  pose")]
+    i0 = got.index("fernOdom.initICPModel vertices=fern normals=fern")
+    n_cons = int(re.search(r"constraints=(\d+)", got[i0 + 3]).group(1))
+    assert n_cons % 2 == 0 and 60 <= n_cons <= 100                  # every fern constraint comes with its pin (Deformation.cpp:79-85)
+    tick = 402
+    want = ["fernOdom.initICPModel vertices=fern normals=fern",
+            "fernOdom.initICP vertices=view normals=view",
+            "fernOdom.track rgbOnly=0 icpWeight=100 pyramid=0 fastOdom=0 so3=0",
+            "global.constrain fernMatch=1 constraints=%d relative=0" % n_cons,
+            "predictIndices time=%d maxDepth=20 timeDelta=%d" % (tick, TD),
+            "fuse time=%d maxDepth=20 weighting=%s" % (tick, got[i0 + 5].split("=")[-1]),
+            "predictIndices time=%d maxDepth=20 timeDelta=%d" % (tick, TD),
+            "clean time=%d conf=%g nodes=6 timeDelta=%d maxDepth=20 isFern=1" % (tick, CONF, TD),
+            "combinedPredict ACTIVE maxDepth=20 conf=%g time=%d maxTime=%d timeDelta=%d" % (CONF, tick, tick, TD),
+            "fillIn vertex passthrough=0; normal passthrough=0; image passthrough=0"]
+    assert got[i0:] == want, "\n".join(got[i0:])
+    assert not any(l.startswith("modelToModel") or l.startswith("synthesizeDepth") for l in got)
+    ref.close()
+
+    # the oracle's frame loop on a rendered revisit, accepting solver: the same steps
+    from elasticfusion_amd import synth
+    seq = synth.Sequence(seed=0xEF0001)
+    o = efo.Fusion(timeDelta=TD, confidence=CONF)
+    o.set_close_loops(True)
+    o.enable_ferns(seed=7)
+    seen = []
+
+    def solver(fernMatch, rows, poses, times):
+        seen.append((fernMatch, rows.copy(), poses.copy(), times.copy()))
+        g = np.zeros((6, 16), np.float32)
+        g[:, 0] = np.linspace(-1, 1, 6)
+        g[:, 3] = g[:, 7] = g[:, 11] = 1
+        g[:, 15] = 1
+        moved = poses.copy()
+        moved[:, :3, 3] += 0.001
+        return dict(graph=g, poses=moved) if fernMatch else None
+
+    o.set_deform_solver(solver)
+    r0, d0, P0 = seq.frame(0)
+    o.process_frame(r0, d0, 0, T_wc=P0)
+    kf = o.ferns().frame(0)
+    o.set_tick(402)
+    efo.lib().efo_fusion_trace(o.h_, 1)
+    o.process_frame(r0, d0, 1, T_wc=P0 @ drift)
+    take = efo.lib().efo_fusion_take_trace
+    take.restype = C.c_char_p
+    lines = [l for l in take(o.h_).decode().splitlines() if not l.startswith("  pose") and not l.startswith("ferns.")]
+    g = o.global_loop()
+    assert g.closest == 0 and g.accepted == 1 and g.icp_error < 3e-4 and g.icp_count > 2400
+    j0 = lines.index(want[0])
+    strip = lambda L: [re.sub(r"(constraints|weighting)=\S+", r"\1=*", l) for l in L]
+    assert strip(lines[j0:]) == strip(want), "\n".join(lines[j0:])
+    assert not any(l.startswith("modelToModel") or l.startswith("synthesizeDepth") for l in lines)
+    fm, rows, poses, times = seen[0]
+    assert fm and len(poses) == 1 + 1 and list(times) == [1, 1]            # the keyframe, then the trajectory so far
+    plain = rows[rows[:, 9] == 0]
+    pins = rows[rows[:, 9] == 1]
+    assert len(plain) == len(pins) == g.n_constraints and np.array_equal(pins[:, 0:3], pins[:, 3:6]) and np.array_equal(plain[:, 3:6], pins[:, 3:6])
+    assert set(plain[:, 6]) == {402.0} and set(plain[:, 7]) == {1.0}       # source: now; target: when the keyframe was stored
+    rec = np.array(g.T_wc_recovery).reshape(4, 4)
+    assert np.abs(rec - P0).max() < 0.02 and np.abs(o.pose() - rec).max() < 1e-12     # the tracker found the keyframe's pose again; adopted
+    assert np.abs(o.ferns().frame(0)["T_wc"][:3, 3] - (kf["T_wc"][:3, 3] + 0.001)).max() < 1e-12   # the solver's poses went back to the keyframes
+    assert np.abs(o.trajectory()[0][:3, 3] - (P0[:3, 3] + 0.001)).max() < 1e-12                    # ... and to the trajectory
