@@ -117,6 +117,7 @@ struct efo_fusion {
 
   explicit efo_fusion(const efo_fusion_params& pp) : p(pp) {
     cam = efo_cam{p.width, p.height, p.fx, p.fy, p.cx, p.cy};
+    gloop.closest = -1;
     frameToModel = efo_odom_create(p.width, p.height, p.cx, p.cy, p.fx, p.fy);
     modelToModel = efo_odom_create(p.width, p.height, p.cx, p.cy, p.fx, p.fy);
     size_t P = (size_t)p.width * p.height;
