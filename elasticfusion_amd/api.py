@@ -319,6 +319,120 @@ class Ferns:
         return self._f("photometric_check")(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(T), int(i))
 
 
+class Closure:
+    """ef_closure_*: the host side of the loop closures around the fern database (ElasticFusion.cpp:392-445, 511-526, 588-589, 609-618)."""
+
+    def __init__(self, n=500, depthCut=3.0, photoThresh=115.0, fernThresh=0.3095, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, seed=0):
+        L = lib()
+        L.ef_closure_create.restype = L.ef_closure_ferns.restype = P
+        L.ef_closure_create.argtypes = [c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, C.c_uint]
+        L.ef_closure_destroy.argtypes = L.ef_closure_ferns.argtypes = [P]
+        L.ef_closure_global.argtypes = [P, P, c_i, P, P, P, c_i, FERN_TRACKER, P, P, c_i, P, P, P]
+        L.ef_closure_local.argtypes = [P, P, c_i, c_i, P, c_i, P, P]
+        L.ef_closure_end_frame.argtypes = [P, P, c_i, P, P, P, c_i]
+        L.ef_closure_counts.argtypes = [P, P, P, P, P]
+        L.ef_closure_last_rows.argtypes = [P, P, c_i, P, P]
+        L.ef_closure_relative.argtypes = [P, P, c_i]
+        L.ef_closure_trajectory.argtypes = [P, P, c_i]
+        self.w, self.h = width // 8, height // 8
+        self._h = L.ef_closure_create(int(n), depthCut, photoThresh, fernThresh, int(width), int(height), fx, fy, cx, cy, int(seed))
+        if not self._h:
+            raise EFError("ef_closure_create: bad arguments")
+        self.ferns = Ferns.__new__(Ferns)        # a view of the database the closure object owns
+        self.ferns._L, self.ferns._h, self.ferns._owned = L, L.ef_closure_ferns(self._h), False
+        self.ferns.num, self.ferns.w, self.ferns.h = int(n), self.w, self.h
+        for name, res in (("count", c_i), ("last_closest", c_i), ("block_hd_aware", c_f), ("photometric_check", c_f)):
+            self.ferns._f(name).restype = res
+        self.ferns._f("count").argtypes = self.ferns._f("last_closest").argtypes = [P]
+        self.ferns._f("get_frame").argtypes = [P, c_i, P, P, P, P, P, P, P]
+        self.ferns._f("get_table").argtypes = [P, P]
+
+    def close(self):
+        if self._h:
+            lib().ef_closure_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _view(self, rgb, verts, norms):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        return rgb, np.ascontiguousarray(verts, np.float32).reshape(self.h, self.w, 4), np.ascontiguousarray(norms, np.float32).reshape(self.h, self.w, 4)
+
+    def globalClosure(self, rgb, verts, norms, T_wc, tick, tracker, nodes4):
+        """-> (accepted, T_recovery [4, 4], graph [nodes, 16]); tracker as in Ferns.findFrame"""
+        rgb, verts, norms = self._view(rgb, verts, norms)
+        T = np.ascontiguousarray(T_wc, np.float64).reshape(4, 4)
+        nodes4 = np.ascontiguousarray(nodes4, np.float32).reshape(-1, 4)
+        px = self.w * self.h * 4
+
+        def tramp(_user, fv, fn, Tf, cv, cn, Tio, err, cnt):
+            A = lambda p, n, dt: np.ctypeslib.as_array(p, shape=(n,)).astype(dt).copy()
+            Te, e, k = tracker(A(fv, px, np.float32).reshape(self.h, self.w, 4), A(fn, px, np.float32).reshape(self.h, self.w, 4),
+                               A(Tf, 16, np.float64).reshape(4, 4), A(cv, px, np.float32).reshape(self.h, self.w, 4),
+                               A(cn, px, np.float32).reshape(self.h, self.w, 4), A(Tio, 16, np.float64).reshape(4, 4))
+            Te = np.ascontiguousarray(Te, np.float64).reshape(16)
+            for i in range(16):
+                Tio[i] = Te[i]
+            err[0], cnt[0] = float(e), float(k)
+
+        cb = FERN_TRACKER(tramp)
+        Tr = np.zeros((4, 4), np.float64)
+        g = np.zeros((1024, 16), np.float32)
+        n = c_i(0)
+        rc = lib().ef_closure_global(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(norms), _ptr(T), int(tick), cb, None, _ptr(nodes4), len(nodes4),
+                                     _ptr(Tr), _ptr(g), C.byref(n))
+        if rc < 0:
+            _chk(rc)
+        return rc == 1, Tr, g[:n.value].copy()
+
+    def localClosure(self, constraints8, tick, nodes4):
+        cons = np.ascontiguousarray(constraints8, np.float64).reshape(-1, 8)
+        nodes4 = np.ascontiguousarray(nodes4, np.float32).reshape(-1, 4)
+        g = np.zeros((1024, 16), np.float32)
+        n = c_i(0)
+        rc = lib().ef_closure_local(self._h, _ptr(cons), len(cons), int(tick), _ptr(nodes4), len(nodes4), _ptr(g), C.byref(n))
+        if rc < 0:
+            _chk(rc)
+        return rc == 1, g[:n.value].copy()
+
+    def endFrame(self, rgb, verts, norms, T_wc, tick) -> bool:
+        rgb, verts, norms = self._view(rgb, verts, norms)
+        T = np.ascontiguousarray(T_wc, np.float64).reshape(4, 4)
+        rc = lib().ef_closure_end_frame(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(norms), _ptr(T), int(tick))
+        if rc < 0:
+            _chk(rc)
+        return rc == 1
+
+    def counts(self):
+        v = [c_i(0) for _ in range(4)]
+        _chk(lib().ef_closure_counts(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("deforms", "fernDeforms", "relative", "trajectory"), (x.value for x in v)))
+
+    @staticmethod
+    def _rows(arr, n):
+        return np.array([list(r.src) + list(r.target) + [r.src_time, r.target_time, r.relative, r.pin] for r in arr[:n]], np.float64).reshape(-1, 10)
+
+    def lastRows(self):
+        """-> (rows [n, 10] handed to the optimiser by the last closure, its energy, its mean constraint error)"""
+        n = lib().ef_closure_last_rows(self._h, None, 0, None, None)
+        arr = (GraphConstraint * max(n, 1))()
+        e, m = c_f(0), c_f(0)
+        lib().ef_closure_last_rows(self._h, arr, n, C.byref(e), C.byref(m))
+        return self._rows(arr, n), e.value, m.value
+
+    def relativeConstraints(self):
+        n = lib().ef_closure_relative(self._h, None, 0)
+        arr = (GraphConstraint * max(n, 1))()
+        lib().ef_closure_relative(self._h, arr, n)
+        return self._rows(arr, n)
+
+    def trajectory(self):
+        n = lib().ef_closure_trajectory(self._h, None, 0)
+        T = np.zeros((max(n, 1), 4, 4), np.float64)
+        lib().ef_closure_trajectory(self._h, _ptr(T), n)
+        return T[:n]
+
+
 class ElasticFusion:
     """Mirror of ``class ElasticFusion`` (Core/ElasticFusion.h) over the C ABI."""
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/ef_hip.h"
+#include "ef_deform_solver.hpp"
 #include "ef_linalg_dev.hpp"
 
 namespace {
@@ -291,3 +292,159 @@ float ef_ferns_photometric_check(const ef_ferns* f, const uint8_t* rgb, int ch, 
 }
 
 }  // extern "C"
+
+// ---- host-side state and decisions of the loop closures around the fern database (ElasticFusion.cpp:392-445, 511-526, 588-589,
+// 609-618): which constraints reach which deformation graph, what an accepted closure changes.  No device work: the caller brings the
+// 1/8-resolution views, the pose, the sampled graph nodes and (through ef_fern_tracker) the fern-to-view registration.
+struct ef_closure {
+  ef_ferns* ferns = nullptr;
+  float fernThresh = 0.3095f;
+  int deforms = 0, fernDeforms = 0;
+  int64_t lastDeformTime = 0;                 // Deformation::lastDeformTime of the LOCAL deformation
+  std::vector<efd::Constraint> relativeCons;  // ElasticFusion::relativeCons
+  std::vector<double> trajectory;             // t_T_wc
+  std::vector<int64_t> trajectoryTimes;
+  std::vector<efd::Constraint> lastRows;      // what the last closure handed to the optimiser
+  float lastError = 0, lastMeanConsErr = 0;
+
+  void poses(bool withTrajectory, std::vector<double>& P, std::vector<int64_t>& t) const {
+    const size_t nf = ferns->frames.size();
+    P.resize(nf * 16);
+    t.resize(nf);
+    for (size_t i = 0; i < nf; ++i) { efl::se3_matrix(ferns->frames[i]->T_wc, &P[i * 16]); t[i] = ferns->frames[i]->srcTime; }
+    if (withTrajectory) { P.insert(P.end(), trajectory.begin(), trajectory.end()); t.insert(t.end(), trajectoryTimes.begin(), trajectoryTimes.end()); }
+  }
+  void adopt(bool withTrajectory, const std::vector<double>& P) {
+    const size_t nf = ferns->frames.size();
+    for (size_t i = 0; i < nf; ++i) ferns->frames[i]->T_wc = efl::se3_from_matrix(&P[i * 16]);
+    if (withTrajectory) std::copy(P.begin() + nf * 16, P.end(), trajectory.begin());
+  }
+};
+
+extern "C" {
+
+ef_closure* ef_closure_create(int num_ferns, float depth_cut, float photo_thresh, float fern_thresh, int width, int height, float fx, float fy, float cx,
+                              float cy, unsigned seed) {
+  ef_ferns* f = ef_ferns_create(num_ferns, (int)(depth_cut * 1000), photo_thresh, width, height, fx, fy, cx, cy, seed);   // ElasticFusion.cpp:53
+  if (!f) return nullptr;
+  ef_closure* c = new ef_closure();
+  c->ferns = f;
+  c->fernThresh = fern_thresh;
+  return c;
+}
+void ef_closure_destroy(ef_closure* c) {
+  if (!c) return;
+  ef_ferns_destroy(c->ferns);
+  delete c;
+}
+ef_ferns* ef_closure_ferns(ef_closure* c) { return c ? c->ferns : nullptr; }
+
+// ElasticFusion.cpp:392-445 (lost == false)
+int ef_closure_global(ef_closure* c, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int tick,
+                      ef_fern_tracker tracker, void* user, const float* nodes4, int n_nodes, double* T_recovery16_out, float* graph16_out, int* nodes_out) {
+  if (!c || !T_recovery16_out || !graph16_out || !nodes_out || n_nodes < 0 || (n_nodes > 0 && !nodes4)) return EF_EINVAL;
+  *nodes_out = 0;
+  c->lastRows.clear();
+  double cons[64 * 6];
+  int n = 0;
+  const int closest = ef_ferns_find_frame(c->ferns, rgb, ch, verts4, norms4, T_wc16, tick, 0, tracker, user, T_recovery16_out, cons, 64, &n);   // :395-402
+  if (closest < -1) return closest;
+  if (closest == -1) return 0;                                                                     // :410
+  const int64_t fernTime = c->ferns->frames[closest]->srcTime;
+  std::vector<efd::Constraint>& rows = c->lastRows;
+  for (int i = 0; i < n && i < 64; ++i) {                                                          // :415-422: addConstraint(src, target, tick, srcTime, pin = true)
+    const double* s = cons + i * 6;
+    rows.push_back(efd::Constraint{{s[0], s[1], s[2]}, {s[3], s[4], s[5]}, (uint64_t)tick, (uint64_t)fernTime, false, false});
+    rows.push_back(efd::Constraint{{s[3], s[4], s[5]}, {s[3], s[4], s[5]}, (uint64_t)fernTime, (uint64_t)fernTime, false, true});
+  }
+  rows.insert(rows.end(), c->relativeCons.begin(), c->relativeCons.end());                         // :424-426
+  std::vector<float> global;                                                                       // Deformation::sampleGraphFrom: every 5th local sample
+  if (n_nodes / 5 > efd::K)
+    for (int i = 0; i < n_nodes; i += 5) global.insert(global.end(), nodes4 + (size_t)i * 4, nodes4 + (size_t)i * 4 + 4);
+  std::vector<double> P;
+  std::vector<int64_t> t;
+  c->poses(true, P, t);
+  efd::Result r{false, 0, 0.f, 0.f};
+  const int gn = (int)(global.size() / 4);
+  const bool ok = efd::constrain(global.data(), gn, rows.data(), (int)rows.size(), true, 0, P.data(), t.data(), (int)t.size(), graph16_out, &r);   // :428
+  c->lastError = r.error;
+  c->lastMeanConsErr = r.meanConsErr;
+  if (!ok) return 0;
+  c->adopt(true, P);
+  c->fernDeforms += gn > 0;                                                                        // :439
+  *nodes_out = gn;
+  return 1;
+}
+
+// ElasticFusion.cpp:488-526 once the gates are open: constraints8 as ef_get_local_loop returns them (pin flag = deforms == 0 is the caller's)
+int ef_closure_local(ef_closure* c, const double* constraints8, int n, int tick, const float* nodes4, int n_nodes, float* graph16_out, int* nodes_out) {
+  if (!c || !constraints8 || !graph16_out || !nodes_out || n < 0 || n_nodes < 0 || (n_nodes > 0 && !nodes4)) return EF_EINVAL;
+  *nodes_out = 0;
+  std::vector<efd::Constraint>& rows = c->lastRows;
+  rows.clear();
+  for (int i = 0; i < n; ++i) {                                                                    // Deformation.cpp:73-86
+    const double* q = constraints8 + (size_t)i * 8;
+    rows.push_back(efd::Constraint{{q[0], q[1], q[2]}, {q[3], q[4], q[5]}, (uint64_t)tick, (uint64_t)q[6], false, false});
+    if (q[7] != 0) rows.push_back(efd::Constraint{{q[3], q[4], q[5]}, {q[3], q[4], q[5]}, (uint64_t)q[6], (uint64_t)q[6], false, true});
+  }
+  std::vector<double> P;
+  std::vector<int64_t> t;
+  c->poses(false, P, t);
+  std::vector<efd::Constraint> rel;
+  efd::Result r{false, 0, 0.f, 0.f};
+  const bool ok = efd::constrain(nodes4, n_nodes, rows.data(), (int)rows.size(), false, (uint64_t)c->lastDeformTime, P.data(), t.data(), (int)t.size(),
+                                 graph16_out, &r, &rel);                                             // :513-514
+  c->lastError = r.error;
+  c->lastMeanConsErr = r.meanConsErr;
+  if (!ok) return 0;
+  c->adopt(false, P);
+  c->lastDeformTime = tick;                                                                        // Deformation.cpp:199-201
+  c->deforms += n_nodes > 0;                                                                       // :523
+  for (size_t i = 0; rel.size() >= 3 && i < rel.size(); i += rel.size() / 3) c->relativeCons.push_back(rel[i]);   // :522-524
+  *nodes_out = n_nodes;
+  return 1;
+}
+
+// ElasticFusion.cpp:588-589 and 609-618: the frame's final pose joins the trajectory, the final fill-in view may become a keyframe
+int ef_closure_end_frame(ef_closure* c, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int tick) {
+  if (!c || !T_wc16) return EF_EINVAL;
+  c->trajectory.insert(c->trajectory.end(), T_wc16, T_wc16 + 16);
+  c->trajectoryTimes.push_back(tick);
+  return ef_ferns_add_frame(c->ferns, rgb, ch, verts4, norms4, T_wc16, tick, c->fernThresh);
+}
+
+int ef_closure_counts(const ef_closure* c, int* deforms, int* fern_deforms, int* relative, int* trajectory) {
+  if (!c) return EF_EINVAL;
+  if (deforms) *deforms = c->deforms;
+  if (fern_deforms) *fern_deforms = c->fernDeforms;
+  if (relative) *relative = (int)c->relativeCons.size();
+  if (trajectory) *trajectory = (int)c->trajectoryTimes.size();
+  return EF_OK;
+}
+static void put_rows(const std::vector<efd::Constraint>& v, ef_graph_constraint* out, int max_rows) {
+  for (size_t i = 0; i < v.size() && (int)i < max_rows; ++i) {
+    for (int k = 0; k < 3; ++k) { out[i].src[k] = v[i].src[k]; out[i].target[k] = v[i].target[k]; }
+    out[i].src_time = (int64_t)v[i].srcTime; out[i].target_time = (int64_t)v[i].targetTime; out[i].relative = v[i].relative; out[i].pin = v[i].pin;
+  }
+}
+int ef_closure_last_rows(const ef_closure* c, ef_graph_constraint* rows, int max_rows, float* error, float* mean_constraint_error) {
+  if (!c) return EF_EINVAL;
+  if (rows) put_rows(c->lastRows, rows, max_rows);
+  if (error) *error = c->lastError;
+  if (mean_constraint_error) *mean_constraint_error = c->lastMeanConsErr;
+  return (int)c->lastRows.size();
+}
+int ef_closure_relative(const ef_closure* c, ef_graph_constraint* rows, int max_rows) {
+  if (!c) return EF_EINVAL;
+  if (rows) put_rows(c->relativeCons, rows, max_rows);
+  return (int)c->relativeCons.size();
+}
+int ef_closure_trajectory(const ef_closure* c, double* poses16, int max_poses) {
+  if (!c) return EF_EINVAL;
+  const int n = (int)c->trajectoryTimes.size();
+  if (poses16) memcpy(poses16, c->trajectory.data(), (size_t)(n < max_poses ? n : max_poses) * 16 * sizeof(double));
+  return n;
+}
+
+}  // extern "C"
+

@@ -187,6 +187,32 @@ int ef_ferns_set_frame_pose(ef_ferns* f, int id, const double* T_wc16);
 /* the two private measures, for tests: Ferns::blockHDAware of two stored frames; Ferns::photometricCheck of a view against frame id */
 float ef_ferns_block_hd_aware(const ef_ferns* f, int id_a, int id_b);
 float ef_ferns_photometric_check(const ef_ferns* f, const uint8_t* rgb, int rgb_channels, const float* verts4, const double* T_est16, int id);
+/* ---- the host side of the loop closures around that database (ElasticFusion.cpp:392-445, 511-526, 588-589, 609-618): one object holds
+ * the fern database, the relative constraints local closures leave behind, the trajectory (t_T_wc) and the two deformation counters, and
+ * takes the decisions — which constraints go to which graph, what an accepted closure changes (keyframe and trajectory poses deformed
+ * along).  No device work: the caller brings the 1/8-resolution fill-in views, the pose, the sampled graph (ef_sample_graph; the global
+ * graph is every 5th node of it, Deformation::sampleGraphFrom) and the fern-to-view registration (ef_fern_tracker).  Built and tested on
+ * the host this round; ef_process_frame does not call it yet. */
+typedef struct ef_closure ef_closure;
+ef_closure* ef_closure_create(int num_ferns, float depth_cut, float photo_thresh, float fern_thresh, int width, int height, float fx, float fy, float cx,
+                              float cy, unsigned seed);   /* Ferns(500, depthCut * 1000, photoThresh); fernThresh 0.3095 */
+void ef_closure_destroy(ef_closure* c);
+ef_ferns* ef_closure_ferns(ef_closure* c);                /* owned by the closure object */
+/* mid-frame, after predict() (:392-445): fern match -> fern constraints with their pins + the kept relative constraints -> global
+ * deformation.  1: accepted — T_recovery16_out is the new pose, graph16_out / nodes_out go to the clean pass with is_fern = 1 and the
+ * local closure is skipped; 0: no match or rejected (T_recovery16_out still holds the registration, identity without a candidate). */
+int ef_closure_global(ef_closure* c, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16, int tick,
+                      ef_fern_tracker tracker, void* user, const float* nodes4, int n_nodes, double* T_recovery16_out, float* graph16_out, int* nodes_out);
+/* the local closure's far half (:511-526), gates already open: constraints8 as ef_get_local_loop returns them.  1: accepted (graph16_out
+ * over all n_nodes; the keyframe poses followed; a third of the new relative constraints kept), 0: rejected */
+int ef_closure_local(ef_closure* c, const double* constraints8, int n, int tick, const float* nodes4, int n_nodes, float* graph16_out, int* nodes_out);
+/* end of the frame (:588-589, 609-618): pose -> trajectory, final fill-in view -> Ferns::addFrame; returns 1 when it became a keyframe */
+int ef_closure_end_frame(ef_closure* c, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16, int tick);
+int ef_closure_counts(const ef_closure* c, int* deforms, int* fern_deforms, int* relative_constraints, int* trajectory_poses);
+/* introspection for tests: the rows the last closure handed to the optimiser (returns their number) and its two error figures */
+int ef_closure_last_rows(const ef_closure* c, ef_graph_constraint* rows_or_null, int max_rows, float* error_or_null, float* mean_constraint_error_or_null);
+int ef_closure_relative(const ef_closure* c, ef_graph_constraint* rows_or_null, int max_rows);
+int ef_closure_trajectory(const ef_closure* c, double* poses16_or_null, int max_poses);
 int ef_predict(ef_ctx* ctx);                                  /* ElasticFusion::predict() */
 int ef_get_pose(ef_ctx* ctx, double* T_wc16);                 /* get_T_wc(); synchronises */
 int ef_get_tick(ef_ctx* ctx, int* tick);                      /* getTick() */

@@ -193,6 +193,8 @@ typedef struct efo_global_loop {
 void efo_fusion_set_tick(efo_fusion*, int tick);
 void efo_fusion_enable_ferns(efo_fusion*, int num, float photoThresh, float fernThresh, unsigned seed);
 efo_ferns* efo_fusion_ferns(efo_fusion*);
+/* the 1/8-resolution fill-in views of the last frame: which = 0 what Ferns::findFrame saw mid-frame, 1 what Ferns::addFrame saw at its end */
+int efo_fusion_fern_view(const efo_fusion*, int which, uint8_t* rgba, float* verts4, float* norms4);
 void efo_fusion_set_deform_solver(efo_fusion*, efo_deform_solver fn, void* user);
 void efo_fusion_global_loop(const efo_fusion*, efo_global_loop* info);
 int efo_fusion_relative_constraints(const efo_fusion*, double* rows10, int max_rows);

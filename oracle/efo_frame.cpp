@@ -141,6 +141,7 @@ struct efo_fusion {
 
   // the 1/8-resolution views of the fill-in the fern database works on (Ferns.cpp:91-93,178-180: Resize::image / vertex)
   struct FernView { std::vector<uint8_t> img; std::vector<float> verts, norms; };
+  FernView lastViews[2];   // what findFrame (0) and addFrame (1) of the last frame saw (efo_fusion_fern_view)
   FernView fernView() const {
     FernView v;
     const size_t px = (size_t)(p.width / 8) * (p.height / 8);
@@ -200,6 +201,7 @@ struct efo_fusion {
     double M[16], E[16];
     pose16(M);
     const FernView v = fernView();
+    lastViews[0] = v;
     std::vector<double> cons((size_t)64 * 6);
     int n = 0;
     tr("ferns.findFrame time=%d lost=0", tick);
@@ -435,6 +437,7 @@ struct efo_fusion {
       double Mt[16];
       pose16(Mt);
       const FernView v = fernView();
+      lastViews[1] = v;
       const int kept = efo_ferns_add_frame(ferns, v.img.data(), 4, v.verts.data(), v.norms.data(), Mt, tick, fernThresh);
       tr("ferns.addFrame time=%d -> %d", tick, kept);
     }
@@ -486,6 +489,14 @@ void efo_fusion_enable_ferns(efo_fusion* f, int num, float photoThresh, float fe
   f->fernThresh = fernThresh;
 }
 efo_ferns* efo_fusion_ferns(efo_fusion* f) { return f->ferns; }
+int efo_fusion_fern_view(const efo_fusion* f, int which, uint8_t* rgba, float* verts4, float* norms4) {
+  const efo_fusion::FernView& v = f->lastViews[which ? 1 : 0];
+  if (v.img.empty()) return 0;
+  std::memcpy(rgba, v.img.data(), v.img.size());
+  std::memcpy(verts4, v.verts.data(), v.verts.size() * 4);
+  std::memcpy(norms4, v.norms.data(), v.norms.size() * 4);
+  return 1;
+}
 void efo_fusion_set_deform_solver(efo_fusion* f, efo_deform_solver fn, void* user) { f->deformSolver = fn; f->deformUser = user; }
 void efo_fusion_global_loop(const efo_fusion* f, efo_global_loop* info) { *info = f->gloop; }
 int efo_fusion_relative_constraints(const efo_fusion* f, double* rows10, int max_rows) {

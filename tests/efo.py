@@ -582,6 +582,12 @@ class Fusion:
         f._owned = False
         return f
 
+    def fern_view(self, which):
+        """(rgba, verts, norms) at 1/8 resolution: which = 0 mid-frame (findFrame), 1 end of frame (addFrame); None if that step did not run"""
+        h, w = self.p.height // 8, self.p.width // 8
+        img, v, n = np.zeros((h, w, 4), np.uint8), np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+        return (img, v, n) if lib().efo_fusion_fern_view(self.h_, c_i(which), ptr(img), ptr(v), ptr(n)) else None
+
     def set_deform_solver(self, fn):
         """fn(fernMatch, rows [n, 10], poses [k, 4, 4], pose_times [k]) -> None | dict(graph [nodes, 16], poses [k, 4, 4], new_relative rows [m, 10])"""
         def tramp(user, fernMatch, rows, n, poses, times, k, graph_out, nodes_out, rel_out, n_rel):
