@@ -345,14 +345,14 @@ int ef_closure_global(ef_closure* c, const uint8_t* rgb, int ch, const float* ve
   if (!c || !T_recovery16_out || !graph16_out || !nodes_out || n_nodes < 0 || (n_nodes > 0 && !nodes4)) return EF_EINVAL;
   *nodes_out = 0;
   c->lastRows.clear();
-  double cons[64 * 6];
+  double cons[128 * 6];   // at most 99 constraints: every (num / 50)-th fern, Ferns.cpp:268
   int n = 0;
-  const int closest = ef_ferns_find_frame(c->ferns, rgb, ch, verts4, norms4, T_wc16, tick, 0, tracker, user, T_recovery16_out, cons, 64, &n);   // :395-402
+  const int closest = ef_ferns_find_frame(c->ferns, rgb, ch, verts4, norms4, T_wc16, tick, 0, tracker, user, T_recovery16_out, cons, 128, &n);   // :395-402
   if (closest < -1) return closest;
   if (closest == -1) return 0;                                                                     // :410
   const int64_t fernTime = c->ferns->frames[closest]->srcTime;
   std::vector<efd::Constraint>& rows = c->lastRows;
-  for (int i = 0; i < n && i < 64; ++i) {                                                          // :415-422: addConstraint(src, target, tick, srcTime, pin = true)
+  for (int i = 0; i < n && i < 128; ++i) {                                                          // :415-422: addConstraint(src, target, tick, srcTime, pin = true)
     const double* s = cons + i * 6;
     rows.push_back(efd::Constraint{{s[0], s[1], s[2]}, {s[3], s[4], s[5]}, (uint64_t)tick, (uint64_t)fernTime, false, false});
     rows.push_back(efd::Constraint{{s[3], s[4], s[5]}, {s[3], s[4], s[5]}, (uint64_t)fernTime, (uint64_t)fernTime, false, true});

@@ -202,7 +202,8 @@ int efo_ferns_find_frame(efo_ferns* f, const uint8_t* rgb, int ch, const float* 
       f->lastClosest = minId;
       int n = 0;
       const M4d E = se3_matrix(T_wc_est);
-      for (int i = 0; i < f->num; i += f->num / 50) {
+      const int step = f->num / 50;   // the reference never terminates below 50 ferns; nothing is sampled here
+      for (int i = 0; step > 0 && i < f->num; i += step) {
         const FernTest& t = f->conservatory[i];
         const float* v = verts4 + ((size_t)t.py * f->width + t.px) * 4;
         if (v[2] > 0 && int(v[2] * 1000.0f) < f->maxDepth) {

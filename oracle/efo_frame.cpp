@@ -202,10 +202,10 @@ struct efo_fusion {
     pose16(M);
     const FernView v = fernView();
     lastViews[0] = v;
-    std::vector<double> cons((size_t)64 * 6);
+    std::vector<double> cons((size_t)128 * 6);
     int n = 0;
     tr("ferns.findFrame time=%d lost=0", tick);
-    const int closest = efo_ferns_find_frame(ferns, v.img.data(), 4, v.verts.data(), v.norms.data(), M, tick, 0, &fernTrack, this, E, cons.data(), 64, &n);   // :395-402
+    const int closest = efo_ferns_find_frame(ferns, v.img.data(), 4, v.verts.data(), v.norms.data(), M, tick, 0, &fernTrack, this, E, cons.data(), 128, &n);   // :395-402
     tr("ferns.findFrame -> closest=%d constraints=%d", closest, n);
     gloop.closest = closest;
     gloop.n_constraints = n;
