@@ -212,7 +212,7 @@ int do_predict(ef_ctx* c) {
   return EF_OK;
 }
 
-// ElasticFusion.cpp:447-527 (the fern branch :391-444 and Deformation::constrain itself are out of scope: the optimisation is
+// ElasticFusion.cpp:447-527 (the fern branch :391-444 is not wired in yet, see ef_closure_* in ef_ferns.hip; the optimisation is
 // the registered solver's).  Synchronises once, where the reference reads the constraint buffers back (Resize.cpp:108,146).
 int local_loop_closure(ef_ctx* c, int log_slot) {
   hipStream_t s = c->stream;

@@ -143,7 +143,7 @@ class ElasticFusion {
   void setSo3(const bool& val);
   void setFrameToFrameRGB(const bool& val);
   void setConfidenceThreshold(const float& val);
-  void setFernThresh(const float& val);     // accepted and ignored (no fern database in open loop)
+  void setFernThresh(const float& val);     // accepted and ignored (the fern database, ef_ferns_*, is not part of processFrame yet)
   void setDepthCutoff(const float& val);
 
   const bool& getLost() { return lost; }

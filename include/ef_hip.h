@@ -48,7 +48,8 @@ typedef struct ef_config {
   int pyramid;                /* setPyramid      (1)                                */
   int rgb_only;               /* setRgbOnly      (0)                                */
   int close_loops;            /* closeLoops (0 = -o): 1 runs the LOCAL loop closure's front half every frame (below);
-                                 fern-based global closure and the graph optimiser stay out of scope */
+                                 the fern-based global closure is not part of ef_process_frame yet: its host-side parts are
+                                 ef_ferns_* / ef_solve_deformation / ef_closure_* below */
   uint32_t max_surfels;       /* surfel capacity; reference: 3072*3072 (GlobalModel.cpp:22-24) */
   int device;                 /* HIP device ordinal                                 */
   void* stream;               /* hipStream_t to run on, or NULL to create a private one */
@@ -84,8 +85,8 @@ int ef_set_input_overlap(ef_ctx* ctx, int on);
 int ef_set_graph_replay(ef_ctx* ctx, int on);
 /* Device half of a loop closure: hands a deformation graph (HOST pointer, nodes x 16 floats sorted by time, layout of
  * GlobalModel::clean's rawGraph, GlobalModel.cpp:536-546) to the NEXT ef_process_frame, whose clean pass applies it to the
- * whole map exactly as ElasticFusion.cpp:558-585 does (synthesizeDepth first unless is_fern).  Finding the loop closure and
- * optimising the graph stay with the caller (Ferns / Deformation are out of scope). */
+ * whole map exactly as ElasticFusion.cpp:558-585 does (synthesizeDepth first unless is_fern).  For a caller that finds loop closures
+ * and optimises the graph itself — or with ef_closure_* / ef_solve_deformation below. */
 int ef_set_deformation(ef_ctx* ctx, const float* graph_host, int nodes, int is_fern);
 /* ---- local loop closure, front half (ElasticFusion.cpp:447-527; contexts created with close_loops = 1) ----
  * After tracking, every frame: the INACTIVE part of the model (surfels not seen for time_delta frames) is predicted into the
