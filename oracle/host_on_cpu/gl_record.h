@@ -37,7 +37,7 @@ struct State {
   GLuint next_id = 1;
   GLuint query_result = 0;                                      // what glGetQueryObjectuiv hands back (set by the bridge)
   int query_once = -1;                                          // >= 0: handed back by the NEXT query only, then query_result again
-  int readpixels_fill = -1;                                     // >= 0: glReadPixels fills its destination with this byte
+  int readpixels_fill = -1;                                     // >= 0: glReadPixels fills its destination with this byte (-1: with zeros)
   std::vector<std::vector<unsigned char>> readpixels_queue;     // if not empty: successive glReadPixels calls copy these out, in order
   std::vector<int> query_queue;                                 // if not empty: successive queries hand these back, in order
   std::vector<unsigned char> buffer_data;                       // what glGetBufferSubData copies out (e.g. the surfel map)
@@ -133,10 +133,10 @@ inline void glReadPixels(GLint x, GLint y, GLsizei w, GLsizei h, GLenum fmt, GLe
     const std::vector<unsigned char>& b = glrec::S().readpixels_queue.front();
     memcpy(dst, b.data(), b.size());
     glrec::S().readpixels_queue.erase(glrec::S().readpixels_queue.begin());
-  } else if (glrec::S().readpixels_fill >= 0 && dst) {
+  } else if (dst) {   // nothing scripted: a cleared framebuffer (never the destination's uninitialised heap contents)
     const int ch = fmt == GL_RGB ? 3 : fmt == GL_RGBA ? 4 : 1;
     const int bytes = type == GL_FLOAT || type == GL_UNSIGNED_INT ? 4 : type == GL_UNSIGNED_SHORT ? 2 : 1;
-    memset(dst, glrec::S().readpixels_fill, (size_t)w * h * ch * bytes);
+    memset(dst, glrec::S().readpixels_fill >= 0 ? glrec::S().readpixels_fill : 0, (size_t)w * h * ch * bytes);
   }
 }
 inline void glGetBufferSubData(GLenum target, GLintptr off, GLsizeiptr size, void* dst) {
