@@ -199,7 +199,7 @@ class Ferns:
     [h, w, 4] float32.  ``tracker(fern_verts, fern_norms, T_wc_fern, verts, norms, T_wc) -> (T_wc_est, icp_error, icp_count)``
     stands where the reference runs its 80x60 RGBDOdometry (Ferns.cpp:243-258)."""
 
-    _prefix = "ef_ferns_"      # tests/efo.py binds the same class to the oracle's restatement (efo_ferns_*)
+    _prefix = "ef_ferns_"      # symbol prefix and library are overridable: a subclass can bind another implementation of the same C interface
 
     def _library(self):
         return lib()
