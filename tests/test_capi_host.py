@@ -3,6 +3,7 @@ declares, refuses to run without a GPU (no silent fallback), and the host-side m
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -88,3 +89,56 @@ def test_cpp_shim_library_and_replay_tool_exist_and_fail_loudly(tmp_path):
     if not os.path.exists("/dev/kfd"):
         r = subprocess.run([exe, "-l", log, "-q"], stderr=subprocess.PIPE, text=True)
         assert r.returncode == 1 and "libefusion_hip error" in r.stderr
+
+
+def test_host_side_entry_points_from_plain_c(tmp_path):
+    """the host-only part of the C ABI (fern database, deformation optimiser) called from a C program: no Python, no GPU"""
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "ef_hip.h"
+static void tracker(void* u, const float* fv, const float* fn, const double* Tf, const float* cv, const float* cn, double* T, float* e, float* c) {
+  (void)u; (void)fv; (void)fn; (void)Tf; (void)cv; (void)cn; (void)T; *e = 1e-5f; *c = 4000.f;
+}
+int main(void) {
+  enum { W = 80, H = 60 };
+  static unsigned char rgb[W * H * 3];
+  static float verts[W * H * 4], norms[W * H * 4];
+  double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}, Te[16], cons[128 * 6];
+  int n = 0, x, y;
+  for (y = 0; y < H; ++y)
+    for (x = 0; x < W; ++x) {
+      const int i = y * W + x;
+      const float z = 1.5f + 0.2f * (float)((x * 7 + y * 3) % 11) / 11.f;
+      rgb[i * 3] = (unsigned char)(x * 3); rgb[i * 3 + 1] = (unsigned char)(y * 4); rgb[i * 3 + 2] = (unsigned char)(x + y);
+      verts[i * 4] = (x - 40.f) / 66.f * z; verts[i * 4 + 1] = (y - 30.f) / 66.f * z; verts[i * 4 + 2] = z; verts[i * 4 + 3] = 1.f;
+      norms[i * 4 + 2] = -1.f;
+    }
+  ef_ferns* f = ef_ferns_create(500, 3000, 115.f, 640, 480, 528.f, 528.f, 320.f, 240.f, 42u);
+  if (!f) return 1;
+  if (ef_ferns_add_frame(f, rgb, 3, verts, norms, I, 1, 0.3095f) != 1) return 2;
+  if (ef_ferns_add_frame(f, rgb, 3, verts, norms, I, 2, 0.3095f) != 0) return 3;          /* the same view again is no new keyframe */
+  if (ef_ferns_find_frame(f, rgb, 3, verts, norms, I, 100, 0, tracker, 0, Te, cons, 128, &n) != -1) return 4;   /* too recent */
+  if (ef_ferns_find_frame(f, rgb, 3, verts, norms, I, 400, 0, tracker, 0, Te, cons, 128, &n) != 0 || n < 30) return 5;
+  ef_ferns_destroy(f);
+  float nodes[8 * 4], graph[8 * 16], err, mean;
+  ef_graph_constraint c[4];
+  memset(c, 0, sizeof(c));
+  for (x = 0; x < 8; ++x) { nodes[x * 4] = 0.2f * x; nodes[x * 4 + 1] = 0.05f * (x % 3); nodes[x * 4 + 2] = 1.5f + 0.03f * (x % 2); nodes[x * 4 + 3] = 10.f + x; }
+  for (x = 0; x < 4; ++x) {
+    c[x].src[0] = 0.3 * x + 0.1; c[x].src[1] = 0.02 * x; c[x].src[2] = 1.5;
+    c[x].target[0] = c[x].src[0] + 0.004; c[x].target[1] = c[x].src[1] - 0.002; c[x].target[2] = c[x].src[2] + 0.003;
+    c[x].src_time = 30; c[x].target_time = 11;
+  }
+  if (ef_solve_deformation(nodes, 8, c, 4, 0, 0, 0, 0, 0, graph, &err, &mean, 0, 0) != EF_OK) return 6;
+  printf("ok %d %.3g %.3g\n", n, err, mean);
+  return mean < 1e-3f ? 0 : 7;
+}
+''')
+    exe = tmp_path / "host"
+    lib_dir = os.path.join(ROOT, "elasticfusion_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L" + lib_dir, "-lefusion_hip",
+                           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), (out.returncode, out.stdout)
