@@ -41,8 +41,13 @@ def _gen_frame(args):
 _gen_frame.cache = {}
 
 
-def generate_frames(seed: int, n: int, w: int = W, h: int = H):
-    workers = max(1, min(16, (os.cpu_count() or 2) - 1))
+PREROLL = 100   # untimed frames before --warmup: the map reaches its steady state (stable surfels, model-fed tracker, clean() removing
+               # stale unstable surfels) whatever --steps / --warmup the caller chose, so the timed region is the representative workload
+
+
+def generate_frames(seed: int, n: int, w: int = W, h: int = H, ranks_on_host: int = 1):
+    # the host cores are shared by all ranks of the node: 8 ranks x 16 workers would starve each other
+    workers = max(1, min(16, (os.cpu_count() or 2) // max(1, ranks_on_host) - 1))
     with ProcessPoolExecutor(max_workers=workers) as ex:
         return list(ex.map(_gen_frame, [(seed, k, w, h) for k in range(n)], chunksize=4))
 
@@ -120,8 +125,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
     # synthetic frames first: the generator forks worker processes, which must happen before HIP / RCCL are initialised
-    n_frames = a.warmup + a.steps + 1  # frame 0 seeds the map (tick 1) and is never timed
-    frames = generate_frames(multi.sequence_seed(rank), n_frames, w, h)
+    n_frames = 1 + PREROLL + a.warmup + a.steps  # frame 0 seeds the map (tick 1); pre-roll and warm-up are never timed
+    frames = generate_frames(multi.sequence_seed(rank), n_frames, w, h, ranks_on_host=world)
 
     import torch
     import torch.distributed as dist
@@ -149,8 +154,8 @@ def main():
         else:
             ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
 
-    step(0)
-    for k in range(1, a.warmup + 1):
+    first_timed = 1 + PREROLL + a.warmup
+    for k in range(first_timed):
         step(k)
     # per-kernel HIP-event sampling of the dominant kernel inside the timed region (1 frame in 8)
     lib = api.lib()
@@ -162,7 +167,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(a.warmup + 1, a.warmup + 1 + a.steps):
+    for k in range(first_timed, first_timed + a.steps):
         step(k)
     torch.cuda.synchronize()
     if world > 1:
@@ -175,6 +180,7 @@ def main():
     Tgt = frames[n_frames - 1][2]
     err_t = float(np.linalg.norm(T[:3, 3] - Tgt[:3, 3]))
     count = ef.lastCount()
+    stable = int((ef.downloadMap()[:, 3] > ef.getConfidenceThreshold()).sum()) if rank == 0 else 0
 
     # the only collective: 32 B per rank over xGMI (RCCL all_gather)
     allstats = multi.gather_stats([dt, float(a.steps), err_t, float(count)], device="cuda")
@@ -189,25 +195,31 @@ def main():
     if have_ktime:
         class KT(C.Structure):
             _fields_ = [("name", C.c_char_p), ("avg_us", C.c_float), ("launches", C.c_int), ("bytes_per_launch", C.c_double),
-                        ("raw_avg_us", C.c_float), ("empty_pair_us", C.c_float)]
+                        ("bytes_per_launch_survey", C.c_double)]
         kt = KT()
         if lib.ef_get_kernel_timing(ef.h, C.byref(kt)) == 0 and kt.launches > 0:
+            # avg_us: the dispatches' own begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of the sampled launches
+            # inside the timed region -- the duration rocprofv3 --kernel-trace reports for the same kernel (profiles/)
             achieved = kt.bytes_per_launch / (kt.avg_us * 1e-6) / 1e9
-            # HBM-side bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the last
-            # measurement committed under profiles/ by tools/pmc_traffic.sh, for this same kernel and workload
-            traffic = None
+            achieved_survey = kt.bytes_per_launch_survey / (kt.avg_us * 1e-6) / 1e9
+            # HBM-side bytes per launch: rocprofv3 PMC passes cannot run inside this process, so this is the measurement
+            # COMMITTED under profiles/ by tools/pmc_traffic.sh for this kernel and workload (see traffic_source), not a live value
+            traffic, traffic_source = None, None
             try:
                 if (w, h) != (W, H):
                     raise KeyError("the committed PMC measurement is for the default workload")
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    traffic = int(json.load(f)["traffic_bytes_per_launch"])
+                    pj = json.load(f)
+                traffic = int(pj["traffic_bytes_per_launch"])
+                traffic_source = "committed PMC measurement (profiles/pmc_traffic.json: " + str(pj.get("source", "tools/pmc_traffic.sh")) + "), not measured in this run"
             except Exception:
                 pass
             roofline = {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "avg_us": round(float(kt.avg_us), 3), "event_pair_raw_us": round(float(kt.raw_avg_us), 3),
-                        "event_pair_empty_us": round(float(kt.empty_pair_us), 3), "launches_sampled": int(kt.launches),
-                        "algorithmic_bytes_per_launch": int(kt.bytes_per_launch)}
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                        "avg_us": round(float(kt.avg_us), 3), "timer": "dispatch begin/end timestamps (hipExtLaunchKernelGGL events), = rocprofv3 kernel-trace duration",
+                        "launches_sampled": int(kt.launches), "algorithmic_bytes_per_launch": int(kt.bytes_per_launch),
+                        "algorithmic_bytes_per_launch_survey_48B": int(kt.bytes_per_launch_survey),
+                        "frac_survey_48B": round(achieved_survey / HBM_PEAK_GBS, 4), "frac_of_achievable_6300": round(achieved / 6300.0, 4)}
     roofline_splat = None
     if have_ktime and hasattr(lib, "ef_get_splat_timing"):
         ks = KT()
@@ -235,7 +247,8 @@ def main():
                                "SO(3)+ICP+RGB 3-level tracking (10/5/4 its) + surfel fuse/clean/predict; "
                                + ("stand-in for configs[1] (dyson_lab.klg is not available offline)" if (w, h) == (W, H) else
                                   "configs[2]: 1280x960 stream, ~1.2 M-surfel map"),
-                   "resolution": [w, h], "sequences": world, "surfels_end": int(count),
+                   "resolution": [w, h], "sequences": world, "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
+                   "preroll_frames": PREROLL, "surfels_end": int(count),
                    "pose_err_vs_generating_traj_m": round(err_t, 5),
                    "per_rank_fps": [round(x, 2) for x in agg["per_rank_fps"]]},
         "roofline": roofline,
@@ -243,6 +256,7 @@ def main():
     }
     if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (the scaling runs reuse the N=1 figure)
         out["cpu_baseline"] = cpu_baseline(frames[: min(len(frames), 40)], w=w, h=h)
+    out["config"]["stable_surfels_end"] = int(stable)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

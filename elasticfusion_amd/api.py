@@ -136,7 +136,7 @@ def default_config(**kw) -> ef_config:
 
 class LocalLoop(C.Structure):   # ef_local_loop
     _fields_ = [("attempted", c_i), ("cov_ok", c_i), ("gates_ok", c_i), ("n_constraints", c_i), ("applied", c_i),
-                ("graph_nodes", c_i), ("stats", c_f * 6), ("cov_diag", C.c_double * 6), ("T_wc_curr", C.c_double * 16),
+                ("graph_nodes", c_i), ("graph_capacity", c_i), ("pad_", c_i), ("stats", c_f * 6), ("cov_diag", C.c_double * 6), ("T_wc_curr", C.c_double * 16),
                 ("T_wc_est", C.c_double * 16)]
 
 
@@ -498,8 +498,10 @@ class ElasticFusion:
             if g is None:
                 return 0
             g = np.ascontiguousarray(g, np.float32).reshape(-1, 16)
-            C.memmove(graph_out, g.ctypes.data, g.nbytes)
             nodes_out[0] = len(g)
+            if len(g) > info.contents.graph_capacity:   # graph_out only has room for graph_capacity nodes: let the engine reject the count
+                return 1
+            C.memmove(graph_out, g.ctypes.data, g.nbytes)
             return 1
         self._solver = LOOP_SOLVER(tramp)
         _chk(lib().ef_set_loop_solver(self.h, self._solver, None), self.h)
@@ -576,8 +578,8 @@ class ElasticFusion:
 
     def trajectory(self):
         n = c_i(0)
-        _chk(lib().ef_get_trajectory(self.h, None, None, c_i(0), C.byref(n)), self.h)
-        cap = 1 << 16
+        _chk(lib().ef_get_tick(self.h, C.byref(n)), self.h)   # at most one logged pose per processed frame
+        cap = max(int(n.value), 1)
         T = np.zeros((cap, 16), np.float64)
         ts = np.zeros(cap, np.int64)
         _chk(lib().ef_get_trajectory(self.h, _ptr(T), _ptr(ts), c_i(cap), C.byref(n)), self.h)

@@ -82,5 +82,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, extra_flags: list[str]) -> str:
+    """TEST / DEVELOPMENT builds of libefusion_hip under another name (libefusion_hip_<name>.so, selected with EF_HIP_LIB in the Python
+    harness; never loaded by the product): e.g. build_variant("valu", ["-DEF_ACCUM_VALU"]) = the normal-equation kernel with
+    its outer products on the VALU instead of the matrix pipe, for A/B runs on one GPU box."""
+    target = os.path.join(HERE, f"libefusion_hip_{name}.so")
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", f"_{name}.o"))
+        procs.append((src, subprocess.Popen([_hipcc(), *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj], stdout=subprocess.PIPE,
+                                            stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target, *objs, "-Wl,-rpath,/opt/rocm/lib"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return target
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:   # python -m elasticfusion_amd.build --variant valu -DEF_ACCUM_VALU
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

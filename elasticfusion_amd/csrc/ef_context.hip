@@ -54,8 +54,7 @@ struct ef_ctx {
   hipEvent_t ev_input_done = nullptr, ev_track_done = nullptr, ev_staged = nullptr;
   hipEvent_t ev_frame_done[2] = {nullptr, nullptr};   // end of the frame that last used each set of frame images
   int frame_parity = 0;
-  int overlap_mode = 1;          // 1: whole input stage after the previous tracker; 2: copy + bilateral filter already during it
-  unsigned pre_lds = 0;          // extra dynamic LDS of the bilateral kernel = an occupancy cap while it shares the GPU
+  int overlap_mode = 1;          // ef_set_input_overlap: 1 = whole input stage after the previous tracker; 2 = copy + bilateral filter already during it
   bool overlap = false;
   bool staged_pending = false;
   uint8_t* h_rgb = nullptr;      // pinned staging
@@ -116,7 +115,6 @@ struct ef_ctx {
   TrackGraph tgraph[2];
   // HIP-event sampling of the dominant kernel (ef_kernel_timing)
   int ktime_every = 0;
-  float kt_empty_pair_us = 0.f;   // what an event pair measures with nothing between the two records
   std::vector<hipEvent_t> kt_start, kt_stop;
   eft::KernelProbe probe{nullptr, nullptr, 0, 0};
   // second sampled kernel: the IndexMap point splat (k_index_splat of the first predictIndices of a frame)
@@ -134,6 +132,22 @@ namespace {
       return EF_EHIP;                                                                           \
     }                                                                                           \
   } while (0)
+
+// Every entry point that takes a context runs on the CONTEXT's device, whatever device is current on the calling thread
+// (two contexts on two GPUs in one process, or a context used from a thread that never called hipSetDevice), and
+// leaves the thread's current device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(const ef_ctx* c) {
+    if (c && hipGetDevice(&prev) == hipSuccess && prev != c->cfg.device) switched = hipSetDevice(c->cfg.device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 template <typename T>
 int dev_alloc(ef_ctx* c, T** p, size_t n, int fill = 0) {
@@ -204,6 +218,21 @@ void timer_end(ef_ctx* c, const char* name) {
     if (!strcmp(t.name, name)) { (void)hipEventRecord(t.b, c->stream); return; }
 }
 
+int grow_trajectory(ef_ctx* c) {
+  double* bigger = nullptr;
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  hipError_t e = hipMalloc((void**)&bigger, (size_t)c->traj_cap * 2 * 16 * sizeof(double));
+  if (e != hipSuccess) { c->err = std::string("hipMalloc (trajectory log): ") + hipGetErrorString(e); return EF_ENOMEM; }
+  e = hipMemcpy(bigger, c->traj, (size_t)c->traj_cap * 16 * sizeof(double), hipMemcpyDeviceToDevice);
+  if (e != hipSuccess) { (void)hipFree(bigger); c->err = std::string("hipMemcpy (trajectory log): ") + hipGetErrorString(e); return EF_EHIP; }
+  for (auto& p : c->allocs)
+    if (p == (void*)c->traj) p = bigger;
+  (void)hipFree(c->traj);
+  c->traj = bigger;
+  c->traj_cap *= 2;
+  return EF_OK;
+}
+
 int do_predict(ef_ctx* c) {
   // ElasticFusion::predict(), ElasticFusion.cpp:621-653: combinedPredict(ACTIVE) + FillIn (fused into the resolve)
   efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick,
@@ -248,6 +277,7 @@ int local_loop_closure(ef_ctx* c, int log_slot) {
   memset(&L, 0, sizeof(L));
   c->loop_constraints.clear();
   L.attempted = 1;
+  L.graph_capacity = 1023;   // GlobalModel::MAX_NODES - 1 (GlobalModel.cpp:24): rows of loop_graph / graph_dev
   const eft::TrackState& hc = c->h_states[0];
   const eft::TrackState& he = c->h_states[1];
   efl::SE3 Tc, Te;
@@ -356,8 +386,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   }
   if (kind == hipMemcpyHostToDevice) { EF_HIP(c, hipEventRecord(c->ev_staged, sb)); c->staged_pending = true; }
   timer_begin(c, "Preprocess");
-  efm::preprocess_depth(depth_in, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb,
-                        overlap ? c->pre_lds : 0u);
+  efm::preprocess_depth(depth_in, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb, 0u);
   timer_end(c, "Preprocess");
   if (overlap && c->overlap_mode == 2) EF_HIP(c, hipStreamWaitEvent(sb, c->ev_track_done, 0));
   if (track_this && overlap) {   // the single-stream script builds all pyramids together below (eft::build_pyramids)
@@ -368,8 +397,12 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
 
   const bool rgbOnly = c->cfg.rgb_only != 0;
   // t_T_wc.push_back / poseLogTimes.push_back, ElasticFusion.cpp:588-589: the pose is logged by the kernel that produces it
-  const int log_slot = (int)c->stamps.size() < c->traj_cap ? (int)c->stamps.size() : -1;
-  if (log_slot >= 0) c->stamps.push_back(timestamp);
+  if ((int)c->stamps.size() >= c->traj_cap) {   // t_T_wc grows without bound in the reference: double the device log (rare: every 2^16+ frames)
+    const int r = grow_trajectory(c);
+    if (r != EF_OK) return r;
+  }
+  const int log_slot = (int)c->stamps.size();
+  c->stamps.push_back(timestamp);
   if (c->tick == 1) {  // ElasticFusion.cpp:290-296
     if (overlap) EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
     timer_begin(c, "feedbackBuffers");
@@ -417,9 +450,14 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
           hipGraph_t graph = nullptr;
           EF_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
           eft::track(pyr_copy, c->st, c->intr, tp, s, nullptr);
-          EF_HIP(c, hipStreamEndCapture(s, &graph));
-          EF_HIP(c, hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0));
-          (void)hipGraphDestroy(graph);
+          hipError_t ce = hipStreamEndCapture(s, &graph);   // always ends the capture, whatever was recorded
+          if (ce == hipSuccess) ce = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+          if (graph) (void)hipGraphDestroy(graph);
+          if (ce != hipSuccess) {
+            g->exec = nullptr;
+            c->err = std::string("hipGraph capture of the tracker: ") + hipGetErrorString(ce);
+            return EF_EHIP;
+          }
           g->key = key;
           memcpy(&g->tp, &tp, sizeof(tp));
         }
@@ -496,20 +534,11 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->depth_filtered_alt, P);
   EF_ALLOC(c, c->depth_metric_alt, P);
   EF_ALLOC(c, c->depth_metric_filtered_alt, P);
-  {
-    int lo = 0, hi = 0;   // numerically lower = higher priority; the input stream must never delay the tracker
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const bool low = getenv("EF_OVERLAP_PRIO") != nullptr && atoi(getenv("EF_OVERLAP_PRIO")) != 0;
-    EF_HIP(c, hipStreamCreateWithPriority(&c->in_stream, hipStreamNonBlocking, low ? lo : 0));
-  }
+  EF_HIP(c, hipStreamCreateWithFlags(&c->in_stream, hipStreamNonBlocking));
   for (auto& e : c->ev_frame_done) EF_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  c->use_graph = getenv("EF_GRAPH") != nullptr && atoi(getenv("EF_GRAPH")) != 0;
-  if (getenv("EF_OVERLAP")) c->overlap_mode = atoi(getenv("EF_OVERLAP")) == 2 ? 2 : 1;
-  if (getenv("EF_PRE_LDS")) c->pre_lds = (unsigned)atoi(getenv("EF_PRE_LDS"));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_input_done, hipEventDisableTiming));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_track_done, hipEventDisableTiming));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
-  c->overlap = getenv("EF_OVERLAP") != nullptr && atoi(getenv("EF_OVERLAP")) != 0;   // measured: see DESIGN.md §6
   EF_HIP(c, hipHostMalloc((void**)&c->h_rgb, P * 3));
   EF_HIP(c, hipHostMalloc((void**)&c->h_depth, P * 2));
   // tracker pyramids (zero-filled: the stale y/z planes of quirk Q3 are then deterministic)
@@ -601,7 +630,7 @@ int ctx_init(ef_ctx* c) {
     EF_HIP(c, hipHostMalloc((void**)&c->h_states, 2 * sizeof(eft::TrackState)));
     hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->st2, (W / 20) * (H / 20), W * H);
   }
-  c->traj_cap = 1 << 16;
+  c->traj_cap = 1 << 10;   // doubled on demand (grow_trajectory)
   EF_ALLOC(c, c->traj, (size_t)c->traj_cap * 16);
   // T_wc = identity (ElasticFusion.h: T_wc_curr default) -> publish the float matrices
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->st, (W / 20) * (H / 20), W * H);
@@ -669,10 +698,13 @@ int ef_create(const ef_config* cfg, ef_ctx** out) {
     return EF_EHIP;
   }
   if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "bad device ordinal"; return EF_EINVAL; }
-  e = hipSetDevice(cfg->device);
-  if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return EF_EHIP; }
   ef_ctx* c = new ef_ctx();
   c->cfg = *cfg;
+  DeviceGuard dg_(c);   // the context's device for the allocations below; the caller's current device is restored on return
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != cfg->device) { g_create_error = "hipSetDevice failed"; delete c; return EF_EHIP; }
+  }
   c->cam = efm::Cam{cfg->width, cfg->height, cfg->fx, cfg->fy, cfg->cx, cfg->cy};
   c->intr = eft::Intr{cfg->fx, cfg->fy, cfg->cx, cfg->cy};
   if (cfg->stream) {
@@ -695,6 +727,7 @@ int ef_create(const ef_config* cfg, ef_ctx** out) {
 
 void ef_destroy(ef_ctx* c) {
   if (!c) return;
+  DeviceGuard dg_(c);
   ctx_free(c);
   delete c;
 }
@@ -703,12 +736,14 @@ void* ef_stream(ef_ctx* c) { return c ? (void*)c->stream : nullptr; }
 static int check_capacity(ef_ctx* c);
 int ef_synchronize(ef_ctx* c) {
   if (!c) return EF_EINVAL;
+  DeviceGuard dg_(c);
   EF_HIP(c, hipStreamSynchronize(c->stream));
   return check_capacity(c);
 }
 
 int ef_process_frame(ef_ctx* c, const uint8_t* rgb, const uint16_t* depth, int64_t timestamp, float wm, const double* T) {
   if (!c || !rgb || !depth) return EF_EINVAL;
+  DeviceGuard dg_(c);
   const size_t P = (size_t)c->cam.cols * c->cam.rows;
   // the pinned staging buffers may still be in flight from the previous frame's async copy: wait for that copy only
   if (c->staged_pending) { EF_HIP(c, hipEventSynchronize(c->ev_staged)); c->staged_pending = false; }
@@ -718,11 +753,18 @@ int ef_process_frame(ef_ctx* c, const uint8_t* rgb, const uint16_t* depth, int64
 }
 int ef_process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_dev, int64_t timestamp, float wm, const double* T) {
   if (!c || !rgb_dev || !depth_dev) return EF_EINVAL;
+  DeviceGuard dg_(c);
   return process_frame(c, rgb_dev, depth_dev, hipMemcpyDeviceToDevice, timestamp, wm, T);
 }
-int ef_set_input_overlap(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->overlap = on != 0; return EF_OK; }
+int ef_set_input_overlap(ef_ctx* c, int on) {
+  if (!c || on < 0 || on > 2) return EF_EINVAL;
+  c->overlap = on != 0;
+  c->overlap_mode = on == 2 ? 2 : 1;
+  return EF_OK;
+}
 int ef_set_deformation(ef_ctx* c, const float* graph, int nodes, int is_fern) {
   if (!c || nodes < 0 || (nodes > 0 && !graph)) return EF_EINVAL;
+  DeviceGuard dg_(c);
   if (nodes >= 1024) { c->err = "ef_set_deformation: at most 1023 nodes (GlobalModel::MAX_NODES)"; return EF_EINVAL; }
   if (nodes > 0) EF_HIP(c, hipMemcpyAsync(c->graph_dev, graph, (size_t)nodes * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
   if (nodes > 0) EF_HIP(c, hipStreamSynchronize(c->stream));   // the caller's buffer is borrowed for the call only
@@ -791,6 +833,7 @@ int ef_get_local_loop(ef_ctx* c, ef_local_loop* info, double* constraints, int m
 }
 int ef_sample_graph(ef_ctx* c, float* nodes4, int max_nodes, int* n_out) {
   if (!c || !nodes4 || !n_out || max_nodes <= 0) return EF_EINVAL;
+  DeviceGuard dg_(c);
   float* dev = nullptr;
   EF_HIP(c, hipMalloc((void**)&dev, ((size_t)max_nodes * 4 + 4) * sizeof(float)));
   unsigned* n_dev = (unsigned*)(dev + (size_t)max_nodes * 4);
@@ -807,11 +850,13 @@ int ef_sample_graph(ef_ctx* c, float* nodes4, int max_nodes, int* n_out) {
 int ef_set_graph_replay(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->use_graph = on != 0; return EF_OK; }
 int ef_predict(ef_ctx* c) {
   if (!c) return EF_EINVAL;
+  DeviceGuard dg_(c);
   EF_HIP(c, hipMemsetAsync(&c->st->dense_count, 0, sizeof(unsigned), c->stream));
   return do_predict(c);
 }
 int ef_get_pose(ef_ctx* c, double* T16) {
   if (!c || !T16) return EF_EINVAL;
+  DeviceGuard dg_(c);
   eft::TrackState h;
   EF_HIP(c, hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   EF_HIP(c, hipStreamSynchronize(c->stream));
@@ -825,6 +870,7 @@ int ef_get_tick(ef_ctx* c, int* tick) { if (!c || !tick) return EF_EINVAL; *tick
 int ef_set_tick(ef_ctx* c, int tick) { if (!c) return EF_EINVAL; c->tick = tick; return EF_OK; }
 int ef_get_tracking_stats(ef_ctx* c, float* out6, double* A36, double* b6) {
   if (!c || !out6) return EF_EINVAL;
+  DeviceGuard dg_(c);
   eft::TrackState h;
   EF_HIP(c, hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   EF_HIP(c, hipStreamSynchronize(c->stream));
@@ -836,6 +882,7 @@ int ef_get_tracking_stats(ef_ctx* c, float* out6, double* A36, double* b6) {
 }
 int ef_get_covariance(ef_ctx* c, double* cov36) {
   if (!c || !cov36) return EF_EINVAL;
+  DeviceGuard dg_(c);
   eft::TrackState h;
   EF_HIP(c, hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   EF_HIP(c, hipStreamSynchronize(c->stream));
@@ -844,6 +891,7 @@ int ef_get_covariance(ef_ctx* c, double* cov36) {
 }
 int ef_debug_clocks(ef_ctx* c, unsigned long long* out16) {
   if (!c || !out16) return EF_EINVAL;
+  DeviceGuard dg_(c);
   eft::TrackState h;
   EF_HIP(c, hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   EF_HIP(c, hipStreamSynchronize(c->stream));
@@ -852,6 +900,7 @@ int ef_debug_clocks(ef_ctx* c, unsigned long long* out16) {
 }
 int ef_get_trajectory(ef_ctx* c, double* T16s, int64_t* stamps, int max_frames, int* n_frames) {
   if (!c || !n_frames) return EF_EINVAL;
+  DeviceGuard dg_(c);
   int n = (int)c->stamps.size();
   if (n > max_frames) n = max_frames;
   if (T16s && n) {
@@ -862,13 +911,15 @@ int ef_get_trajectory(ef_ctx* c, double* T16s, int64_t* stamps, int max_frames, 
   *n_frames = n;
   return EF_OK;
 }
-// clean() clamps the new surfel count to the capacity and raises a device flag; the getters that synchronise report it
-// (the reference's fixed 3072 x 3072 vertex buffer simply overflows, GlobalModel.cpp:22-24)
+// clean() clamps the new surfel count to the capacity and raises a device flag (the reference's fixed 3072 x 3072 vertex
+// buffer simply overflows, GlobalModel.cpp:22-24).  The flag is a WARNING: ef_synchronize reports it once (EF_ECAPACITY) and
+// clears it; the clamped map stays readable (ef_map_count / ef_map_download / ef_save_ply proceed with the clamped count).
 static int check_capacity(ef_ctx* c) {
   int flag = 0;
   EF_HIP(c, hipMemcpyAsync(&flag, c->overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   EF_HIP(c, hipStreamSynchronize(c->stream));
   if (flag) {
+    EF_HIP(c, hipMemsetAsync(c->overflow, 0, sizeof(int), c->stream));
     c->err = "surfel capacity exceeded (ef_config.max_surfels = " + std::to_string(c->capacity) + "): the newest surfels were dropped";
     return EF_ECAPACITY;
   }
@@ -876,12 +927,14 @@ static int check_capacity(ef_ctx* c) {
 }
 int ef_map_count(ef_ctx* c, uint32_t* count) {
   if (!c || !count) return EF_EINVAL;
+  DeviceGuard dg_(c);
   EF_HIP(c, hipMemcpyAsync(count, &c->st->map_counts[c->cur], sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   EF_HIP(c, hipStreamSynchronize(c->stream));
-  return check_capacity(c);
+  return EF_OK;
 }
 int ef_map_download(ef_ctx* c, float* surfels, uint32_t max_surfels, uint32_t* count) {
   if (!c || !count) return EF_EINVAL;
+  DeviceGuard dg_(c);
   uint32_t n = 0;
   int r = ef_map_count(c, &n);
   if (r != EF_OK) return r;
@@ -900,6 +953,7 @@ int ef_map_download(ef_ctx* c, float* surfels, uint32_t max_surfels, uint32_t* c
 }
 int ef_map_upload(ef_ctx* c, const float* surfels, uint32_t count) {
   if (!c || (!surfels && count)) return EF_EINVAL;
+  DeviceGuard dg_(c);
   if (count > c->capacity) { c->err = "ef_map_upload: count exceeds max_surfels"; return EF_ECAPACITY; }
   float* tmp = nullptr;
   if (count) {
@@ -955,6 +1009,7 @@ int ef_write_ply(const char* path, const float* surfels, uint32_t count, float c
 }
 int ef_save_freiburg(ef_ctx* c, const char* path) {
   if (!c || !path) return EF_EINVAL;
+  DeviceGuard dg_(c);
   const int n = (int)c->stamps.size();
   std::vector<double> T((size_t)n * 16);
   int got = 0;
@@ -966,6 +1021,7 @@ int ef_save_freiburg(ef_ctx* c, const char* path) {
 }
 int ef_save_ply(ef_ctx* c, const char* path) {
   if (!c || !path) return EF_EINVAL;
+  DeviceGuard dg_(c);
   uint32_t n = 0;
   int r = ef_map_count(c, &n);
   if (r != EF_OK) return r;
@@ -987,6 +1043,7 @@ int ef_set_depth_cutoff(ef_ctx* c, float v) { if (!c) return EF_EINVAL; c->cfg.d
 
 int ef_get_image(ef_ctx* c, int which, void* dst, size_t bytes) {
   if (!c || !dst) return EF_EINVAL;
+  DeviceGuard dg_(c);
   const size_t P = (size_t)c->cam.cols * c->cam.rows;
   const void* src = nullptr;
   size_t need = 0;
@@ -1030,6 +1087,7 @@ int ef_get_image(ef_ctx* c, int which, void* dst, size_t bytes) {
 }
 int ef_get_image_resized(ef_ctx* c, int which, int factor, void* dst, size_t bytes) {
   if (!c || !dst || factor < 1) return EF_EINVAL;
+  DeviceGuard dg_(c);
   const int W = c->cam.cols, H = c->cam.rows, dw = W / factor, dh = H / factor;
   const void* src = nullptr;
   int elem = 0;
@@ -1064,6 +1122,7 @@ int ef_get_image_resized(ef_ctx* c, int which, int factor, void* dst, size_t byt
 }
 int ef_get_tracker_buffer(ef_ctx* c, int which, int level, void* dst, size_t bytes) {
   if (!c || !dst || level < 0 || level >= eft::NUM_PYRS) return EF_EINVAL;
+  DeviceGuard dg_(c);
   const size_t n = (size_t)(c->cam.cols >> level) * (c->cam.rows >> level);
   const void* src = nullptr;
   size_t need = 0;
@@ -1091,6 +1150,7 @@ int ef_get_tracker_buffer(ef_ctx* c, int which, int level, void* dst, size_t byt
 int ef_enable_timing(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->timing = on != 0; return EF_OK; }
 int ef_get_timings(ef_ctx* c, ef_timing* out, int max, int* n) {
   if (!c || !n) return EF_EINVAL;
+  DeviceGuard dg_(c);
   EF_HIP(c, hipStreamSynchronize(c->stream));
   int k = 0;
   for (auto& t : c->timers) {
@@ -1107,6 +1167,7 @@ int ef_get_timings(ef_ctx* c, ef_timing* out, int max, int* n) {
 // ---- device helpers ----
 int ef_kernel_timing(ef_ctx* c, int every_n_frames) {
   if (!c || every_n_frames < 0) return EF_EINVAL;
+  DeviceGuard dg_(c);
   EF_HIP(c, hipStreamSynchronize(c->stream));
   c->ktime_every = every_n_frames;
   c->probe.used = 0;
@@ -1132,25 +1193,12 @@ int ef_kernel_timing(ef_ctx* c, int every_n_frames) {
     c->probe.start = c->kt_start.data();
     c->probe.stop = c->kt_stop.data();
     c->probe.capacity = cap;
-    // calibrate: the span an empty start/stop pair reports on this stream (the two marker packets themselves)
-    const int reps = 64;
-    for (int i = 0; i < reps; ++i) {
-      EF_HIP(c, hipEventRecord(c->kt_start[i], c->stream));
-      EF_HIP(c, hipEventRecord(c->kt_stop[i], c->stream));
-    }
-    EF_HIP(c, hipStreamSynchronize(c->stream));
-    double tot = 0;
-    for (int i = 0; i < reps; ++i) {
-      float ms = 0;
-      EF_HIP(c, hipEventElapsedTime(&ms, c->kt_start[i], c->kt_stop[i]));
-      tot += ms;
-    }
-    c->kt_empty_pair_us = (float)(1e3 * tot / reps);
   }
   return EF_OK;
 }
 int ef_get_kernel_timing(ef_ctx* c, ef_kernel_time* out) {
   if (!c || !out) return EF_EINVAL;
+  DeviceGuard dg_(c);
   EF_HIP(c, hipStreamSynchronize(c->stream));
   double total_ms = 0;
   for (int i = 0; i < c->probe.used; ++i) {
@@ -1161,19 +1209,19 @@ int ef_get_kernel_timing(ef_ctx* c, ef_kernel_time* out) {
   const bool icp = !c->cfg.rgb_only && c->cfg.icp_weight > 0, rgb = c->cfg.rgb_only || c->cfg.icp_weight < 100;
   out->name = "k_se3_accum (level 0: icpStep + rgbStep Jacobian rows + reference-order sums)";
   out->launches = c->probe.used;
-  out->raw_avg_us = c->probe.used ? (float)(1e3 * total_ms / c->probe.used) : 0.f;
-  out->empty_pair_us = c->kt_empty_pair_us;
-  out->avg_us = out->raw_avg_us > out->empty_pair_us ? out->raw_avg_us - out->empty_pair_us : out->raw_avg_us;
+  out->avg_us = c->probe.used ? (float)(1e3 * total_ms / c->probe.used) : 0.f;
   // algorithmic bytes of ONE launch of this kernel (DESIGN.md "Roofline accounting"): icpStep 48 B per pixel-visit
   // (4 planar float3 maps); rgbStep reads the 4-byte packed correspondence of every pixel — the
   // reference's 16-byte DataTerm + 12-byte cloud are gone, so they are not counted — the ~10 % valid pixels' gathers
   // (depth + 2 gradients) are left out (data dependent): a lower bound, which can only understate `achieved`
   out->bytes_per_launch = (double)c->cam.cols * c->cam.rows * ((icp ? 48.0 : 0.0) + (rgb ? 4.0 : 0.0));
+  out->bytes_per_launch_survey = (double)c->cam.cols * c->cam.rows * (icp ? 48.0 : 0.0);   // the ICP reduction alone
   return EF_OK;
 }
 
 int ef_get_splat_timing(ef_ctx* c, ef_kernel_time* out) {
   if (!c || !out) return EF_EINVAL;
+  DeviceGuard dg_(c);
   EF_HIP(c, hipStreamSynchronize(c->stream));
   double total_ms = 0;
   for (int i = 0; i < c->probe_splat.used; ++i) {
@@ -1185,12 +1233,11 @@ int ef_get_splat_timing(ef_ctx* c, ef_kernel_time* out) {
   EF_HIP(c, hipMemcpy(&count, &c->st->map_counts[c->cur], sizeof(count), hipMemcpyDeviceToHost));
   out->name = "k_index_splat (IndexMap::predictIndices: per-surfel transform + project + 64-bit atomicMin z-buffer)";
   out->launches = c->probe_splat.used;
-  out->raw_avg_us = c->probe_splat.used ? (float)(1e3 * total_ms / c->probe_splat.used) : 0.f;
-  out->empty_pair_us = c->kt_empty_pair_us;
-  out->avg_us = out->raw_avg_us > out->empty_pair_us ? out->raw_avg_us - out->empty_pair_us : out->raw_avg_us;
+  out->avg_us = c->probe_splat.used ? (float)(1e3 * total_ms / c->probe_splat.used) : 0.f;
   // algorithmic bytes: the two float4 streams the pass needs (position+confidence, colour+times: 32 B / surfel; the
   // reference's vertex shader fetches all 48) + one 8-byte z-buffer update per surfel (an upper bound: culled surfels issue none)
   out->bytes_per_launch = 40.0 * (double)count;
+  out->bytes_per_launch_survey = 48.0 * (double)count;   // 48 B per surfel read by the reference's vertex shader
   return EF_OK;
 }
 

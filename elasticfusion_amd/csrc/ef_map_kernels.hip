@@ -6,6 +6,7 @@
 // GL-defined behaviour is specified as N1-N5 in SURVEY.md §8a (restated in DESIGN.md).
 #include "ef_device.hpp"
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 #include "ef_map.hpp"
 
 using namespace ef;
@@ -1087,11 +1088,12 @@ void seed_map(const Cam& cam, const uint8_t* rgb3, const float* dm, const float*
 
 void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSoA map, const unsigned* count_dev, float maxDepth,
                      int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s, eft::KernelProbe* probe) {
+  // the probe's events receive the kernel's own begin / end timestamps (what rocprofv3 --kernel-trace reports as its duration)
   const bool sample = probe && probe->used < probe->capacity;
-  if (sample) (void)hipEventRecord(probe->start[probe->used], s);
-  hipLaunchKernelGGL(k_index_splat, dim3(SURFEL_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, time, map, count_dev, maxDepth, timeDelta, zbuf,
-                     out.colmajor);
-  if (sample) (void)hipEventRecord(probe->stop[probe->used++], s);
+  hipEvent_t e0 = sample ? probe->start[probe->used] : nullptr, e1 = sample ? probe->stop[probe->used] : nullptr;
+  if (sample) probe->used++;
+  hipExtLaunchKernelGGL(k_index_splat, dim3(SURFEL_GRID), dim3(BLK), 0, s, e0, e1, 0, cam, T_cw16_dev, time, map, count_dev, maxDepth, timeDelta,
+                        zbuf, out.colmajor);
   hipLaunchKernelGGL(k_index_resolve, dim3(ceil_div(cam.cols * cam.rows, BLK)), dim3(BLK), 0, s, cam, T_cw16_dev, map, zbuf, out);
 }
 

@@ -10,6 +10,7 @@
 #include "ef_linalg_dev.hpp"
 #include "ef_solve_dev.hpp"
 #include <stddef.h>
+#include <hip/hip_ext.h>
 #include "ef_track.hpp"
 
 using namespace ef;
@@ -806,58 +807,71 @@ __device__ __forceinline__ float sigma_from_sums(int sigma, int rgbSize, bool rg
 // Adding an exact 0.0f (zero rows of rejected pixels, zero-padded lanes of the reference's shared[32]) never changes
 // a sum, so only the non-trivial additions are performed.
 // ------------------------------------------------------------------------------------------
-constexpr int ROW_STRIDE = 8 * 32;   // floats per pass in LDS: 8 components (7 row entries + found) x 32 lanes
+constexpr int ROW_STRIDE = 8 * 32;   // floats per pass in LDS (SO(3) kernel): 8 components x 32 lanes
 
-__device__ __forceinline__ void store_row(float* rows, int k, int l, const float (&row)[7], float found) {
-  float* r = rows + k * ROW_STRIDE + l;
-#pragma unroll
-  for (int c = 0; c < 7; ++c) r[c * 32] = row[c];
-  r[7 * 32] = found;
-}
+// ------------------------------------------------------------------------------------------
+// The normal equations of one icpStep / rgbStep, in the reference's summation order, with no LDS and no barrier
+// in the main loop.
+//
+// Quad layout.  A wavefront covers HALF a virtual warp: lane = 4 v + j, v = 0..15 the virtual thread, j = 0..3 the lane's
+// slot in its quad.  The quad of virtual thread g works through g's pixel visits (passes k = 0, 1, 2, ... = pixels g,
+// g + 16384, ...) four at a time:
+//   phase A  lane j computes the Jacobian row of pass 4 s + j (loads split by data dependence exactly as before: stage 1 =
+//            everything the pixel itself addresses, stage 2 = the gathers behind the projective association), for CH
+//            steps s at once so that 5 x (6 + 6) loads per lane are in flight;
+//   phase B  the four rows of a step are transposed inside the quad (two DPP butterfly stages: lane i ends up with
+//            component i of every pass) and accumulated as rank-1 updates A += r r^T in pass order by the matrix pipe:
+//            v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4x4 outer products, one per quad, each output element
+//            one fmaf(a_i, b_j, c_ij) (bit for bit an f32 FMA, subnormals kept: cdna_hip_programming.md "FP32-input
+//            MFMA") -- three of them per pass cover the 28 products + the inlier count of JtJJtrSE3 (types.cuh:98-143):
+//            lo x lo, lo x hi, hi x hi with lo = (r0..r3), hi = (r4, r5, r6, found).  Duplicate (i > j) and unused
+//            outputs are simply not stored.  The VALU sees only the 32 transposition moves per step; the 12 MFMAs run
+//            beside the other wave's phase A.  (EF_NO_FMA builds, where every product is rounded before it is added,
+//            and EF_ACCUM_VALU builds do the same outer products with quad broadcasts on the VALU.)
+//   tree     warpReduceSum (reduce.cu:57-95): offset 16 is the other half's wave (one LDS exchange, the only barrier of the
+//            kernel), offsets 8..1 are lane shuffles by 32..4.
+// A workgroup is two virtual warps x {ICP, RGB} x two halves = 8 waves; waves i and i + 4 share a SIMD, so every SIMD
+// hosts one ICP wave (memory + ALU heavy) and one RGB wave (light).  256 workgroups = one per CU, one dispatch round.
+// Output: one partial per virtual warp and accumulator (acc-major), then -- last arriver of the four workgroups of a
+// reference block, ticket hand-over as below -- blockReduceSum's second stage (8-warp tree), leaving the 64 block
+// partials the update step consumes.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int ACC_NW = 2;   // virtual warps per workgroup
 
-// the FMA chains of one (virtual thread, part) over passes [0, kend): JtJJtrSE3 member order (types.cuh:98-143) is
-// s = 0..26 over i = 0..5, j = i..6; 27 = row[6]^2 (residual), 28 = inliers.
-//   part 0: s 0..6   (i=0)            part 1: s 7..12 (i=1), 25,26 (i=5)
-//   part 2: s 13..17 (i=2), 22..24 (i=4)   part 3: s 18..21 (i=3), 27, 28
-__device__ __forceinline__ void se3_chains(const float* __restrict__ R, int l, int part, int kend, float (&acc)[8]) {
-  if (part == 0) {
-    for (int k = 0; k < kend; ++k) {
-      const float* r = R + k * ROW_STRIDE + l;
-      const float r0 = r[0], r1 = r[32], r2 = r[64], r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192];
-      acc[0] = EF_FMA(r0, r0, acc[0]); acc[1] = EF_FMA(r0, r1, acc[1]); acc[2] = EF_FMA(r0, r2, acc[2]); acc[3] = EF_FMA(r0, r3, acc[3]);
-      acc[4] = EF_FMA(r0, r4, acc[4]); acc[5] = EF_FMA(r0, r5, acc[5]); acc[6] = EF_FMA(r0, r6, acc[6]);
-    }
-  } else if (part == 1) {
-    for (int k = 0; k < kend; ++k) {
-      const float* r = R + k * ROW_STRIDE + l;
-      const float r1 = r[32], r2 = r[64], r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192];
-      acc[0] = EF_FMA(r1, r1, acc[0]); acc[1] = EF_FMA(r1, r2, acc[1]); acc[2] = EF_FMA(r1, r3, acc[2]); acc[3] = EF_FMA(r1, r4, acc[3]);
-      acc[4] = EF_FMA(r1, r5, acc[4]); acc[5] = EF_FMA(r1, r6, acc[5]);
-      acc[6] = EF_FMA(r5, r5, acc[6]); acc[7] = EF_FMA(r5, r6, acc[7]);
-    }
-  } else if (part == 2) {
-    for (int k = 0; k < kend; ++k) {
-      const float* r = R + k * ROW_STRIDE + l;
-      const float r2 = r[64], r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192];
-      acc[0] = EF_FMA(r2, r2, acc[0]); acc[1] = EF_FMA(r2, r3, acc[1]); acc[2] = EF_FMA(r2, r4, acc[2]); acc[3] = EF_FMA(r2, r5, acc[3]);
-      acc[4] = EF_FMA(r2, r6, acc[4]);
-      acc[5] = EF_FMA(r4, r4, acc[5]); acc[6] = EF_FMA(r4, r5, acc[6]); acc[7] = EF_FMA(r4, r6, acc[7]);
-    }
-  } else {
-    for (int k = 0; k < kend; ++k) {
-      const float* r = R + k * ROW_STRIDE + l;
-      const float r3 = r[96], r4 = r[128], r5 = r[160], r6 = r[192], f = r[224];
-      acc[0] = EF_FMA(r3, r3, acc[0]); acc[1] = EF_FMA(r3, r4, acc[1]); acc[2] = EF_FMA(r3, r5, acc[2]); acc[3] = EF_FMA(r3, r6, acc[3]);
-      acc[4] = EF_FMA(r6, r6, acc[4]);
-      acc[5] += f;
-    }
-  }
+__device__ __forceinline__ float quad_xor1(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float quad_xor2(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), Q * 0x55, 0xF, 0xF, true)); }
+// 4x4 transpose across (lane-in-quad, register): afterwards m[q] of lane i holds what m[i] of lane q held
+__device__ __forceinline__ void quad_transpose(float (&m)[4], int j) {
+  const bool o1 = (j & 1) != 0, o2 = (j & 2) != 0;
+  const float a0 = quad_xor1(m[0]), a1 = quad_xor1(m[1]), a2 = quad_xor1(m[2]), a3 = quad_xor1(m[3]);
+  const float s0 = o1 ? a1 : m[0], s1 = o1 ? m[1] : a0, s2 = o1 ? a3 : m[2], s3 = o1 ? m[3] : a2;
+  const float b0 = quad_xor2(s0), b1 = quad_xor2(s1), b2 = quad_xor2(s2), b3 = quad_xor2(s3);
+  m[0] = o2 ? b2 : s0; m[1] = o2 ? b3 : s1; m[2] = o2 ? s2 : b0; m[3] = o2 ? s3 : b1;
 }
-__device__ __forceinline__ int se3_member(int part, int i) {  // accumulator slot -> JtJJtrSE3 member index (-1: unused)
-  if (part == 0) return i < 7 ? i : -1;
-  if (part == 1) return i < 6 ? 7 + i : 25 + (i - 6);
-  if (part == 2) return i < 5 ? 13 + i : 22 + (i - 5);
-  return i < 4 ? 18 + i : (i < 6 ? 27 + (i - 4) : -1);
+// c[i] (lane j of the quad) = fma(a of lane i, b of lane j, c[i]): sixteen 4x4 rank-1 updates per wavefront
+__device__ __forceinline__ f32x4 quad_outer(float a, float b, f32x4 c) {
+#if defined(EF_NO_FMA) || defined(EF_ACCUM_VALU)
+  c.x = EF_FMA(quad_bcast<0>(a), b, c.x);
+  c.y = EF_FMA(quad_bcast<1>(a), b, c.y);
+  c.z = EF_FMA(quad_bcast<2>(a), b, c.z);
+  c.w = EF_FMA(quad_bcast<3>(a), b, c.w);
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+#endif
+}
+// (which outer product, register i, lane-in-quad j) -> JtJJtrSE3 member index, or -1 for duplicates / unused outputs.
+// kind 0: lo x lo, 1: lo x hi, 2: hi x hi with lo = row[0..3], hi = (row[4], row[5], row[6], found)
+__device__ __forceinline__ int quad_member(int kind, int i, int j) {
+  if (kind == 0) return i <= j ? efs::se3_member_of(i, j) : -1;
+  if (kind == 1) return j < 3 ? efs::se3_member_of(i, 4 + j) : -1;
+  if (i > j) return -1;
+  if (j == 3) return i == 3 ? 28 : -1;            // found^2 = found: the inlier count
+  if (i == 2) return 27;                          // row[6]^2: the residual
+  return efs::se3_member_of(4 + i, 4 + j);
 }
 
 struct Se3Inputs {            // device pointers: the Gauss-Newton state the accumulation reads
@@ -865,15 +879,21 @@ struct Se3Inputs {            // device pointers: the Gauss-Newton state the acc
   const float* tcurr;         // 3
   const float* Rprev_inv;     // 9
   const float* tprev;         // 3
-  const int* rgb_slots;       // residual-pass sums (TrackState::rgb_slots), or null => sigma_fixed
+  const int* rgb_slots;       // residual-pass sums (RGB_SLOTS x 16 ints), or null => sigma_fixed
   const int* broken;          // rgbOnly early-exit flag, or null
   float sigma_fixed;
   bool rgbOnly;
   // Workgroup b runs on XCD b % 8 and every XCD has its own L2.  With the swizzle on, the workgroups of one XCD own a
   // CONTIGUOUS range of virtual warps (= of pixels in every pass), so the lines of the model maps that neighbouring virtual
   // warps share through the projective association (shifted 128-byte segments) are fetched once per XCD instead of once per
-  // workgroup; where a virtual warp's partial sums land does not change.
-  bool xcd_swizzle = false;
+  // workgroup, and the four workgroups of a reference block sit behind one L2; where a partial sum lands does not change.
+  bool xcd_swizzle = true;
+};
+struct Se3Out {
+  float* partials_icp;        // SE3_ACCS x VWARPS, acc-major
+  float* partials_rgb;
+  float* block_partials;      // [term][SE3_ACCS][64] (terms present in the launch, ICP first), or null with tickets
+  unsigned* tickets;          // 64 arrival counters (zero between launches), or null: leave the virtual-warp partials only
 };
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sums, bool broken, bool icp, bool rgb, bool rgbOnly,
                                                 float icpWeight, Intr knext, bool level_changes, efs::SolveScratch& S,
@@ -958,7 +978,7 @@ template <bool HAS_ICP, bool HAS_RGB>
 __device__ __forceinline__ void visit_stage2b(const IcpView& IV, const RgbView& RV, const IcpPose& P, float sigma, const VisitLoads& L,
                                               const VisitGathers& G, float (&irow)[7], float& ifound, float (&grow)[7], float& gfound) {
   ifound = gfound = 0.f;
-  if (G.pidx >= 0) {
+  if (HAS_ICP && G.pidx >= 0) {
     const f3 ncurr_g = mul(P.Rcurr, L.ncurr);
     const float dist = norm(G.vprev_g - G.vcurr_g);
     const float sine = norm(cross(ncurr_g, G.nprev_g));
@@ -973,7 +993,7 @@ __device__ __forceinline__ void visit_stage2b(const IcpView& IV, const RgbView& 
       ifound = 1.f;
     }
   }
-  if (G.zi >= 0) {
+  if (HAS_RGB && G.zi >= 0) {
     const float diff = (float)((int)((L.corr >> 22) & 0x1FFu) - 255);
     float w = sigma + fabsf(diff);
     w = w > 1.19209290E-07F ? 1.0f / w : 1.0f;
@@ -994,296 +1014,168 @@ __device__ __forceinline__ void visit_stage2b(const IcpView& IV, const RgbView& 
   }
 }
 
-// developer instrumentation (-DEF_ACCUM_CLOCKS): wall_clock64() stamps of the first and the last workgroup of the level-0
-// launch into TrackState::dbg_clock (the state block is found from the Rcurr pointer the kernel gets)
-#ifdef EF_ACCUM_CLOCKS
-__device__ unsigned long long g_accum_stamps[2 * VWARPS];   // entry / exit of every workgroup of the last level-0 launch
-#define EF_ASTAMP_ALL(slot)                                                                                       \
-  do {                                                                                                            \
-    if (N > 8 * VTHREADS && threadIdx.x == 0) g_accum_stamps[(slot) * VWARPS + blockIdx.x] = wall_clock64();      \
-  } while (0)
-#define EF_ASTAMP(i)                                                                                              \
-  do {                                                                                                            \
-    if (N > 8 * VTHREADS && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == VWARPS - 1)) {                      \
-      TrackState* st_ = (TrackState*)((char*)in.Rcurr - offsetof(TrackState, Rcurr));                             \
-      st_->dbg_clock[(blockIdx.x ? 8 : 0) + (i)] = wall_clock64();                                                \
-    }                                                                                                             \
-  } while (0)
-#else
-#define EF_ASTAMP(i) do { } while (0)
-#define EF_ASTAMP_ALL(slot) do { } while (0)
-#endif
-// NW = virtual warps per workgroup (1 in the product).  NW = 2 with 640 threads (EF_ACCUM_NW=2: 256 workgroups, one per CU,
-// all resident in ONE dispatch round, two pixel-visits per thread in flight together) was built to remove the second dispatch
-// round of the 512 ten-wave workgroups and measured the same launch time (9.06 vs 9.30 us, same frames/s): a CU needs the same
-// time for its 1216 visits whether they arrive as one workgroup or as two in sequence, so the launch is bound by the memory
-// phase of the whole chip bursting at once, not by the number of rounds.
-template <int BLOCK, int KC, int NW, bool HAS_ICP, bool HAS_RGB, bool PACKED>
-__device__ __forceinline__ void se3_accum_body(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, float* __restrict__ partials_icp,
-                                               float* __restrict__ partials_rgb) {
-  static_assert(BLOCK >= 256 * NW && BLOCK % 64 == 0, "phase B needs 256 threads per virtual warp");
-  __shared__ float rows[NW][2][KC * ROW_STRIDE];
-  const int t = threadIdx.x;
-  const int wg = in.xcd_swizzle ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
-  const int W0 = wg * NW;
-  const int cols = HAS_ICP ? IV.cols : RV.cols, nrows = HAS_ICP ? IV.rows : RV.rows;
-  const int N = cols * nrows;
-  const int K = (N + VTHREADS - 1) / VTHREADS;
-  EF_ASTAMP(0);
-  EF_ASTAMP_ALL(0);
-  const int broken = in.broken ? *in.broken : 0;   // consumed below, after the loads are in flight
-  // Issue order = everything that needs no other load first: the residual-pass sums (sigma), the pose (scalar loads),
-  // then the first task's pixel-addressed loads (frame tier); only then is anything waited for.
-  int slot_a = 0, slot_b = 0;
-  const bool with_slots = HAS_RGB && in.rgb_slots;
-  if (with_slots && t < 64) { slot_a = in.rgb_slots[t * 16]; slot_b = in.rgb_slots[t * 16 + 1]; }
+// One wavefront = one half of virtual warp W for ONE term: all passes of its 16 virtual threads, accumulated into c[0..2]
+// (lo x lo, lo x hi, hi x hi; register i of lane 4 v + j holds element (i, j) of virtual thread v's 4x4 block).
+// slot_a / slot_b: this lane's residual-pass slot (count, sum diff^2) when sigma comes from the slots.
+template <int CH, bool ICP, bool PACKED>
+__device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int g, int j, int N, int K,
+                                            int slot_a, int slot_b, bool with_slots, f32x4 (&c)[3]) {
+  const int S = (K + 3) >> 2;
   IcpPose P;
-  if (HAS_ICP) {
+  if (ICP) {
     P.Rcurr = m33_load(in.Rcurr);
     P.tcurr = {in.tcurr[0], in.tcurr[1], in.tcurr[2]};
     P.Rprev_inv = m33_load(in.Rprev_inv);
     P.tprev = {in.tprev[0], in.tprev[1], in.tprev[2]};
   }
   __builtin_amdgcn_sched_barrier(0);   // keep the (scalar) pose loads ahead of the vector loads below: they overlap
-  // every thread owns up to MAXT pixel-visits of a chunk: task (w, s = t + jj * BLOCK) for j = w * MAXT1 + jj, i.e. the same
-  // slot of every virtual warp of the workgroup; their stage-1 loads all go out together
-  constexpr int MAXT1 = (KC * 32 + BLOCK - 1) / BLOCK;
-  constexpr int MAXT = NW * MAXT1;
-  VisitLoads L0[MAXT];
-  if (PACKED) {
+  VisitLoads L0[CH];
+  if (ICP || PACKED) {
 #pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      const int w = j / MAXT1, s0 = t + (j % MAXT1) * BLOCK;
-      L0[j] = visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, s0 < min(KC, K) * 32 ? (s0 >> 5) * VTHREADS + (W0 + w) * 32 + (s0 & 31) : N, N);
+    for (int u = 0; u < CH; ++u) {
+      const int k = 4 * u + j;
+      L0[u] = visit_stage1<ICP, !ICP>(IV, RV, k < K ? k * VTHREADS + g : N, N);
     }
   }
-  if (broken) return;  // rgbOnly "break": the level is over (k_se3_finish does the bookkeeping)
   float sigma = in.sigma_fixed;
-  if (with_slots) {
-    __shared__ float sigma_s;
-    if (t < 64) {
+  if (!ICP && with_slots) {
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        slot_a += __shfl_down(slot_a, off, 64);
-        slot_b += __shfl_down(slot_b, off, 64);
-      }
-      if (t == 0) sigma_s = sigma_from_sums(slot_b, slot_a, in.rgbOnly);
+    for (int off = 32; off > 0; off >>= 1) {
+      slot_a += __shfl_down(slot_a, off, 64);
+      slot_b += __shfl_down(slot_b, off, 64);
     }
-    __syncthreads();
-    sigma = sigma_s;
+    sigma = sigma_from_sums(__shfl(slot_b, 0, 64), __shfl(slot_a, 0, 64), in.rgbOnly);
   }
-  EF_ASTAMP(1);
-  // phase-B identity of this thread: 256 threads per virtual warp
-  const int wB = t >> 8, l = t & 31, term = (t >> 5) & 1, part = (t >> 6) & 3;
-  const bool chain_thread = t < 256 * NW && (term == 0 ? HAS_ICP : HAS_RGB);
-  const int g = (W0 + wB) * 32 + l;
-  const int nk = g < N ? (N - g + VTHREADS - 1) / VTHREADS : 0;   // passes virtual thread g really makes
-  float acc[8];
+  for (int s0 = 0; s0 < S; s0 += CH) {
+    float rows[CH][8];
+    if (ICP || PACKED) {
+      VisitLoads L[CH];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    const int kc = min(KC, K - k0);
-    if (PACKED) {
-      VisitLoads L[MAXT];
-#pragma unroll
-      for (int j = 0; j < MAXT; ++j) {
-        const int w = j / MAXT1, s1 = t + (j % MAXT1) * BLOCK;
-        L[j] = k0 == 0 ? L0[j]
-                       : visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, s1 < kc * 32 ? (k0 + (s1 >> 5)) * VTHREADS + (W0 + w) * 32 + (s1 & 31) : N, N);
+      for (int u = 0; u < CH; ++u) {
+        const int k = 4 * (s0 + u) + j;
+        L[u] = s0 == 0 ? L0[u] : visit_stage1<ICP, !ICP>(IV, RV, k < K ? k * VTHREADS + g : N, N);
       }
-      VisitGathers G[MAXT];
+      VisitGathers G[CH];
 #pragma unroll
-      for (int j = 0; j < MAXT; ++j) G[j] = visit_stage2a<HAS_ICP, HAS_RGB>(IV, RV, P, L[j]);
+      for (int u = 0; u < CH; ++u) G[u] = visit_stage2a<ICP, !ICP>(IV, RV, P, L[u]);
 #pragma unroll
-      for (int j = 0; j < MAXT; ++j) {
-        const int w = j / MAXT1, s1 = t + (j % MAXT1) * BLOCK;
-        if (s1 < kc * 32) {
-          float irow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, grow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          float ifound, gfound;
-          visit_stage2b<HAS_ICP, HAS_RGB>(IV, RV, P, sigma, L[j], G[j], irow, ifound, grow, gfound);
-          if (HAS_ICP) store_row(rows[w][0], s1 >> 5, s1 & 31, irow, ifound);
-          if (HAS_RGB) store_row(rows[w][1], s1 >> 5, s1 & 31, grow, gfound);
-        }
+      for (int u = 0; u < CH; ++u) {
+        float irow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, grow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float ifound, gfound;
+        visit_stage2b<ICP, !ICP>(IV, RV, P, sigma, L[u], G[u], irow, ifound, grow, gfound);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) rows[u][q] = ICP ? irow[q] : grow[q];
+        rows[u][7] = ICP ? ifound : gfound;
       }
-    } else {
-      for (int sw = t; sw < NW * kc * 32; sw += BLOCK) {
-        const int w = sw / (kc * 32), s = sw - w * (kc * 32);
-        const int k = s >> 5, sl = s & 31;
-        const int p = (k0 + k) * VTHREADS + (W0 + w) * 32 + sl;
-        if (HAS_ICP) {
-          float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          float found = 0.f;
-          if (p < N) {
-            const int y = p / cols, x = p - y * cols;
-            if (icp_row(IV, P, x, y, row)) found = 1.f;
+    } else {   // operator tier's photometric term: 16-byte DataTerm + explicit point cloud (types.cuh:81-86)
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int k = 4 * (s0 + u) + j;
+        const int p = k < K ? k * VTHREADS + g : N;
+        float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const bool found = p < N && rgb_row<false>(RV, sigma, p, row);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) rows[u][q] = row[q];
+        rows[u][7] = found ? 1.f : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      if (s0 + u < S) {   // uniform
+        float lo[4] = {rows[u][0], rows[u][1], rows[u][2], rows[u][3]};
+        float hi[4] = {rows[u][4], rows[u][5], rows[u][6], rows[u][7]};
+        quad_transpose(lo, j);
+        quad_transpose(hi, j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (4 * (s0 + u) + q < K) {   // uniform; passes in order: the chain of every accumulator is the reference thread's
+            c[0] = quad_outer(lo[q], lo[q], c[0]);
+#ifdef EF_MFMA_SWAP_AB   // development: the cross term with A and B exchanged (were the instruction's output indexed [b][a])
+            c[1] = quad_outer(hi[q], lo[q], c[1]);
+#else
+            c[1] = quad_outer(lo[q], hi[q], c[1]);
+#endif
+            c[2] = quad_outer(hi[q], hi[q], c[2]);
           }
-          store_row(rows[w][0], k, sl, row, found);
-        }
-        if (HAS_RGB) {
-          float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          float found = 0.f;
-          if (p < N && rgb_row<PACKED>(RV, sigma, p, row)) found = 1.f;
-          store_row(rows[w][1], k, sl, row, found);
         }
       }
     }
-    __syncthreads();
-    EF_ASTAMP(2);
-    if (chain_thread) se3_chains(rows[wB][term], l, part, min(kc, nk - k0), acc);
-    __syncthreads();
-    EF_ASTAMP(3);
   }
-  if (chain_thread) {
-    // warpReduceSum, reduce.cu:57-95: val += shfl_down(val, offset) for offset = 16..1 (lane 0 of each virtual warp)
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 32);
-    if (l == 0) {
-      float* out = (term == 0 ? partials_icp : partials_rgb) + W0 + wB;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int a = se3_member(part, i);
-        if (a >= 0) out[(size_t)a * VWARPS] = acc[i];
-      }
-    }
-  }
-  EF_ASTAMP(4);
-  EF_ASTAMP_ALL(1);
 }
-template <int BLOCK, int KC, int NW, bool HAS_ICP, bool HAS_RGB, bool PACKED>
-__global__ void __launch_bounds__(BLOCK) k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, float* __restrict__ partials_icp,
-                                                     float* __restrict__ partials_rgb) {
-  se3_accum_body<BLOCK, KC, NW, HAS_ICP, HAS_RGB, PACKED>(IV, RV, in, partials_icp, partials_rgb);
-}
-// EXPERIMENT, off by default (EF_ACCUM_BLOCKWISE=1).  Small levels (N <= 8 passes): one workgroup per REFERENCE BLOCK (256 virtual threads = 8 virtual warps, 1024 threads), 64
-// workgroups.  The block's 8-warp tree then runs inside the workgroup (LDS + width-8 shuffles: the second stage of the
-// reference's blockReduceSum, whose other 24 lanes hold exact zeros), the kernel leaves the 64 block partials directly and
-// the finishing kernel needs neither its first stage nor the ticket hand-over between workgroups.  Per pass the workgroup
-// reads 256 consecutive pixels of every planar map.  Same chains, same trees, same bits.
-constexpr int ACCB_BLOCK = 1024, ACCB_KC = 5;
-template <int KC, bool HAS_ICP, bool HAS_RGB>
-__global__ void __launch_bounds__(ACCB_BLOCK) k_se3_accum_block(const IcpView IV, const RgbView RV, const Se3Inputs in,
-                                                                float* __restrict__ block_partials) {
-  constexpr int BLOCK = ACCB_BLOCK;
-  __shared__ float rows[8][2][KC * ROW_STRIDE];
-  __shared__ float wsum[2 * SE3_ACCS][8];
-  const int t = threadIdx.x, b = blockIdx.x;
+
+template <int CH, bool HAS_ICP, bool HAS_RGB, bool PACKED>
+__global__ void __launch_bounds__(64 * 2 * ACC_NW * ((HAS_ICP && HAS_RGB) ? 2 : 1))
+k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, const Se3Out out) {
+  constexpr int NT = (HAS_ICP && HAS_RGB) ? 2 : 1;
+  constexpr int BLOCK = 64 * 2 * ACC_NW * NT;
+  __shared__ float xch[ACC_NW][NT][12][64];
+  __shared__ int last_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int v = lane >> 2, j = lane & 3;
+  const int wg = in.xcd_swizzle ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int tix = wave / (2 * ACC_NW);                       // 0: the launch's first term
+  const bool rgb_wave = HAS_RGB && (!HAS_ICP || tix == 1);
+  const int rem = wave % (2 * ACC_NW), wl = rem >> 1, half = rem & 1;
+  const int W = wg * ACC_NW + wl;
+  const int g = W * 32 + half * 16 + v;
   const int cols = HAS_ICP ? IV.cols : RV.cols, nrows = HAS_ICP ? IV.rows : RV.rows;
   const int N = cols * nrows;
   const int K = (N + VTHREADS - 1) / VTHREADS;
   const int broken = in.broken ? *in.broken : 0;
-  int slot_a = 0, slot_b = 0;
   const bool with_slots = HAS_RGB && in.rgb_slots;
-  if (with_slots && t < 64) { slot_a = in.rgb_slots[t * 16]; slot_b = in.rgb_slots[t * 16 + 1]; }
-  IcpPose P;
-  if (HAS_ICP) {
-    P.Rcurr = m33_load(in.Rcurr);
-    P.tcurr = {in.tcurr[0], in.tcurr[1], in.tcurr[2]};
-    P.Rprev_inv = m33_load(in.Rprev_inv);
-    P.tprev = {in.tprev[0], in.tprev[1], in.tprev[2]};
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // task id = t + j * BLOCK of a chunk: pass id >> 8, virtual thread id & 255 of this reference block
-  constexpr int MAXT = (KC * 256 + BLOCK - 1) / BLOCK;
-  VisitLoads L0[MAXT];
+  int slot_a = 0, slot_b = 0;
+  if (rgb_wave && with_slots) { slot_a = in.rgb_slots[lane * 16]; slot_b = in.rgb_slots[lane * 16 + 1]; }
+  if (broken) return;  // rgbOnly "break": the level is over (the update step does the bookkeeping)
+  f32x4 c[3];
 #pragma unroll
-  for (int j = 0; j < MAXT; ++j) {
-    const int id = t + j * BLOCK;
-    L0[j] = visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, id < min(KC, K) * 256 ? (id >> 8) * VTHREADS + b * 256 + (id & 255) : N, N);
-  }
-  if (broken) return;
-  float sigma = in.sigma_fixed;
-  if (with_slots) {
-    __shared__ float sigma_s;
-    if (t < 64) {
+  for (int q = 0; q < 3; ++q) c[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (HAS_ICP && !rgb_wave) accum_quads<CH, true, PACKED>(IV, RV, in, g, j, N, K, 0, 0, false, c);
+  if (HAS_RGB && rgb_wave) accum_quads<CH, false, PACKED>(IV, RV, in, g, j, N, K, slot_a, slot_b, with_slots, c);
+  // warpReduceSum, reduce.cu:57-95: val += shfl_down(val, offset) for offset = 16 (the other half's wave), 8, 4, 2, 1
+  if (half == 1) {
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        slot_a += __shfl_down(slot_a, off, 64);
-        slot_b += __shfl_down(slot_b, off, 64);
-      }
-      if (t == 0) sigma_s = sigma_from_sums(slot_b, slot_a, in.rgbOnly);
-    }
-    __syncthreads();
-    sigma = sigma_s;
-  }
-  // phase-B roles: 8 virtual warps x 256 (lane, term, part) = 2048 roles, two per thread (virtual warps t >> 8 and (t >> 8) + 4)
-  const int l = t & 31, term = (t >> 5) & 1, part = (t >> 6) & 3;
-  const bool chain_thread = term == 0 ? HAS_ICP : HAS_RGB;
-  float acc[2][8];
-  int nk[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int g = (b * 8 + (t >> 8) + 4 * q) * 32 + l;
-    nk[q] = g < N ? (N - g + VTHREADS - 1) / VTHREADS : 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[q][i] = 0.f;
-  }
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    const int kc = min(KC, K - k0);
-    VisitLoads L[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      const int id = t + j * BLOCK;
-      L[j] = k0 == 0 ? L0[j] : visit_stage1<HAS_ICP, HAS_RGB>(IV, RV, id < kc * 256 ? (k0 + (id >> 8)) * VTHREADS + b * 256 + (id & 255) : N, N);
-    }
-    VisitGathers G[MAXT];
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) G[j] = visit_stage2a<HAS_ICP, HAS_RGB>(IV, RV, P, L[j]);
-#pragma unroll
-    for (int j = 0; j < MAXT; ++j) {
-      const int id = t + j * BLOCK;
-      if (id < kc * 256) {
-        float irow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, grow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float ifound, gfound;
-        visit_stage2b<HAS_ICP, HAS_RGB>(IV, RV, P, sigma, L[j], G[j], irow, ifound, grow, gfound);
-        const int vt = id & 255;
-        if (HAS_ICP) store_row(rows[vt >> 5][0], id >> 8, vt & 31, irow, ifound);
-        if (HAS_RGB) store_row(rows[vt >> 5][1], id >> 8, vt & 31, grow, gfound);
-      }
-    }
-    __syncthreads();
-    if (chain_thread) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) se3_chains(rows[(t >> 8) + 4 * q][term], l, part, min(kc, nk[q] - k0), acc[q]);
-    }
-    __syncthreads();
-  }
-  if (chain_thread) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      // warpReduceSum, reduce.cu:57-95
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) acc[q][i] += __shfl_down(acc[q][i], off, 32);
-      if (l == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int a = se3_member(part, i);
-          if (a >= 0) wsum[term * SE3_ACCS + a][(t >> 8) + 4 * q] = acc[q][i];
-        }
-      }
+    for (int q = 0; q < 3; ++q) {
+      xch[wl][tix][q * 4 + 0][lane] = c[q].x; xch[wl][tix][q * 4 + 1][lane] = c[q].y;
+      xch[wl][tix][q * 4 + 2][lane] = c[q].z; xch[wl][tix][q * 4 + 3][lane] = c[q].w;
     }
   }
   __syncthreads();
-  // blockReduceSum's second stage (reduce.cu:97-117): lanes 0..7 of warp 0 hold the 8 warp sums, the rest exact zeros
-  if (t < 2 * SE3_ACCS * 8) {
-    const int a = t >> 3, w = t & 7, tm = a / SE3_ACCS;
-    const bool present = tm == 0 ? HAS_ICP : HAS_RGB;
-    float v = present ? wsum[a][w] : 0.f;
-    v += __shfl_down(v, 4, 8);
-    v += __shfl_down(v, 2, 8);
-    v += __shfl_down(v, 1, 8);
-    if (present && w == 0) block_partials[(a - ((HAS_ICP || tm == 0) ? 0 : SE3_ACCS)) * 64 + b] = v;
+  if (half == 0) {
+    float* dst = (rgb_wave ? out.partials_rgb : out.partials_icp) + W;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      float r[4] = {c[q].x + xch[wl][tix][q * 4 + 0][lane], c[q].y + xch[wl][tix][q * 4 + 1][lane],
+                    c[q].z + xch[wl][tix][q * 4 + 2][lane], c[q].w + xch[wl][tix][q * 4 + 3][lane]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int off = 32; off >= 4; off >>= 1) r[i] += __shfl_down(r[i], off, 64);
+        const int a = quad_member(q, i, j);
+        if (v == 0 && a >= 0) coherent_store(dst + (size_t)a * VWARPS, r[i]);
+      }
+    }
+    drain_stores();
   }
+  if (!out.tickets) return;
+  // blockReduceSum's second stage (reduce.cu:97-117) by the last of the reference block's workgroups: lanes 0..7 of the
+  // reference's warp 0 hold the 8 warp sums, the other 24 exact zeros => a shuffle tree of width 8
+  __syncthreads();
+  const int rb = (wg * ACC_NW) >> 3;   // reference block of this workgroup's virtual warps
+  if (t == 0) last_s = (take_ticket(out.tickets + rb) == (unsigned)(8 / ACC_NW - 1));
+  __syncthreads();
+  if (!last_s) return;
+  for (int e = t; e < NT * SE3_ACCS * 8; e += BLOCK) {   // whole 8-lane groups (BLOCK is a multiple of 8)
+    const int a = e >> 3, w = e & 7, tm = a / SE3_ACCS;
+    const bool rgb_term = HAS_RGB && (!HAS_ICP || tm == 1);
+    const float* src = (rgb_term ? out.partials_rgb : out.partials_icp) + (size_t)(a - tm * SE3_ACCS) * VWARPS;
+    float x = coherent_load(src + rb * 8 + w);
+    x += __shfl_down(x, 4, 8);
+    x += __shfl_down(x, 2, 8);
+    x += __shfl_down(x, 1, 8);
+    if (w == 0) out.block_partials[a * 64 + rb] = x;
+  }
+  if (t == 0) out.tickets[rb] = 0;
 }
-#ifdef EF_ACCUM_CLOCKS
-extern "C" int ef_debug_accum_stamps(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_accum_stamps), sizeof(unsigned long long) * 2 * VWARPS) == hipSuccess ? 0 : -1;
-}
-#endif
 
 // The rest of the reference tree over the 512 virtual-warp partials of `na` accumulators (acc-major):
 //   blockReduceSum's second stage: lanes 0..7 of warp 0 hold the 8 warp sums, the other 24 lanes hold 0.0f
@@ -1444,68 +1336,48 @@ __device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sum
   efs::SolveInputs in{icp, rgb, rgbOnly, icpWeight, knext, level_changes};
   efs::gauss_newton_update_wave(st, sums, in, S);
 }
-// K6c': the rest of the reference tree + the update, as ONE small launch of 64 workgroups (one per reference block):
-//   each reduces the 8 virtual-warp partials of its block (blockReduceSum's second stage: lanes 0..7 hold the warp
-//   sums, the other 24 lanes of the reference hold 0.0f => shuffle tree of width 8) and hands the block partial over
-//   with write-through stores + a ticket; the LAST workgroup runs reduceSum<<<1,1024>>> (two warp32 trees + one add)
-//   over the 64 block partials and then the Gauss-Newton step on its first wavefront.
-// A single workgroup reading all 512 x 58 warp partials would be bound by one CU's memory pipe (~9 us for 118 KB).
+// K6c': reduceSum<<<1,1024>>> (two warp32 trees + one add over the 64 block partials k_se3_accum leaves) and then the
+// Gauss-Newton step on the first wavefront: ONE workgroup, no first stage, no hand-over.
 constexpr int FINISH_BLOCK = 512;
 struct FinishArgs {
   bool icp, rgb, rgbOnly;
   float icpWeight;
   Intr knext;
   bool level_changes;
-  bool blocks_ready;   // the 64 block partials were left by k_se3_accum_block: one workgroup, no first stage, no hand-over
 };
-__global__ void __launch_bounds__(FINISH_BLOCK) k_se3_finish(TrackState* st, const float* __restrict__ partials_icp,
-                                                             const float* __restrict__ partials_rgb, float* block_partials,
-                                                             const FinishArgs A) {
+// sums_s[term * SE3_ACCS + acc] = sum of the 64 block partials; call with the whole workgroup (BLOCK threads)
+template <int BLOCK>
+__device__ __forceinline__ void block_partials_tree(const float* __restrict__ block_partials, bool icp, bool rgb, float* sums_s) {
+  const int t = threadIdx.x;
+  const int na = (icp ? SE3_ACCS : 0) + (rgb ? SE3_ACCS : 0);
+  constexpr int PASSES = (2 * SE3_ACCS * 64 + BLOCK - 1) / BLOCK;
+  float v[PASSES];
+#pragma unroll
+  for (int q = 0; q < PASSES; ++q) {
+    const int idx = t + q * BLOCK;
+    v[q] = idx < na * 64 ? block_partials[idx] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < PASSES; ++q) {
+    const int idx = t + q * BLOCK;
+    float x = v[q];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, 32);
+    const float w1 = __shfl(x, 32, 64);
+    if (idx < na * 64 && (idx & 63) == 0) sums_s[(icp ? 0 : SE3_ACCS) + (idx >> 6)] = x + w1;
+  }
+}
+__global__ void __launch_bounds__(FINISH_BLOCK) k_se3_finish(TrackState* st, const float* __restrict__ block_partials, const FinishArgs A) {
   __shared__ efs::SolveScratch S;
   __shared__ float sums_s[2 * SE3_ACCS];
-  __shared__ int last_s;
-  const int t = threadIdx.x, b = blockIdx.x;
+  const int t = threadIdx.x;
   efs::SolvePrefetch PF{};
   if (t < 64) PF = efs::solve_prefetch(st);   // in flight while the partial sums are reduced
   if (st->rgb_broken) {  // rgbOnly "break": only the bookkeeping of the update step runs
-    if (b == 0 && t < 64) solve_step_wave(st, nullptr, true, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S, PF);
+    if (t < 64) solve_step_wave(st, nullptr, true, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S, PF);
     return;
   }
-  const int na = (A.icp ? SE3_ACCS : 0) + (A.rgb ? SE3_ACCS : 0);
-  if (!A.blocks_ready) {
-  if (t < na * 8) {   // na * 8 <= 464: whole 8-lane groups
-    const int a = t >> 3, w = t & 7;
-    const float* src = (A.icp && a < SE3_ACCS) ? partials_icp + (size_t)a * VWARPS : partials_rgb + (size_t)(a - (A.icp ? SE3_ACCS : 0)) * VWARPS;
-    float v = src[b * 8 + w];
-    v += __shfl_down(v, 4, 8);
-    v += __shfl_down(v, 2, 8);
-    v += __shfl_down(v, 1, 8);
-    if (w == 0) { coherent_store(block_partials + a * 64 + b, v); drain_stores(); }
-  }
-  __syncthreads();
-  if (t == 0) last_s = (take_ticket(&st->acc_ticket_final) == 63u);
-  __syncthreads();
-  if (!last_s) return;
-  }
-  {
-    constexpr int PASSES = (2 * SE3_ACCS * 64 + FINISH_BLOCK - 1) / FINISH_BLOCK;
-    float v[PASSES];
-#pragma unroll
-    for (int q = 0; q < PASSES; ++q) {
-      const int idx = t + q * FINISH_BLOCK;
-      v[q] = idx < na * 64 ? (A.blocks_ready ? block_partials[idx] : coherent_load(block_partials + idx)) : 0.f;
-    }
-#pragma unroll
-    for (int q = 0; q < PASSES; ++q) {
-      const int idx = t + q * FINISH_BLOCK;
-      float x = v[q];
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, 32);
-      const float w1 = __shfl(x, 32, 64);
-      if (idx < na * 64 && (idx & 63) == 0) sums_s[(A.icp ? 0 : SE3_ACCS) + (idx >> 6)] = x + w1;
-    }
-  }
-  if (t == 0 && !A.blocks_ready) st->acc_ticket_final = 0;
+  block_partials_tree<FINISH_BLOCK>(block_partials, A.icp, A.rgb, sums_s);
   __syncthreads();
   if (t < 64) solve_step_wave(st, sums_s, false, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S, PF);
 }
@@ -1818,27 +1690,15 @@ void project_to_point_cloud(const float* depth, int cols, int rows, Intr k, floa
 }
 
 namespace {
-constexpr int ACC_BLOCK_BIG = 640, ACC_BLOCK_SMALL = 256, ACC_KC = 19;
-// one normal-equation accumulation launch (either tier)
+// one normal-equation accumulation launch (either tier); start / stop: optional events that receive the kernel's own begin / end
+// timestamps (hipExtLaunchKernelGGL: what rocprofv3 --kernel-trace reports as the dispatch's duration)
 template <bool HAS_ICP, bool HAS_RGB, bool PACKED>
-void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in_, int N, float* partials_icp, float* partials_rgb, hipStream_t s) {
-  static const int swz = getenv("EF_ACCUM_XCD") ? atoi(getenv("EF_ACCUM_XCD")) : 1;   // developer knob: 0 = linear block -> virtual warp
-  Se3Inputs in = in_;
-  in.xcd_swizzle = swz != 0;
-  // developer knob: EF_ACCUM_BLOCK=256 runs level 0 with 4-wave workgroups too (all 512 resident at once, three
-  // pixel-visits per thread) instead of 10-wave ones (one visit per thread, two dispatch rounds): same end-to-end time
-  static const int big = getenv("EF_ACCUM_BLOCK") ? atoi(getenv("EF_ACCUM_BLOCK")) : ACC_BLOCK_BIG;
-  // developer knob: EF_ACCUM_NW=2 runs level 0 as 256 ten-wave workgroups of two virtual warps each (one dispatch round)
-  static const int nw = getenv("EF_ACCUM_NW") ? atoi(getenv("EF_ACCUM_NW")) : 1;
-  if (N > 8 * VTHREADS && big != 256 && nw == 2)
-    hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_BIG, ACC_KC, 2, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS / 2), dim3(ACC_BLOCK_BIG), 0, s, IV, RV, in,
-                       partials_icp, partials_rgb);
-  else if (N > 8 * VTHREADS && big != 256)
-    hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_BIG, ACC_KC, 1, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(ACC_BLOCK_BIG), 0, s, IV, RV, in,
-                       partials_icp, partials_rgb);
-  else
-    hipLaunchKernelGGL((k_se3_accum<ACC_BLOCK_SMALL, ACC_KC, 1, HAS_ICP, HAS_RGB, PACKED>), dim3(VWARPS), dim3(ACC_BLOCK_SMALL), 0, s, IV, RV, in,
-                       partials_icp, partials_rgb);
+void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int N, const Se3Out& out, hipStream_t s, hipEvent_t start = nullptr,
+                  hipEvent_t stop = nullptr) {
+  constexpr int BLOCK = 64 * 2 * ACC_NW * ((HAS_ICP && HAS_RGB) ? 2 : 1);
+  const dim3 grid(VWARPS / ACC_NW), block(BLOCK);
+  if (N > 8 * VTHREADS) hipExtLaunchKernelGGL((k_se3_accum<5, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
+  else hipExtLaunchKernelGGL((k_se3_accum<2, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
 }
 }  // namespace
 
@@ -1853,7 +1713,7 @@ void icp_step_op(const IcpArgs& a, const float* vmap_curr, const float* nmap_cur
   (void)hipMemcpyAsync(pose, h, sizeof(h), hipMemcpyHostToDevice, s);
   (void)hipStreamSynchronize(s);  // h is a stack buffer
   Se3Inputs in{pose, pose + 9, pose + 12, pose + 21, nullptr, nullptr, 0.f, false};
-  launch_accum<true, false, false>(V, RV, in, cols * rows, scratch, scratch, s);
+  launch_accum<true, false, false>(V, RV, in, cols * rows, Se3Out{scratch, scratch, nullptr, nullptr}, s);
   hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SE3_ACCS, out29_dev);
 }
 void rgb_residual_op(const RgbResidualArgs& a, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
@@ -1877,7 +1737,7 @@ void rgb_step_op(const void* corres, float sigma, const float* cloud, float fx, 
   IcpView IV{};
   RgbView V{corres, nullptr, cloud, dIdx, dIdy, cols, rows, Intr{fx, fy, 0, 0}, sobelScale};
   Se3Inputs in{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sigma, false};
-  launch_accum<false, true, false>(IV, V, in, cols * rows, scratch, scratch, s);
+  launch_accum<false, true, false>(IV, V, in, cols * rows, Se3Out{scratch, scratch, nullptr, nullptr}, s);
   hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SE3_ACCS, out29_dev);
 }
 void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* nextImage, int cols, int rows, float* scratch, float* out11_dev,
@@ -2059,21 +1919,14 @@ void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, cons
   Se3Inputs in{st->Rcurr, st->tcurr, st->Rprev_inv, st->tprev, &st->rgb_slots[0][0], &st->rgb_broken, 0.f, tp.rgbOnly};
   float* prgb = p.partials + SE3_ACCS * VWARPS;
   float* pblk = p.partials + 2 * SE3_ACCS * VWARPS;
-  // developer knob: EF_ACCUM_BLOCKWISE=1 runs the small levels as 64 reference-block workgroups + a single-workgroup finishing
-  // kernel (bit-identical; measured 2 % slower end to end than 512 virtual-warp workgroups + the two-stage finish)
-  static const int blockwise_knob = getenv("EF_ACCUM_BLOCKWISE") ? atoi(getenv("EF_ACCUM_BLOCKWISE")) : 0;
-  const bool blockwise = blockwise_knob != 0 && N <= 8 * VTHREADS;
-  if (sample) (void)hipEventRecord(probe->start[probe->used], s);
-  if (blockwise) {
-    if (icp && rgb) hipLaunchKernelGGL((k_se3_accum_block<ACCB_KC, true, true>), dim3(64), dim3(ACCB_BLOCK), 0, s, IV, GV, in, pblk);
-    else if (icp) hipLaunchKernelGGL((k_se3_accum_block<ACCB_KC, true, false>), dim3(64), dim3(ACCB_BLOCK), 0, s, IV, GV, in, pblk);
-    else hipLaunchKernelGGL((k_se3_accum_block<ACCB_KC, false, true>), dim3(64), dim3(ACCB_BLOCK), 0, s, IV, GV, in, pblk);
-  } else if (icp && rgb) launch_accum<true, true, true>(IV, GV, in, N, p.partials, prgb, s);
-  else if (icp) launch_accum<true, false, true>(IV, GV, in, N, p.partials, prgb, s);
-  else launch_accum<false, true, true>(IV, GV, in, N, p.partials, prgb, s);
-  if (sample) (void)hipEventRecord(probe->stop[probe->used++], s);
-  const FinishArgs fa{icp, rgb, tp.rgbOnly, tp.icpWeight, knext, level_changes, blockwise};
-  hipLaunchKernelGGL(k_se3_finish, dim3(blockwise ? 1 : 64), dim3(FINISH_BLOCK), 0, s, st, (const float*)p.partials, (const float*)prgb, pblk, fa);
+  const Se3Out out{p.partials, prgb, pblk, st->acc_tickets};
+  hipEvent_t e0 = sample ? probe->start[probe->used] : nullptr, e1 = sample ? probe->stop[probe->used] : nullptr;
+  if (sample) probe->used++;
+  if (icp && rgb) launch_accum<true, true, true>(IV, GV, in, N, out, s, e0, e1);
+  else if (icp) launch_accum<true, false, true>(IV, GV, in, N, out, s, e0, e1);
+  else launch_accum<false, true, true>(IV, GV, in, N, out, s, e0, e1);
+  const FinishArgs fa{icp, rgb, tp.rgbOnly, tp.icpWeight, knext, level_changes};
+  hipLaunchKernelGGL(k_se3_finish, dim3(1), dim3(FINISH_BLOCK), 0, s, st, (const float*)pblk, fa);
 }
 }  // namespace
 

@@ -30,7 +30,7 @@ extern "C" {
 #define EF_EHIP (-2)     /* HIP runtime error (message has the hipError string) */
 #define EF_ENOMEM (-3)
 #define EF_ESTATE (-4)   /* call not valid in the current state */
-#define EF_ECAPACITY (-5) /* surfel capacity exceeded: the map was clamped to max_surfels (reported by ef_synchronize / ef_map_count) */
+#define EF_ECAPACITY (-5) /* surfel capacity exceeded: the map was clamped to max_surfels (a warning: ef_synchronize reports it once and clears it; the clamped map stays readable) */
 
 typedef struct ef_ctx ef_ctx;
 
@@ -75,11 +75,11 @@ int ef_process_frame(ef_ctx* ctx, const uint8_t* rgb, const uint16_t* depth, int
                      float weight_multiplier, const double* in_T_wc16);
 int ef_process_frame_dev(ef_ctx* ctx, const uint8_t* rgb_dev, const uint16_t* depth_dev, int64_t timestamp,
                          float weight_multiplier, const double* in_T_wc16);
-/* Input-stage overlap (default off; EF_OVERLAP=1 in the environment or this setter turns it on): the part of a frame that
+/* Input-stage overlap (default off; on = 1, or 2 to start the copy-in and the bilateral filter already during the previous tracker): the part of a frame that
  * needs only the new images (copy-in, bilateral filter + metric depth, frame-side pyramids) is enqueued on a second
  * internal stream and runs while the previous frame is still being fused.  Results are identical either way. */
 int ef_set_input_overlap(ef_ctx* ctx, int on);
-/* hipGraph replay of the tracker (default off; EF_GRAPH=1): the ~70 kernel launches of one getIncrementalTransformation
+/* hipGraph replay of the tracker (default off): the ~70 kernel launches of one getIncrementalTransformation
  * (RGBDOdometry.cpp:259-571) are captured once per pyramid parity and replayed with one hipGraphLaunch per frame.
  * Identical results; it only trims host-side launch work (BASELINE.json configs[4]). */
 int ef_set_graph_replay(ef_ctx* ctx, int on);
@@ -104,13 +104,16 @@ typedef struct ef_local_loop {
   int n_constraints;        /* surface constraints sampled (0 unless gates_ok) */
   int applied;              /* the solver accepted: pose replaced, graph (if any) applied by this frame's clean */
   int graph_nodes;
+  int graph_capacity;       /* nodes the solver's graph_out has room for (1023 = GlobalModel::MAX_NODES - 1); set before the solver is called */
+  int reserved_;
   float stats[6];           /* modelToModel: lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count */
   double cov_diag[6];       /* diagonal of getCovariance() up to and including the first entry above covThresh */
   double T_wc_curr[16];     /* pose after frame-to-model tracking, row-major */
   double T_wc_est[16];      /* pose proposed by the model-to-model registration */
 } ef_local_loop;
 /* constraints: n rows of 8 doubles {vert_w_curr xyz (source), vert_w_est xyz (target), time the inactive surface was last seen,
- * pin (1 while no deformation has been applied yet, ElasticFusion.cpp:507-508)}.  graph_out has room for 1023 x 16 floats.
+ * pin (1 while no deformation has been applied yet, ElasticFusion.cpp:507-508)}.  graph_out has room for info->graph_capacity x 16 floats
+ * (1023): a solver must not write more; a *nodes_out beyond it makes the frame fail with EF_EINVAL.
  * Return non-zero to accept (Deformation::constrain returning true); called on the thread inside ef_process_frame. */
 typedef int (*ef_loop_solver)(void* user, const ef_local_loop* info, const double* constraints, int n, float* graph_out, int* nodes_out);
 int ef_set_loop_solver(ef_ctx* ctx, ef_loop_solver fn, void* user);   /* NULL: gates and constraints are still evaluated */
@@ -279,14 +282,14 @@ typedef struct ef_timing { const char* name; float ms; } ef_timing;
 int ef_enable_timing(ef_ctx* ctx, int on);
 int ef_get_timings(ef_ctx* ctx, ef_timing* out, int max, int* n);
 
-/* HIP-event sampling of the dominant kernel (the level-0 icpStep+rgbStep normal-equation kernel) on the
- * context's stream, every `every_n_frames`-th frame (0 = off; resets the samples).  ef_get_kernel_timing
- * synchronises and returns the average launch duration, the number of sampled launches and the
- * algorithmic bytes one launch must move -- bench.py's roofline leg. */
-/* avg_us = raw_avg_us - empty_pair_us: an event pair with nothing between the two records already spans
- * empty_pair_us on the stream (measured when sampling is switched on); the difference is the kernel. */
+/* Sampling of the dominant kernel (the level-0 icpStep+rgbStep normal-equation kernel) every `every_n_frames`-th frame (0 = off;
+ * resets the samples): the sampled launches go through hipExtLaunchKernelGGL with a start and a stop event, which receive the
+ * DISPATCH's own begin / end timestamps -- the duration rocprofv3 --kernel-trace reports for the same launch, no marker packets
+ * in between.  ef_get_kernel_timing synchronises and returns the average launch duration, the number of sampled launches and the
+ * algorithmic bytes one launch must move (bytes_per_launch_survey: SURVEY.md 8d's narrower numerator) --
+ * bench.py's roofline leg. */
 typedef struct ef_kernel_time {
-  const char* name; float avg_us; int launches; double bytes_per_launch; float raw_avg_us; float empty_pair_us;
+  const char* name; float avg_us; int launches; double bytes_per_launch; double bytes_per_launch_survey;
 } ef_kernel_time;
 int ef_kernel_timing(ef_ctx* ctx, int every_n_frames);
 int ef_get_kernel_timing(ef_ctx* ctx, ef_kernel_time* out);

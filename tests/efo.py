@@ -133,21 +133,46 @@ class backend:
         _BACKEND = None
 
 
+def _load(path):
+    so = C.CDLL(path)
+    so.efo_odom_create.restype = P
+    so.efo_odom_buffer.restype = P
+    so.efo_fusion_create.restype = P
+    so.efo_fusion_buffer.restype = P
+    so.efo_fusion_odometry.restype = P
+    so.efo_se3_log_norm.restype = C.c_double
+    so.efo_expf_spec.restype = c_f
+    so.efo_expf_spec.argtypes = [c_f]
+    return so
+
+
 def lib():
     global _LIB
     if _BACKEND is not None:
         return _BACKEND
     if _LIB is None:
-        _LIB = C.CDLL(build())
-        _LIB.efo_odom_create.restype = P
-        _LIB.efo_odom_buffer.restype = P
-        _LIB.efo_fusion_create.restype = P
-        _LIB.efo_fusion_buffer.restype = P
-        _LIB.efo_fusion_odometry.restype = P
-        _LIB.efo_se3_log_norm.restype = C.c_double
-        _LIB.efo_expf_spec.restype = c_f
-        _LIB.efo_expf_spec.argtypes = [c_f]
+        _LIB = _load(build())
     return _LIB
+
+
+class whole_library:
+    """with efo.whole_library("nofma"): EVERYTHING of this module (Fusion objects included) runs on the oracle built with
+    -DEFO_NO_FMA -- the arithmetic the reference's own sources compute when compiled without contraction (oracle/README.md).
+    Objects must be created and destroyed inside the block."""
+
+    def __init__(self, which):
+        assert which == "nofma", which
+
+    def __enter__(self):
+        global _LIB
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libefo_oracle_nofma.so"])
+        self._saved = lib()
+        _LIB = _load(NOFMA_SO)
+        return self
+
+    def __exit__(self, *a):
+        global _LIB
+        _LIB = self._saved
 
 
 def covariance(lastA):

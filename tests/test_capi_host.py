@@ -65,6 +65,22 @@ def test_product_sources_never_reference_the_oracle():
     assert not bad, bad
 
 
+def test_shipped_libraries_read_no_environment_variables():
+    """No developer knob reaches the product through the environment: libefusion_hip.so and libefusion.so do not import getenv
+    (or secure_getenv), so EF_* variables cannot change which kernel a drop-in library runs."""
+    import subprocess
+    from elasticfusion_amd import api, build
+    build.build()
+    for so in (api.LIB_PATH, os.path.join(os.path.dirname(api.LIB_PATH), "libefusion.so")):
+        syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+        assert not re.search(r"\bU (secure_)?getenv\b", syms), so
+    for base in ("elasticfusion_amd/csrc", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".hip", ".hpp", ".h", ".cpp")):
+                    assert "getenv" not in open(os.path.join(dp, f), errors="ignore").read(), f
+
+
 def test_cpp_shim_library_and_replay_tool_exist_and_fail_loudly(tmp_path):
     """libefusion.so (class ElasticFusion of include/ElasticFusion.h) and the headless replay front-end are built by
     build(); without a GPU the front-end must exit with an error, not fall back."""

@@ -391,7 +391,8 @@ def test_two_contexts_interleaved(hip):
 
 def test_capacity_overflow_is_reported(hip):
     """max_surfels = width * height holds the first frame exactly; the surfels later frames add do not fit: the map is clamped,
-    nothing is written out of bounds, and the synchronising getters say so (EF_ECAPACITY) instead of staying silent."""
+    nothing is written out of bounds, and ef_synchronize says so ONCE (EF_ECAPACITY is a warning: it is cleared when read, and the
+    clamped map stays readable — count, download, PLY dump — as the reference's overflowing buffer would)."""
     from elasticfusion_amd import synth
     W, H = 320, 240
     sq = synth.Sequence(seed=0xEF0003, width=W, height=H)
@@ -404,10 +405,63 @@ def test_capacity_overflow_is_reported(hip):
         rgb, depth, _ = sq.frame(20 * k)
         ef.processFrame(rgb, depth, k)
     with pytest.raises(hip.EFError, match="capacity"):
-        ef.lastCount()
+        ef.synchronize()
+    ef.synchronize()                                                   # reported once, then cleared
+    assert ef.lastCount() == W * H                                     # clamped, readable
+    m = ef.downloadMap()
+    assert m.shape == (W * H, 12) and np.isfinite(m[:, :3]).all()
+    rgb, depth, _ = sq.frame(80)
+    ef.processFrame(rgb, depth, 4)                                     # overflows again: reported again
     with pytest.raises(hip.EFError, match="capacity"):
         ef.synchronize()
     ef.close()
+
+
+def test_trajectory_log_grows_without_bound(hip):
+    """t_T_wc has no capacity in the reference; the device-resident log starts at 1024 poses and doubles on demand."""
+    from elasticfusion_amd import synth
+    W, H = 100, 76
+    sq = synth.Sequence(seed=0xEF0003, width=W, height=H)
+    ef = hip.ElasticFusion(width=W, height=H, fx=sq.fx, fy=sq.fy, cx=sq.cx, cy=sq.cy, maxSurfels=1 << 16)
+    rgb, depth, _ = sq.frame(0)
+    n = 2100
+    for k in range(n):
+        T = np.eye(4)
+        T[0, 3] = 1e-4 * k
+        ef.processFrame(rgb, depth, k * 1000, in_T_wc=None if k == 0 else T)
+    Ts, ts = ef.trajectory()
+    assert len(Ts) == n and np.array_equal(ts, np.arange(n) * 1000)
+    assert np.allclose(Ts[:, 0, 3], 1e-4 * np.arange(n), atol=1e-12) and np.array_equal(Ts[1500][:3, :3], np.eye(3))
+    ef.close()
+
+
+def test_context_used_from_another_thread(hip, seq):
+    """Every entry point binds the context's device itself (ef_config.device), so a context may be driven by a thread that never
+    called hipSetDevice; the results are those of the creating thread."""
+    import threading
+    ef = hip.ElasticFusion()
+    out = {}
+
+    def work():
+        try:
+            for k in range(3):
+                rgb, depth, _ = seq.frame(k)
+                ef.processFrame(rgb, depth, k)
+            out["T"] = ef.get_T_wc()
+            out["n"] = ef.lastCount()
+        except Exception as e:   # noqa: BLE001
+            out["err"] = e
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert "err" not in out, out.get("err")
+    ref = hip.ElasticFusion()
+    for k in range(3):
+        rgb, depth, _ = seq.frame(k)
+        ref.processFrame(rgb, depth, k)
+    assert np.array_equal(out["T"], ref.get_T_wc()) and out["n"] == ref.lastCount()
+    ef.close()
+    ref.close()
 
 
 def test_api_errors(hip):
