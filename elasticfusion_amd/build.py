@@ -36,7 +36,7 @@ def needs_build() -> bool:
     t = os.path.getmtime(LIB)
     root = os.path.dirname(HERE)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".o")]
-    deps += [os.path.join(root, "include", "ef_hip.h"), os.path.join(root, "include", "ElasticFusion.h"), os.path.join(root, "include", "efusion_klg.hpp"),
+    deps += [os.path.join(root, "include", "ef_hip.h"), os.path.join(root, "include", "ElasticFusion.h"), os.path.join(root, "include", "efusion_klg.hpp"), os.path.join(root, "include", "efusion_jpeg.hpp"),
              os.path.join(root, "tools", "efusion_replay.cpp"), __file__]
     replay = os.path.join(HERE, "efusion_replay")
     return not os.path.exists(replay) or any(os.path.getmtime(d) > min(t, os.path.getmtime(replay)) for d in deps)
@@ -68,14 +68,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"link failed:\n{r.stdout}")
     # libefusion.so: host-only C++ (compiled by hipcc for the shared __host__ __device__ linear-algebra header)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", SHIM_LIB,
-           os.path.join(CSRC, "efusion_shim.hip"), "-L" + HERE, "-lefusion_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+           os.path.join(CSRC, "efusion_shim.hip"), "-L" + HERE, "-lefusion_hip", "-lz", "-ldl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"libefusion.so build failed:\n{r.stdout}")
     # headless replay front-end (plain g++: it only sees include/ElasticFusion.h)
     replay = os.path.join(HERE, "efusion_replay")
     cmd = ["g++", "-O2", "-std=c++17", os.path.join(os.path.dirname(HERE), "tools", "efusion_replay.cpp"), "-o", replay, "-L" + HERE,
-           "-lefusion", "-lefusion_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link," + HERE]
+           "-lefusion", "-lefusion_hip", "-lz", "-ldl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link," + HERE]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"efusion_replay build failed:\n{r.stdout}")

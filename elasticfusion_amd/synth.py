@@ -128,10 +128,12 @@ class Sequence:
         return rgb, depth, self.pose(k)
 
 
-def write_klg(path: str, frames, timestamps=None, compress_depth: bool = False) -> None:
+def write_klg(path: str, frames, timestamps=None, compress_depth: bool = False, jpeg_quality: int | None = None) -> None:
     """Writes frames [(rgb HxWx3 u8, depth HxW u16, ...)] as a .klg log (layout of Tools/RawLogReader.cpp:29,63-109):
     int32 numFrames, then per frame int64 timestamp, int32 depthSize, int32 imageSize, depth bytes (raw little-endian
-    u16, or one zlib stream when ``compress_depth``), image bytes (raw RGB8: imageSize == 3*W*H means "not JPEG")."""
+    u16, or one zlib stream when ``compress_depth``), image bytes (raw RGB8: imageSize == 3*W*H means "not JPEG"; with
+    ``jpeg_quality`` one baseline JPEG image per frame, as the reference's recorder writes them — needs Pillow)."""
+    import io
     import struct
     import zlib
     with open(path, "wb") as f:
@@ -142,6 +144,13 @@ def write_klg(path: str, frames, timestamps=None, compress_depth: bool = False) 
             if compress_depth:
                 d = zlib.compress(d)
             ts = int(timestamps[k]) if timestamps is not None else k * 33333
-            f.write(struct.pack("<qii", ts, len(d), rgb.nbytes))
+            img = rgb.tobytes()
+            if jpeg_quality is not None:
+                from PIL import Image
+                buf = io.BytesIO()
+                Image.fromarray(rgb, "RGB").save(buf, format="JPEG", quality=int(jpeg_quality))
+                img = buf.getvalue()
+                assert len(img) != rgb.nbytes
+            f.write(struct.pack("<qii", ts, len(d), len(img)))
             f.write(d)
-            f.write(rgb.tobytes())
+            f.write(img)

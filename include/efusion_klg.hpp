@@ -1,7 +1,8 @@
 // .klg log reader of the headless front-end — the file format and the frame-iteration protocol of the reference's
 // Tools/RawLogReader.cpp:22-109 (int32 numFrames; per frame int64 timestamp, int32 depthSize, int32 imageSize, depth bytes raw u16
-// or zlib, colour bytes raw RGB8; JPEG-compressed colour is rejected: libjpeg is not available in this image).  Header-only,
-// written from scratch; libefusion.so also exports it as a C API (efk_*, bottom of this file) for non-C++ hosts and tests.
+// or zlib, colour bytes raw RGB8 or one JPEG image — decoded through the system libjpeg, loaded at the first such frame, with the
+// R/B exchange of the reference's JPEGLoader.h:79-84, see efusion_jpeg.hpp).  Header-only, written from scratch; libefusion.so also
+// exports it as a C API (efk_*, bottom of this file) for non-C++ hosts and tests.
 //
 // Protocol, as the reference's: `while (r.hasMore()) { r.getNext(); use r.rgb / r.depth / r.timestamp; }`.
 // hasMore() is `currentFrame + 1 < numFrames` (RawLogReader.cpp:127-129): the reference's run loop therefore never delivers the
@@ -12,11 +13,14 @@
 #include <zlib.h>
 
 #include <cstdint>
+#include <memory>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include "efusion_jpeg.hpp"
 
 namespace efusion {
 
@@ -60,7 +64,10 @@ class KlgReader {
     }
     if (imageSize == numPixels * 3) std::memcpy(rgb.data(), imageRead.data(), rgb.size());
     else if (imageSize == 0) std::memset(rgb.data(), 0, rgb.size());
-    else throw std::runtime_error("JPEG-compressed colour frames are not supported in this build (no libjpeg)");
+    else {   // RawLogReader.cpp:94-96: anything else is a JPEG image
+      if (!jpeg) jpeg.reset(new JpegDecoder());
+      jpeg->readData(imageRead.data(), (size_t)imageSize, rgb.data(), rgb.size());
+    }
     if (flipColors)
       for (size_t i = 0; i + 2 < rgb.size(); i += 3) std::swap(rgb[i], rgb[i + 2]);
     ++currentFrame;
@@ -71,6 +78,7 @@ class KlgReader {
   int32_t numFrames = 0;
   int numPixels;
   std::vector<uint8_t> depthRead, imageRead;
+  std::unique_ptr<JpegDecoder> jpeg;   // created at the first JPEG-compressed frame
 };
 
 }  // namespace efusion

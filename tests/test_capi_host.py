@@ -158,3 +158,45 @@ int main(void) {
                            "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok "), (out.returncode, out.stdout)
+
+
+def test_klg_reader_decodes_jpeg_colour(tmp_path):
+    """The product's .klg reader on a JPEG-compressed log, without the reference at hand (the GPU box has no /root/reference):
+    libjpeg is loaded at run time; the decoded frame is the independent decoder's (Pillow) with R and B exchanged."""
+    pytest = __import__("pytest")
+    pytest.importorskip("PIL")
+    import ctypes as C
+    import io
+    import numpy as np
+    from PIL import Image
+    from elasticfusion_amd import api, build, synth
+    build.build()
+    so = C.CDLL(os.path.join(os.path.dirname(api.LIB_PATH), "libefusion.so"))
+    so.efk_open.restype = C.c_void_p
+    so.efk_last_error.restype = C.c_char_p
+    W, H = 160, 120
+    seq = synth.Sequence(seed=0xEF0007, width=W, height=H)
+    frames = [seq.frame(k) for k in range(3)]
+    log = str(tmp_path / "j.klg")
+    synth.write_klg(log, frames, jpeg_quality=85)
+    h = so.efk_open(log.encode(), W, H, 1, 0)
+    assert h, so.efk_last_error()
+    for k in range(3):
+        ts = C.c_int64(0)
+        depth = np.zeros((H, W), np.uint16)
+        rgb = np.zeros((H, W, 3), np.uint8)
+        assert so.efk_next(C.c_void_p(h), C.byref(ts), depth.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p)) == 1, so.efk_last_error()
+        buf = io.BytesIO()
+        Image.fromarray(frames[k][0], "RGB").save(buf, format="JPEG", quality=85)
+        pil = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+        assert np.array_equal(depth, frames[k][1])
+        assert np.abs(rgb.astype(int) - pil[..., ::-1].astype(int)).max() <= 2, k
+    so.efk_close(C.c_void_p(h))
+    # a corrupt JPEG frame is an error, not a crash
+    bad = bytearray(open(log, "rb").read())
+    bad[4 + 16 + W * H * 2 + 200:4 + 16 + W * H * 2 + 260] = b"\x00" * 60
+    bad[4 + 16 + W * H * 2:4 + 16 + W * H * 2 + 2] = b"\x12\x34"        # no SOI marker
+    open(str(tmp_path / "bad.klg"), "wb").write(bytes(bad))
+    h = so.efk_open(str(tmp_path / "bad.klg").encode(), W, H, 1, 0)
+    assert so.efk_next(C.c_void_p(h), None, None, None) == 0 and b"JPEG" in so.efk_last_error()
+    so.efk_close(C.c_void_p(h))

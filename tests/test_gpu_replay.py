@@ -63,3 +63,38 @@ def test_klg_replay_with_close_loops(tmp_path, seq):
     assert int(words[words.index("surfels") + 1]) == o.map_count(), r.stdout
     traj = np.loadtxt(log + ".freiburg")
     assert np.abs(traj[-1, 1:4] - o.pose()[:3, 3]).max() <= 1e-6
+
+
+def test_jpeg_klg_replay(tmp_path, seq):
+    """BASELINE.json configs[1] is a replay of a recorded log, whose colour frames are JPEG images: the front-end decodes them through
+    the system libjpeg (include/efusion_jpeg.hpp; the decoder is pinned against the reference's own reader in tests/test_klg_vs_reference.py)
+    and the run equals the oracle's on the same decoded frames."""
+    pytest.importorskip("PIL")
+    import ctypes as C
+    from elasticfusion_amd import api, synth
+    n = 5
+    frames = [seq.frame(k) for k in range(n)]
+    log = str(tmp_path / "jpeg.klg")
+    synth.write_klg(log, frames, compress_depth=True, jpeg_quality=92)
+    so = C.CDLL(os.path.join(os.path.dirname(api.LIB_PATH), "libefusion.so"))
+    so.efk_open.restype = C.c_void_p
+    h = C.c_void_p(so.efk_open(log.encode(), 640, 480, 0, 0))
+    o = efo.Fusion()
+    k = 0
+    while so.efk_has_more(h):
+        ts = C.c_int64(0)
+        depth = np.zeros((480, 640), np.uint16)
+        rgb = np.zeros((480, 640, 3), np.uint8)
+        assert so.efk_next(h, C.byref(ts), depth.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p)) == 1
+        assert np.array_equal(depth, frames[k][1]) and not np.array_equal(rgb, frames[k][0])
+        o.process_frame(rgb, depth, ts.value)
+        k += 1
+    so.efk_close(h)
+    assert k == n - 1
+    exe = os.path.join(os.path.dirname(api.LIB_PATH), "efusion_replay")
+    r = subprocess.run([exe, "-l", log], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    words = r.stdout.split()
+    assert int(words[1]) == n - 1 and int(words[words.index("surfels") + 1]) == o.map_count(), r.stdout
+    traj = np.loadtxt(log + ".freiburg")
+    assert np.abs(traj[-1, 1:4] - o.pose()[:3, 3]).max() <= 1e-6

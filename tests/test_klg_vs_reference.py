@@ -72,6 +72,38 @@ def test_reader_matches_the_compiled_reference(libs, tmp_path, compress, flip):
     assert len(got_all) == 5 and got_all[-1][0] == stamps[-1] and np.array_equal(got_all[-1][1], frames[-1][1])
 
 
+@pytest.mark.parametrize("flip", [False, True])
+def test_jpeg_colour_frames_match_the_compiled_reference(libs, tmp_path, flip):
+    """JPEG-compressed colour (RawLogReader.cpp:94-96 -> JPEGLoader.h:40-90): both readers hand the same stream to the same libjpeg
+    runtime, so the bytes must be identical — including the R/B exchange JPEGLoader applies to what the decoder returns (quirk Q5) —
+    and an independent decoder (Pillow's) confirms which way round that is."""
+    pytest.importorskip("PIL")
+    import io
+    from PIL import Image
+    from elasticfusion_amd import synth
+    mine, ref = libs
+    seq = synth.Sequence(seed=0xEF0006, width=W, height=H)
+    frames = [seq.frame(k) for k in range(4)]
+    log = str(tmp_path / "j.klg")
+    synth.write_klg(log, frames, compress_depth=True, jpeg_quality=90)
+    n_ref, got_ref = read_all(ref, "efrk_", C.c_void_p(ref.efrk_open(log.encode(), W, H, int(flip))))
+    h = mine.efk_open(log.encode(), W, H, 0, int(flip))
+    assert h, mine.efk_last_error()
+    n, got = read_all(mine, "efk_", C.c_void_p(h))
+    assert n == n_ref == 4 and len(got) == len(got_ref) == 3
+    for k, ((ta, da, ca), (tb, db, cb)) in enumerate(zip(got, got_ref)):
+        assert ta == tb and np.array_equal(da, db) and np.array_equal(da, frames[k][1])
+        assert np.array_equal(ca, cb), k
+        buf = io.BytesIO()
+        Image.fromarray(frames[k][0], "RGB").save(buf, format="JPEG", quality=90)
+        pil = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+        want = pil if flip else pil[..., ::-1]        # JPEGLoader stores {t2, t1, t0}; flipColors swaps back
+        assert np.abs(ca.astype(int) - want.astype(int)).max() <= 2, k     # two libjpeg builds may round the IDCT differently by one
+        src = frames[k][0].astype(int)                # lossy, but unmistakably the source with (without) its channels exchanged
+        d_swapped, d_plain = np.abs(ca.astype(int) - src[..., ::-1]).mean(), np.abs(ca.astype(int) - src).mean()
+        assert (d_plain < d_swapped) if flip else (d_swapped < d_plain), (d_swapped, d_plain)
+
+
 def test_reader_errors(libs, tmp_path):
     mine, _ = libs
     assert mine.efk_open(str(tmp_path / "missing.klg").encode(), W, H, 0, 0) is None

@@ -1,7 +1,7 @@
 // Headless replay front-end: what MainController::run() does around ElasticFusion::processFrame
 // (MainController.cpp:201-254) with the GUI removed.  Reads a .klg log (format of Tools/RawLogReader.cpp:29,63-109:
 // int32 numFrames; per frame int64 timestamp, int32 depthSize, int32 imageSize, depth bytes (raw u16 or zlib),
-// image bytes (raw RGB8; JPEG frames are rejected — libjpeg is not available in this image)), replays it through
+// image bytes (raw RGB8, or one JPEG image decoded through the system libjpeg: include/efusion_jpeg.hpp)), replays it through
 // libefusion.so and writes <log>.freiburg (+ <log>.ply with -ply).
 //
 //   efusion_replay -l seq.klg [-w 640 -h 480] [-cal fx fy cx cy] [-d depthCut] [-c confidence] [-t timeDelta]
