@@ -597,6 +597,10 @@ class ElasticFusion:
         _chk(lib().ef_map_download(self.h, _ptr(out), c_u32(n), C.byref(got)), self.h)
         return out[:got.value].copy()
 
+    def setReferenceDownload(self, on=True):
+        """downloadMap / savePly read what GlobalModel::downloadMap reads (the pre-clean buffer, quirk Q14) instead of model()"""
+        _chk(lib().ef_set_reference_download(self.h, c_i(int(on))), self.h)
+
     def uploadMap(self, surfels: np.ndarray):
         s = np.ascontiguousarray(surfels, np.float32).reshape(-1, 12)
         _chk(lib().ef_map_upload(self.h, _ptr(s), c_u32(len(s))), self.h)

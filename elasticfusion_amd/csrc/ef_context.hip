@@ -70,6 +70,10 @@ struct ef_ctx {
   // global model
   efm::SurfelSoA maps[2]{};
   int cur = 0;
+  // ef_set_reference_download: the reference's vbos[renderSource] after a frame (GlobalModel.cpp:521,667,693: what its update pass
+  // wrote, never overwritten by clean) — the buffer GlobalModel::downloadMap and savePly actually read (quirk Q14)
+  efm::SurfelSoA shadow{};
+  bool reference_download = false;
   uint32_t capacity = 0;
   uint32_t* winner = nullptr;
   efm::Candidates cand{};
@@ -490,6 +494,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       timer_begin(c, "Fuse::Data+Update");
       efm::fuse(c->cam, c->st->pose_f, c->tick, c->rgb, c->depth_metric, c->depth_metric_filtered, c->im, c->maxDepthProcessed,
                 &c->st->weighting, c->maps[c->cur], &c->st->map_counts[c->cur], c->cand, c->winner, s);
+      if (c->reference_download) efm::copy_map(c->maps[c->cur], &c->st->map_counts[c->cur], c->shadow, s);
       timer_end(c, "Fuse::Data+Update");
       timer_begin(c, "indexMap2");
       efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
@@ -941,14 +946,26 @@ int ef_map_download(ef_ctx* c, float* surfels, uint32_t max_surfels, uint32_t* c
   if (n > max_surfels) n = max_surfels;
   *count = n;
   if (!surfels || !n) return EF_OK;
-  // NB the reference's downloadMap() reads the pre-clean ping-pong buffer (quirk Q14); this returns model()
+  // The reference's downloadMap() reads the buffer its update pass wrote — the map BEFORE clean — truncated to the count AFTER
+  // clean (quirk Q14); by default this returns model(), the map as it stands; ef_set_reference_download selects the reference's.
   float* tmp = nullptr;
   EF_HIP(c, hipMalloc((void**)&tmp, (size_t)n * 48));
-  efm::soa_to_aos(c->maps[c->cur], n, tmp, c->stream);
+  efm::soa_to_aos(c->reference_download ? c->shadow : c->maps[c->cur], n, tmp, c->stream);
   hipError_t e = hipMemcpyAsync(surfels, tmp, (size_t)n * 48, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(tmp);
   EF_HIP(c, e);
+  return EF_OK;
+}
+int ef_set_reference_download(ef_ctx* c, int on) {
+  if (!c) return EF_EINVAL;
+  DeviceGuard dg_(c);
+  if (on && !c->shadow.pos_conf) {   // zero-filled like the reference's vertex buffers (GlobalModel.cpp:72-75)
+    EF_ALLOC(c, c->shadow.pos_conf, c->capacity);
+    EF_ALLOC(c, c->shadow.col_time, c->capacity);
+    EF_ALLOC(c, c->shadow.nrm_rad, c->capacity);
+  }
+  c->reference_download = on != 0;
   return EF_OK;
 }
 int ef_map_upload(ef_ctx* c, const float* surfels, uint32_t count) {

@@ -80,6 +80,9 @@ void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint1
 // ---- layout conversion at the API boundary ----
 void aos_to_soa(const float* aos, uint32_t count, SurfelSoA soa, hipStream_t s);
 void soa_to_aos(SurfelSoA soa, uint32_t count, float* aos, hipStream_t s);
+// dst[0, *count_dev) = src[0, *count_dev): the full-map copy the reference's update pass makes into its second vertex buffer
+// (GlobalModel.cpp:458-524); only used to reproduce GlobalModel::downloadMap's buffer choice (ef_set_reference_download)
+void copy_map(SurfelSoA src, const unsigned* count_dev, SurfelSoA dst, hipStream_t s);
 
 // ---- first frame (vertex_feedback x2 + init_unstable) ----
 void seed_map(const Cam& cam, const uint8_t* rgb3, const float* depth_metric, const float* depth_metric_filtered, int time,

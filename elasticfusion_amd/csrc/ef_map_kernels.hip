@@ -1060,6 +1060,19 @@ void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint1
   hipLaunchKernelGGL(k_preprocess<true>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), extra_lds, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered, metric,
                      metric_filtered);
 }
+namespace {
+__global__ void k_copy_map(SurfelSoA src, const unsigned* __restrict__ count_dev, SurfelSoA dst) {
+  const unsigned n = *count_dev;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    dst.pos_conf[i] = src.pos_conf[i];
+    dst.col_time[i] = src.col_time[i];
+    dst.nrm_rad[i] = src.nrm_rad[i];
+  }
+}
+}  // namespace
+void copy_map(SurfelSoA src, const unsigned* count_dev, SurfelSoA dst, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy_map, dim3(SURFEL_GRID), dim3(BLK), 0, s, src, count_dev, dst);
+}
 void aos_to_soa(const float* aos, uint32_t count, SurfelSoA soa, hipStream_t s) {
   if (count) hipLaunchKernelGGL(k_aos_to_soa, dim3(ceil_div((int)count, 256)), dim3(256), 0, s, (const float4*)aos, count, soa);
 }

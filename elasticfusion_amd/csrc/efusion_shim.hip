@@ -82,6 +82,8 @@ ElasticFusion::ElasticFusion(const int timeDelta_, const int countThresh, const 
   chk(ef_create(&cfg, &c), nullptr, "ElasticFusion::ElasticFusion");
   ctx.reset(c);
   if (closeLoops) chk(ef_set_loop_thresholds(c, countThresh, errThresh, covThresh), c, "ElasticFusion::ElasticFusion");
+  // drop-in: getGlobalModel().downloadMap() and savePly() return what the reference's return (the pre-clean buffer, quirk Q14)
+  chk(ef_set_reference_download(c, 1), c, "ElasticFusion::ElasticFusion");
   indexMap.ctx = globalModel.ctx = c;
   indexMap.w = cfg.width;
   indexMap.h = cfg.height;
@@ -169,6 +171,7 @@ const SE3d& ElasticFusion::get_T_wc() {
 }
 
 void ElasticFusion::savePly() { chk(ef_save_ply(C(ctx.get()), (saveFilename + ".ply").c_str()), ctx.get(), "savePly"); }
+void ElasticFusion::setReferenceDownload(bool on) { chk(ef_set_reference_download(C(ctx.get()), on), ctx.get(), "setReferenceDownload"); }
 void ElasticFusion::synchronize() { chk(ef_synchronize(C(ctx.get())), ctx.get(), "synchronize"); }
 
 unsigned int GlobalModelView::lastCount() {

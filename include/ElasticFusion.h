@@ -156,6 +156,9 @@ class ElasticFusion {
   const int& getFernDeforms() { return fernDeforms; }
   void savePly();                            // <fileName>.ply, binary little endian (ElasticFusion.cpp:684-781)
 
+  // getGlobalModel().downloadMap() / savePly(): true (default) = the buffer GlobalModel::downloadMap reads in the reference (the map
+  // BEFORE the frame's clean pass, truncated to the count after it: GlobalModel.cpp:673-706); false = model(), the map as it stands
+  void setReferenceDownload(bool on);
   void synchronize();                        // wait for everything enqueued so far
   void* context() { return ctx.get(); }      // the ef_ctx* underneath (include/ef_hip.h)
 

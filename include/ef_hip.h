@@ -229,6 +229,12 @@ int ef_get_trajectory(ef_ctx* ctx, double* T_wc16_array, int64_t* timestamps, in
 int ef_map_count(ef_ctx* ctx, uint32_t* count);               /* GlobalModel::lastCount(); synchronises */
 int ef_map_download(ef_ctx* ctx, float* surfels, uint32_t max_surfels, uint32_t* count); /* downloadMap(), 12 floats each */
 int ef_map_upload(ef_ctx* ctx, const float* surfels, uint32_t count);  /* test/bench seeding */
+/* Which buffer ef_map_download / ef_save_ply read.  0 (default): model(), the map as it stands after the frame's clean pass.
+ * 1: what GlobalModel::downloadMap really reads (GlobalModel.cpp:673-706, quirk Q14): vbos[renderSource], i.e. the buffer the frame's
+ * UPDATE pass wrote (the map before clean) truncated to the count AFTER clean — entries beyond the pre-clean count are whatever older
+ * update passes left there (zeros at first).  Byte-for-byte the reference's downloadMap / savePly output for a run; costs one map copy
+ * per frame.  Switch it on before the first frame (class ElasticFusion of libefusion.so does). */
+int ef_set_reference_download(ef_ctx* ctx, int on);
 int ef_save_freiburg(ef_ctx* ctx, const char* path);          /* trajectory dump of ~ElasticFusion, :112-139 */
 int ef_save_ply(ef_ctx* ctx, const char* path);               /* ElasticFusion::savePly, :684-781 */
 /* the same two writers on HOST arrays (no context, no GPU): byte for byte the reference's files — the trajectory with six

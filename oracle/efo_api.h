@@ -117,6 +117,7 @@ void efo_fusion_process_frame(efo_fusion*, const uint8_t* rgb, const uint16_t* d
 void efo_fusion_get_pose(const efo_fusion*, double* T_wc16);
 int efo_fusion_map_count(const efo_fusion*);
 void efo_fusion_map_download(const efo_fusion*, float* surfels /* count*12 */);
+void efo_fusion_map_download_reference(const efo_fusion*, float* surfels /* count*12: the buffer GlobalModel::downloadMap reads (Q14) */);
 int efo_fusion_tick(const efo_fusion*);
 /* host threads used by the parallel loops of the restatement (bilateral rows, reduction blocks); results do not depend on it */
 void efo_set_threads(int n);

@@ -112,6 +112,7 @@ struct efo_fusion {
   std::vector<float> fvertex, fnormal;
   // GlobalModel
   std::vector<float> surfels, surfelsTmp, newUnstable;
+  std::vector<float> renderSource;   // the reference's second vertex buffer as its update pass leaves it (quirk Q14); zeros at first
   int count = 0;
   float lastWeighting = 0;
 
@@ -406,6 +407,10 @@ struct efo_fusion {
         int nNew = efo_fuse(&cam, M, tick, rgb.data(), depthMetric.data(), depthMetricFiltered.data(), indexMap.data(),
                             vertConf.data(), colorTime.data(), normRad.data(), maxDepthProcessed, weighting,
                             surfels.data(), count, newUnstable.data());
+        // the update pass writes every surfel into the OTHER vertex buffer (GlobalModel.cpp:458-524), which clean never touches:
+        // that buffer is what GlobalModel::downloadMap reads afterwards (quirk Q14)
+        if (renderSource.size() < (size_t)p.maxSurfels * 12) renderSource.assign((size_t)p.maxSurfels * 12, 0.f);
+        std::memcpy(renderSource.data(), surfels.data(), (size_t)count * 48);
         efo_predict_indices(&cam, M, tick, surfels.data(), count, maxDepthProcessed, p.timeDelta, indexMap.data(),
                             vertConf.data(), colorTime.data(), normRad.data());
         int room = p.maxSurfels;
@@ -464,6 +469,11 @@ void efo_fusion_process_frame(efo_fusion* f, const uint8_t* rgb, const uint16_t*
 void efo_fusion_get_pose(const efo_fusion* f, double* T) { f->pose16(T); }
 int efo_fusion_map_count(const efo_fusion* f) { return f->count; }
 void efo_fusion_map_download(const efo_fusion* f, float* s) { std::memcpy(s, f->surfels.data(), (size_t)f->count * 48); }
+// GlobalModel::downloadMap as the reference has it (GlobalModel.cpp:673-706): vbos[renderSource] truncated to the post-clean count
+void efo_fusion_map_download_reference(const efo_fusion* f, float* s) {
+  std::memset(s, 0, (size_t)f->count * 48);
+  if (!f->renderSource.empty()) std::memcpy(s, f->renderSource.data(), (size_t)f->count * 48);
+}
 int efo_fusion_tick(const efo_fusion* f) { return f->tick; }
 void efo_set_threads(int n) { efo::threads() = n < 1 ? 1 : n; }
 void efo_fusion_set_deformation(efo_fusion* f, const float* graph, int nodes, int isFern) {

@@ -683,6 +683,12 @@ class Fusion:
         lib().efo_fusion_map_download(self.h_, ptr(out))
         return out
 
+    def map_reference(self):
+        """GlobalModel::downloadMap as the reference has it: the pre-clean buffer truncated to the post-clean count (quirk Q14)"""
+        out = np.zeros((self.map_count(), 12), np.float32)
+        lib().efo_fusion_map_download_reference(self.h_, ptr(out))
+        return out
+
     def tick(self):
         return lib().efo_fusion_tick(self.h_)
 

@@ -469,3 +469,30 @@ def test_api_errors(hip):
         hip.ElasticFusion(width=642)
     with pytest.raises(hip.EFError):
         hip.ElasticFusion(maxSurfels=1000)
+
+
+def test_reference_download_mode_matches_the_reference_buffer_choice(hip, seq, tmp_path):
+    """ef_set_reference_download(1): ef_map_download / ef_save_ply return what GlobalModel::downloadMap reads in the reference —
+    the buffer the frame's update pass wrote (the map before clean) truncated to the count after clean (quirk Q14; observed from
+    the compiled reference in tests/test_oracle_vs_reference_frame.py) — frame after frame the oracle's copy of that buffer."""
+    import ctypes as C
+    ef = hip.ElasticFusion(confidence=1.0)
+    ef.setReferenceDownload(True)
+    o = efo.Fusion(confidence=1.0)
+    differs = 0
+    for k in range(6):
+        rgb, depth, T = seq.frame(k)
+        ef.processFrame(rgb, depth, k * 33333, in_T_wc=None if k == 0 else T)
+        o.process_frame(rgb, depth, k * 33333, T_wc=None if k == 0 else T)
+        got, want = ef.downloadMap(), o.map_reference()
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), k
+        differs += int(not np.array_equal(want, o.map()))
+    assert differs >= 4                                   # from the second frame on the two buffers are not the same thing
+    ef.savePly(str(tmp_path / "run.ply"))
+    lib = hip.lib()
+    want = o.map_reference()
+    assert lib.ef_write_ply(str(tmp_path / "want.ply").encode(), want.ctypes.data_as(C.c_void_p), C.c_uint(len(want)), C.c_float(1.0)) == 0
+    assert open(tmp_path / "run.ply", "rb").read() == open(tmp_path / "want.ply", "rb").read()
+    ef.setReferenceDownload(False)                        # back to model(): the map as it stands
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    ef.close()

@@ -598,3 +598,45 @@ def test_accepted_global_closure_flow(tmp_path):
     assert np.abs(rec - P0).max() < 0.02 and np.abs(o.pose() - rec).max() < 1e-12     # the tracker found the keyframe's pose again; adopted
     assert np.abs(o.ferns().frame(0)["T_wc"][:3, 3] - (kf["T_wc"][:3, 3] + 0.001)).max() < 1e-12   # the solver's poses went back to the keyframes
     assert np.abs(o.trajectory()[0][:3, 3] - (P0[:3, 3] + 0.001)).max() < 1e-12                    # ... and to the trajectory
+
+
+def test_download_map_reads_the_update_pass_buffer_and_save_ply_of_a_run(tmp_path):
+    """Quirk Q14, observed: GlobalModel::downloadMap (hence savePly) copies from the vertex buffer the frame's UPDATE pass wrote, not
+    from the one clean() filled — and reads the post-clean count from it.  The oracle keeps that buffer too (map_reference); the
+    reference's own savePly fed with the oracle's buffer after a real run writes the same file as the product's writer."""
+    import efo
+    from elasticfusion_amd import build, synth
+    so = lib()
+    ref = Ref(so, str(tmp_path / "ref"), confidence=1.0)
+    seq = synth.Sequence(0xEF0004)
+    o = efo.Fusion(confidence=1.0)
+    log = ""
+    for k in range(4):
+        rgb, depth, T = seq.frame(k)
+        o.process_frame(rgb, depth, k * 33333, T_wc=None if k == 0 else T)
+        if k == 3:
+            so.efe_script_next_query(o.map_count())     # the clean pass's primitive query = lastCount()
+        log = ref.frame(rgb, depth, k * 33333, None if k == 0 else T)
+    lines = log.splitlines()
+
+    def tf_buffer(program):
+        i = next(n for n, ln in enumerate(lines) if ln.startswith("program Bind: " + program))
+        return next(ln.split()[-1] for ln in lines[i:] if ln.startswith("glBindBufferBase 0x8c8e 0"))
+    updated, cleaned = tf_buffer("update.vert"), tf_buffer("copy_unstable.vert")
+    assert updated != cleaned
+    buf = o.map_reference()
+    model = o.map()
+    assert buf.shape == model.shape and not np.array_equal(buf, model)            # the two buffers really differ after a frame
+    so.efe_take_log(ref.h)
+    so.efe_script_readbacks(-1, 0, buf.ctypes.data, buf.nbytes)
+    so.efe_save_ply(ref.h)
+    so.efe_script_readbacks(-1, 0, None, 0)
+    dl = so.efe_take_log(ref.h).decode().splitlines()
+    read_from = next(ln.split()[-1] for ln in dl if ln.startswith("glBindBuffer 0x8f36") and not ln.endswith(" 0"))   # GL_COPY_READ_BUFFER
+    assert read_from == updated, (read_from, updated, cleaned)
+    hip = C.CDLL(build.build())
+    hip.ef_write_ply.argtypes = [C.c_char_p, P, C.c_uint, C.c_float]
+    assert hip.ef_write_ply(str(tmp_path / "mine.ply").encode(), buf.ctypes.data, len(buf), 1.0) == 0
+    a, b = open(tmp_path / "ref.ply", "rb").read(), open(tmp_path / "mine.ply", "rb").read()
+    assert a == b and len(a) > 100000
+    ref.close()
