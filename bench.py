@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames-cache", default=None, help="development: keep the generated synthetic frames in this .npz between runs "
+                    "(A/B runs of library variants on one GPU box, tools/gpu_r2.sh); never used by the driver")
     ap.add_argument("--width", type=int, default=W, help="1280 (with --height 960) = BASELINE.json configs[2]: the first frame seeds "
                     "~1.2 M surfels, i.e. the 1 M-surfel HBM-bound map; NOT the headline metric")
     ap.add_argument("--height", type=int, default=H)
@@ -126,7 +128,14 @@ def main():
 
     # synthetic frames first: the generator forks worker processes, which must happen before HIP / RCCL are initialised
     n_frames = 1 + PREROLL + a.warmup + a.steps  # frame 0 seeds the map (tick 1); pre-roll and warm-up are never timed
-    frames = generate_frames(multi.sequence_seed(rank), n_frames, w, h, ranks_on_host=world)
+    cache = f"{a.frames_cache}.{rank}.{w}x{h}.{n_frames}.npz" if a.frames_cache else None
+    if cache and os.path.exists(cache):
+        z = np.load(cache)
+        frames = [(z["rgb"][k], z["depth"][k], z["T"][k]) for k in range(n_frames)]
+    else:
+        frames = generate_frames(multi.sequence_seed(rank), n_frames, w, h, ranks_on_host=world)
+        if cache:
+            np.savez(cache, rgb=np.stack([f[0] for f in frames]), depth=np.stack([f[1] for f in frames]), T=np.stack([f[2] for f in frames]))
 
     import torch
     import torch.distributed as dist

@@ -115,7 +115,7 @@ struct ef_ctx {
   // hipGraph replay of the tracker (BASELINE.json configs[4]): the ~70 launches of getIncrementalTransformation are
   // captured once per pyramid parity (the SO(3) reference / frame intensity buffers swap every frame) and replayed
   bool use_graph = false;
-  struct TrackGraph { hipGraphExec_t exec = nullptr; const void* key = nullptr; eft::TrackParams tp{}; };
+  struct TrackGraph { hipGraphExec_t exec = nullptr; const void* key = nullptr; eft::TrackParams tp{}; eft::TrackTail tail{}; };
   TrackGraph tgraph[2];
   // HIP-event sampling of the dominant kernel (ef_kernel_timing)
   int ktime_every = 0;
@@ -270,8 +270,8 @@ int local_loop_closure(ef_ctx* c, int log_slot) {
   tp.rgbOnly = false; tp.pyramid = c->cfg.pyramid != 0; tp.fastOdom = c->cfg.fast_odom != 0; tp.so3 = false; tp.icpWeight = 10.f;   // :471
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
-  eft::track(c->pyr2, c->st2, c->intr, tp, s, nullptr);
-  eft::track_end(c->st2, true, 1.0f, nullptr, -1, s);
+  const eft::TrackTail tail2 = eft::track(c->pyr2, c->st2, c->intr, tp, s, nullptr);
+  eft::track_end(c->st2, tail2, true, 1.0f, nullptr, -1, s);
   eft::sample_constraints((const float*)c->pm.vertex, c->old.time, W, H, step, c->cons_dev, s);  // :485-486
   EF_HIP(c, hipMemcpyAsync(&c->h_states[0], c->st, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
   EF_HIP(c, hipMemcpyAsync(&c->h_states[1], c->st2, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
@@ -441,6 +441,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       timer_end(c, "odomInit");
       timer_begin(c, "odom");
       const bool sample = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0;
+      eft::TrackTail tail{};
       if (c->use_graph && !sample && !c->timing) {
         // key: which of the two intensity pyramids is "next" this frame + the knobs baked into the launch arguments
         const void* key = c->pyr.nextImage[0];
@@ -453,7 +454,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
           eft::Pyramid pyr_copy = c->pyr;   // track() swaps the copy's pointers; the real swap is done below
           hipGraph_t graph = nullptr;
           EF_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-          eft::track(pyr_copy, c->st, c->intr, tp, s, nullptr);
+          g->tail = eft::track(pyr_copy, c->st, c->intr, tp, s, nullptr);
           hipError_t ce = hipStreamEndCapture(s, &graph);   // always ends the capture, whatever was recorded
           if (ce == hipSuccess) ce = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
           if (graph) (void)hipGraphDestroy(graph);
@@ -467,10 +468,11 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
         }
         EF_HIP(c, hipGraphLaunch(g->exec, s));
         eft::track_swap(c->pyr, tp);
+        tail = g->tail;
       } else {
-        eft::track(c->pyr, c->st, c->intr, tp, s, sample ? &c->probe : nullptr);
+        tail = eft::track(c->pyr, c->st, c->intr, tp, s, sample ? &c->probe : nullptr);
       }
-      eft::track_end(c->st, rgb, weightMultiplier, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
+      eft::track_end(c->st, tail, rgb, weightMultiplier, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
       timer_end(c, "odom");
     } else {
       if (overlap) EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));

@@ -18,7 +18,7 @@ namespace efs {
 
 // developer instrumentation: -DEF_STAGE_CLOCKS stamps wall_clock64() (100 MHz) into TrackState::dbg_clock
 #ifdef EF_STAGE_CLOCKS
-#define EF_STAMP(st, i) do { if ((threadIdx.x & 63) == 0) (st)->dbg_clock[i] = wall_clock64(); } while (0)
+#define EF_STAMP(st, i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) (st)->dbg_clock[i] = wall_clock64(); } while (0)
 #else
 #define EF_STAMP(st, i) do { } while (0)
 #endif
@@ -42,10 +42,13 @@ struct SolveScratch {     // LDS, one per workgroup that runs a solve
   double ti[3];
   double KR[9];
   float pose[12];         // scratch for the float composition
-  // state of the previous iteration, fetched by every workgroup's first wave while the partial sums are still in flight
-  // (which workgroup will run the update is not known until the ticket is drawn): resultRt, Rprev | tprev
+  // state of the previous iteration, fetched by the first wave while the partial sums are still in flight: resultRt, Rprev | tprev
   double prevRt[16];
   float prevPose[12];
+  // what the step leaves for the workgroup that evaluated it (every workgroup evaluates it; workgroup 0 also publishes it)
+  float krkinv[9], kt[3];   // K R K^-1, K t of the coming iteration
+  float Rcurr[9], tcurr[3]; // the new pose
+  int broken;               // rgbOnly "break" flag after this step
 };
 // the per-lane part of that prefetch (registers until the update starts)
 struct SolvePrefetch {
@@ -53,15 +56,18 @@ struct SolvePrefetch {
   float pose;     // lane < 9: Rprev[lane]; 9..11: tprev[lane - 9]
   int slot_a, slot_b;
   float lastRGBErrorLevel;
+  int broken;
 };
-__device__ __forceinline__ SolvePrefetch solve_prefetch(const eft::TrackState* st) {
+// prev: the state the last update left; slots: the {count, sum diff^2} slots of the residual pass that update belongs to
+__device__ __forceinline__ SolvePrefetch solve_prefetch(const eft::TrackState* st, const eft::GNState* prev, const int* slots) {
   const int lane = threadIdx.x & 63;
   SolvePrefetch P;
-  P.rt = st->resultRt[lane & 15];
+  P.rt = prev->resultRt[lane & 15];
   P.pose = lane < 9 ? st->Rprev[lane] : st->tprev[lane < 12 ? lane - 9 : 0];
-  P.slot_a = st->rgb_slots[lane][0];
-  P.slot_b = st->rgb_slots[lane][1];
-  P.lastRGBErrorLevel = st->lastRGBErrorLevel;
+  P.slot_a = slots[lane * 16];
+  P.slot_b = slots[lane * 16 + 1];
+  P.lastRGBErrorLevel = prev->lastRGBErrorLevel;
+  P.broken = prev->rgb_broken;
   return P;
 }
 __device__ __forceinline__ void solve_prefetch_publish(const SolvePrefetch& P, SolveScratch& S) {
@@ -165,8 +171,10 @@ struct SolveInputs {
 };
 
 // The update step proper.  sums: 58 floats in LDS (ICP members 0..28, RGB members 29..57).  Called by ONE converged
-// wavefront (lanes 0..63).  Writes lastA/lastb, resultRt, Rcurr/tcurr, krkinv/kt into st.
-__device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, const float* sums, const SolveInputs in, SolveScratch& S) {
+// wavefront (lanes 0..63).  Leaves resultRt, Rcurr/tcurr, krkinv/kt in S; with `publish` also writes them into `next`
+// and lastA/lastb into st.
+__device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, eft::GNState* next, bool publish, const float* sums,
+                                                         const SolveInputs in, SolveScratch& S) {
   const int lane = threadIdx.x & 63;
   // ---- A = A_rgb + w^2 A_icp, b = b_rgb + w b_icp (RGBDOdometry.cpp:522-534), one element per lane ----
   double a = 0.0;
@@ -187,8 +195,8 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, co
     } else {
       v = (double)sums[eft::SE3_ACCS + m];
     }
-    if (lane < 36) { a = v; st->lastA[lane] = v; }
-    else if (lane < 42) { S.b[lane - 36] = v; st->lastb[lane - 36] = v; }
+    if (lane < 36) { a = v; if (publish) st->lastA[lane] = v; }
+    else if (lane < 42) { S.b[lane - 36] = v; if (publish) st->lastb[lane - 36] = v; }
   }
   wave_sync();
   EF_STAMP(st, 4);
@@ -235,7 +243,7 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, co
     S.Rt[lane] = s;
   }
   wave_sync();
-  if (lane < 16) st->resultRt[lane] = S.Rt[lane];
+  if (publish && lane < 16) next->resultRt[lane] = S.Rt[lane];
   // ---- currentT = [Rprev|tprev] * rgbOdom^-1 in float, Isometry inverse = (R^T, -R^T t) (quirk Q13) ----
   if (lane < 12) {
     // iR = oR^T with oR = float(resultRt 3x3), ot = float(resultRt translation)
@@ -254,10 +262,14 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, co
       float i0 = iR[0], i1 = iR[3], i2 = iR[6];
       if (c == 1) { i0 = iR[1]; i1 = iR[4]; i2 = iR[7]; }
       if (c == 2) { i0 = iR[2]; i1 = iR[5]; i2 = iR[8]; }
-      st->Rcurr[lane] = Rp[r * 3] * i0 + Rp[r * 3 + 1] * i1 + Rp[r * 3 + 2] * i2;
+      const float v = Rp[r * 3] * i0 + Rp[r * 3 + 1] * i1 + Rp[r * 3 + 2] * i2;
+      S.Rcurr[lane] = v;
+      if (publish) next->Rcurr[lane] = v;
     } else {
       const int r = lane - 9;
-      st->tcurr[r] = (Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2]) + S.prevPose[9 + r];
+      const float v = (Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2]) + S.prevPose[9 + r];
+      S.tcurr[r] = v;
+      if (publish) next->tcurr[r] = v;
     }
   }
   EF_STAMP(st, 7);
@@ -297,12 +309,15 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, co
       double s = 0;
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) s += S.KR[r * 3 + kk] * S.inv[1][kk * 3 + c];
-      st->krkinv[lane] = (float)s;
+      S.krkinv[lane] = (float)s;
+      if (publish) next->krkinv[lane] = (float)s;
     } else if (lane >= 16 && lane < 19) {
       const int r = lane - 16;
       const double t0 = -S.ti[0], t1 = -S.ti[1], t2 = -S.ti[2];
       const double k0 = (r == 0) ? K[0] : 0.0, k1 = (r == 1) ? K[4] : 0.0, k2 = (r == 0) ? K[2] : (r == 1 ? K[5] : 1.0);
-      st->kt[r] = (float)(k0 * t0 + k1 * t1 + k2 * t2);
+      const float v = (float)(k0 * t0 + k1 * t1 + k2 * t2);
+      S.kt[r] = v;
+      if (publish) next->kt[r] = v;
     }
   }
   wave_sync();

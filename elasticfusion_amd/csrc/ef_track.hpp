@@ -18,14 +18,28 @@ constexpr int VWARPS = VTHREADS / 32;
 constexpr int RGB_SLOTS = 64;
 constexpr int SE3_ACCS = 29;         // JtJJtrSE3, types.cuh:98-143
 constexpr int SO3_ACCS = 11;         // JtJJtrSO3, types.cuh:145-168
-// ICP block then RGB block of virtual-warp partials, then the 64 reference-block partials of both terms
-constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * VWARPS + 2 * SE3_ACCS * 64;
+// SE(3) normal equations: k_se3_accum leaves one partial per accumulator and PAIR of virtual warps (warps w and w + 4 of a reference
+// block: blockReduceSum's first tree level is done inside the workgroup), layout [term][acc][block 0..63][pair 0..3];
+// the SO(3) kernel leaves one partial per accumulator and virtual warp, layout [acc][warp]
+constexpr int SE3_PAIRS = VWARPS / 2;
+constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * SE3_PAIRS > SO3_ACCS * VWARPS ? 2 * SE3_ACCS * SE3_PAIRS : SO3_ACCS * VWARPS;
 
 struct Intr { float fx, fy, cx, cy; };
 __host__ __device__ inline Intr intr_level(const Intr& k, int level) {  // CameraModel::operator()(level), types.cuh:92-95
   const int div = 1 << level;
   return Intr{k.fx / div, k.fy / div, k.cx / div, k.cy / div};
 }
+
+// What one Gauss-Newton update hands to the next.  Double-buffered (TrackState::gn): the update of iteration i is evaluated at the
+// head of iteration i + 1's first kernel by EVERY workgroup redundantly (reading gn[cur], the pair partials and the residual sums);
+// workgroup 0 alone writes the result into gn[cur ^ 1], so no workgroup ever reads a word another one is writing.
+struct GNState {
+  float Rcurr[9], tcurr[3];
+  double resultRt[16];
+  float krkinv[9], kt[3];     // K R K^-1 and K t of the coming iteration (RGBDOdometry.cpp:407-417)
+  float lastRGBErrorLevel;    // rgbOnly early-exit bookkeeping (RGBDOdometry.cpp:445-450)
+  int rgb_broken;
+};
 
 // Everything the 19-iteration loop mutates lives here, in HBM, so that no iteration needs the host
 // (the reference round-trips 3x per iteration: RGBDOdometry.cpp:424-512).
@@ -37,16 +51,13 @@ struct TrackState {
   double t_prev[3];
   // constants of one getIncrementalTransformation call
   float Rprev[9], tprev[3], Rprev_inv[9];
-  // Gauss-Newton variables
-  float Rcurr[9], tcurr[3];
-  double resultRt[16];
-  float krkinv[9], kt[3];     // K R K^-1 and K t of the coming iteration (RGBDOdometry.cpp:407-417)
+  // Gauss-Newton variables, double-buffered (see GNState); track() starts in gn[0]
+  GNState gn[2];
   // {count, sum diff^2} of the residual pass, integer => order independent (reduce.cu:687-709).  Spread over
   // RGB_SLOTS cache lines (workgroup b adds to slot b % RGB_SLOTS) so the device-scope atomics do not serialise
-  // on one address; consumers add the slots up.
-  int rgb_slots[RGB_SLOTS][16];
-  float lastRGBErrorLevel;    // rgbOnly early-exit bookkeeping (RGBDOdometry.cpp:445-450)
-  int rgb_broken;
+  // on one address; consumers add the slots up.  Two sets: iteration i adds into set i & 1 while the update of
+  // iteration i - 1 (same kernel, head) still reads the other one; k_se3_accum of iteration i re-zeroes set (i + 1) & 1.
+  int rgb_slots[2][RGB_SLOTS][16];
   // outputs (RGBDOdometry.h:74-82)
   float lastICPError, lastICPCount, lastRGBError, lastRGBCount, lastSO3Error, lastSO3Count;
   double lastA[36], lastb[6];
@@ -58,9 +69,6 @@ struct TrackState {
   float so3_lastError, so3_lastCount;
   int so3_done;
   unsigned so3_ticket;        // last-workgroup-done counter
-  // normal-equation kernel: arrival counters of the 64 reference blocks (8 virtual warps each) and of the blocks
-  unsigned acc_tickets[64];
-  unsigned acc_ticket_final;
   // per-frame scalars produced on the device
   float weighting;            // fusion weight (ElasticFusion.cpp:371-383)
   // denseEnough() tally of the last predict() (Resize::image samples with r,g,b > 0; ElasticFusion.cpp:256-268):
@@ -179,13 +187,22 @@ void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, fl
                     uint8_t* rgb_keep = nullptr);   // rgb_keep: also store the frame's RGB there (the caller's buffer is only borrowed)
 // initFirstRGB, RGBDOdometry.cpp:246-257
 void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
-// getIncrementalTransformation, RGBDOdometry.cpp:259-571, entirely enqueued
-void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe = nullptr);
+// getIncrementalTransformation, RGBDOdometry.cpp:259-571, entirely enqueued.  The update step of an iteration is evaluated at the head of the
+// NEXT iteration's first kernel, the last one at the head of track_end's: TrackTail says where that chain stands (which GNState buffer,
+// which residual-sum set, the step's parameters).  Pass it to the track_end that follows on the same stream.
+struct TrackTail {
+  int cur, slots;
+  bool has_head, icp, rgb, rgbOnly;
+  float icpWeight;
+  Intr k0;
+  const float* pairs;
+};
+TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe = nullptr);
 void track_swap(Pyramid& p, const TrackParams& tp);   // the pointer swap track() ends with (for hipGraph replay)
 // tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +
 // velocity weighting (ElasticFusion.cpp:369-383) + the float matrices of the map passes
 // traj / slot: device trajectory log (16 doubles per frame; t_T_wc of ElasticFusion.cpp:588) or null
-void track_end(TrackState* st, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s);
+void track_end(TrackState* st, const TrackTail& tail, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s);
 // caller-supplied pose (in_T_wc, ElasticFusion.cpp:367-369): sets q/t from the row-major 4x4, optionally keeping the old
 // pose as "previous" for the velocity weighting, publishes the float matrices, re-arms the denseEnough() tally
 void pose_injected(TrackState* st, const double* T_wc16, bool save_prev, float weightMultiplier, bool with_weighting, double* traj,

@@ -712,29 +712,69 @@ struct ResidualPackedView {
   int cols, rows;
   float maxDepthDelta;
 };
+// One Gauss-Newton iteration's FIRST kernel: the update step of the previous iteration (head) + this iteration's
+// correspondence search (body).
+//   head  Every workgroup evaluates the update redundantly — reduceSum over the pair partials k_se3_accum left (59 KB, L2-resident
+//         after the first touch per XCD), the 6x6 solve, the SE(3) update, the next K R K^-1 / K t (ef_solve_dev.hpp, one wavefront) —
+//         so that no workgroup waits for another one: the only exchange between workgroups is the kernel boundary, which is
+//         cheaper on this part than any in-launch hand-over (MI355X_MICROARCH.md "boundary" vs "handoff-flag" rows).  Workgroup 0
+//         publishes the result into the other GNState buffer and the statistics into the TrackState.  The body's pixel-addressed
+//         loads are issued before the head, so they are in flight while it runs.
+//   body  residualKernel (reduce.cu:603-787) on the packed correspondences, as before.
+struct StepArgs {
+  bool has_head;              // false for the first iteration of a call: K R K^-1 / K t come from prev as they are
+  bool has_body;              // false when the photometric term is off (the launch is one workgroup: head only)
+  bool icp, rgb, rgbOnly;     // of the update step (RGBDOdometry.cpp:266-267)
+  float icpWeight;
+  Intr knext;                 // intrinsics of THIS iteration's level (for the head's K R K^-1)
+  bool level_changes;         // this iteration runs at another level than the one whose update the head evaluates
+};
+__device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* prev, GNState* next, bool publish, const float* sums,
+                                                const StepArgs& A, efs::SolveScratch& S, const efs::SolvePrefetch& PF);
+template <int BLOCK>
+__device__ __forceinline__ void pair_partials_tree(const float* __restrict__ pairs, bool icp, bool rgb, float* sums_s);
+
 template <int PPT>
-__global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_residual(const ResidualPackedView V, const float* __restrict__ krkinv,
-                                                                const float* __restrict__ ktp, int* sums,
-                                                                const int* __restrict__ skip_flag) {
+__global__ void __launch_bounds__(REDUCE_BLOCK) k_track_step(const ResidualPackedView V, TrackState* st, const GNState* __restrict__ prev,
+                                                              GNState* next, const float* __restrict__ pairs,
+                                                              const int* __restrict__ slots_prev, int* slots_out, const StepArgs A) {
   __shared__ int lds[2 * REDUCE_BLOCK / 64];
+  __shared__ efs::SolveScratch S;
+  __shared__ float sums_s[2 * SE3_ACCS];
   const int N = V.cols * V.rows, cols = V.cols, rows = V.rows;
-  const int base = blockIdx.x * REDUCE_BLOCK * PPT + threadIdx.x;
-  // stage 1: everything addressed by the pixel itself, branch-free (an out-of-range lane reads pixel N-1 and is masked
-  // out), issued together with the flag and the warp matrix so that one memory round trip covers all of it
-  const int skip = *skip_flag;
+  const int t = threadIdx.x;
+  const int base = blockIdx.x * REDUCE_BLOCK * PPT + t;
+  // stage 1 of the body: everything addressed by the pixel itself, branch-free (an out-of-range lane reads pixel N-1 and is masked
+  // out), issued before the head so that one memory round trip covers all of it
   uint8_t m[PPT], ni[PPT];
   float d1s[PPT];
 #pragma unroll
   for (int j = 0; j < PPT; ++j) {
-    const int k = base + j * REDUCE_BLOCK, q = k < N ? k : N - 1;
-    m[j] = V.mask[q];
-    d1s[j] = V.nextDepth[q];  // mask guarantees !isnan(d1)
-    ni[j] = V.nextImage[q];
+    const int k = base + j * REDUCE_BLOCK, q = (A.has_body && k < N) ? k : (A.has_body ? N - 1 : 0);
+    m[j] = A.has_body ? V.mask[q] : (uint8_t)0;
+    d1s[j] = A.has_body ? V.nextDepth[q] : 0.f;  // mask guarantees !isnan(d1)
+    ni[j] = A.has_body ? V.nextImage[q] : (uint8_t)0;
     if (k >= N) m[j] = 0;
   }
-  const m33 K = m33_load(krkinv);
-  const f3 kt{ktp[0], ktp[1], ktp[2]};
-  if (skip) return;
+  m33 K;
+  f3 kt;
+  int skip;
+  if (A.has_head) {
+    efs::SolvePrefetch PF{};
+    if (t < 64) PF = efs::solve_prefetch(st, prev, slots_prev);
+    pair_partials_tree<REDUCE_BLOCK>(pairs, A.icp, A.rgb, sums_s);
+    __syncthreads();
+    if (t < 64) solve_step_wave(st, prev, next, blockIdx.x == 0, sums_s, A, S, PF);
+    __syncthreads();
+    K = m33_load(S.krkinv);
+    kt = f3{S.kt[0], S.kt[1], S.kt[2]};
+    skip = S.broken;
+  } else {
+    K = m33_load(prev->krkinv);
+    kt = f3{prev->kt[0], prev->kt[1], prev->kt[2]};
+    skip = prev->rgb_broken;
+  }
+  if (!A.has_body || skip) return;
   // stage 2: the warped pixel's gathers of all PPT pixels in flight together
   int cnt = 0, sq = 0;
   int gi[PPT], u0s[PPT], v0s[PPT];
@@ -766,7 +806,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_rgb_residual(const ResidualPac
     }
     V.corres[k] = packed;
   }
-  block_reduce_atomic_int2<REDUCE_BLOCK>(cnt, sq, lds, sums + (blockIdx.x % RGB_SLOTS) * 16);
+  block_reduce_atomic_int2<REDUCE_BLOCK>(cnt, sq, lds, slots_out + (blockIdx.x % RGB_SLOTS) * 16);
 }
 
 // {count, sum diff^2} = sum over the RGB_SLOTS slots; call with the whole first wave (threadIdx.x < 64) converged
@@ -832,9 +872,9 @@ constexpr int ROW_STRIDE = 8 * 32;   // floats per pass in LDS (SO(3) kernel): 8
 //            kernel), offsets 8..1 are lane shuffles by 32..4.
 // A workgroup is two virtual warps x {ICP, RGB} x two halves = 8 waves; waves i and i + 4 share a SIMD, so every SIMD
 // hosts one ICP wave (memory + ALU heavy) and one RGB wave (light).  256 workgroups = one per CU, one dispatch round.
-// Output: one partial per virtual warp and accumulator (acc-major), then -- last arriver of the four workgroups of a
-// reference block, ticket hand-over as below -- blockReduceSum's second stage (8-warp tree), leaving the 64 block
-// partials the update step consumes.
+// The two virtual warps of a workgroup are warps m and m + 4 of one reference block, i.e. a pair that the first level of
+// blockReduceSum's 8-warp tree adds: that addition is done here too, and the kernel leaves ONE partial per accumulator
+// and pair (256 x 58 floats, plain stores, no hand-over between workgroups: the consumer is the next kernel).
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int ACC_NW = 2;   // virtual warps per workgroup
@@ -888,12 +928,10 @@ struct Se3Inputs {            // device pointers: the Gauss-Newton state the acc
   // warps share through the projective association (shifted 128-byte segments) are fetched once per XCD instead of once per
   // workgroup, and the four workgroups of a reference block sit behind one L2; where a partial sum lands does not change.
   bool xcd_swizzle = true;
+  int* slots_zero = nullptr;  // residual-pass slots to re-zero for the next iteration (frame tier), or null
 };
 struct Se3Out {
-  float* partials_icp;        // SE3_ACCS x VWARPS, acc-major
-  float* partials_rgb;
-  float* block_partials;      // [term][SE3_ACCS][64] (terms present in the launch, ICP first), or null with tickets
-  unsigned* tickets;          // 64 arrival counters (zero between launches), or null: leave the virtual-warp partials only
+  float* pairs;               // [term present in the launch, ICP first][SE3_ACCS][64 blocks][4 pairs]: sum of virtual warps w and w + 4
 };
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sums, bool broken, bool icp, bool rgb, bool rgbOnly,
                                                 float icpWeight, Intr knext, bool level_changes, efs::SolveScratch& S,
@@ -1018,9 +1056,22 @@ __device__ __forceinline__ void visit_stage2b(const IcpView& IV, const RgbView& 
 // (lo x lo, lo x hi, hi x hi; register i of lane 4 v + j holds element (i, j) of virtual thread v's 4x4 block).
 // slot_a / slot_b: this lane's residual-pass slot (count, sum diff^2) when sigma comes from the slots.
 template <int CH, bool ICP, bool PACKED>
-__device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int g, int j, int N, int K,
+__device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int gbase, int N, int K,
                                             int slot_a, int slot_b, bool with_slots, f32x4 (&c)[3]) {
   const int S = (K + 3) >> 2;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 3;                    // quad layout (phase B): lane = 4 v + j
+#ifdef EF_ACCUM_QUAD_LOADS
+  const int jl = j, g = gbase + (lane >> 2); // phase A in the quad layout too: a quarter-wave touches four 16-byte segments per load
+  const int gather_from = lane;
+#else
+  // Phase A runs in the LOAD layout, lane = 16 jl + vl: a quarter-wave (16 lanes) covers 16 consecutive pixels of ONE pass, so
+  // every planar load touches one 64-byte segment per quarter-wave (four 16-byte pieces of four different rows in the quad
+  // layout: 4x the tag look-ups of the CU's one address pipe).  The rows then move to the quad layout through the LDS crossbar
+  // (ds_bpermute: lane 4 v + j takes lane 16 j + v's), 8 moves per step.
+  const int jl = lane >> 4, g = gbase + (lane & 15);
+  const int gather_from = (16 * j + (lane >> 2)) * 4;
+#endif
   IcpPose P;
   if (ICP) {
     P.Rcurr = m33_load(in.Rcurr);
@@ -1033,7 +1084,7 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
   if (ICP || PACKED) {
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
-      const int k = 4 * u + j;
+      const int k = 4 * u + jl;
       L0[u] = visit_stage1<ICP, !ICP>(IV, RV, k < K ? k * VTHREADS + g : N, N);
     }
   }
@@ -1052,7 +1103,7 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
       VisitLoads L[CH];
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
-        const int k = 4 * (s0 + u) + j;
+        const int k = 4 * (s0 + u) + jl;
         L[u] = s0 == 0 ? L0[u] : visit_stage1<ICP, !ICP>(IV, RV, k < K ? k * VTHREADS + g : N, N);
       }
       VisitGathers G[CH];
@@ -1070,7 +1121,7 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
     } else {   // operator tier's photometric term: 16-byte DataTerm + explicit point cloud (types.cuh:81-86)
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
-        const int k = 4 * (s0 + u) + j;
+        const int k = 4 * (s0 + u) + jl;
         const int p = k < K ? k * VTHREADS + g : N;
         float row[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const bool found = p < N && rgb_row<false>(RV, sigma, p, row);
@@ -1082,6 +1133,10 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       if (s0 + u < S) {   // uniform
+#ifndef EF_ACCUM_QUAD_LOADS
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rows[u][q] = __int_as_float(__builtin_amdgcn_ds_bpermute(gather_from, __float_as_int(rows[u][q])));
+#endif
         float lo[4] = {rows[u][0], rows[u][1], rows[u][2], rows[u][3]};
         float hi[4] = {rows[u][4], rows[u][5], rows[u][6], rows[u][7]};
         quad_transpose(lo, j);
@@ -1107,17 +1162,16 @@ template <int CH, bool HAS_ICP, bool HAS_RGB, bool PACKED>
 __global__ void __launch_bounds__(64 * 2 * ACC_NW * ((HAS_ICP && HAS_RGB) ? 2 : 1))
 k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, const Se3Out out) {
   constexpr int NT = (HAS_ICP && HAS_RGB) ? 2 : 1;
-  constexpr int BLOCK = 64 * 2 * ACC_NW * NT;
   __shared__ float xch[ACC_NW][NT][12][64];
-  __shared__ int last_s;
+  __shared__ float pair[NT][12][4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int v = lane >> 2, j = lane & 3;
   const int wg = in.xcd_swizzle ? (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
   const int tix = wave / (2 * ACC_NW);                       // 0: the launch's first term
   const bool rgb_wave = HAS_RGB && (!HAS_ICP || tix == 1);
   const int rem = wave % (2 * ACC_NW), wl = rem >> 1, half = rem & 1;
-  const int W = wg * ACC_NW + wl;
-  const int g = W * 32 + half * 16 + v;
+  const int W = 8 * (wg >> 2) + (wg & 3) + 4 * wl;   // workgroup 4 b + m owns virtual warps m and m + 4 of reference block b
+  const int gbase = W * 32 + half * 16;   // first of this wavefront's 16 virtual threads
   const int cols = HAS_ICP ? IV.cols : RV.cols, nrows = HAS_ICP ? IV.rows : RV.rows;
   const int N = cols * nrows;
   const int K = (N + VTHREADS - 1) / VTHREADS;
@@ -1125,12 +1179,14 @@ k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, const Se3Out
   const bool with_slots = HAS_RGB && in.rgb_slots;
   int slot_a = 0, slot_b = 0;
   if (rgb_wave && with_slots) { slot_a = in.rgb_slots[lane * 16]; slot_b = in.rgb_slots[lane * 16 + 1]; }
+  // re-arm the residual-pass slots the NEXT iteration's correspondence search adds into (nobody reads them during this launch)
+  if (in.slots_zero && blockIdx.x == 0 && t < RGB_SLOTS) { in.slots_zero[t * 16] = 0; in.slots_zero[t * 16 + 1] = 0; }
   if (broken) return;  // rgbOnly "break": the level is over (the update step does the bookkeeping)
   f32x4 c[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) c[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (HAS_ICP && !rgb_wave) accum_quads<CH, true, PACKED>(IV, RV, in, g, j, N, K, 0, 0, false, c);
-  if (HAS_RGB && rgb_wave) accum_quads<CH, false, PACKED>(IV, RV, in, g, j, N, K, slot_a, slot_b, with_slots, c);
+  if (HAS_ICP && !rgb_wave) accum_quads<CH, true, PACKED>(IV, RV, in, gbase, N, K, 0, 0, false, c);
+  if (HAS_RGB && rgb_wave) accum_quads<CH, false, PACKED>(IV, RV, in, gbase, N, K, slot_a, slot_b, with_slots, c);
   // warpReduceSum, reduce.cu:57-95: val += shfl_down(val, offset) for offset = 16 (the other half's wave), 8, 4, 2, 1
   if (half == 1) {
 #pragma unroll
@@ -1140,41 +1196,36 @@ k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, const Se3Out
     }
   }
   __syncthreads();
+  float r[12];
   if (half == 0) {
-    float* dst = (rgb_wave ? out.partials_rgb : out.partials_icp) + W;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      float r[4] = {c[q].x + xch[wl][tix][q * 4 + 0][lane], c[q].y + xch[wl][tix][q * 4 + 1][lane],
-                    c[q].z + xch[wl][tix][q * 4 + 2][lane], c[q].w + xch[wl][tix][q * 4 + 3][lane]};
+      r[q * 4 + 0] = c[q].x + xch[wl][tix][q * 4 + 0][lane]; r[q * 4 + 1] = c[q].y + xch[wl][tix][q * 4 + 1][lane];
+      r[q * 4 + 2] = c[q].z + xch[wl][tix][q * 4 + 2][lane]; r[q * 4 + 3] = c[q].w + xch[wl][tix][q * 4 + 3][lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+#pragma unroll
+      for (int off = 32; off >= 4; off >>= 1) r[i] += __shfl_down(r[i], off, 64);
+    // blockReduceSum's second stage (reduce.cu:97-117), first level: the 8 warp sums of a reference block sit in lanes 0..7 of its
+    // warp 0 (the other 24 lanes hold exact zeros) and shfl_down(offset 4) adds warp w + 4 to warp w: the workgroup holds exactly
+    // such a pair, the upper one hands its sums over
+    if (wl == 1 && v == 0) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) pair[tix][i][j] = r[i];
+    }
+  }
+  __syncthreads();
+  if (half == 0 && wl == 0 && v == 0) {
+    float* dst = out.pairs + (size_t)tix * SE3_ACCS * SE3_PAIRS + wg;   // wg = 4 * reference block + pair
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int off = 32; off >= 4; off >>= 1) r[i] += __shfl_down(r[i], off, 64);
         const int a = quad_member(q, i, j);
-        if (v == 0 && a >= 0) coherent_store(dst + (size_t)a * VWARPS, r[i]);
+        if (a >= 0) dst[(size_t)a * SE3_PAIRS] = r[q * 4 + i] + pair[tix][q * 4 + i][j];
       }
-    }
-    drain_stores();
   }
-  if (!out.tickets) return;
-  // blockReduceSum's second stage (reduce.cu:97-117) by the last of the reference block's workgroups: lanes 0..7 of the
-  // reference's warp 0 hold the 8 warp sums, the other 24 exact zeros => a shuffle tree of width 8
-  __syncthreads();
-  const int rb = (wg * ACC_NW) >> 3;   // reference block of this workgroup's virtual warps
-  if (t == 0) last_s = (take_ticket(out.tickets + rb) == (unsigned)(8 / ACC_NW - 1));
-  __syncthreads();
-  if (!last_s) return;
-  for (int e = t; e < NT * SE3_ACCS * 8; e += BLOCK) {   // whole 8-lane groups (BLOCK is a multiple of 8)
-    const int a = e >> 3, w = e & 7, tm = a / SE3_ACCS;
-    const bool rgb_term = HAS_RGB && (!HAS_ICP || tm == 1);
-    const float* src = (rgb_term ? out.partials_rgb : out.partials_icp) + (size_t)(a - tm * SE3_ACCS) * VWARPS;
-    float x = coherent_load(src + rb * 8 + w);
-    x += __shfl_down(x, 4, 8);
-    x += __shfl_down(x, 2, 8);
-    x += __shfl_down(x, 1, 8);
-    if (w == 0) out.block_partials[a * 64 + rb] = x;
-  }
-  if (t == 0) out.tickets[rb] = 0;
 }
 
 // The rest of the reference tree over the 512 virtual-warp partials of `na` accumulators (acc-major):
@@ -1260,20 +1311,19 @@ __global__ void k_track_begin(TrackState* st, bool so3, Intr kso3, Intr kfirst) 
   if (threadIdx.x != 0) return;
   double R[9];
   efl::quat_to_mat<double>(st->q, R);
-  for (int i = 0; i < 9; ++i) st->Rprev[i] = st->Rcurr[i] = (float)R[i];
-  for (int i = 0; i < 3; ++i) st->tprev[i] = st->tcurr[i] = (float)st->t[i];
+  GNState& g = st->gn[0];   // track() starts in buffer 0
+  for (int i = 0; i < 9; ++i) st->Rprev[i] = g.Rcurr[i] = (float)R[i];
+  for (int i = 0; i < 3; ++i) st->tprev[i] = g.tcurr[i] = (float)st->t[i];
   efl::m3_inverse<float>(st->Rprev, st->Rprev_inv);
   for (int i = 0; i < 4; ++i) st->q_prev[i] = st->q[i];
   for (int i = 0; i < 3; ++i) st->t_prev[i] = st->t[i];
-  efl::m4_identity(st->resultRt);
-  for (int i = 0; i < RGB_SLOTS; ++i) st->rgb_slots[i][0] = st->rgb_slots[i][1] = 0;
-  st->rgb_broken = 0;
-  st->lastRGBErrorLevel = 3.402823466e+38f;
+  efl::m4_identity(g.resultRt);
+  for (int i = 0; i < RGB_SLOTS; ++i) st->rgb_slots[0][i][0] = st->rgb_slots[0][i][1] = st->rgb_slots[1][i][0] = st->rgb_slots[1][i][1] = 0;
+  g.rgb_broken = 0;
+  g.lastRGBErrorLevel = 3.402823466e+38f;
   st->so3_iterations = 0;
   st->dbg_clock[11] = ~0ull; st->dbg_clock[12] = 0;
   st->so3_ticket = 0;
-  st->acc_ticket_final = 0;
-  for (int i = 0; i < 64; ++i) st->acc_tickets[i] = 0;
   st->dense_count = 0;
   if (so3) {
     efl::m3_identity(st->so3_resultR);
@@ -1285,17 +1335,18 @@ __global__ void k_track_begin(TrackState* st, bool so3, Intr kso3, Intr kfirst) 
     so3_matrices(st->so3_resultR, kso3, st->so3_mats);
   } else {
     st->so3_done = 1;
-    compute_krk(st->resultRt, kfirst, st->krkinv, st->kt);
+    compute_krk(g.resultRt, kfirst, g.krkinv, g.kt);
   }
 }
 
-// K6c: the Gauss-Newton update (RGBDOdometry.cpp:440-551 + OdometryProvider.h:73-96) on one wavefront, one matrix
-// element per lane (ef_solve_dev.hpp); called by the last workgroup of k_se3_accum.
 constexpr int SOLVE_BLOCK = 512;
-// bookkeeping around the update (rgbOnly early exit, statistics); all lanes of wave 0 take the same path
-__device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sums, bool broken, bool icp, bool rgb, bool rgbOnly,
-                                                float icpWeight, Intr knext, bool level_changes, efs::SolveScratch& S,
-                                                const efs::SolvePrefetch& PF) {
+// K6c: the Gauss-Newton update (RGBDOdometry.cpp:440-551 + OdometryProvider.h:73-96) on one wavefront, one matrix
+// element per lane (ef_solve_dev.hpp); evaluated at the head of k_track_step / k_track_end by every workgroup.
+// bookkeeping around the update (rgbOnly early exit, statistics); all lanes of wave 0 take the same path.  S receives what the
+// calling workgroup needs (krkinv, kt, Rcurr, tcurr, broken); with `publish` the whole GNState goes to `next` and the
+// statistics to st.
+__device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* prev, GNState* next, bool publish, const float* sums,
+                                                const StepArgs& A, efs::SolveScratch& S, const efs::SolvePrefetch& PF) {
   const int lane = threadIdx.x & 63;
   int sigma = PF.slot_b, rgbSize = PF.slot_a;   // {count, sum diff^2} slots of the residual pass, prefetched
 #pragma unroll
@@ -1305,81 +1356,81 @@ __device__ __forceinline__ void solve_step_wave(TrackState* st, const float* sum
   }
   rgbSize = __shfl(rgbSize, 0, 64);
   sigma = __shfl(sigma, 0, 64);
-  st->rgb_slots[lane][0] = 0;
-  st->rgb_slots[lane][1] = 0;
   efs::solve_prefetch_publish(PF, S);
   const float lastLevelErr = PF.lastRGBErrorLevel;
+  const bool broken = PF.broken != 0;
   const float rgbError = (float)(sqrt((double)sigma) / (rgbSize == 0 ? 1 : rgbSize));
-  const bool brk = !broken && rgbOnly && rgbError > lastLevelErr;   // "break": skip the rest of this level
+  const bool brk = !broken && A.rgbOnly && rgbError > lastLevelErr;   // "break": skip the rest of this level
   if (broken || brk) {
+    // nothing of the pose changes; at a level change the flag clears and K R K^-1 / K t are re-evaluated for the new level
     if (lane == 0) {
-      st->rgb_broken = level_changes ? 0 : 1;
-      if (level_changes) { st->lastRGBErrorLevel = 3.402823466e+38f; compute_krk(st->resultRt, knext, st->krkinv, st->kt); }
+      S.broken = A.level_changes ? 0 : 1;
+      if (A.level_changes) {
+        compute_krk(prev->resultRt, A.knext, S.krkinv, S.kt);
+      } else {
+        for (int i = 0; i < 9; ++i) S.krkinv[i] = prev->krkinv[i];
+        for (int i = 0; i < 3; ++i) S.kt[i] = prev->kt[i];
+      }
+      for (int i = 0; i < 9; ++i) S.Rcurr[i] = prev->Rcurr[i];
+      for (int i = 0; i < 3; ++i) S.tcurr[i] = prev->tcurr[i];
+      if (publish) {
+        for (int i = 0; i < 9; ++i) { next->Rcurr[i] = S.Rcurr[i]; next->krkinv[i] = S.krkinv[i]; }
+        for (int i = 0; i < 3; ++i) { next->tcurr[i] = S.tcurr[i]; next->kt[i] = S.kt[i]; }
+        for (int i = 0; i < 16; ++i) next->resultRt[i] = prev->resultRt[i];
+        next->rgb_broken = S.broken;
+        next->lastRGBErrorLevel = A.level_changes ? 3.402823466e+38f : lastLevelErr;
+      }
     }
+    efs::wave_sync();
     return;
   }
   if (lane == 0) {
-    st->lastRGBErrorLevel = level_changes ? 3.402823466e+38f : rgbError;
-    st->lastRGBError = rgbError;
-    st->lastRGBCount = (float)rgbSize;
-    if (icp) {
-      st->lastICPError = sqrtf(sums[27]) / sums[28];
-      st->lastICPCount = sums[28];
-    } else {
-      // RGBDOdometry.cpp:492-493 evaluates sqrt(residual[0]) / residual[1] on an UNINITIALISED residual[] when the ICP term is
-      // off; the specification (oracle) zero-initialises it: NaN error, zero count
-      st->lastICPError = __int_as_float(0x7fc00000);
-      st->lastICPCount = 0.f;
+    S.broken = 0;
+    if (publish) {
+      next->rgb_broken = 0;
+      next->lastRGBErrorLevel = A.level_changes ? 3.402823466e+38f : rgbError;
+      st->lastRGBError = rgbError;
+      st->lastRGBCount = (float)rgbSize;
+      if (A.icp) {
+        st->lastICPError = sqrtf(sums[27]) / sums[28];
+        st->lastICPCount = sums[28];
+      } else {
+        // RGBDOdometry.cpp:492-493 evaluates sqrt(residual[0]) / residual[1] on an UNINITIALISED residual[] when the ICP term is
+        // off; the specification (oracle) zero-initialises it: NaN error, zero count
+        st->lastICPError = __int_as_float(0x7fc00000);
+        st->lastICPCount = 0.f;
+      }
     }
   }
   EF_STAMP(st, 3);
-  efs::SolveInputs in{icp, rgb, rgbOnly, icpWeight, knext, level_changes};
-  efs::gauss_newton_update_wave(st, sums, in, S);
+  efs::SolveInputs in{A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes};
+  efs::gauss_newton_update_wave(st, next, publish, sums, in, S);
 }
-// K6c': reduceSum<<<1,1024>>> (two warp32 trees + one add over the 64 block partials k_se3_accum leaves) and then the
-// Gauss-Newton step on the first wavefront: ONE workgroup, no first stage, no hand-over.
-constexpr int FINISH_BLOCK = 512;
-struct FinishArgs {
-  bool icp, rgb, rgbOnly;
-  float icpWeight;
-  Intr knext;
-  bool level_changes;
-};
-// sums_s[term * SE3_ACCS + acc] = sum of the 64 block partials; call with the whole workgroup (BLOCK threads)
+// reduceSum over what k_se3_accum leaves: pairs[term][acc][block][pair] -> the rest of blockReduceSum's 8-warp tree (offsets 2, 1
+// over the four pair sums of a block: (p0 + p2) + (p1 + p3)), then reduceSum<<<1,1024>>> over the 64 block partials (two warp32
+// trees + one add).  sums_s[term * SE3_ACCS + acc]; call with the whole workgroup (BLOCK threads), follow with __syncthreads().
+// One 16-byte load per (acc, block), all of a thread's loads in flight together, one wavefront per accumulator.
 template <int BLOCK>
-__device__ __forceinline__ void block_partials_tree(const float* __restrict__ block_partials, bool icp, bool rgb, float* sums_s) {
+__device__ __forceinline__ void pair_partials_tree(const float* __restrict__ pairs, bool icp, bool rgb, float* sums_s) {
+  static_assert(BLOCK % 64 == 0, "one wavefront per accumulator");
   const int t = threadIdx.x;
   const int na = (icp ? SE3_ACCS : 0) + (rgb ? SE3_ACCS : 0);
   constexpr int PASSES = (2 * SE3_ACCS * 64 + BLOCK - 1) / BLOCK;
-  float v[PASSES];
+  float4 v[PASSES];
 #pragma unroll
   for (int q = 0; q < PASSES; ++q) {
     const int idx = t + q * BLOCK;
-    v[q] = idx < na * 64 ? block_partials[idx] : 0.f;
+    v[q] = idx < na * 64 ? ((const float4*)pairs)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int q = 0; q < PASSES; ++q) {
     const int idx = t + q * BLOCK;
-    float x = v[q];
+    float x = (v[q].x + v[q].z) + (v[q].y + v[q].w);
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, 32);
     const float w1 = __shfl(x, 32, 64);
     if (idx < na * 64 && (idx & 63) == 0) sums_s[(icp ? 0 : SE3_ACCS) + (idx >> 6)] = x + w1;
   }
-}
-__global__ void __launch_bounds__(FINISH_BLOCK) k_se3_finish(TrackState* st, const float* __restrict__ block_partials, const FinishArgs A) {
-  __shared__ efs::SolveScratch S;
-  __shared__ float sums_s[2 * SE3_ACCS];
-  const int t = threadIdx.x;
-  efs::SolvePrefetch PF{};
-  if (t < 64) PF = efs::solve_prefetch(st);   // in flight while the partial sums are reduced
-  if (st->rgb_broken) {  // rgbOnly "break": only the bookkeeping of the update step runs
-    if (t < 64) solve_step_wave(st, nullptr, true, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S, PF);
-    return;
-  }
-  block_partials_tree<FINISH_BLOCK>(block_partials, A.icp, A.rgb, sums_s);
-  __syncthreads();
-  if (t < 64) solve_step_wave(st, sums_s, false, A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes, S, PF);
 }
 
 // tail of getIncrementalTransformation (RGBDOdometry.cpp:555-570) + velocity weighting
@@ -1416,22 +1467,44 @@ __device__ inline void log_pose(const TrackState* st, double* traj, int slot) {
   for (int i = 0; i < 3; ++i) T.t[i] = st->t[i];
   efl::se3_matrix(T, traj + (size_t)slot * 16);
 }
-__global__ void k_track_end(TrackState* st, bool rgb, float weightMultiplier, double* traj, int slot) {
-  if (threadIdx.x != 0) return;
+// Last kernel of getIncrementalTransformation: the update step of the LAST iteration (same head as k_track_step; with no iteration at
+// all the pose is prev's), then the tail on one lane: 0.3 m guard, SVD re-orthonormalisation (RGBDOdometry.cpp:555-570),
+// velocity weighting (ElasticFusion.cpp:369-383), the float matrices of the map passes, the trajectory log.
+__global__ void __launch_bounds__(REDUCE_BLOCK) k_track_end(TrackState* st, const GNState* __restrict__ prev, GNState* next,
+                                                             const float* __restrict__ pairs, const int* __restrict__ slots_prev, const StepArgs A,
+                                                             bool rgb, float weightMultiplier, double* traj, int slot) {
+  __shared__ efs::SolveScratch S;
+  __shared__ float sums_s[2 * SE3_ACCS];
+  const int t = threadIdx.x;
+  if (A.has_head) {
+    efs::SolvePrefetch PF{};
+    if (t < 64) PF = efs::solve_prefetch(st, prev, slots_prev);
+    pair_partials_tree<REDUCE_BLOCK>(pairs, A.icp, A.rgb, sums_s);
+    __syncthreads();
+    if (t < 64) solve_step_wave(st, prev, next, true, sums_s, A, S, PF);
+    __syncthreads();
+  } else if (t == 0) {
+    for (int i = 0; i < 9; ++i) S.Rcurr[i] = prev->Rcurr[i];
+    for (int i = 0; i < 3; ++i) S.tcurr[i] = prev->tcurr[i];
+  }
+  if (t != 0) return;
+  float Rcurr[9], tcurr[3];
+  for (int i = 0; i < 9; ++i) Rcurr[i] = S.Rcurr[i];
+  for (int i = 0; i < 3; ++i) tcurr[i] = S.tcurr[i];
   if (rgb) {
-    const float d0 = st->tcurr[0] - st->tprev[0], d1 = st->tcurr[1] - st->tprev[1], d2 = st->tcurr[2] - st->tprev[2];
+    const float d0 = tcurr[0] - st->tprev[0], d1 = tcurr[1] - st->tprev[1], d2 = tcurr[2] - st->tprev[2];
     if ((double)sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
-      for (int i = 0; i < 9; ++i) st->Rcurr[i] = st->Rprev[i];
-      for (int i = 0; i < 3; ++i) st->tcurr[i] = st->tprev[i];
+      for (int i = 0; i < 9; ++i) Rcurr[i] = st->Rprev[i];
+      for (int i = 0; i < 3; ++i) tcurr[i] = st->tprev[i];
     }
   }
   double Rc[9], Rp[9];
-  for (int i = 0; i < 9; ++i) Rc[i] = (double)st->Rcurr[i];
+  for (int i = 0; i < 9; ++i) Rc[i] = (double)Rcurr[i];
   efl::polar3(Rc, Rp);
   efl::SE3 T;
   efl::se3_set_rotation(T, Rp);
   for (int i = 0; i < 4; ++i) st->q[i] = T.q[i];
-  for (int i = 0; i < 3; ++i) st->t[i] = (double)st->tcurr[i];
+  for (int i = 0; i < 3; ++i) st->t[i] = (double)tcurr[i];
   publish_pose(st);
   compute_weighting(st, weightMultiplier);
   log_pose(st, traj, slot);
@@ -1617,8 +1690,8 @@ __global__ void __launch_bounds__(SO3_BLOCK) k_so3_iteration(const uint8_t* __re
     // the rest of resultRt is the identity k_track_begin wrote (nothing touches it before the first SE(3) iteration)
     double Rt[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     for (int x = 0; x < 3; ++x)
-      for (int y = 0; y < 3; ++y) { Rt[x * 4 + y] = resR[x * 3 + y]; st->resultRt[x * 4 + y] = resR[x * 3 + y]; }
-    compute_krk(Rt, kfirst, st->krkinv, st->kt);
+      for (int y = 0; y < 3; ++y) { Rt[x * 4 + y] = resR[x * 3 + y]; st->gn[0].resultRt[x * 4 + y] = resR[x * 3 + y]; }
+    compute_krk(Rt, kfirst, st->gn[0].krkinv, st->gn[0].kt);
     st->so3_done = 1;
   } else {
     so3_matrices(resR, k, st->so3_mats);
@@ -1634,9 +1707,13 @@ __global__ void __launch_bounds__(SO3_BLOCK) k_so3_op(const uint8_t* __restrict_
 }
 __global__ void __launch_bounds__(SOLVE_BLOCK) k_final_tree_op(const float* __restrict__ partials, int na, float* __restrict__ out) {
   __shared__ float bs[SE3_ACCS * 64];
-  __shared__ float sums[SE3_ACCS];
-  if (na == SE3_ACCS) final_tree<SOLVE_BLOCK, SE3_ACCS, false>(partials, bs, sums);
-  else final_tree<SOLVE_BLOCK, SO3_ACCS, false>(partials, bs, sums);
+  __shared__ float sums[2 * SE3_ACCS];
+  if (na == SE3_ACCS) {   // k_se3_accum's pair partials (one term)
+    pair_partials_tree<SOLVE_BLOCK>(partials, true, false, sums);
+    __syncthreads();
+  } else {
+    final_tree<SOLVE_BLOCK, SO3_ACCS, false>(partials, bs, sums);
+  }
   if ((int)threadIdx.x < na) out[threadIdx.x] = sums[threadIdx.x];
 }
 
@@ -1713,7 +1790,7 @@ void icp_step_op(const IcpArgs& a, const float* vmap_curr, const float* nmap_cur
   (void)hipMemcpyAsync(pose, h, sizeof(h), hipMemcpyHostToDevice, s);
   (void)hipStreamSynchronize(s);  // h is a stack buffer
   Se3Inputs in{pose, pose + 9, pose + 12, pose + 21, nullptr, nullptr, 0.f, false};
-  launch_accum<true, false, false>(V, RV, in, cols * rows, Se3Out{scratch, scratch, nullptr, nullptr}, s);
+  launch_accum<true, false, false>(V, RV, in, cols * rows, Se3Out{scratch}, s);
   hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SE3_ACCS, out29_dev);
 }
 void rgb_residual_op(const RgbResidualArgs& a, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
@@ -1737,7 +1814,7 @@ void rgb_step_op(const void* corres, float sigma, const float* cloud, float fx, 
   IcpView IV{};
   RgbView V{corres, nullptr, cloud, dIdx, dIdy, cols, rows, Intr{fx, fy, 0, 0}, sobelScale};
   Se3Inputs in{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sigma, false};
-  launch_accum<false, true, false>(IV, V, in, cols * rows, Se3Out{scratch, scratch, nullptr, nullptr}, s);
+  launch_accum<false, true, false>(IV, V, in, cols * rows, Se3Out{scratch}, s);
   hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SE3_ACCS, out29_dev);
 }
 void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* nextImage, int cols, int rows, float* scratch, float* out11_dev,
@@ -1899,38 +1976,44 @@ void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s) {
 
 namespace {
 template <int PPT>
-void launch_residual(const Pyramid& p, TrackState* st, int level, hipStream_t s) {
+void launch_step(const Pyramid& p, TrackState* st, int level, int cur, int slots_out, const StepArgs& A, hipStream_t s) {
   const int cols = p.W(level), rows = p.H(level), N = cols * rows;
   ResidualPackedView RV{p.rgbMask[level], p.lastDepth[level], p.nextDepth[level], p.lastImage[level], p.nextImage[level], p.corres[level], cols, rows,
                         0.07f /* maxDepthDeltaRGB, RGBDOdometry.cpp:41 */};
-  hipLaunchKernelGGL(k_rgb_residual<PPT>, dim3(ceil_div(N, REDUCE_BLOCK * PPT)), dim3(REDUCE_BLOCK), 0, s, RV, (const float*)st->krkinv,
-                     (const float*)st->kt, &st->rgb_slots[0][0], (const int*)&st->rgb_broken);
+  const int grid = A.has_body ? ceil_div(N, REDUCE_BLOCK * PPT) : 1;
+  hipLaunchKernelGGL(k_track_step<PPT>, dim3(grid), dim3(REDUCE_BLOCK), 0, s, RV, st, (const GNState*)&st->gn[cur], &st->gn[cur ^ 1],
+                     (const float*)p.partials, (const int*)&st->rgb_slots[slots_out ^ 1][0][0], &st->rgb_slots[slots_out][0][0], A);
 }
-void launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const TrackParams& tp, bool icp, bool rgb, Intr knext,
-                      bool level_changes, hipStream_t s, KernelProbe* probe) {
+// one Gauss-Newton iteration = two launches: k_track_step (update of the previous iteration + correspondence search) and
+// k_se3_accum (normal equations).  `it` = index of the iteration within the call; cur = GNState buffer to read.
+// Returns the buffer the NEXT step reads.
+int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const TrackParams& tp, bool icp, bool rgb, int it, int cur,
+                     bool level_changes, hipStream_t s, KernelProbe* probe) {
   const int cols = p.W(level), rows = p.H(level), N = cols * rows;
   const bool sample = probe && level == 0 && probe->used < probe->capacity;
-  if (rgb) {
-    if (N >= 256 * 1024) launch_residual<2>(p, st, level, s);
-    else launch_residual<1>(p, st, level, s);
+  const int sp = it & 1;
+  StepArgs A{it > 0, rgb, icp, rgb, tp.rgbOnly, tp.icpWeight, kl, level_changes};
+  if (A.has_head || A.has_body) {
+    if (N >= 256 * 1024) launch_step<2>(p, st, level, cur, sp, A, s);
+    else launch_step<1>(p, st, level, cur, sp, A, s);
   }
+  if (A.has_head) cur ^= 1;
+  const GNState* g = &st->gn[cur];
   IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres};
   RgbView GV{p.corres[level], p.lastDepth[level], nullptr, p.dIdx[level], p.dIdy[level], cols, rows, kl, 1.0f / 8.0f};
-  Se3Inputs in{st->Rcurr, st->tcurr, st->Rprev_inv, st->tprev, &st->rgb_slots[0][0], &st->rgb_broken, 0.f, tp.rgbOnly};
-  float* prgb = p.partials + SE3_ACCS * VWARPS;
-  float* pblk = p.partials + 2 * SE3_ACCS * VWARPS;
-  const Se3Out out{p.partials, prgb, pblk, st->acc_tickets};
+  Se3Inputs in{g->Rcurr, g->tcurr, st->Rprev_inv, st->tprev, &st->rgb_slots[sp][0][0], &g->rgb_broken, 0.f, tp.rgbOnly};
+  in.slots_zero = &st->rgb_slots[sp ^ 1][0][0];
+  const Se3Out out{p.partials};
   hipEvent_t e0 = sample ? probe->start[probe->used] : nullptr, e1 = sample ? probe->stop[probe->used] : nullptr;
   if (sample) probe->used++;
   if (icp && rgb) launch_accum<true, true, true>(IV, GV, in, N, out, s, e0, e1);
   else if (icp) launch_accum<true, false, true>(IV, GV, in, N, out, s, e0, e1);
   else launch_accum<false, true, true>(IV, GV, in, N, out, s, e0, e1);
-  const FinishArgs fa{icp, rgb, tp.rgbOnly, tp.icpWeight, knext, level_changes};
-  hipLaunchKernelGGL(k_se3_finish, dim3(1), dim3(FINISH_BLOCK), 0, s, st, (const float*)pblk, fa);
+  return cur;
 }
 }  // namespace
 
-void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe) {
+TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe) {
   const bool icp = !tp.rgbOnly && tp.icpWeight > 0;       // RGBDOdometry.cpp:266-267
   const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
   int iterations[NUM_PYRS];
@@ -1948,18 +2031,18 @@ void track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_
                          (const uint8_t*)p.nextImage[so3_level], p.W(so3_level), p.H(so3_level), intr_level(k, so3_level),
                          intr_level(k, first_level), it, st, p.partials);
   }
+  int it = 0, cur = 0, prev_level = first_level;
   for (int i = NUM_PYRS - 1; i >= 0; --i) {
     const Intr kl = intr_level(k, i);
     for (int j = 0; j < iterations[i]; ++j) {
-      const bool last_of_level = (j == iterations[i] - 1);
-      int next_level = i;
-      if (last_of_level)
-        for (int n = i - 1; n >= 0; --n)
-          if (iterations[n] > 0) { next_level = n; break; }
-      launch_iteration(p, st, i, kl, tp, icp, rgb, intr_level(k, next_level), last_of_level, s, probe);
+      cur = launch_iteration(p, st, i, kl, tp, icp, rgb, it, cur, i != prev_level, s, probe);
+      prev_level = i;
+      ++it;
     }
   }
   track_swap(p, tp);
+  // the last iteration's update is evaluated at the head of k_track_end (track_end below)
+  return TrackTail{cur, (it - 1) & 1, it > 0, icp, rgb, tp.rgbOnly, tp.icpWeight, intr_level(k, 0), p.partials};
 }
 // host-side tail of getIncrementalTransformation: the frame's intensity pyramid becomes the SO(3) reference of the next
 // (RGBDOdometry.cpp:284-288 swaps lastNextImage / nextImage); separate so that a replayed hipGraph can do it without launching
@@ -1969,8 +2052,10 @@ void track_swap(Pyramid& p, const TrackParams& tp) {
 }
 
 // exported for the context: finishing kernels
-void track_end(TrackState* st, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s) {
-  hipLaunchKernelGGL(k_track_end, dim3(1), dim3(64), 0, s, st, rgb, weightMultiplier, traj, slot);
+void track_end(TrackState* st, const TrackTail& u, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s) {
+  const StepArgs A{u.has_head, false, u.icp, u.rgb, u.rgbOnly, u.icpWeight, u.k0, true};
+  hipLaunchKernelGGL(k_track_end, dim3(1), dim3(REDUCE_BLOCK), 0, s, st, (const GNState*)&st->gn[u.cur], &st->gn[u.cur ^ 1], u.pairs,
+                     (const int*)&st->rgb_slots[u.slots & 1][0][0], A, rgb, weightMultiplier, traj, slot);
 }
 void pose_injected(TrackState* st, const double* T_wc16, bool save_prev, float weightMultiplier, bool with_weighting, double* traj, int slot,
                    hipStream_t s) {

@@ -20,6 +20,11 @@ if [ $qrc -ne 0 ]; then
   done
 fi
 [ "$mode" = "quick" ] && exit 0
+if [ "$mode" = "ab" ]; then   # bash tools/gpu_r2.sh <tag> ab <variants...>
+  shift 2
+  bash tools/gpu_ab.sh $tag "$@"
+  exit 0
+fi
 if [ "$mode" = "full" ]; then
   timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $out/${tag}_tests.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_tests.log
   tail -25 $out/${tag}_tests.log
