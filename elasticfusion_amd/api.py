@@ -134,6 +134,11 @@ def default_config(**kw) -> ef_config:
     return cfg
 
 
+class GlobalLoop(C.Structure):   # ef_global_loop
+    _fields_ = [("attempted", c_i), ("closest", c_i), ("n_constraints", c_i), ("accepted", c_i), ("graph_nodes", c_i), ("icp_error", c_f),
+                ("icp_count", c_f), ("T_wc_recovery", C.c_double * 16)]
+
+
 class LocalLoop(C.Structure):   # ef_local_loop
     _fields_ = [("attempted", c_i), ("cov_ok", c_i), ("gates_ok", c_i), ("n_constraints", c_i), ("applied", c_i),
                 ("graph_nodes", c_i), ("graph_capacity", c_i), ("pad_", c_i), ("stats", c_f * 6), ("cov_diag", C.c_double * 6), ("T_wc_curr", C.c_double * 16),
@@ -168,7 +173,7 @@ def graph_constraints(rows):
     return arr
 
 
-def solve_deformation(nodes4, rows, fernMatch=False, last_deform_time=0, poses=None, pose_times=None):
+def solve_deformation(nodes4, rows, fernMatch=False, last_deform_time=0, poses=None, pose_times=None, gates=None):
     """ef_solve_deformation (Deformation::constrain in general form, host only).  rows as graph_constraints takes them.
     -> dict(accepted, graph [n, 16], error, meanConsErr, poses [k, 4, 4] deformed along, new_relative rows)"""
     nodes4 = np.ascontiguousarray(nodes4, np.float32).reshape(-1, 4)
@@ -179,9 +184,10 @@ def solve_deformation(nodes4, rows, fernMatch=False, last_deform_time=0, poses=N
     assert len(times) == len(P16)
     rel = (GraphConstraint * max(len(rows), 1))()
     n_rel, e, m = c_i(0), c_f(0), c_f(0)
-    rc = lib().ef_solve_deformation(_ptr(nodes4), c_i(len(nodes4)), cons, c_i(len(rows)), c_i(int(bool(fernMatch))), C.c_int64(int(last_deform_time)),
-                                    _ptr(P16) if len(P16) else None, _ptr(times) if len(P16) else None, c_i(len(P16)), _ptr(g), C.byref(e), C.byref(m),
-                                    rel, C.byref(n_rel))
+    gz = None if gates is None else (c_f * 3)(*[float(x) for x in gates])
+    rc = lib().ef_solve_deformation_gated(_ptr(nodes4), c_i(len(nodes4)), cons, c_i(len(rows)), c_i(int(bool(fernMatch))), C.c_int64(int(last_deform_time)),
+                                          _ptr(P16) if len(P16) else None, _ptr(times) if len(P16) else None, c_i(len(P16)), _ptr(g), C.byref(e),
+                                          C.byref(m), rel, C.byref(n_rel), gz)
     if rc not in (0, -4):
         _chk(rc)
     new_rel = [(list(r.src), list(r.target), r.src_time, r.target_time, True, False) for r in rel[:n_rel.value]]
@@ -322,8 +328,10 @@ class Ferns:
 class Closure:
     """ef_closure_*: the host side of the loop closures around the fern database (ElasticFusion.cpp:392-445, 511-526, 588-589, 609-618)."""
 
-    def __init__(self, n=500, depthCut=3.0, photoThresh=115.0, fernThresh=0.3095, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, seed=0):
+    def __init__(self, n=500, depthCut=3.0, photoThresh=115.0, fernThresh=0.3095, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, seed=0,
+                 _borrowed=None):
         L = lib()
+        self._owned = _borrowed is None
         L.ef_closure_create.restype = L.ef_closure_ferns.restype = P
         L.ef_closure_create.argtypes = [c_i, c_f, c_f, c_f, c_i, c_i, c_f, c_f, c_f, c_f, C.c_uint]
         L.ef_closure_destroy.argtypes = L.ef_closure_ferns.argtypes = [P]
@@ -335,7 +343,8 @@ class Closure:
         L.ef_closure_relative.argtypes = [P, P, c_i]
         L.ef_closure_trajectory.argtypes = [P, P, c_i]
         self.w, self.h = width // 8, height // 8
-        self._h = L.ef_closure_create(int(n), depthCut, photoThresh, fernThresh, int(width), int(height), fx, fy, cx, cy, int(seed))
+        self._h = _borrowed if _borrowed is not None else L.ef_closure_create(int(n), depthCut, photoThresh, fernThresh, int(width), int(height), fx, fy,
+                                                                              cx, cy, int(seed))
         if not self._h:
             raise EFError("ef_closure_create: bad arguments")
         self.ferns = Ferns.__new__(Ferns)        # a view of the database the closure object owns
@@ -348,9 +357,9 @@ class Closure:
         self.ferns._f("get_table").argtypes = [P, P]
 
     def close(self):
-        if self._h:
+        if self._h and self._owned:
             lib().ef_closure_destroy(self._h)
-            self._h = None
+        self._h = None
 
     __del__ = close
 
@@ -402,6 +411,10 @@ class Closure:
         if rc < 0:
             _chk(rc)
         return rc == 1
+
+    def setGates(self, entry=0.06, meanConsErr=3e-4, energy=0.12):
+        """the three gates of the global deformation (ef_closure_set_gates); defaults = the reference's constants"""
+        _chk(lib().ef_closure_set_gates(P(self._h) if not isinstance(self._h, P) else self._h, c_f(entry), c_f(meanConsErr), c_f(energy)))
 
     def counts(self):
         v = [c_i(0) for _ in range(4)]
@@ -505,6 +518,27 @@ class ElasticFusion:
             return 1
         self._solver = LOOP_SOLVER(tramp)
         _chk(lib().ef_set_loop_solver(self.h, self._solver, None), self.h)
+
+    # --- global loop closure (ElasticFusion.cpp:392-445, 609-618; closeLoops=True contexts) ---
+    def enableGlobalClosure(self, n=500, photoThresh=115.0, fernThresh=0.3095, seed=0):
+        """ef_enable_global_closure: the fern database, its 1/8-resolution tracker and the closure bookkeeping inside processFrame"""
+        _chk(lib().ef_enable_global_closure(self.h, c_i(int(n)), c_f(photoThresh), c_f(fernThresh), C.c_uint(int(seed))), self.h)
+        lib().ef_get_closure.restype = P
+        lib().ef_get_closure.argtypes = [P]
+        self._closure = Closure(n=n, width=self.cfg.width, height=self.cfg.height, _borrowed=lib().ef_get_closure(self.h))
+        return self._closure
+
+    def getFerns(self):
+        """the fern database of the context (Ferns view: len() = frames.size(), lastClosest(), frame(i))"""
+        return self._closure.ferns
+
+    def closure(self):
+        return self._closure
+
+    def globalLoop(self) -> GlobalLoop:
+        g = GlobalLoop()
+        _chk(lib().ef_get_global_loop(self.h, C.byref(g)), self.h)
+        return g
 
     def useBuiltinLoopSolver(self, on=True):
         """the built-in deformation-graph optimiser where Deformation::constrain stands (ef_use_builtin_loop_solver)"""

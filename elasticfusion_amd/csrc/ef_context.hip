@@ -112,6 +112,23 @@ struct ef_ctx {
   ef_local_loop loop{};
   std::vector<double> loop_constraints;    // n x 8
   std::vector<float> loop_graph;
+  // global loop closure (ElasticFusion.cpp:392-445, 588-589, 609-618; ef_enable_global_closure): the host-side closure object (fern
+  // database, relative constraints, trajectory; ef_ferns.hip), the 1/8-resolution fill-in views it works on, and a third tracker
+  // instance at 1/8 resolution for the fern-to-view registration (Ferns.cpp:243-258: RGBDOdometry rgbd(w / 8, h / 8, ...))
+  ef_closure* closure = nullptr;
+  ef_global_loop gloop{};
+  int fern_w = 0, fern_h = 0;
+  uchar4* view_img_dev = nullptr;          // Resize::image / vertex (x2) of the fill-in maps, factor 8
+  float4* view_vert_dev = nullptr;
+  float4* view_norm_dev = nullptr;
+  uint8_t* h_view = nullptr;               // pinned: image | vertices | normals
+  eft::Pyramid pyr3{};
+  eft::TrackState* st3 = nullptr;
+  eft::Intr intr3{};
+  float4* fern_maps_dev = nullptr;         // fern vertices | fern normals | view vertices | view normals (+ a zero image)
+  float* h_nodes_pinned = nullptr;         // graph nodes sampled at the end of the previous frame (Deformation::sampleGraphModel, :593)
+  int n_nodes_host = 0;
+  double h_pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   // hipGraph replay of the tracker (BASELINE.json configs[4]): the ~70 launches of getIncrementalTransformation are
   // captured once per pyramid parity (the SO(3) reference / frame intensity buffers swap every frame) and replayed
   bool use_graph = false;
@@ -245,17 +262,126 @@ int do_predict(ef_ctx* c) {
   return EF_OK;
 }
 
-// ElasticFusion.cpp:447-527 (the fern branch :391-444 is not wired in yet, see ef_closure_* in ef_ferns.hip; the optimisation is
-// the registered solver's).  Synchronises once, where the reference reads the constraint buffers back (Resize.cpp:108,146).
-int local_loop_closure(ef_ctx* c, int log_slot) {
+// The 1/8-resolution views of the fill-in maps the fern database works on (Ferns.cpp:91-93,178-180: Resize::image / Resize::vertex x2),
+// the current pose and (optionally) a fresh sample of the graph nodes, brought to the host with ONE synchronisation.
+int read_fern_view(ef_ctx* c, bool with_nodes) {
+  hipStream_t s = c->stream;
+  const int W = c->cam.cols, dw = c->fern_w, dh = c->fern_h, n = dw * dh;
+  const dim3 g((unsigned)((n + 255) / 256));
+  hipLaunchKernelGGL(k_resize_nearest<uint32_t>, g, dim3(256), 0, s, (const uint32_t*)c->fm.image, W, dw, dh, 8, (uint32_t*)c->view_img_dev);
+  hipLaunchKernelGGL(k_resize_nearest<float4>, g, dim3(256), 0, s, (const float4*)c->fm.vertex, W, dw, dh, 8, c->view_vert_dev);
+  hipLaunchKernelGGL(k_resize_nearest<float4>, g, dim3(256), 0, s, (const float4*)c->fm.normal, W, dw, dh, 8, c->view_norm_dev);
+  EF_HIP(c, hipMemcpyAsync(c->h_view, c->view_img_dev, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  EF_HIP(c, hipMemcpyAsync(c->h_view + (size_t)n * 4, c->view_vert_dev, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+  EF_HIP(c, hipMemcpyAsync(c->h_view + (size_t)n * 20, c->view_norm_dev, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+  EF_HIP(c, hipMemcpyAsync(&c->h_states[0], c->st, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
+  if (with_nodes) {   // Deformation::sampleGraphModel at the end of the frame (ElasticFusion.cpp:593): every 5000th surfel of the new map
+    unsigned* n_dev = (unsigned*)(c->nodes_dev + (size_t)1024 * 4);
+    efm::sample_graph(c->maps[c->cur], &c->st->map_counts[c->cur], 5000, 1023, c->nodes_dev, n_dev, s);
+    EF_HIP(c, hipMemcpyAsync(c->h_nodes_pinned, c->nodes_dev, ((size_t)1024 * 4 + 1) * sizeof(float), hipMemcpyDeviceToHost, s));
+  }
+  EF_HIP(c, hipStreamSynchronize(s));
+  efl::SE3 T;
+  for (int i = 0; i < 4; ++i) T.q[i] = c->h_states[0].q[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = c->h_states[0].t[i];
+  efl::se3_matrix(T, c->h_pose);
+  if (with_nodes) {
+    unsigned nn = 0;
+    memcpy(&nn, c->h_nodes_pinned + (size_t)1024 * 4, sizeof(unsigned));
+    c->n_nodes_host = (int)nn;
+  }
+  return EF_OK;
+}
+
+// Ferns.cpp:243-258 on the device: the stored keyframe is the model (initICPModel with its pose), the current view the frame
+// (initICP(vertices, normals)); getIncrementalTransformation(T, rgbOnly = false, icpWeight = 100, pyramid = false, fastOdom = false,
+// so3 = false) = ten ICP-only iterations at the 1/8 resolution itself.  One synchronisation (pose + statistics back).
+void fern_tracker_device(void* user, const float* fv, const float* fn, const double* Tf, const float* cv, const float* cn, double* T_io, float* err,
+                         float* cnt) {
+  ef_ctx* c = (ef_ctx*)user;
+  hipStream_t s = c->stream;
+  const size_t n = (size_t)c->fern_w * c->fern_h;
+  float4* d_fv = c->fern_maps_dev;
+  float4* d_fn = d_fv + n;
+  float4* d_cv = d_fn + n;
+  float4* d_cn = d_cv + n;
+  const uint8_t* zero_image = (const uint8_t*)(d_cn + n);
+  (void)hipMemcpyAsync(d_fv, fv, n * 16, hipMemcpyHostToDevice, s);
+  (void)hipMemcpyAsync(d_fn, fn, n * 16, hipMemcpyHostToDevice, s);
+  (void)hipMemcpyAsync(d_cv, cv, n * 16, hipMemcpyHostToDevice, s);
+  (void)hipMemcpyAsync(d_cn, cn, n * 16, hipMemcpyHostToDevice, s);
+  (void)Tf;   // the caller hands T_io = T_wc_fern in (Ferns.cpp:250); the model maps are transformed with it
+  eft::pose_injected(c->st3, T_io, false, 1.0f, false, nullptr, 0, s);
+  eft::init_icp_model(c->pyr3, (const float*)d_fv, (const float*)d_fn, (const float*)d_fv, (const float*)d_fn, c->st3, 6.0f, s);
+  eft::init_icp_maps(c->pyr3, (const float*)d_cv, (const float*)d_cn, zero_image, c->st3, 6.0f, s);
+  eft::TrackParams tp;
+  tp.rgbOnly = false; tp.pyramid = false; tp.fastOdom = false; tp.so3 = false; tp.icpWeight = 100.f;
+  tp.distThres = 0.10f;
+  tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
+  const eft::TrackTail tail = eft::track(c->pyr3, c->st3, c->intr3, tp, s, nullptr);
+  eft::track_end(c->st3, tail, false, 1.0f, nullptr, -1, s);
+  (void)hipMemcpyAsync(&c->h_states[1], c->st3, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s);
+  (void)hipStreamSynchronize(s);
+  const eft::TrackState& h = c->h_states[1];
+  efl::SE3 T;
+  for (int i = 0; i < 4; ++i) T.q[i] = h.q[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = h.t[i];
+  efl::se3_matrix(T, T_io);
+  *err = h.lastICPError;
+  *cnt = h.lastICPCount;
+  c->gloop.icp_error = h.lastICPError;
+  c->gloop.icp_count = h.lastICPCount;
+}
+
+// ElasticFusion.cpp:392-445 with lost == false; returns 1 when a fern was matched AND the global deformation accepted with a graph
+int global_loop_closure(ef_ctx* c, int log_slot, int* accepted_with_graph) {
+  *accepted_with_graph = 0;
+  ef_global_loop& G = c->gloop;
+  memset(&G, 0, sizeof(G));
+  G.attempted = 1;
+  G.closest = -1;
+  const int r0 = read_fern_view(c, false);
+  if (r0 != EF_OK) return r0;
+  const size_t n = (size_t)c->fern_w * c->fern_h;
+  c->loop_graph.assign((size_t)1024 * 16, 0.f);
+  int nodes = 0;
+  const int r = ef_closure_global(c->closure, c->h_view, 4, (const float*)(c->h_view + n * 4), (const float*)(c->h_view + n * 20), c->h_pose, c->tick,
+                                  &fern_tracker_device, c, c->h_nodes_pinned, c->n_nodes_host, G.T_wc_recovery, c->loop_graph.data(), &nodes);
+  if (r < 0) { c->err = "ef_closure_global failed"; return r; }
+  G.closest = ef_ferns_last_closest(ef_closure_ferns(c->closure));   // Ferns::lastClosest: -1 unless a keyframe passed every gate
+  if (G.closest >= 0) {   // the rows handed to the optimiser: two per fern constraint (the constraint and its pin) + the kept relative ones
+    const int rows = ef_closure_last_rows(c->closure, nullptr, 0, nullptr, nullptr), rel = ef_closure_relative(c->closure, nullptr, 0);
+    G.n_constraints = rows > rel ? (rows - rel) / 2 : 0;
+  }
+  if (r != 1) return EF_OK;
+  if (nodes < 0 || nodes >= 1024) { c->err = "global closure: 0..1023 graph nodes (GlobalModel::MAX_NODES)"; return EF_EINVAL; }
+  G.accepted = 1;
+  G.graph_nodes = nodes;
+  // T_wc := the recovered pose (:429); the frame's logged pose follows (:588); the velocity weighting of :369-383 stays
+  eft::pose_injected(c->st, G.T_wc_recovery, false, 1.0f, false, log_slot >= 0 ? c->traj : nullptr, log_slot, c->stream);
+  if (nodes > 0) {
+    EF_HIP(c, hipMemcpyAsync(c->graph_dev, c->loop_graph.data(), (size_t)nodes * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    EF_HIP(c, hipStreamSynchronize(c->stream));
+    c->graph_nodes = nodes;
+    c->graph_is_fern = 1;                                                                            // fernAccepted, :441,584
+    *accepted_with_graph = 1;
+  }
+  return EF_OK;
+}
+
+// ElasticFusion.cpp:447-527.  The optimisation is the registered solver's, the built-in one's, or — with the global closure enabled —
+// the closure object's (keyframe poses follow, relative constraints are kept).  Synchronises once, where the reference reads the
+// constraint buffers back (Resize.cpp:108,146).  have_active: the ACTIVE prediction at the new pose (predict() of :387) was already made.
+int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
   hipStream_t s = c->stream;
   const int W = c->cam.cols, H = c->cam.rows, step = 20 /* consSample, ElasticFusion.cpp:62 */;
   const int cw = W / step, ch = H / step;
   const efm::FillMaps none{nullptr, nullptr, nullptr};
   const unsigned* count = &c->st->map_counts[c->cur];
-  // predict() of :387: the ACTIVE view at the pose just estimated (its fill-in only feeds the fern database: skipped)
-  efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], count, c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick, c->cfg.time_delta,
-                        c->zbuf, c->pm, none, nullptr, nullptr, false, nullptr, s);
+  // predict() of :387: the ACTIVE view at the pose just estimated (its fill-in only feeds the fern database: made by the caller then)
+  if (!have_active)
+    efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], count, c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick, c->cfg.time_delta,
+                          c->zbuf, c->pm, none, nullptr, nullptr, false, nullptr, s);
   // :451-459, IndexMap::INACTIVE: surfels last seen at or before tick - timeDelta
   efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], count, c->maxDepthProcessed, c->cfg.confidence, 0, c->tick - c->cfg.time_delta,
                         c->cfg.time_delta, c->zbuf, c->old, none, nullptr, nullptr, false, nullptr, s);
@@ -325,6 +451,13 @@ int local_loop_closure(ef_ctx* c, int log_slot) {
   bool accepted = false;
   if (c->solver) {
     accepted = c->solver(c->solver_user, &L, c->loop_constraints.data(), L.n_constraints, c->loop_graph.data(), &nodes) != 0;   // :513-514
+  } else if (c->closure) {
+    // Deformation::constrain in full (:511-526): graph sampled at the end of the previous frame, keyframe poses deformed along,
+    // a third of the new relative constraints kept for later global closures
+    const int r = ef_closure_local(c->closure, c->loop_constraints.data(), L.n_constraints, c->tick, c->h_nodes_pinned, c->n_nodes_host,
+                                   c->loop_graph.data(), &nodes);
+    if (r < 0) { c->err = "ef_closure_local failed"; return r; }
+    accepted = r == 1;
   } else {
     // the built-in optimiser on the graph Deformation::sampleGraphModel would have sampled at the end of the previous frame
     // (ElasticFusion.cpp:593): every 5000th surfel of the map as it stands now
@@ -482,10 +615,23 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
     EF_HIP(c, hipEventRecord(c->ev_track_done, s));
     // mid-frame predict() of ElasticFusion.cpp:387 is dead work without loop closure: skipped
     if (c->cfg.close_loops) {
-      timer_begin(c, "localLoop");
-      const int r = local_loop_closure(c, log_slot);
-      timer_end(c, "localLoop");
-      if (r != EF_OK) return r;
+      int fern_graph = 0;
+      if (c->closure) {   // :387-445: predict() with its fill-in at the new pose, then the fern database
+        timer_begin(c, "globalLoop");
+        efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence, c->tick,
+                              c->tick, c->cfg.time_delta, c->zbuf, c->pm, c->fm, c->depth_filtered, c->rgb, c->cfg.frame_to_frame_rgb != 0, nullptr, s);
+        const int r = global_loop_closure(c, log_slot, &fern_graph);
+        timer_end(c, "globalLoop");
+        if (r != EF_OK) return r;
+      }
+      if (!fern_graph) {   // :447: rawGraph.size() == 0
+        timer_begin(c, "localLoop");
+        const int r = local_loop_closure(c, log_slot, c->closure != nullptr);
+        timer_end(c, "localLoop");
+        if (r != EF_OK) return r;
+      } else {
+        memset(&c->loop, 0, sizeof(c->loop));
+      }
     }
     if (!rgbOnly) {  // ElasticFusion.cpp:536-585
       timer_begin(c, "indexMap");
@@ -520,6 +666,15 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   timer_begin(c, "IndexMap::ACTIVE");
   do_predict(c);  // ElasticFusion.cpp:599
   timer_end(c, "IndexMap::ACTIVE");
+  if (c->closure) {   // :588-589, 593, 609-618: pose -> trajectory, graph nodes re-sampled, final fill-in view -> Ferns::addFrame
+    timer_begin(c, "ferns");
+    const int r0 = read_fern_view(c, true);
+    if (r0 != EF_OK) return r0;
+    const size_t n = (size_t)c->fern_w * c->fern_h;
+    const int r = ef_closure_end_frame(c->closure, c->h_view, 4, (const float*)(c->h_view + n * 4), (const float*)(c->h_view + n * 20), c->h_pose, c->tick);
+    timer_end(c, "ferns");
+    if (r < 0) { c->err = "ef_closure_end_frame failed"; return r; }
+  }
   EF_HIP(c, hipEventRecord(c->ev_frame_done[c->frame_parity], s));
   c->tick++;
   EF_HIP(c, hipGetLastError());
@@ -659,6 +814,9 @@ void ctx_free(ef_ctx* c) {
   if (c->h_depth) (void)hipHostFree(c->h_depth);
   if (c->h_cons) (void)hipHostFree(c->h_cons);
   if (c->h_states) (void)hipHostFree(c->h_states);
+  if (c->h_view) (void)hipHostFree(c->h_view);
+  if (c->h_nodes_pinned) (void)hipHostFree(c->h_nodes_pinned);
+  if (c->closure) ef_closure_destroy(c->closure);
   for (auto& t : c->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : c->kt_start) (void)hipEventDestroy(e);
   for (auto e : c->kt_stop) (void)hipEventDestroy(e);
@@ -807,6 +965,12 @@ int ef_solve_local_deformation(const float* nodes4, int n_nodes, const double* c
 int ef_solve_deformation(const float* nodes4, int n_nodes, const ef_graph_constraint* constraints, int n_constraints, int fern_match,
                          int64_t last_deform_time, double* poses16, const int64_t* pose_times, int n_poses, float* graph16_out, float* error_out,
                          float* mean_constraint_error_out, ef_graph_constraint* new_relative_out, int* n_new_relative_out) {
+  return ef_solve_deformation_gated(nodes4, n_nodes, constraints, n_constraints, fern_match, last_deform_time, poses16, pose_times, n_poses, graph16_out,
+                                    error_out, mean_constraint_error_out, new_relative_out, n_new_relative_out, nullptr);
+}
+int ef_solve_deformation_gated(const float* nodes4, int n_nodes, const ef_graph_constraint* constraints, int n_constraints, int fern_match,
+                               int64_t last_deform_time, double* poses16, const int64_t* pose_times, int n_poses, float* graph16_out, float* error_out,
+                               float* mean_constraint_error_out, ef_graph_constraint* new_relative_out, int* n_new_relative_out, const float* gates3) {
   if (!nodes4 || !constraints || !graph16_out || n_nodes < 0 || n_nodes > 1023 || n_constraints < 0 || n_poses < 0 || (n_poses > 0 && (!poses16 || !pose_times)))
     return EF_EINVAL;
   std::vector<efd::Constraint> cons((size_t)n_constraints);
@@ -817,8 +981,9 @@ int ef_solve_deformation(const float* nodes4, int n_nodes, const ef_graph_constr
   }
   efd::Result r{false, 0, 0.f, 0.f};
   std::vector<efd::Constraint> rel;
+  const efd::Gates gates = gates3 ? efd::Gates{gates3[0], gates3[1], gates3[2]} : efd::Gates();
   const bool updated = efd::constrain(nodes4, n_nodes, cons.data(), n_constraints, fern_match != 0, (uint64_t)last_deform_time, poses16, pose_times, n_poses,
-                                      graph16_out, &r, new_relative_out ? &rel : nullptr);
+                                      graph16_out, &r, new_relative_out ? &rel : nullptr, gates);
   if (n_new_relative_out) *n_new_relative_out = (int)rel.size();
   for (size_t i = 0; new_relative_out && i < rel.size(); ++i) {
     ef_graph_constraint& o = new_relative_out[i];
@@ -829,6 +994,57 @@ int ef_solve_deformation(const float* nodes4, int n_nodes, const ef_graph_constr
   if (mean_constraint_error_out) *mean_constraint_error_out = r.meanConsErr;
   return updated ? EF_OK : EF_ESTATE;
 }
+int ef_enable_global_closure(ef_ctx* c, int num_ferns, float photo_thresh, float fern_thresh, unsigned seed) {
+  if (!c || num_ferns < 50) return EF_EINVAL;
+  DeviceGuard dg_(c);
+  if (!c->cfg.close_loops) { c->err = "ef_enable_global_closure: the context was created with close_loops = 0"; return EF_ESTATE; }
+  if (c->closure) { c->err = "ef_enable_global_closure: already enabled"; return EF_ESTATE; }
+  const int W = c->cam.cols, H = c->cam.rows;
+  if ((W / 8) % 4 || (H / 8) % 4 || W % 8 || H % 8) { c->err = "ef_enable_global_closure: width and height must be multiples of 32"; return EF_EINVAL; }
+  c->fern_w = W / 8;
+  c->fern_h = H / 8;
+  const size_t n = (size_t)c->fern_w * c->fern_h;
+  EF_ALLOC(c, c->view_img_dev, n);
+  EF_ALLOC(c, c->view_vert_dev, n);
+  EF_ALLOC(c, c->view_norm_dev, n);
+  EF_ALLOC(c, c->fern_maps_dev, 5 * n);   // 4 maps + a zero image (the 1/8 tracker never reads colour: icpWeight = 100)
+  EF_HIP(c, hipHostMalloc((void**)&c->h_view, n * 36));
+  EF_HIP(c, hipHostMalloc((void**)&c->h_nodes_pinned, ((size_t)1024 * 4 + 4) * sizeof(float)));
+  memset(c->h_nodes_pinned, 0, ((size_t)1024 * 4 + 4) * sizeof(float));
+  c->intr3 = eft::Intr{c->cfg.fx / 8, c->cfg.fy / 8, c->cfg.cx / 8, c->cfg.cy / 8};   // Ferns.cpp:31-36
+  c->pyr3.width = c->fern_w;
+  c->pyr3.height = c->fern_h;
+  for (int i = 0; i < eft::NUM_PYRS; ++i) {
+    const size_t m = (size_t)(c->fern_w >> i) * (c->fern_h >> i);
+    EF_ALLOC(c, c->pyr3.depth_tmp[i], m);
+    EF_ALLOC(c, c->pyr3.vmap_curr[i], 3 * m);
+    EF_ALLOC(c, c->pyr3.nmap_curr[i], 3 * m);
+    EF_ALLOC(c, c->pyr3.vmap_g_prev[i], 3 * m);
+    EF_ALLOC(c, c->pyr3.nmap_g_prev[i], 3 * m);
+    EF_ALLOC(c, c->pyr3.lastDepth[i], m);
+    EF_ALLOC(c, c->pyr3.nextDepth[i], m);
+    EF_ALLOC(c, c->pyr3.lastImage[i], m);
+    EF_ALLOC(c, c->pyr3.nextImage[i], m);
+    EF_ALLOC(c, c->pyr3.lastNextImage[i], m);
+    EF_ALLOC(c, c->pyr3.dIdx[i], m);
+    EF_ALLOC(c, c->pyr3.dIdy[i], m);
+    EF_ALLOC(c, c->pyr3.corres[i], m);
+    EF_ALLOC(c, c->pyr3.rgbMask[i], m);
+  }
+  EF_ALLOC(c, c->pyr3.partials, (size_t)eft::PARTIAL_FLOATS);
+  EF_ALLOC(c, c->st3, 1);
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, c->stream, c->st3, 1, c->fern_w * c->fern_h);
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  c->closure = ef_closure_create(num_ferns, c->cfg.depth_cut, photo_thresh, fern_thresh, W, H, c->cfg.fx, c->cfg.fy, c->cfg.cx, c->cfg.cy, seed);
+  if (!c->closure) { c->err = "ef_closure_create failed"; return EF_ENOMEM; }
+  return EF_OK;
+}
+int ef_get_global_loop(ef_ctx* c, ef_global_loop* info) {
+  if (!c || !info) return EF_EINVAL;
+  *info = c->gloop;
+  return EF_OK;
+}
+ef_closure* ef_get_closure(ef_ctx* c) { return c ? c->closure : nullptr; }
 int ef_get_local_loop(ef_ctx* c, ef_local_loop* info, double* constraints, int max_constraints, int* n_out) {
   if (!c || !info) return EF_EINVAL;
   *info = c->loop;

@@ -176,7 +176,13 @@ struct Graph {
 };
 
 // DeformationGraph::optimiseGraphSparse (DeformationGraph.cpp:416-492) on a built graph.  Result.ok is its return value.
-inline Result optimise(Graph& G, const Constraint* constraints, int m, bool fernMatch) {
+// The three gates of a GLOBAL closure (fernMatch): nothing to do below `entry` metres of mean constraint error (DeformationGraph.cpp:425);
+// accepted only when the optimised mean constraint error is below `meanConsErr` and the energy below `energy` (Deformation.cpp:153).
+// The defaults are the reference's hard-coded constants.
+struct Gates {
+  float entry = 0.06f, meanConsErr = 0.0003f, energy = 0.12f;
+};
+inline Result optimise(Graph& G, const Constraint* constraints, int m, bool fernMatch, const Gates& gates = Gates()) {
   std::vector<Node>& nodes = G.nodes;
   const int n = (int)nodes.size();
   Result res{false, 0, 0.f, 0.f};
@@ -212,7 +218,7 @@ inline Result optimise(Graph& G, const Constraint* constraints, int m, bool fern
     return e / (float)cons.size();
   };
   res.meanConsErr = mean_error();
-  if (fernMatch && res.meanConsErr < 0.06) return res;   // the keyframe already agrees with the map: nothing to close
+  if (fernMatch && res.meanConsErr < gates.entry) return res;   // the keyframe already agrees with the map: nothing to close
   res.ok = true;
   if (unknowns == 0) return res;
   const double sr = std::sqrt(W_REG), sc = std::sqrt(W_CON);
@@ -353,7 +359,8 @@ inline void apply_to_pose(const Graph& G, const Carrier (&c)[K], double* T16) {
 // new_relative: what a local closure leaves behind for later global ones (Deformation.cpp:160-173) — per plain constraint the
 // DEFORMED source against its target, relative.
 inline bool constrain(const float* nodes4, int n, const Constraint* constraints, int m, bool fernMatch, uint64_t last_deform_time, double* poses16,
-                      const int64_t* pose_times, int n_poses, float* graph16, Result* result, std::vector<Constraint>* new_relative = nullptr) {
+                      const int64_t* pose_times, int n_poses, float* graph16, Result* result, std::vector<Constraint>* new_relative = nullptr,
+                      const Gates& gates = Gates()) {
   Graph G;
   Result res{false, 0, 0.f, 0.f};
   if (result) *result = res;
@@ -364,9 +371,9 @@ inline bool constrain(const float* nodes4, int n, const Constraint* constraints,
     pose_carriers(G, poses16 + (size_t)i * 16, (uint64_t)pose_times[i], c);
     for (int j = 0; j < K; ++j) pc[(size_t)i * K + j] = c[j];
   }
-  res = optimise(G, constraints, m, fernMatch);
+  res = optimise(G, constraints, m, fernMatch, gates);
   if (result) *result = res;
-  if (!(!fernMatch || (res.ok && res.meanConsErr < 0.0003 && res.error < 0.12))) return false;
+  if (!(!fernMatch || (res.ok && res.meanConsErr < gates.meanConsErr && res.error < gates.energy))) return false;
   for (int i = 0; i < n_poses; ++i) {
     Carrier c[K];
     for (int j = 0; j < K; ++j) c[j] = pc[(size_t)i * K + j];

@@ -299,6 +299,7 @@ float ef_ferns_photometric_check(const ef_ferns* f, const uint8_t* rgb, int ch, 
 struct ef_closure {
   ef_ferns* ferns = nullptr;
   float fernThresh = 0.3095f;
+  efd::Gates gates;   // ef_closure_set_gates; the reference's constants by default
   int deforms = 0, fernDeforms = 0;
   int64_t lastDeformTime = 0;                 // Deformation::lastDeformTime of the LOCAL deformation
   std::vector<efd::Constraint> relativeCons;  // ElasticFusion::relativeCons
@@ -366,7 +367,8 @@ int ef_closure_global(ef_closure* c, const uint8_t* rgb, int ch, const float* ve
   c->poses(true, P, t);
   efd::Result r{false, 0, 0.f, 0.f};
   const int gn = (int)(global.size() / 4);
-  const bool ok = efd::constrain(global.data(), gn, rows.data(), (int)rows.size(), true, 0, P.data(), t.data(), (int)t.size(), graph16_out, &r);   // :428
+  const bool ok = efd::constrain(global.data(), gn, rows.data(), (int)rows.size(), true, 0, P.data(), t.data(), (int)t.size(), graph16_out, &r, nullptr,
+                                 c->gates);   // :428
   c->lastError = r.error;
   c->lastMeanConsErr = r.meanConsErr;
   if (!ok) return 0;
@@ -413,6 +415,16 @@ int ef_closure_end_frame(ef_closure* c, const uint8_t* rgb, int ch, const float*
   return ef_ferns_add_frame(c->ferns, rgb, ch, verts4, norms4, T_wc16, tick, c->fernThresh);
 }
 
+int ef_closure_set_fern_thresh(ef_closure* c, float fern_thresh) {
+  if (!c) return EF_EINVAL;
+  c->fernThresh = fern_thresh;
+  return EF_OK;
+}
+int ef_closure_set_gates(ef_closure* c, float entry_mean_error, float accept_mean_error, float accept_energy) {
+  if (!c) return EF_EINVAL;
+  c->gates = efd::Gates{entry_mean_error, accept_mean_error, accept_energy};
+  return EF_OK;
+}
 int ef_closure_counts(const ef_closure* c, int* deforms, int* fern_deforms, int* relative, int* trajectory) {
   if (!c) return EF_EINVAL;
   if (deforms) *deforms = c->deforms;

@@ -530,7 +530,7 @@ __device__ __forceinline__ void fill_in_px(const Cam& cam, int x, int y, uchar4 
 }
 __device__ __forceinline__ void dense_sample(const Cam& cam, int x, int y, uchar4 si, unsigned* counter) {
   // Resize::image: dest (a,b) <- source texel (20a+10, 20b+10), consSample = 20 (ElasticFusion.cpp:62-70)
-  if (x % 20 == 10 && y % 20 == 10 && x / 20 < cam.cols / 20 && y / 20 < cam.rows / 20)
+  if (counter && x % 20 == 10 && y % 20 == 10 && x / 20 < cam.cols / 20 && y / 20 < cam.rows / 20)
     if (si.x > 0 && si.y > 0 && si.z > 0) atomicAdd(counter, 1u);
 }
 

@@ -56,11 +56,12 @@ void SE3d::matrix(double* out16) const {
 }
 
 ElasticFusion::ElasticFusion(const int timeDelta_, const int countThresh, const float errThresh, const float covThresh,
-                             const bool closeLoops, const bool /*iclnuim*/, const bool /*reloc*/, const float /*photoThresh*/,
+                             const bool closeLoops, const bool iclnuim_, const bool reloc, const float photoThresh,
                              const float confidence, const float depthCut, const float icpThresh, const bool fastOdom,
-                             const float /*fernThresh*/, const bool so3, const bool frameToFrameRGB, const std::string fileName,
+                             const float fernThresh, const bool so3, const bool frameToFrameRGB, const std::string fileName,
                              const int device)
-    : saveFilename(fileName), timeDelta(timeDelta_), confidenceThreshold(confidence), closeLoops(closeLoops) {
+    : saveFilename(fileName), timeDelta(timeDelta_), confidenceThreshold(confidence), closeLoops(closeLoops), iclnuim(iclnuim_) {
+  if (reloc) throw std::runtime_error("ElasticFusion: reloc = true (relocalisation when tracking is lost) is not built in this library");
   ef_config cfg;
   ef_default_config(&cfg);
   cfg.width = Resolution::getInstance().width();
@@ -81,10 +82,14 @@ ElasticFusion::ElasticFusion(const int timeDelta_, const int countThresh, const 
   ef_ctx* c = nullptr;
   chk(ef_create(&cfg, &c), nullptr, "ElasticFusion::ElasticFusion");
   ctx.reset(c);
-  if (closeLoops) chk(ef_set_loop_thresholds(c, countThresh, errThresh, covThresh), c, "ElasticFusion::ElasticFusion");
+  if (closeLoops) {   // the reference's closed-loop mode: global (fern) closure, then local closure, built-in optimiser for both
+    chk(ef_set_loop_thresholds(c, countThresh, errThresh, covThresh), c, "ElasticFusion::ElasticFusion");
+    chk(ef_use_builtin_loop_solver(c, 1), c, "ElasticFusion::ElasticFusion");
+    chk(ef_enable_global_closure(c, 500, photoThresh, fernThresh, 0u), c, "ElasticFusion::ElasticFusion");   // Ferns(500, depthCut * 1000, photoThresh), :53
+  }
   // drop-in: getGlobalModel().downloadMap() and savePly() return what the reference's return (the pre-clean buffer, quirk Q14)
   chk(ef_set_reference_download(c, 1), c, "ElasticFusion::ElasticFusion");
-  indexMap.ctx = globalModel.ctx = c;
+  indexMap.ctx = globalModel.ctx = localDeformation.ctx = c;
   indexMap.w = cfg.width;
   indexMap.h = cfg.height;
   if (!saveFilename.empty()) {  // the reference truncates <file>.freiburg in its constructor (ElasticFusion.cpp:97-102)
@@ -93,7 +98,26 @@ ElasticFusion::ElasticFusion(const int timeDelta_, const int countThresh, const 
 }
 
 ElasticFusion::~ElasticFusion() {
-  if (ctx && !saveFilename.empty()) (void)ef_save_freiburg(C(ctx.get()), (saveFilename + ".freiburg").c_str());
+  if (!ctx) return;
+  try {
+    if (iclnuim) savePly();   // ElasticFusion.cpp:108-110
+  } catch (...) {
+  }
+  if (saveFilename.empty()) return;
+  if (!iclnuim) {
+    (void)ef_save_freiburg(C(ctx.get()), (saveFilename + ".freiburg").c_str());
+    return;
+  }
+  // iclnuim: the timestamps are written as they came, not as microseconds / 1e6 (ElasticFusion.cpp:124-128)
+  int n = 0;
+  if (ef_get_trajectory(C(ctx.get()), nullptr, nullptr, 0, &n) != EF_OK) return;
+  int tick_now = 1;
+  (void)ef_get_tick(C(ctx.get()), &tick_now);
+  std::vector<double> T((size_t)tick_now * 16);
+  std::vector<int64_t> ts((size_t)tick_now);
+  if (ef_get_trajectory(C(ctx.get()), T.data(), ts.data(), tick_now, &n) != EF_OK) return;
+  for (int i = 0; i < n; ++i) ts[i] *= 1000000;   // ef_write_freiburg divides by 1e6 and prints six decimals, which is the reference's format here
+  (void)ef_write_freiburg((saveFilename + ".freiburg").c_str(), T.data(), ts.data(), n);
 }
 
 void ElasticFusion::processFrame(const uint8_t* rgb, const uint16_t* depth, const int64_t& timestamp, const float weightMultiplier,
@@ -101,10 +125,65 @@ void ElasticFusion::processFrame(const uint8_t* rgb, const uint16_t* depth, cons
   double M[16];
   if (in_T_wc) in_T_wc->matrix(M);
   chk(ef_process_frame(C(ctx.get()), rgb, depth, timestamp, weightMultiplier, in_T_wc ? M : nullptr), ctx.get(), "processFrame");
-  if (closeLoops) {   // deforms += rawGraph.size() > 0, ElasticFusion.cpp:523
+  if (closeLoops) {
+    ef_ctx* c = C(ctx.get());
+    ef_closure* cl = ef_get_closure(c);
+    ef_global_loop G;
+    chk(ef_get_global_loop(c, &G), c, "processFrame");
     const ef_local_loop& L = getLocalLoop();
-    deforms += (L.applied && L.graph_nodes > 0) ? 1 : 0;
+    const int n_frames = cl ? ef_ferns_count(ef_closure_ferns(cl)) : 0;
+    auto rows_to_constraints = [&](bool fern) {
+      std::vector<SurfaceConstraint> out;
+      if (fern) {
+        const int n = ef_closure_last_rows(cl, nullptr, 0, nullptr, nullptr);
+        std::vector<ef_graph_constraint> rows((size_t)(n > 0 ? n : 1));
+        ef_closure_last_rows(cl, rows.data(), n, nullptr, nullptr);
+        for (int i = 0; i < n; ++i)
+          if (!rows[i].relative && !rows[i].pin) out.push_back(SurfaceConstraint{{rows[i].src[0], rows[i].src[1], rows[i].src[2]}, {rows[i].target[0], rows[i].target[1], rows[i].target[2]}});
+      } else {
+        std::vector<double> cons((size_t)(L.n_constraints > 0 ? L.n_constraints : 1) * 8);
+        int n = 0;
+        ef_local_loop tmp;
+        chk(ef_get_local_loop(c, &tmp, cons.data(), L.n_constraints, &n), c, "processFrame");
+        for (int i = 0; i < n; ++i) out.push_back(SurfaceConstraint{{cons[i * 8], cons[i * 8 + 1], cons[i * 8 + 2]}, {cons[i * 8 + 3], cons[i * 8 + 4], cons[i * 8 + 5]}});
+      }
+      return out;
+    };
+    if (G.accepted) {   // ElasticFusion.cpp:428-441
+      double Tf[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      if (cl && G.closest >= 0) ef_ferns_get_frame(ef_closure_ferns(cl), G.closest, nullptr, nullptr, nullptr, Tf, nullptr, nullptr, nullptr);
+      poseMatches.push_back(PoseMatch{G.closest, n_frames, SE3d::fromMatrix(Tf), SE3d::fromMatrix(G.T_wc_recovery), rows_to_constraints(true), true});
+      fernDeforms += G.graph_nodes > 0 ? 1 : 0;
+    } else if (L.applied) {   // :514-526
+      poseMatches.push_back(PoseMatch{n_frames - 1, n_frames, SE3d::fromMatrix(L.T_wc_est), SE3d::fromMatrix(L.T_wc_curr), rows_to_constraints(false), false});
+      deforms += L.graph_nodes > 0 ? 1 : 0;
+    }
   }
+}
+
+const FernsView& ElasticFusion::getFerns() {
+  fernsView.frames.clear();
+  fernsView.lastClosest = -1;
+  ef_closure* cl = ef_get_closure(C(ctx.get()));
+  if (!cl) return fernsView;
+  ef_ferns* f = ef_closure_ferns(cl);
+  const int n = ef_ferns_count(f);
+  for (int i = 0; i < n; ++i) {
+    double T[16];
+    int t = 0;
+    ef_ferns_get_frame(f, i, nullptr, nullptr, &t, T, nullptr, nullptr, nullptr);
+    fernsView.frames.push_back(FernFrame{i, t, SE3d::fromMatrix(T)});
+  }
+  fernsView.lastClosest = ef_ferns_last_closest(f);
+  return fernsView;
+}
+
+std::vector<float> DeformationView::getGraph() {
+  std::vector<float> nodes((size_t)1024 * 4);
+  int n = 0;
+  chk(ef_sample_graph(C(ctx), nodes.data(), 1023, &n), ctx, "getGraph");
+  nodes.resize((size_t)n * 4);
+  return nodes;
 }
 #ifdef EFUSION_USE_SOPHUS
 void ElasticFusion::processFrame(const uint8_t* rgb, const uint16_t* depth, const int64_t& timestamp, const float weightMultiplier,
@@ -154,7 +233,9 @@ void ElasticFusion::setConfidenceThreshold(const float& v) {
   chk(ef_set_confidence_threshold(C(ctx.get()), v), ctx.get(), "setConfidenceThreshold");
   confidenceThreshold = v;
 }
-void ElasticFusion::setFernThresh(const float&) {}
+void ElasticFusion::setFernThresh(const float& v) {
+  if (ef_closure* cl = ef_get_closure(C(ctx.get()))) ef_closure_set_fern_thresh(cl, v);
+}
 void ElasticFusion::setDepthCutoff(const float& v) { chk(ef_set_depth_cutoff(C(ctx.get()), v), ctx.get(), "setDepthCutoff"); }
 
 const int& ElasticFusion::getTick() {

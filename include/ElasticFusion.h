@@ -11,9 +11,13 @@
 //  * getIndexMap()/getGlobalModel()/getModelToModel() return small HBM-backed facades with the members the
 //    front-end actually reads (lastCount, lastICPError, lastICPCount, downloadMap, host copies of the predicted
 //    images); there is no GL texture or VBO behind them.
-//  * closeLoops = true runs the LOCAL loop closure's front half every frame (ElasticFusion.cpp:447-511: inactive-model
-//    prediction, model-to-model registration, gates, surface constraints); the deformation-graph optimiser on its far
-//    side is supplied by the caller (setLoopSolver / ef_set_loop_solver).  Fern-based global closure is not built.
+//  * closeLoops = true is the reference's closed-loop mode: every frame the fern-based GLOBAL closure (ElasticFusion.cpp:392-445:
+//    fern match on the mid-frame fill-in view, 1/8-resolution registration on the device, global deformation) and, when that
+//    does not fire, the LOCAL one (:447-527), both optimised by the built-in deformation-graph solver (no CHOLMOD); Ferns::addFrame
+//    at the end of the frame.  The fern table's seed is fixed (the reference uses time(0)); setLoopSolver() replaces the local
+//    optimiser.  reloc = true (relocalisation when lost) is not built: the constructor throws.
+//  * getTextures / getFeedbackBuffers / computeFeedbackBuffers / normaliseDepth are OpenGL objects and display passes in the
+//    reference and have no counterpart here.
 //  * errors throw std::runtime_error instead of assert()/exit(0).
 #ifndef EFUSION_ELASTICFUSION_H_
 #define EFUSION_ELASTICFUSION_H_
@@ -103,6 +107,34 @@ class IndexMapView {
   int w = 0, h = 0;
 };
 
+// Ferns::SurfaceConstraint (Core/Ferns.h) and PoseMatch (Core/PoseMatch.h): what getPoseMatches() hands to the front-end's drawing code
+struct SurfaceConstraint {
+  double sourcePoint[3], targetPoint[3];
+};
+struct PoseMatch {
+  int firstId, secondId;
+  SE3d T_wc_first, T_wc_second;
+  std::vector<SurfaceConstraint> constraints;
+  bool fern;
+};
+// Ferns facade: what MainController reads (frames.size(), lastClosest, the keyframe poses it draws)
+struct FernFrame {
+  int id, srcTime;
+  SE3d T_wc;
+};
+struct FernsView {
+  std::vector<FernFrame> frames;
+  int lastClosest = -1;
+};
+// Deformation facade: getGraph() = the sampled graph nodes {x, y, z, time} of the current model (Deformation::sampleGraphModel)
+class DeformationView {
+ public:
+  std::vector<float> getGraph();
+ private:
+  friend class ::efusion::ElasticFusion;
+  void* ctx = nullptr;
+};
+
 class ElasticFusion {
  public:
   // same parameters, order and defaults as Core/ElasticFusion.h:42-58; `device` selects the HIP device
@@ -127,6 +159,9 @@ class ElasticFusion {
 
   IndexMapView& getIndexMap() { return indexMap; }
   GlobalModelView& getGlobalModel() { return globalModel; }
+  const FernsView& getFerns();                           // refreshed on each call (empty in open loop)
+  DeformationView& getLocalDeformation() { return localDeformation; }
+  const std::vector<PoseMatch>& getPoseMatches() { return poseMatches; }   // one entry per accepted closure (ElasticFusion.cpp:431,517)
   // closeLoops: the model-to-model tracker of the local loop closure; open loop: the frame-to-model tracker's statistics
   const OdometryStats& getModelToModel();   // refreshed from the device on each call
   // local loop closure (closeLoops = true): the solver standing where Deformation::constrain stands (include/ef_hip.h), and
@@ -143,7 +178,7 @@ class ElasticFusion {
   void setSo3(const bool& val);
   void setFrameToFrameRGB(const bool& val);
   void setConfidenceThreshold(const float& val);
-  void setFernThresh(const float& val);     // accepted and ignored (the fern database, ef_ferns_*, is not part of processFrame yet)
+  void setFernThresh(const float& val);     // Ferns::addFrame's dissimilarity threshold from now on
   void setDepthCutoff(const float& val);
 
   const bool& getLost() { return lost; }
@@ -166,6 +201,10 @@ class ElasticFusion {
   std::unique_ptr<void, ef_ctx_deleter> ctx;
   IndexMapView indexMap;
   GlobalModelView globalModel;
+  DeformationView localDeformation;
+  FernsView fernsView;
+  std::vector<PoseMatch> poseMatches;
+  bool iclnuim = false;
   OdometryStats stats;
   SE3d T_wc;
   std::string saveFilename;

@@ -47,9 +47,8 @@ typedef struct ef_config {
   int frame_to_frame_rgb;     /* frameToFrameRGB (0)                                */
   int pyramid;                /* setPyramid      (1)                                */
   int rgb_only;               /* setRgbOnly      (0)                                */
-  int close_loops;            /* closeLoops (0 = -o): 1 runs the LOCAL loop closure's front half every frame (below);
-                                 the fern-based global closure is not part of ef_process_frame yet: its host-side parts are
-                                 ef_ferns_* / ef_solve_deformation / ef_closure_* below */
+  int close_loops;            /* closeLoops (0 = -o): 1 runs the LOCAL loop closure every frame (below) and, once
+                                 ef_enable_global_closure was called, the fern-based GLOBAL one before it */
   uint32_t max_surfels;       /* surfel capacity; reference: 3072*3072 (GlobalModel.cpp:22-24) */
   int device;                 /* HIP device ordinal                                 */
   void* stream;               /* hipStream_t to run on, or NULL to create a private one */
@@ -146,6 +145,12 @@ int ef_solve_deformation(const float* nodes4, int n_nodes, const ef_graph_constr
                          int64_t last_deform_time, double* poses16_inout, const int64_t* pose_times, int n_poses, float* graph16_out,
                          float* error_out, float* mean_constraint_error_out, ef_graph_constraint* new_relative_out_or_null,
                          int* n_new_relative_out_or_null);
+/* the same with the three gates of a global closure spelled out (NULL = the reference's constants {0.06, 3e-4, 0.12}: entry below which
+ * there is nothing to close, acceptance bounds on the optimised mean constraint error and on the energy) */
+int ef_solve_deformation_gated(const float* nodes4, int n_nodes, const ef_graph_constraint* constraints, int n_constraints, int fern_match,
+                               int64_t last_deform_time, double* poses16_inout, const int64_t* pose_times, int n_poses, float* graph16_out,
+                               float* error_out, float* mean_constraint_error_out, ef_graph_constraint* new_relative_out_or_null,
+                               int* n_new_relative_out_or_null, const float* gates3_or_null);
 /* icpCountThresh, icpErrThresh, covThresh of the constructor (ElasticFusion.h:44-46; defaults 35000, 5e-05, 1e-05) */
 int ef_set_loop_thresholds(ef_ctx* ctx, int icp_count_thresh, float icp_err_thresh, float cov_thresh);
 int ef_get_local_loop(ef_ctx* ctx, ef_local_loop* info, double* constraints_or_null, int max_constraints, int* n_out_or_null);
@@ -195,8 +200,8 @@ float ef_ferns_photometric_check(const ef_ferns* f, const uint8_t* rgb, int rgb_
  * the fern database, the relative constraints local closures leave behind, the trajectory (t_T_wc) and the two deformation counters, and
  * takes the decisions — which constraints go to which graph, what an accepted closure changes (keyframe and trajectory poses deformed
  * along).  No device work: the caller brings the 1/8-resolution fill-in views, the pose, the sampled graph (ef_sample_graph; the global
- * graph is every 5th node of it, Deformation::sampleGraphFrom) and the fern-to-view registration (ef_fern_tracker).  Built and tested on
- * the host this round; ef_process_frame does not call it yet. */
+ * graph is every 5th node of it, Deformation::sampleGraphFrom) and the fern-to-view registration (ef_fern_tracker).  ef_process_frame
+ * drives one of these itself once ef_enable_global_closure was called (below). */
 typedef struct ef_closure ef_closure;
 ef_closure* ef_closure_create(int num_ferns, float depth_cut, float photo_thresh, float fern_thresh, int width, int height, float fx, float fy, float cx,
                               float cy, unsigned seed);   /* Ferns(500, depthCut * 1000, photoThresh); fernThresh 0.3095 */
@@ -213,10 +218,39 @@ int ef_closure_local(ef_closure* c, const double* constraints8, int n, int tick,
 /* end of the frame (:588-589, 609-618): pose -> trajectory, final fill-in view -> Ferns::addFrame; returns 1 when it became a keyframe */
 int ef_closure_end_frame(ef_closure* c, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16, int tick);
 int ef_closure_counts(const ef_closure* c, int* deforms, int* fern_deforms, int* relative_constraints, int* trajectory_poses);
+/* the gates of the GLOBAL deformation (defaults = the reference's hard-coded 0.06 m entry, 3e-4 m / 0.12 acceptance: DeformationGraph.cpp:425,
+ * Deformation.cpp:153; tuned on room-scale trajectories) */
+int ef_closure_set_gates(ef_closure* c, float entry_mean_error, float accept_mean_error, float accept_energy);
+int ef_closure_set_fern_thresh(ef_closure* c, float fern_thresh);   /* ElasticFusion::setFernThresh: Ferns::addFrame's threshold from now on */
 /* introspection for tests: the rows the last closure handed to the optimiser (returns their number) and its two error figures */
 int ef_closure_last_rows(const ef_closure* c, ef_graph_constraint* rows_or_null, int max_rows, float* error_or_null, float* mean_constraint_error_or_null);
 int ef_closure_relative(const ef_closure* c, ef_graph_constraint* rows_or_null, int max_rows);
 int ef_closure_trajectory(const ef_closure* c, double* poses16_or_null, int max_poses);
+/* ---- the GLOBAL loop closure inside ef_process_frame (ElasticFusion.cpp:392-445, 588-589, 609-618; contexts created with
+ * close_loops = 1).  Creates the context's closure object (ef_closure_* above: Ferns(num_ferns, depth_cut * 1000, photo_thresh), the
+ * relative constraints, the trajectory) and a third tracker instance at 1/8 resolution.  From then on every frame (tick > 1):
+ *   after tracking    predict() (ACTIVE + fill-in) at the new pose; the fill-in view, NEAREST-resized by 8, goes to Ferns::findFrame;
+ *                     a candidate keyframe is registered against the view by the 1/8-resolution tracker on the device (ICP only,
+ *                     10 iterations at one level); its surface constraints with their pins + the kept relative constraints go to the
+ *                     global deformation (every 5th graph node); accepted => T_wc := the recovered pose, keyframe and trajectory poses
+ *                     deformed along, the graph applied by this frame's clean pass as a fern match, the local closure skipped;
+ *                     otherwise the local closure runs — through the closure object when the built-in solver is on
+ *                     (ef_use_builtin_loop_solver), so keyframe poses follow and a third of the new relative constraints is kept;
+ *   end of the frame  the final fill-in view goes to Ferns::addFrame, the pose joins the trajectory.
+ * Two stream synchronisations per frame, where the reference reads the views back (Resize.cpp:50-159).  The reference seeds its fern
+ * table from time(0); here the seed is an argument (equal seeds => equal runs).  relocalisation (reloc / lost) is not built. */
+int ef_enable_global_closure(ef_ctx* ctx, int num_ferns, float photo_thresh, float fern_thresh, unsigned seed);
+typedef struct ef_global_loop {
+  int attempted;            /* Ferns::findFrame ran in the last ef_process_frame */
+  int closest;              /* matched keyframe (Ferns::lastClosest), -1: none passed the gates */
+  int n_constraints;        /* surface constraints of the match */
+  int accepted;             /* the global deformation was accepted: pose replaced, graph applied as a fern match */
+  int graph_nodes;
+  float icp_error, icp_count;   /* of the 1/8-resolution registration, when it ran */
+  double T_wc_recovery[16];     /* the registered pose (identity without a candidate) */
+} ef_global_loop;
+int ef_get_global_loop(ef_ctx* ctx, ef_global_loop* info);
+ef_closure* ef_get_closure(ef_ctx* ctx);   /* the context's closure object (NULL before ef_enable_global_closure); owned by the context */
 int ef_predict(ef_ctx* ctx);                                  /* ElasticFusion::predict() */
 int ef_get_pose(ef_ctx* ctx, double* T_wc16);                 /* get_T_wc(); synchronises */
 int ef_get_tick(ef_ctx* ctx, int* tick);                      /* getTick() */

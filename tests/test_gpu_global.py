@@ -1,0 +1,143 @@
+"""GPU: the GLOBAL loop closure wired into ef_process_frame (ef_enable_global_closure; ElasticFusion.cpp:392-445, 588-589, 609-618)
+against the oracle's frame loop with its fern database enabled (oracle/efo_frame.cpp fernClosure, itself equal to the compiled
+ElasticFusion.cpp step for step): which views become keyframes, which keyframe a revisit is matched to, what the 1/8-resolution
+registration on the device recovers (ten ICP-only iterations of the same tracker at 80x60), the constraints, the optimiser's
+verdict, and what the frame does next — a rejected closure hands over to the local closure, an accepted one replaces the pose,
+deforms the map as a fern match and skips it."""
+import numpy as np
+import pytest
+
+import efo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip_api():
+    from elasticfusion_amd import api
+    return api
+
+
+def oracle_with_ferns(seed, gates=None, **kw):
+    from elasticfusion_amd import api
+    o = efo.Fusion(**kw)
+    o.set_close_loops(True)
+    o.enable_ferns(seed=seed)
+    calls = []
+
+    def solver(fernMatch, rows, poses, times):   # Deformation::constrain = the product's host-side optimiser (pinned against the compiled reference)
+        nodes = efo.sample_graph(o.map())
+        if fernMatch:
+            nodes = nodes[::5]                   # Deformation::sampleGraphFrom
+        rr = [(r[0:3], r[3:6], int(r[6]), int(r[7]), int(r[8]), int(r[9])) for r in rows]
+        got = api.solve_deformation(nodes, rr, fernMatch, o._last_deform_time if not fernMatch else 0, poses, times, gates=gates if fernMatch else None)
+        calls.append((fernMatch, len(rows), len(nodes), got["accepted"]))
+        if not got["accepted"]:
+            return None
+        if not fernMatch:
+            o._last_deform_time = o.tick()
+        rel = np.array([list(a) + list(b) + [c, d, 1, 0] for a, b, c, d, _, _ in got["new_relative"]]).reshape(-1, 10)
+        return dict(graph=got["graph"], poses=got["poses"], new_relative=rel)
+    o._last_deform_time = 0
+    o.set_deform_solver(solver)
+    return o, calls
+
+
+def same_frame_state(ef, o, k):
+    assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32)), k
+    assert ef.lastCount() == o.map_count(), k
+    g, go = ef.globalLoop(), o.global_loop()
+    assert (g.attempted, g.closest, g.n_constraints, g.accepted, g.graph_nodes) == (go.attempted, go.closest, go.n_constraints, go.accepted, go.graph_nodes), k
+    assert len(ef.getFerns()) == len(o.ferns()), k
+
+
+def test_keyframes_revisit_registration_and_rejection(hip_api, seq):
+    """The scenario of tests/test_oracle_global.py on the device: six frames with their poses given (one or more become keyframes),
+    the tick advanced by 400, then the fourth view again with 19 cm of injected drift: the fern database proposes the keyframe, the
+    80x60 tracker registers the view to it on the GPU, the optimiser rejects (a few-frame map cannot absorb the drift within the
+    reference's thresholds) and the local closure takes its turn."""
+    api = hip_api
+    seed = 7
+    ef = api.ElasticFusion(closeLoops=True, timeDelta=200, confidence=2.0)
+    ef.useBuiltinLoopSolver(True)
+    ef.enableGlobalClosure(seed=seed)
+    o, calls = oracle_with_ferns(seed, timeDelta=200, confidence=2.0)
+    for k in range(6):
+        rgb, depth, T = seq.frame(k)
+        ef.processFrame(rgb, depth, k, in_T_wc=T)
+        o.process_frame(rgb, depth, k, T_wc=T)
+        same_frame_state(ef, o, k)
+        assert ef.globalLoop().closest == -1
+    assert len(ef.getFerns()) >= 1
+    for i in range(len(ef.getFerns())):          # the same keyframes: codes, poses and stored views
+        a, b = ef.getFerns().frame(i), o.ferns().frame(i)
+        assert np.array_equal(a["codes"], b["codes"]) and a["srcTime"] == b["srcTime"] and np.array_equal(a["T_wc"], b["T_wc"]), i
+        assert np.array_equal(a["verts"], b["verts"]) and np.array_equal(a["rgb"], b["rgb"]), i
+    ef.setTick(ef.getTick() + 400)
+    o.set_tick(o.tick() + 400)
+    d = np.eye(4)
+    a = 0.02
+    d[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+    d[:3, 3] = [0.16, -0.05, 0.09]
+    rgb, depth, T = seq.frame(3)
+    ef.processFrame(rgb, depth, 100, in_T_wc=T @ d)
+    o.process_frame(rgb, depth, 100, T_wc=T @ d)
+    g, go = ef.globalLoop(), o.global_loop()
+    assert g.attempted and g.closest == go.closest >= 0 and g.n_constraints == go.n_constraints > 20
+    # the 80x60 registration on the device: same statistics, same recovered pose as the oracle's tracker at that size
+    assert np.float32(g.icp_error).view(np.uint32) == np.float32(go.icp_error).view(np.uint32) and g.icp_count == go.icp_count > 2400
+    rec, rec_o = np.array(g.T_wc_recovery).reshape(4, 4), np.array(go.T_wc_recovery).reshape(4, 4)
+    assert np.abs(rec - rec_o).max() <= 1e-15 and np.array_equal(rec.astype(np.float32), rec_o.astype(np.float32))
+    assert np.abs(rec[:3, 3] - T[:3, 3]).max() < 0.01 < np.abs((T @ d)[:3, 3] - T[:3, 3]).max()     # the drift is gone in the recovered pose
+    assert not g.accepted and not go.accepted and calls and calls[0][0] and not calls[0][3]          # ... but the optimiser says no
+    rows, err, mean = ef.closure().lastRows()
+    assert err > 0.12 or mean > 3e-4
+    same_frame_state(ef, o, 6)
+    info, _ = ef.localLoop()
+    assert info.attempted == o.local_loop()[0].attempted == 1                                         # the local closure got its turn (:447)
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    ef.close()
+
+
+def test_accepted_global_closure_replaces_pose_and_deforms_as_fern_match(hip_api, seq):
+    """The reference's gates on a global deformation (entry: mean constraint error >= 0.06 m; acceptance: optimised mean error < 3e-4 m,
+    energy < 0.12) were tuned on room-scale trajectories and never open on a map of a dozen frames; with the gates relaxed on both
+    sides (ef_closure_set_gates / the same optimiser behind the oracle's solver hook) an 8 mm drift is closed: the pose becomes the
+    recovered one, the keyframe and trajectory poses are deformed along, this frame's clean pass applies the graph with is_fern = 1
+    (no depth test), the local closure is skipped and fernDeforms counts it — identically in the oracle's frame loop."""
+    api = hip_api
+    seed = 11
+    gates = (0.004, 1.0, 1e6)
+    ef = api.ElasticFusion(closeLoops=True, timeDelta=200, confidence=1.0)
+    ef.useBuiltinLoopSolver(True)
+    ef.enableGlobalClosure(seed=seed).setGates(*gates)
+    o, calls = oracle_with_ferns(seed, gates=gates, timeDelta=200, confidence=1.0)
+    n0 = 14
+    for k in range(n0):                                    # a longer prefix: >= 5000 * 5 * 5 surfels are needed for a global graph of > 4 nodes
+        rgb, depth, T = seq.frame(2 * k)
+        ef.processFrame(rgb, depth, k, in_T_wc=T)
+        o.process_frame(rgb, depth, k, T_wc=T)
+        same_frame_state(ef, o, k)
+    ef.setTick(ef.getTick() + 400)
+    o.set_tick(o.tick() + 400)
+    d = np.eye(4)
+    d[:3, 3] = [0.006, -0.004, 0.003]
+    rgb, depth, T = seq.frame(6)
+    ef.processFrame(rgb, depth, 100, in_T_wc=T @ d)
+    o.process_frame(rgb, depth, 100, T_wc=T @ d)
+    g, go = ef.globalLoop(), o.global_loop()
+    assert (g.attempted, g.closest, g.n_constraints, g.accepted, g.graph_nodes) == (go.attempted, go.closest, go.n_constraints, go.accepted, go.graph_nodes)
+    same_frame_state(ef, o, n0)
+    assert go.accepted and g.graph_nodes > 4 and ef.closure().counts()["fernDeforms"] == 1
+    assert not ef.localLoop()[0].attempted                                                            # skipped (:447)
+    assert np.abs(ef.get_T_wc() - np.array(go.T_wc_recovery).reshape(4, 4)).max() <= 1e-15
+    assert np.abs(ef.closure().trajectory() - o.trajectory()).max() <= 1e-12                          # trajectory deformed along
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    # two more frames: the database and the map carry on identically
+    for k in range(2):
+        rgb, depth, T = seq.frame(7 + k)
+        ef.processFrame(rgb, depth, 101 + k)
+        o.process_frame(rgb, depth, 101 + k)
+        same_frame_state(ef, o, n0 + 1 + k)
+    assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    ef.close()

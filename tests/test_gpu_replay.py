@@ -39,14 +39,15 @@ def test_klg_replay_through_cpp_shim(tmp_path, seq):
 
 
 def test_klg_replay_with_close_loops(tmp_path, seq):
-    """-cl: the C++ class constructed with closeLoops = true runs the local loop closure's front half on every frame; with no
-    solver registered it only evaluates the gates, so the trajectory equals the oracle's run in the same configuration."""
+    """-cl: the C++ class constructed with closeLoops = true is the reference's closed-loop mode — fern database (keyframes stored at the
+    end of every frame, matched mid-frame), global closure, local closure with the built-in optimiser — and equals the oracle's frame
+    loop in the same configuration (fern table from the class's fixed seed 0, the same optimiser behind the oracle's solver hook)."""
     from elasticfusion_amd import api, synth
+    from test_gpu_global import oracle_with_ferns
     n = 8
     frames = [seq.frame(k) for k in range(n)]
     exe = os.path.join(os.path.dirname(api.LIB_PATH), "efusion_replay")
-    o = efo.Fusion(timeDelta=3, confidence=2.0)
-    o.set_close_loops(True)
+    o, calls = oracle_with_ferns(0, timeDelta=3, confidence=2.0)
     attempts = opened = 0
     for k, (rgb, depth, _) in enumerate(frames):
         o.process_frame(rgb, depth, k * 33333)
@@ -59,6 +60,8 @@ def test_klg_replay_with_close_loops(tmp_path, seq):
     assert r.returncode == 0, r.stderr
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("local loop closure")][0].split()
     assert int(line[line.index("attempts") + 1]) == attempts == n - 1 and int(line[line.index("open") + 1]) == opened
+    fern_line = [ln for ln in r.stdout.splitlines() if ln.startswith("fern database")][0].split()
+    assert int(fern_line[fern_line.index("keyframes") + 1]) == len(o.ferns()) >= 1
     words = r.stdout.split()
     assert int(words[words.index("surfels") + 1]) == o.map_count(), r.stdout
     traj = np.loadtxt(log + ".freiburg")

@@ -7,7 +7,7 @@
 //   efusion_replay -l seq.klg [-w 640 -h 480] [-cal fx fy cx cy] [-d depthCut] [-c confidence] [-t timeDelta]
 //                  [-fo] [-nso] [-ftf] [-i icpWeight] [-e endFrame] [-ply] [-dev N] [-q]
 //
-// Open loop (the reference's -o) unless -cl is given.  Like the reference's run loop, the last frame of a log is not
+// Open loop (the reference's -o) unless -cl is given (closed loop: fern database, global and local closures, built-in optimiser).  Like the reference's run loop, the last frame of a log is not
 // processed (RawLogReader::hasMore, see include/efusion_klg.hpp); -all processes every frame.
 #include <chrono>
 #include <cstdio>
@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     else if (a == "-ply") ply = true;
     else if (a == "-q") quiet = true;
     else if (a == "-all") allFrames = true;
-    else if (a == "-solve") solve = true;     // with -cl: close local loops with the built-in deformation-graph optimiser
+    else if (a == "-solve") solve = true;     // kept for old command lines: -cl always closes loops with the built-in optimiser now
     else if (a == "-o") closeLoops = false;   // the default here (the reference closes loops unless -o is given)
     else if (a == "-cl") closeLoops = true;   // local loop closure front half every frame, time window from -t
     else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     // open loop: timeDelta = INT_MAX / 2 exactly as MainController does for -o (MainController.cpp:179-183)
     ElasticFusion eFusion(closeLoops ? timeDelta : 2147483647 / 2, 35000, 5e-05f, 1e-05f, closeLoops, false, false, 115, confidence, depthCut,
                           icp, fastOdom, 0.3095f, so3, ftf, log, dev);
-    if (closeLoops && solve) eFusion.useBuiltinLoopSolver(true);
+    (void)solve;
     int attempts = 0, opened = 0;
     const auto t0 = std::chrono::steady_clock::now();
     int n = 0;
@@ -77,7 +77,12 @@ int main(int argc, char** argv) {
     if (!quiet)
       std::printf("frames %d  %.1f fps  surfels %u  icp %g/%g  t_wc %.9g %.9g %.9g\n", n, n / dt, eFusion.getGlobalModel().lastCount(),
                   (double)eFusion.getModelToModel().lastICPError, (double)eFusion.getModelToModel().lastICPCount, M[3], M[7], M[11]);
-    if (!quiet && closeLoops) std::printf("local loop closure: attempts %d  gates open %d  deformations %d\n", attempts, opened, eFusion.getDeforms());
+    if (!quiet && closeLoops) {
+      std::printf("local loop closure: attempts %d  gates open %d  deformations %d\n", attempts, opened, eFusion.getDeforms());
+      const efusion::FernsView& F = eFusion.getFerns();
+      std::printf("fern database: keyframes %d  global deformations %d  pose matches %d\n", (int)F.frames.size(), eFusion.getFernDeforms(),
+                  (int)eFusion.getPoseMatches().size());
+    }
     if (ply) eFusion.savePly();
   } catch (const std::exception& e) {
     std::fprintf(stderr, "efusion_replay: %s\n", e.what());
