@@ -1993,11 +1993,28 @@ int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const
   const bool sample = probe && level == 0 && probe->used < probe->capacity;
   const int sp = it & 1;
   StepArgs A{it > 0, rgb, icp, rgb, tp.rgbOnly, tp.icpWeight, kl, level_changes};
+#ifdef EF_TRACK_SPLIT
+  // development variant: the update step as its own one-workgroup launch, then the correspondence search alone (three launches per
+  // iteration instead of two)
+  if (A.has_head) {
+    StepArgs H = A;
+    H.has_body = false;
+    launch_step<1>(p, st, level, cur, sp, H, s);
+    cur ^= 1;
+  }
+  if (A.has_body) {
+    StepArgs B = A;
+    B.has_head = false;
+    if (N >= 256 * 1024) launch_step<2>(p, st, level, cur, sp, B, s);
+    else launch_step<1>(p, st, level, cur, sp, B, s);
+  }
+#else
   if (A.has_head || A.has_body) {
     if (N >= 256 * 1024) launch_step<2>(p, st, level, cur, sp, A, s);
     else launch_step<1>(p, st, level, cur, sp, A, s);
   }
   if (A.has_head) cur ^= 1;
+#endif
   const GNState* g = &st->gn[cur];
   IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres};
   RgbView GV{p.corres[level], p.lastDepth[level], nullptr, p.dIdx[level], p.dIdy[level], cols, rows, kl, 1.0f / 8.0f};

@@ -2,6 +2,8 @@
 synthetic frames.  Bars from BASELINE.json's north_star: pose within 1e-4 m / 1e-4 rad, fused surfel
 positions / normals / radii within 1e-5 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -435,33 +437,39 @@ def test_trajectory_log_grows_without_bound(hip):
     ef.close()
 
 
-def test_context_used_from_another_thread(hip, seq):
+def test_context_used_from_another_thread(hip, seq, tmp_path):
     """Every entry point binds the context's device itself (ef_config.device), so a context may be driven by a thread that never
-    called hipSetDevice; the results are those of the creating thread."""
-    import threading
-    ef = hip.ElasticFusion()
-    out = {}
-
-    def work():
-        try:
-            for k in range(3):
-                rgb, depth, _ = seq.frame(k)
-                ef.processFrame(rgb, depth, k)
-            out["T"] = ef.get_T_wc()
-            out["n"] = ef.lastCount()
-        except Exception as e:   # noqa: BLE001
-            out["err"] = e
-    t = threading.Thread(target=work)
-    t.start()
-    t.join()
-    assert "err" not in out, out.get("err")
-    ref = hip.ElasticFusion()
-    for k in range(3):
-        rgb, depth, _ = seq.frame(k)
-        ref.processFrame(rgb, depth, k)
-    assert np.array_equal(out["T"], ref.get_T_wc()) and out["n"] == ref.lastCount()
-    ef.close()
-    ref.close()
+    called hipSetDevice; the results are those of the creating thread.  Run in a child process (with a time limit) so that whatever
+    the HIP runtime does with a finished thread's state at exit cannot hold up the test session."""
+    import subprocess
+    import sys
+    code = """
+import sys, threading
+import numpy as np
+sys.path.insert(0, %r)
+from elasticfusion_amd import api, synth
+seq = synth.Sequence(0xEF0001)
+frames = [seq.frame(k) for k in range(3)]
+ef = api.ElasticFusion()
+out = {}
+def work():
+    try:
+        for k, (rgb, depth, _) in enumerate(frames):
+            ef.processFrame(rgb, depth, k)
+        out["T"] = ef.get_T_wc(); out["n"] = ef.lastCount()
+    except Exception as e:
+        out["err"] = repr(e)
+t = threading.Thread(target=work); t.start(); t.join()
+assert "err" not in out, out
+ref = api.ElasticFusion()
+for k, (rgb, depth, _) in enumerate(frames):
+    ref.processFrame(rgb, depth, k)
+assert np.array_equal(out["T"], ref.get_T_wc()) and out["n"] == ref.lastCount()
+ef.close(); ref.close()
+print("THREAD_OK", out["n"], flush=True)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert "THREAD_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
 def test_api_errors(hip):

@@ -7,7 +7,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for rep in 1 2; do
+for rep in 1 2; do   # two passes: the first also warms the frame cache
   for v in "$@"; do
     lib=$GRAFT_REPO_ROOT/elasticfusion_amd/libefusion_hip.so
     [ "$v" != "-" ] && lib=$GRAFT_REPO_ROOT/elasticfusion_amd/libefusion_hip_$v.so
