@@ -102,7 +102,23 @@ def cpu_baseline(frames, budget_s: float = 20.0, w: int = W, h: int = H):
                                     f"(the map passes stay serial), {dtm:.1f} s"}}
 
 
+def _leave():
+    """the line is out and everything is released: run the registered exit hooks, then skip the interpreter / GPU-runtime teardown"""
+    import atexit
+    try:
+        atexit._run_exitfuncs()
+    except Exception:
+        pass
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
+
+
 def main():
+    import faulthandler
+    faulthandler.enable()
+    # a wedged GPU runtime must not hold the caller for ever: after 9 minutes dump every thread's stack and leave
+    faulthandler.dump_traceback_later(540, exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -194,9 +210,10 @@ def main():
     # the only collective: 32 B per rank over xGMI (RCCL all_gather)
     allstats = multi.gather_stats([dt, float(a.steps), err_t, float(count)], device="cuda")
     if rank != 0:
+        ef.close()
         if world > 1:
             dist.destroy_process_group()
-        return
+        _leave()
     agg = multi.aggregate(allstats)
     t_max, value = agg["t_max"], agg["value"]
 
@@ -267,8 +284,12 @@ def main():
         out["cpu_baseline"] = cpu_baseline(frames[: min(len(frames), 40)], w=w, h=h)
     out["config"]["stable_surfels_end"] = int(stable)
     print(json.dumps(out), flush=True)
+    ef.close()
+    del dev
+    torch.cuda.synchronize()
     if world > 1:
         dist.destroy_process_group()
+    _leave()
 
 
 if __name__ == "__main__":

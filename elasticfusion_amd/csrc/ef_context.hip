@@ -1035,6 +1035,8 @@ int ef_enable_global_closure(ef_ctx* c, int num_ferns, float photo_thresh, float
   EF_ALLOC(c, c->st3, 1);
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, c->stream, c->st3, 1, c->fern_w * c->fern_h);
   EF_HIP(c, hipStreamSynchronize(c->stream));
+  memset(&c->gloop, 0, sizeof(c->gloop));
+  c->gloop.closest = -1;
   c->closure = ef_closure_create(num_ferns, c->cfg.depth_cut, photo_thresh, fern_thresh, W, H, c->cfg.fx, c->cfg.fy, c->cfg.cx, c->cfg.cy, seed);
   if (!c->closure) { c->err = "ef_closure_create failed"; return EF_ENOMEM; }
   return EF_OK;

@@ -1052,6 +1052,21 @@ __device__ __forceinline__ void visit_stage2b(const IcpView& IV, const RgbView& 
   }
 }
 
+// developer instrumentation (-DEF_ACCUM_CLOCKS, tools/accum_clocks.py): wall_clock64() (100 MHz) stamps of the first ICP wavefront of
+// every workgroup of the last level-0 launch
+#ifdef EF_ACCUM_CLOCKS
+__device__ unsigned long long g_accum_stamps[8][VWARPS / ACC_NW];
+#define EF_ASTAMP(i)                                                                                                        \
+  do {                                                                                                                      \
+    if (N > 8 * VTHREADS && threadIdx.x == 0) g_accum_stamps[i][blockIdx.x] = wall_clock64();                               \
+  } while (0)
+extern "C" int ef_debug_accum_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_accum_stamps), sizeof(unsigned long long) * 8 * (VWARPS / ACC_NW)) == hipSuccess ? 0 : -1;
+}
+#else
+#define EF_ASTAMP(i) do { } while (0)
+#endif
+
 // One wavefront = one half of virtual warp W for ONE term: all passes of its 16 virtual threads, accumulated into c[0..2]
 // (lo x lo, lo x hi, hi x hi; register i of lane 4 v + j holds element (i, j) of virtual thread v's 4x4 block).
 // slot_a / slot_b: this lane's residual-pass slot (count, sum diff^2) when sigma comes from the slots.
@@ -1109,6 +1124,7 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
       VisitGathers G[CH];
 #pragma unroll
       for (int u = 0; u < CH; ++u) G[u] = visit_stage2a<ICP, !ICP>(IV, RV, P, L[u]);
+      if (ICP && s0 == 0) EF_ASTAMP(1);   // stage-1 data consumed, gathers issued
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         float irow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, grow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1118,6 +1134,7 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
         for (int q = 0; q < 7; ++q) rows[u][q] = ICP ? irow[q] : grow[q];
         rows[u][7] = ICP ? ifound : gfound;
       }
+      if (ICP && s0 == 0) EF_ASTAMP(2);   // gathers consumed, rows computed
     } else {   // operator tier's photometric term: 16-byte DataTerm + explicit point cloud (types.cuh:81-86)
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
@@ -1182,11 +1199,13 @@ k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, const Se3Out
   // re-arm the residual-pass slots the NEXT iteration's correspondence search adds into (nobody reads them during this launch)
   if (in.slots_zero && blockIdx.x == 0 && t < RGB_SLOTS) { in.slots_zero[t * 16] = 0; in.slots_zero[t * 16 + 1] = 0; }
   if (broken) return;  // rgbOnly "break": the level is over (the update step does the bookkeeping)
+  EF_ASTAMP(0);
   f32x4 c[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) c[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (HAS_ICP && !rgb_wave) accum_quads<CH, true, PACKED>(IV, RV, in, gbase, N, K, 0, 0, false, c);
   if (HAS_RGB && rgb_wave) accum_quads<CH, false, PACKED>(IV, RV, in, gbase, N, K, slot_a, slot_b, with_slots, c);
+  EF_ASTAMP(3);   // transposes + outer products issued
   // warpReduceSum, reduce.cu:57-95: val += shfl_down(val, offset) for offset = 16 (the other half's wave), 8, 4, 2, 1
   if (half == 1) {
 #pragma unroll
@@ -1196,6 +1215,7 @@ k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, const Se3Out
     }
   }
   __syncthreads();
+  EF_ASTAMP(4);   // every wavefront of the workgroup has finished its passes
   float r[12];
   if (half == 0) {
 #pragma unroll
@@ -1226,6 +1246,7 @@ k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, const Se3Out
         if (a >= 0) dst[(size_t)a * SE3_PAIRS] = r[q * 4 + i] + pair[tix][q * 4 + i][j];
       }
   }
+  EF_ASTAMP(5);
 }
 
 // The rest of the reference tree over the 512 virtual-warp partials of `na` accumulators (acc-major):
@@ -1993,9 +2014,11 @@ int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const
   const bool sample = probe && level == 0 && probe->used < probe->capacity;
   const int sp = it & 1;
   StepArgs A{it > 0, rgb, icp, rgb, tp.rgbOnly, tp.icpWeight, kl, level_changes};
-#ifdef EF_TRACK_SPLIT
-  // development variant: the update step as its own one-workgroup launch, then the correspondence search alone (three launches per
-  // iteration instead of two)
+#ifndef EF_TRACK_FUSED
+  // The update step as its own ONE-workgroup launch (head only), then the correspondence search alone (body only): three launches
+  // per iteration.  Evaluating the update redundantly at the head of every workgroup of the correspondence kernel instead (two launches,
+  // -DEF_TRACK_FUSED) was built and measured on one box: 888 vs 1322 frames/s — 600 concurrent copies of a 6 us fp64 chain cost far
+  // more than the kernel boundary they save.
   if (A.has_head) {
     StepArgs H = A;
     H.has_body = false;

@@ -12,6 +12,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a wedged GPU runtime must fail a test, not hold the session for ever: every test (fixtures included) gets 10 minutes unless the
+    # command line says otherwise (pytest-timeout; the thread method also works when the main thread sits in a C call)
+    if config.pluginmanager.hasplugin("timeout") and getattr(config.option, "timeout", None) in (None, 0):
+        config.option.timeout = 600
+        if not getattr(config.option, "timeout_method", None):
+            config.option.timeout_method = "thread"
 
 
 def _gpu_available() -> bool:
