@@ -105,12 +105,14 @@ def cpu_baseline(frames, budget_s: float = 20.0, w: int = W, h: int = H):
 def _leave():
     """the line is out and everything is released: run the registered exit hooks, then skip the interpreter / GPU-runtime teardown"""
     import atexit
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if any("rocprof" in k.lower() or "rocprof" in v.lower() for k, v in os.environ.items()):
+        return   # under rocprofv3 the tool writes its files from the runtime's own exit hooks: leave the normal way
     try:
         atexit._run_exitfuncs()
     except Exception:
         pass
-    sys.stdout.flush()
-    sys.stderr.flush()
     os._exit(0)
 
 
@@ -214,6 +216,7 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         _leave()
+        return
     agg = multi.aggregate(allstats)
     t_max, value = agg["t_max"], agg["value"]
 

@@ -883,6 +883,20 @@ __device__ __forceinline__ float quad_xor1(float x) { return __int_as_float(__bu
 __device__ __forceinline__ float quad_xor2(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
 template <int Q>
 __device__ __forceinline__ float quad_bcast(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), Q * 0x55, 0xF, 0xF, true)); }
+// shfl_down by 32 / 16 / 8 / 4 lanes for the lanes the warp32 tree needs (the lower half, the even rows, the lower lanes of a row):
+// two half-wave / row swaps of gfx950 and two in-row DPP shifts -- one VALU instruction each, no trip through the LDS crossbar
+__device__ __forceinline__ float down32(float x) {   // valid in lanes 0..31
+  const unsigned u = __float_as_uint(x);
+  return __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[1]);
+}
+__device__ __forceinline__ float down16(float x) {   // valid in rows 0 and 2 (lanes 0..15, 32..47)
+  const unsigned u = __float_as_uint(x);
+  return __uint_as_float(__builtin_amdgcn_permlane16_swap(u, u, false, false)[1]);
+}
+template <int N>
+__device__ __forceinline__ float row_down(float x) {   // lane i of a 16-lane row reads lane i + N of the same row (row_shl:N)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 + N, 0xF, 0xF, true));
+}
 // 4x4 transpose across (lane-in-quad, register): afterwards m[q] of lane i holds what m[i] of lane q held
 __device__ __forceinline__ void quad_transpose(float (&m)[4], int j) {
   const bool o1 = (j & 1) != 0, o2 = (j & 2) != 0;
@@ -1224,9 +1238,12 @@ k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, const Se3Out
       r[q * 4 + 2] = c[q].z + xch[wl][tix][q * 4 + 2][lane]; r[q * 4 + 3] = c[q].w + xch[wl][tix][q * 4 + 3][lane];
     }
 #pragma unroll
-    for (int i = 0; i < 12; ++i)
-#pragma unroll
-      for (int off = 32; off >= 4; off >>= 1) r[i] += __shfl_down(r[i], off, 64);
+    for (int i = 0; i < 12; ++i) {   // offsets 8, 4, 2, 1 in virtual threads = 32, 16, 8, 4 lanes
+      r[i] += down32(r[i]);
+      r[i] += down16(r[i]);
+      r[i] += row_down<8>(r[i]);
+      r[i] += row_down<4>(r[i]);
+    }
     // blockReduceSum's second stage (reduce.cu:97-117), first level: the 8 warp sums of a reference block sit in lanes 0..7 of its
     // warp 0 (the other 24 lanes hold exact zeros) and shfl_down(offset 4) adds warp w + 4 to warp w: the workgroup holds exactly
     // such a pair, the upper one hands its sums over
