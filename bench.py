@@ -41,6 +41,7 @@ def _gen_frame(args):
 _gen_frame.cache = {}
 
 
+PROBE_FRAMES = 24   # frames AFTER the timed region on which the two roofline kernels are sampled (see main)
 PREROLL = 100   # untimed frames before --warmup: the map reaches its steady state (stable surfels, model-fed tracker, clean() removing
                # stale unstable surfels) whatever --steps / --warmup the caller chose, so the timed region is the representative workload
 
@@ -126,6 +127,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe-inside", action="store_true", help="development: sample the roofline kernels inside the timed region (1 frame in 8) "
+                    "instead of on the frames that follow it")
     ap.add_argument("--frames-cache", default=None, help="development: keep the generated synthetic frames in this .npz between runs "
                     "(A/B runs of library variants on one GPU box, tools/gpu_r2.sh); never used by the driver")
     ap.add_argument("--width", type=int, default=W, help="1280 (with --height 960) = BASELINE.json configs[2]: the first frame seeds "
@@ -145,7 +148,9 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
     # synthetic frames first: the generator forks worker processes, which must happen before HIP / RCCL are initialised
-    n_frames = 1 + PREROLL + a.warmup + a.steps  # frame 0 seeds the map (tick 1); pre-roll and warm-up are never timed
+    # frame 0 seeds the map (tick 1); pre-roll and warm-up are never timed; the last PROBE_FRAMES frames continue the same replay with
+    # the per-kernel sampling switched on (a sampled launch carries profiling timestamps, which the timed region is kept free of)
+    n_frames = 1 + PREROLL + a.warmup + a.steps + PROBE_FRAMES
     cache = f"{a.frames_cache}.{rank}.{w}x{h}.{n_frames}.npz" if a.frames_cache else None
     if cache and os.path.exists(cache):
         z = np.load(cache)
@@ -187,7 +192,7 @@ def main():
     # per-kernel HIP-event sampling of the dominant kernel inside the timed region (1 frame in 8)
     lib = api.lib()
     have_ktime = hasattr(lib, "ef_kernel_timing")
-    if have_ktime:
+    if have_ktime and a.probe_inside:
         lib.ef_kernel_timing(ef.h, C.c_int(8))
     torch.cuda.synchronize()
     if world > 1:
@@ -201,10 +206,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if have_ktime and not a.probe_inside:   # the same replay goes on; every level-0 accumulation launch and every first index splat is sampled
+        lib.ef_kernel_timing(ef.h, C.c_int(1))
+        for k in range(first_timed + a.steps, first_timed + a.steps + PROBE_FRAMES):
+            step(k)
+        torch.cuda.synchronize()
 
     # pose error of the timed run against the generating trajectory (sanity, not the parity bar)
     T = ef.get_T_wc()
-    Tgt = frames[n_frames - 1][2]
+    Tgt = frames[first_timed + a.steps - 1 + (0 if a.probe_inside else PROBE_FRAMES)][2]
     err_t = float(np.linalg.norm(T[:3, 3] - Tgt[:3, 3]))
     count = ef.lastCount()
     stable = int((ef.downloadMap()[:, 3] > ef.getConfidenceThreshold()).sum()) if rank == 0 else 0
@@ -245,7 +255,8 @@ def main():
                 pass
             roofline = {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                        "avg_us": round(float(kt.avg_us), 3), "timer": "dispatch begin/end timestamps (hipExtLaunchKernelGGL events), = rocprofv3 kernel-trace duration",
+                        "avg_us": round(float(kt.avg_us), 3), "timer": "dispatch begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of every level-0 launch of the "
+                        + (f"{PROBE_FRAMES} frames that follow the timed region (same replay, same map)" if not a.probe_inside else "sampled frames inside the timed region"),
                         "launches_sampled": int(kt.launches), "algorithmic_bytes_per_launch": int(kt.bytes_per_launch),
                         "algorithmic_bytes_per_launch_survey_48B": int(kt.bytes_per_launch_survey),
                         "frac_survey_48B": round(achieved_survey / HBM_PEAK_GBS, 4), "frac_of_achievable_6300": round(achieved / 6300.0, 4)}

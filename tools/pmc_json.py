@@ -45,7 +45,7 @@ def pick(prefix, level0_only=False):
 k, f, w = pick("k_se3_accum")
 doc = {"kernel": re.sub(r"^.*?(k_se3_accum<[^>]*>).*$", r"\1", k), "FETCH_SIZE_KB_per_dispatch": round(f, 3),
        "WRITE_SIZE_KB_per_dispatch": round(w, 3), "fetch_bytes_per_counted_KB": cf, "write_bytes_per_counted_KB": cw,
-       "traffic_bytes_per_launch": int(round(f * cf + w * cw)), "also": {}}
+       "traffic_bytes_per_launch": int(round(f * cf + w * cw)), "source": f"tools/pmc_traffic.sh {tag}", "also": {}}
 for name in ("k_index_splat", "k_index_resolve"):
     p = pick(name)
     if p:
