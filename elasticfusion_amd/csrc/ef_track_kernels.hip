@@ -3,9 +3,10 @@
 // computeRgbResidual, rgbStep, so3Step), Core/Utils/RGBDOdometry.cpp (driver).  The CUDA versions are
 // warp32 / 64x256-thread grid-stride / host-in-the-loop.  Here the fp32 sums keep the reference's summation
 // ORDER (so results are bit-identical to the reference's tree, see "Reference-order fp32 reductions" below) but
-// not its schedule: one workgroup per virtual warp, Jacobian rows staged in LDS, wave64 shuffles for the trees;
-// the 6x6 solve + SE(3) update run in a device kernel so the 19 iterations are enqueued back to back with no
-// host round trip.
+// not its schedule: a quad of lanes per virtual thread, Jacobian rows transposed inside the quad and accumulated as
+// rank-1 updates on the matrix pipe (v_mfma_f32_4x4x1, one fmaf per element), lane swaps for the trees; the 6x6 solve
+// + SE(3) update run in a one-workgroup device kernel so the 19 iterations are enqueued back to back with no host
+// round trip.
 #include "ef_device.hpp"
 #include "ef_linalg_dev.hpp"
 #include "ef_solve_dev.hpp"
@@ -856,9 +857,11 @@ constexpr int ROW_STRIDE = 8 * 32;   // floats per pass in LDS (SO(3) kernel): 8
 // Quad layout.  A wavefront covers HALF a virtual warp: lane = 4 v + j, v = 0..15 the virtual thread, j = 0..3 the lane's
 // slot in its quad.  The quad of virtual thread g works through g's pixel visits (passes k = 0, 1, 2, ... = pixels g,
 // g + 16384, ...) four at a time:
-//   phase A  lane j computes the Jacobian row of pass 4 s + j (loads split by data dependence exactly as before: stage 1 =
-//            everything the pixel itself addresses, stage 2 = the gathers behind the projective association), for CH
-//            steps s at once so that 5 x (6 + 6) loads per lane are in flight;
+//   phase A  one lane per pixel visit computes the Jacobian row of pass 4 s + j (loads split by data dependence exactly as before:
+//            stage 1 = everything the pixel itself addresses, stage 2 = the gathers behind the projective association), for CH
+//            steps s at once so that 5 x (6 + 6) loads per lane are in flight.  This phase runs in a LOAD layout (lane = 16 j + v:
+//            a quarter-wave covers 16 consecutive pixels of one pass) and the finished rows move to the quad layout through the
+//            LDS crossbar (ds_bpermute), see accum_quads;
 //   phase B  the four rows of a step are transposed inside the quad (two DPP butterfly stages: lane i ends up with
 //            component i of every pass) and accumulated as rank-1 updates A += r r^T in pass order by the matrix pipe:
 //            v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4x4 outer products, one per quad, each output element
@@ -2045,6 +2048,7 @@ int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const
   if (A.has_body) {
     StepArgs B = A;
     B.has_head = false;
+    // (four times fewer, four times fatter wavefronts — PPT 8 / 4 — measured 4.5 % slower end to end: DESIGN.md 6)
     if (N >= 256 * 1024) launch_step<2>(p, st, level, cur, sp, B, s);
     else launch_step<1>(p, st, level, cur, sp, B, s);
   }

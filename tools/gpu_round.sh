@@ -1,32 +1,36 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, smoke, bench line, rocprofv3 kernel stats of the same bench command.
-# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag>
+# One GPU-box visit: (optionally) the parity suite and smoke, the bench line, rocprofv3 kernel stats of the same bench command,
+# the side benches, the streaming probe.  Every process runs on a short leash (a wedged runtime must not eat the GPU budget).
+# usage (repo root on the GPU box): bash tools/gpu_round.sh <tag> [tests]
 tag=${1:-run}
+with_tests=${2:-}
 out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -q > $out/${tag}_tests.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_tests.log
-tail -5 $out/${tag}_tests.log
-timeout 300 python __graft_entry__.py --smoke > $out/${tag}_smoke.log 2>&1; echo "smoke rc=$?" >> $out/${tag}_smoke.log
-tail -3 $out/${tag}_smoke.log
-timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?"
+if [ "$with_tests" = "tests" ]; then
+  timeout 600 python -m pytest tests -m gpu -q -x --timeout=300 --durations=8 > $out/${tag}_tests.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_tests.log
+  tail -5 $out/${tag}_tests.log
+  timeout 200 python __graft_entry__.py --smoke > $out/${tag}_smoke.log 2>&1; echo "smoke rc=$?" >> $out/${tag}_smoke.log
+  tail -3 $out/${tag}_smoke.log
+fi
+# the driver's command (default K / W), with the CPU baseline legs
+timeout 300 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?"
 cat $out/${tag}_bench.json
 tail -3 $out/${tag}_bench.err
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${tag} --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $out/${tag}_prof_stdout.log 2>&1
-find /tmp/prof -name "${tag}_kernel_stats.csv" -exec cp {} $out/ \;
-head -12 $out/${tag}_kernel_stats.csv | cut -c1-200
-# side measurements (not the headline): frames handed over as host buffers (PCIe inclusive), and closeLoops
+timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${tag} --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/${tag}_prof_stdout.log 2>&1
+find /tmp/prof -name "${tag}_kernel_stats.csv" -exec cp {} $out/${tag}_bench_kernel_stats.csv \;
+head -12 $out/${tag}_bench_kernel_stats.csv | cut -c1-200
+# the streaming probe's kernels under the same profiler (exact dispatch durations: what a kernel of this shape can reach)
+timeout 120 rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o ${tag}p --output-format csv -- $GRAFT_REPO_ROOT/tools/probe/stream_probe > $out/${tag}_stream_probe_events.json 2>/dev/null
+find /tmp/prof2 -name "${tag}p_kernel_stats.csv" -exec cp {} $out/${tag}_stream_probe_kernel_stats.csv \;
+cat $out/${tag}_stream_probe_kernel_stats.csv | cut -c1-160
+# side measurements (not the headline): frames handed over as host buffers (PCIe inclusive), closed-loop mode, configs[2]
 cd $GRAFT_REPO_ROOT
-timeout 300 python bench.py --no-cpu-baseline --host-frames --steps 200 --warmup 20 > $out/${tag}_hostframes_bench.json 2>/dev/null
+timeout 200 python bench.py --no-cpu-baseline --host-frames > $out/${tag}_hostframes_bench.json 2>/dev/null
 cut -c1-220 $out/${tag}_hostframes_bench.json
-timeout 300 python bench.py --no-cpu-baseline --close-loops --steps 200 --warmup 20 > $out/${tag}_closeloops_bench.json 2>/dev/null
+timeout 200 python bench.py --no-cpu-baseline --close-loops > $out/${tag}_closeloops_bench.json 2>/dev/null
 cut -c1-220 $out/${tag}_closeloops_bench.json
-# configs[2]: 1280x960, ~1 M surfels
-cd $GRAFT_REPO_ROOT
-timeout 600 python bench.py --no-cpu-baseline --width 1280 --height 960 --steps 100 --warmup 10 > $out/${tag}_1280x960_bench.json 2>/dev/null
+timeout 300 python bench.py --no-cpu-baseline --width 1280 --height 960 --steps 100 --warmup 10 > $out/${tag}_1280x960_bench.json 2>/dev/null
 cat $out/${tag}_1280x960_bench.json
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof3 -o ${tag}c3 --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --width 1280 --height 960 --steps 50 --warmup 5 > /dev/null 2>&1
-find /tmp/prof3 -name "${tag}c3_kernel_stats.csv" -exec cp {} $out/${tag}_1280x960_kernel_stats.csv \;

@@ -98,6 +98,15 @@ int main() {
   const double t_stream = timed([&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(k_stream, grid, block, 0, s, a, b, 0, (const float4*)flat, n4, sink); }, s, corr, reps);
   const double t_stream8 = timed([&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(k_stream, dim3(2048), block, 0, s, a, b, 0, (const float4*)flat, n4, sink); }, s, corr, reps);
   const double t_two = timed([&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(k_two_phase, grid, dim3(256), 0, s, a, b, 0, (const float*)curr, (const unsigned*)corr, (const float*)model, sink); }, s, corr, reps);
+  // the fixed cost of a dispatch by its shape (nothing executes): workgroups x threads
+  const int shapes[][2] = {{1, 64}, {1, 256}, {64, 256}, {256, 256}, {600, 256}, {1200, 256}, {256, 512}, {512, 512}, {256, 1024}, {2048, 256}, {4800, 256}};
+  printf("{\"empty_kernel_us_by_shape\": {");
+  for (size_t i = 0; i < sizeof(shapes) / sizeof(shapes[0]); ++i) {
+    const dim3 g(shapes[i][0]), b(shapes[i][1]);
+    const double t = timed([&](hipEvent_t a, hipEvent_t bb) { hipExtLaunchKernelGGL(k_empty, g, b, 0, s, a, bb, 0, sink); }, s, corr, 110);
+    printf("%s\"%dx%d\": %.3f", i ? ", " : "", shapes[i][0], shapes[i][1], t);
+  }
+  printf("}}\n");
   const double bytes = (double)N * 52;
   printf("{\"shape\": \"256 WG x 512 thr, 640x480\", \"empty_us\": %.3f, \"stream_16MB_us\": %.3f, \"stream_16MB_2048wg_us\": %.3f, \"two_phase_16MB_us\": %.3f, "
          "\"stream_GBps\": %.1f, \"two_phase_GBps\": %.1f, \"stream_frac_of_8TBps\": %.4f, \"two_phase_frac_of_8TBps\": %.4f}\n",
