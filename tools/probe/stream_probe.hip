@@ -9,6 +9,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/probe/stream_probe.hip -o tools/probe/stream_probe
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <vector>
 
@@ -107,6 +108,26 @@ int main() {
     printf("%s\"%dx%d\": %.3f", i ? ", " : "", shapes[i][0], shapes[i][1], t);
   }
   printf("}}\n");
+  // host-paired wall time per DEPENDENT launch in a chain of 2000 (what a kernel boundary costs on this stream, no events, no profiler)
+  {
+    int printed = 0;
+    auto chain = [&](const char* name, auto launch) {
+      launch();
+      hipStreamSynchronize(s);
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 2000; ++i) launch();
+      hipStreamSynchronize(s);
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 2000.0;
+      printf("%s\"%s\": %.3f", printed++ ? ", " : "", name, us);
+    };
+    printf("{\"wall_us_per_dependent_launch\": {");
+    chain("1x64 empty", [&] { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s, sink); });
+    chain("256x512 empty", [&] { hipLaunchKernelGGL(k_empty, dim3(256), dim3(512), 0, s, sink); });
+    chain("1200x256 writes 1.2 MB", [&] { hipLaunchKernelGGL(k_between, dim3((N + 255) / 256), dim3(256), 0, s, corr); });
+    chain("256x512 streams 16 MB", [&] { hipLaunchKernelGGL(k_stream, dim3(256), dim3(512), 0, s, (const float4*)flat, n4, sink); });
+    chain("256x256 two-phase 16 MB", [&] { hipLaunchKernelGGL(k_two_phase, dim3(256), dim3(256), 0, s, (const float*)curr, (const unsigned*)corr, (const float*)model, sink); });
+    printf("}}\n");
+  }
   const double bytes = (double)N * 52;
   printf("{\"shape\": \"256 WG x 512 thr, 640x480\", \"empty_us\": %.3f, \"stream_16MB_us\": %.3f, \"stream_16MB_2048wg_us\": %.3f, \"two_phase_16MB_us\": %.3f, "
          "\"stream_GBps\": %.1f, \"two_phase_GBps\": %.1f, \"stream_frac_of_8TBps\": %.4f, \"two_phase_frac_of_8TBps\": %.4f}\n",
