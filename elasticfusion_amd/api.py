@@ -139,6 +139,10 @@ class GlobalLoop(C.Structure):   # ef_global_loop
                 ("icp_count", c_f), ("T_wc_recovery", C.c_double * 16)]
 
 
+class RelocState(C.Structure):   # ef_reloc_state
+    _fields_ = [("lost", c_i), ("tracking_ok", c_i), ("tracking_count", c_i), ("last_frame_recovery", c_i)]
+
+
 class LocalLoop(C.Structure):   # ef_local_loop
     _fields_ = [("attempted", c_i), ("cov_ok", c_i), ("gates_ok", c_i), ("n_constraints", c_i), ("applied", c_i),
                 ("graph_nodes", c_i), ("graph_capacity", c_i), ("pad_", c_i), ("stats", c_f * 6), ("cov_diag", C.c_double * 6), ("T_wc_curr", C.c_double * 16),
@@ -462,7 +466,7 @@ class ElasticFusion:
     def __init__(self, width=640, height=480, fx=528.0, fy=528.0, cx=320.0, cy=240.0, timeDelta=2147483647 // 2,
                  confidence=10.0, depthCut=3.0, icpThresh=10.0, fastOdom=False, so3=True, frameToFrameRGB=False,
                  closeLoops=False, maxSurfels=4 * 1024 * 1024, device=0, stream=None, countThresh=35000, errThresh=5e-05,
-                 covThresh=1e-05):
+                 covThresh=1e-05, reloc=False):
         cfg = default_config(width=width, height=height, fx=fx, fy=fy, cx=cx, cy=cy, time_delta=timeDelta,
                              confidence=confidence, depth_cut=depthCut, icp_weight=icpThresh, fast_odom=int(fastOdom),
                              so3=int(so3), frame_to_frame_rgb=int(frameToFrameRGB), close_loops=int(closeLoops),
@@ -473,6 +477,8 @@ class ElasticFusion:
         self._solver = None
         if closeLoops:
             _chk(lib().ef_set_loop_thresholds(self.h, c_i(countThresh), c_f(errThresh), c_f(covThresh)), self.h)
+        if reloc:
+            self.setRelocalisation(True)
 
     def close(self):
         if getattr(self, "h", None):
@@ -518,6 +524,18 @@ class ElasticFusion:
             return 1
         self._solver = LOOP_SOLVER(tramp)
         _chk(lib().ef_set_loop_solver(self.h, self._solver, None), self.h)
+
+    # --- relocalisation (the reference constructor's `reloc`; ElasticFusion.cpp:326-366, 411-413, 536, 601-604) ---
+    def setRelocalisation(self, on=True):
+        _chk(lib().ef_set_relocalisation(self.h, c_i(int(on))), self.h)
+
+    def relocState(self) -> RelocState:
+        s = RelocState()
+        _chk(lib().ef_get_relocalisation(self.h, C.byref(s)), self.h)
+        return s
+
+    def getLost(self) -> bool:
+        return bool(self.relocState().lost)
 
     # --- global loop closure (ElasticFusion.cpp:392-445, 609-618; closeLoops=True contexts) ---
     def enableGlobalClosure(self, n=500, photoThresh=115.0, fernThresh=0.3095, seed=0):
@@ -612,7 +630,7 @@ class ElasticFusion:
 
     def trajectory(self):
         n = c_i(0)
-        _chk(lib().ef_get_tick(self.h, C.byref(n)), self.h)   # at most one logged pose per processed frame
+        _chk(lib().ef_get_trajectory(self.h, None, None, c_i(2**31 - 1), C.byref(n)), self.h)   # how many poses are logged (one per processed frame)
         cap = max(int(n.value), 1)
         T = np.zeros((cap, 16), np.float64)
         ts = np.zeros(cap, np.int64)

@@ -129,6 +129,10 @@ struct ef_ctx {
   float* h_nodes_pinned = nullptr;         // graph nodes sampled at the end of the previous frame (Deformation::sampleGraphModel, :593)
   int n_nodes_host = 0;
   double h_pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  // relocalisation (ef_set_relocalisation; ElasticFusion.h:283-286,311-312)
+  bool reloc = false, lost = false, last_frame_recovery = false, tracking_ok = true;
+  int tracking_count = 0;
+  eft::TrackState h_reloc{};               // the frame-to-model tracker's state as read back for the verdict
   // hipGraph replay of the tracker (BASELINE.json configs[4]): the ~70 launches of getIncrementalTransformation are
   // captured once per pyramid parity (the SO(3) reference / frame intensity buffers swap every frame) and replayed
   bool use_graph = false;
@@ -254,12 +258,24 @@ int grow_trajectory(ef_ctx* c) {
   return EF_OK;
 }
 
-int do_predict(ef_ctx* c) {
-  // ElasticFusion::predict(), ElasticFusion.cpp:621-653: combinedPredict(ACTIVE) + FillIn (fused into the resolve)
-  efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick,
-                        c->cfg.time_delta, c->zbuf, c->pm, c->fm, c->depth_filtered, c->rgb, c->cfg.frame_to_frame_rgb != 0,
-                        &c->st->dense_count, c->stream);
+int do_predict(ef_ctx* c, bool count_dense = true) {
+  // ElasticFusion::predict(), ElasticFusion.cpp:621-653: combinedPredict(ACTIVE) + FillIn (fused into the resolve).  Right after a
+  // relocalisation the whole model is rendered (time = 0: no surfel is too old); while the camera is lost the fill-in passes the raw
+  // frame through (a second, plain fill-in pass over the fused one: the rare path)
+  efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence,
+                        c->last_frame_recovery ? 0 : c->tick, c->tick, c->cfg.time_delta, c->zbuf, c->pm, c->fm, c->depth_filtered, c->rgb,
+                        c->cfg.frame_to_frame_rgb != 0, count_dense ? &c->st->dense_count : nullptr, c->stream);
+  if (c->lost) efm::fill_in(c->cam, c->pm, c->depth_filtered, c->rgb, true, true, c->fm, c->stream);
   return EF_OK;
+}
+
+// RGBDOdometry::getCovariance of the frame-to-model tracker against the gate of ElasticFusion.cpp:330-337,348-355
+bool reloc_covariance_ok(const eft::TrackState& h) {
+  double cov[36];
+  efl::lu_inverse<double, 6>(h.lastA, cov);
+  for (int i = 0; i < 6; ++i)
+    if (cov[i * 6 + i] > 1e-04) return false;
+  return true;
 }
 
 // The 1/8-resolution views of the fill-in maps the fern database works on (Ferns.cpp:91-93,178-180: Resize::image / Resize::vertex x2),
@@ -333,7 +349,8 @@ void fern_tracker_device(void* user, const float* fv, const float* fn, const dou
   c->gloop.icp_count = h.lastICPCount;
 }
 
-// ElasticFusion.cpp:392-445 with lost == false; returns 1 when a fern was matched AND the global deformation accepted with a graph
+// ElasticFusion.cpp:392-445; *accepted_with_graph = 1 when a fern was matched AND the global deformation accepted with a graph.  A lost
+// camera (relocalisation) takes the matched keyframe's registration as its pose instead (:411-413).
 int global_loop_closure(ef_ctx* c, int log_slot, int* accepted_with_graph) {
   *accepted_with_graph = 0;
   ef_global_loop& G = c->gloop;
@@ -343,6 +360,17 @@ int global_loop_closure(ef_ctx* c, int log_slot, int* accepted_with_graph) {
   const int r0 = read_fern_view(c, false);
   if (r0 != EF_OK) return r0;
   const size_t n = (size_t)c->fern_w * c->fern_h;
+  if (c->lost) {
+    const int r = ef_closure_relocalise(c->closure, c->h_view, 4, (const float*)(c->h_view + n * 4), (const float*)(c->h_view + n * 20), c->h_pose, c->tick,
+                                        &fern_tracker_device, c, G.T_wc_recovery);
+    if (r < 0) { c->err = "ef_closure_relocalise failed"; return r; }
+    G.closest = ef_ferns_last_closest(ef_closure_ferns(c->closure));
+    if (r == 1) {
+      eft::pose_injected(c->st, G.T_wc_recovery, false, 1.0f, false, log_slot >= 0 ? c->traj : nullptr, log_slot, c->stream);
+      c->last_frame_recovery = true;
+    }
+    return EF_OK;
+  }
   c->loop_graph.assign((size_t)1024 * 16, 0.f);
   int nodes = 0;
   const int r = ef_closure_global(c->closure, c->h_view, 4, (const float*)(c->h_view + n * 4), (const float*)(c->h_view + n * 20), c->h_pose, c->tick,
@@ -607,7 +635,29 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       }
       eft::track_end(c->st, tail, rgb, weightMultiplier, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
       timer_end(c, "odom");
+      c->tracking_ok = true;
+      if (c->reloc) {   // :326-366: the tracker's verdict on itself, read back where the reference reads lastICPError / getCovariance()
+        EF_HIP(c, hipMemcpyAsync(&c->h_reloc, c->st, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
+        EF_HIP(c, hipStreamSynchronize(s));
+        c->tracking_ok = c->h_reloc.lastICPError < 1e-04;
+        if (!c->lost) {
+          if (!reloc_covariance_ok(c->h_reloc)) c->tracking_ok = false;
+          if (!c->tracking_ok) {
+            if (++c->tracking_count > 10) c->lost = true;
+          } else {
+            c->tracking_count = 0;
+          }
+        } else if (c->last_frame_recovery) {
+          if (!reloc_covariance_ok(c->h_reloc)) c->tracking_ok = false;
+          if (c->tracking_ok) {
+            c->lost = false;
+            c->tracking_count = 0;
+          }
+          c->last_frame_recovery = false;
+        }
+      }
     } else {
+      c->tracking_ok = true;   // :300: an injected pose is never judged
       if (overlap) EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
       eft::pose_injected(c->st, in_T_wc, true, weightMultiplier, true, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
     }
@@ -618,13 +668,15 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       int fern_graph = 0;
       if (c->closure) {   // :387-445: predict() with its fill-in at the new pose, then the fern database
         timer_begin(c, "globalLoop");
-        efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence, c->tick,
-                              c->tick, c->cfg.time_delta, c->zbuf, c->pm, c->fm, c->depth_filtered, c->rgb, c->cfg.frame_to_frame_rgb != 0, nullptr, s);
+        do_predict(c, false);
+        c->last_frame_recovery = false;                                                           // :393
         const int r = global_loop_closure(c, log_slot, &fern_graph);
         timer_end(c, "globalLoop");
         if (r != EF_OK) return r;
       }
-      if (!fern_graph) {   // :447: rawGraph.size() == 0
+      if (c->lost) {       // :447: a lost camera closes no local loop
+        memset(&c->loop, 0, sizeof(c->loop));
+      } else if (!fern_graph) {   // :447: rawGraph.size() == 0
         timer_begin(c, "localLoop");
         const int r = local_loop_closure(c, log_slot, c->closure != nullptr);
         timer_end(c, "localLoop");
@@ -633,7 +685,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
         memset(&c->loop, 0, sizeof(c->loop));
       }
     }
-    if (!rgbOnly) {  // ElasticFusion.cpp:536-585
+    if (!rgbOnly && c->tracking_ok && !c->lost) {  // ElasticFusion.cpp:536-585
       timer_begin(c, "indexMap");
       const bool sample_splat = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0 && c->probe_splat.start;
       efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
@@ -661,6 +713,8 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       c->graph_nodes = 0;
       c->cur ^= 1;
       timer_end(c, "Fuse::Copy");
+    } else {
+      c->graph_nodes = 0;   // rawGraph is a local of processFrame: a deformation accepted in a frame that does not fuse is never applied
     }
   }
   timer_begin(c, "IndexMap::ACTIVE");
@@ -671,12 +725,14 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
     const int r0 = read_fern_view(c, true);
     if (r0 != EF_OK) return r0;
     const size_t n = (size_t)c->fern_w * c->fern_h;
-    const int r = ef_closure_end_frame(c->closure, c->h_view, 4, (const float*)(c->h_view + n * 4), (const float*)(c->h_view + n * 20), c->h_pose, c->tick);
+    const int r = c->lost ? ef_closure_log_pose(c->closure, c->h_pose, c->tick)   // :601-604: no keyframe while lost
+                          : ef_closure_end_frame(c->closure, c->h_view, 4, (const float*)(c->h_view + n * 4), (const float*)(c->h_view + n * 20), c->h_pose,
+                                                 c->tick);
     timer_end(c, "ferns");
     if (r < 0) { c->err = "ef_closure_end_frame failed"; return r; }
   }
   EF_HIP(c, hipEventRecord(c->ev_frame_done[c->frame_parity], s));
-  c->tick++;
+  if (!c->lost) c->tick++;   // :601-604
   EF_HIP(c, hipGetLastError());
   return EF_OK;
 }
@@ -1039,6 +1095,17 @@ int ef_enable_global_closure(ef_ctx* c, int num_ferns, float photo_thresh, float
   c->gloop.closest = -1;
   c->closure = ef_closure_create(num_ferns, c->cfg.depth_cut, photo_thresh, fern_thresh, W, H, c->cfg.fx, c->cfg.fy, c->cfg.cx, c->cfg.cy, seed);
   if (!c->closure) { c->err = "ef_closure_create failed"; return EF_ENOMEM; }
+  return EF_OK;
+}
+int ef_set_relocalisation(ef_ctx* c, int on) {
+  if (!c) return EF_EINVAL;
+  c->reloc = on != 0;
+  if (!c->reloc) { c->lost = false; c->last_frame_recovery = false; c->tracking_count = 0; c->tracking_ok = true; }
+  return EF_OK;
+}
+int ef_get_relocalisation(ef_ctx* c, ef_reloc_state* out) {
+  if (!c || !out) return EF_EINVAL;
+  out->lost = c->lost; out->tracking_ok = c->tracking_ok; out->tracking_count = c->tracking_count; out->last_frame_recovery = c->last_frame_recovery;
   return EF_OK;
 }
 int ef_get_global_loop(ef_ctx* c, ef_global_loop* info) {

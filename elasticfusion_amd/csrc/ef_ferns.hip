@@ -340,7 +340,7 @@ void ef_closure_destroy(ef_closure* c) {
 }
 ef_ferns* ef_closure_ferns(ef_closure* c) { return c ? c->ferns : nullptr; }
 
-// ElasticFusion.cpp:392-445 (lost == false)
+// ElasticFusion.cpp:392-445 (lost == false; ef_closure_relocalise is the other branch)
 int ef_closure_global(ef_closure* c, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int tick,
                       ef_fern_tracker tracker, void* user, const float* nodes4, int n_nodes, double* T_recovery16_out, float* graph16_out, int* nodes_out) {
   if (!c || !T_recovery16_out || !graph16_out || !nodes_out || n_nodes < 0 || (n_nodes > 0 && !nodes4)) return EF_EINVAL;
@@ -413,6 +413,24 @@ int ef_closure_end_frame(ef_closure* c, const uint8_t* rgb, int ch, const float*
   c->trajectory.insert(c->trajectory.end(), T_wc16, T_wc16 + 16);
   c->trajectoryTimes.push_back(tick);
   return ef_ferns_add_frame(c->ferns, rgb, ch, verts4, norms4, T_wc16, tick, c->fernThresh);
+}
+
+// ElasticFusion.cpp:395-413 for a lost camera: the match itself is the answer (no deformation)
+int ef_closure_relocalise(ef_closure* c, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int tick,
+                          ef_fern_tracker tracker, void* user, double* T_recovery16_out) {
+  if (!c || !T_recovery16_out) return EF_EINVAL;
+  c->lastRows.clear();
+  double cons[128 * 6];
+  int n = 0;
+  const int closest = ef_ferns_find_frame(c->ferns, rgb, ch, verts4, norms4, T_wc16, tick, 1, tracker, user, T_recovery16_out, cons, 128, &n);
+  if (closest < -1) return closest;
+  return closest == -1 ? 0 : 1;
+}
+int ef_closure_log_pose(ef_closure* c, const double* T_wc16, int tick) {
+  if (!c || !T_wc16) return EF_EINVAL;
+  c->trajectory.insert(c->trajectory.end(), T_wc16, T_wc16 + 16);
+  c->trajectoryTimes.push_back(tick);
+  return EF_OK;
 }
 
 int ef_closure_set_fern_thresh(ef_closure* c, float fern_thresh) {

@@ -61,7 +61,6 @@ ElasticFusion::ElasticFusion(const int timeDelta_, const int countThresh, const 
                              const float fernThresh, const bool so3, const bool frameToFrameRGB, const std::string fileName,
                              const int device)
     : saveFilename(fileName), timeDelta(timeDelta_), confidenceThreshold(confidence), closeLoops(closeLoops), iclnuim(iclnuim_) {
-  if (reloc) throw std::runtime_error("ElasticFusion: reloc = true (relocalisation when tracking is lost) is not built in this library");
   ef_config cfg;
   ef_default_config(&cfg);
   cfg.width = Resolution::getInstance().width();
@@ -87,6 +86,7 @@ ElasticFusion::ElasticFusion(const int timeDelta_, const int countThresh, const 
     chk(ef_use_builtin_loop_solver(c, 1), c, "ElasticFusion::ElasticFusion");
     chk(ef_enable_global_closure(c, 500, photoThresh, fernThresh, 0u), c, "ElasticFusion::ElasticFusion");   // Ferns(500, depthCut * 1000, photoThresh), :53
   }
+  if (reloc) chk(ef_set_relocalisation(c, 1), c, "ElasticFusion::ElasticFusion");   // :326-366, 411-413: lost / found through the fern database
   // drop-in: getGlobalModel().downloadMap() and savePly() return what the reference's return (the pre-clean buffer, quirk Q14)
   chk(ef_set_reference_download(c, 1), c, "ElasticFusion::ElasticFusion");
   indexMap.ctx = globalModel.ctx = localDeformation.ctx = c;
@@ -110,12 +110,10 @@ ElasticFusion::~ElasticFusion() {
   }
   // iclnuim: the timestamps are written as they came, not as microseconds / 1e6 (ElasticFusion.cpp:124-128)
   int n = 0;
-  if (ef_get_trajectory(C(ctx.get()), nullptr, nullptr, 0, &n) != EF_OK) return;
-  int tick_now = 1;
-  (void)ef_get_tick(C(ctx.get()), &tick_now);
-  std::vector<double> T((size_t)tick_now * 16);
-  std::vector<int64_t> ts((size_t)tick_now);
-  if (ef_get_trajectory(C(ctx.get()), T.data(), ts.data(), tick_now, &n) != EF_OK) return;
+  if (ef_get_trajectory(C(ctx.get()), nullptr, nullptr, 0x7fffffff, &n) != EF_OK) return;   // one logged pose per processed frame
+  std::vector<double> T((size_t)(n > 0 ? n : 1) * 16);
+  std::vector<int64_t> ts((size_t)(n > 0 ? n : 1));
+  if (ef_get_trajectory(C(ctx.get()), T.data(), ts.data(), n, &n) != EF_OK) return;
   for (int i = 0; i < n; ++i) ts[i] *= 1000000;   // ef_write_freiburg divides by 1e6 and prints six decimals, which is the reference's format here
   (void)ef_write_freiburg((saveFilename + ".freiburg").c_str(), T.data(), ts.data(), n);
 }
@@ -125,6 +123,9 @@ void ElasticFusion::processFrame(const uint8_t* rgb, const uint16_t* depth, cons
   double M[16];
   if (in_T_wc) in_T_wc->matrix(M);
   chk(ef_process_frame(C(ctx.get()), rgb, depth, timestamp, weightMultiplier, in_T_wc ? M : nullptr), ctx.get(), "processFrame");
+  ef_reloc_state rs;
+  chk(ef_get_relocalisation(C(ctx.get()), &rs), ctx.get(), "processFrame");
+  lost = rs.lost != 0;
   if (closeLoops) {
     ef_ctx* c = C(ctx.get());
     ef_closure* cl = ef_get_closure(c);

@@ -15,7 +15,8 @@
 //    fern match on the mid-frame fill-in view, 1/8-resolution registration on the device, global deformation) and, when that
 //    does not fire, the LOCAL one (:447-527), both optimised by the built-in deformation-graph solver (no CHOLMOD); Ferns::addFrame
 //    at the end of the frame.  The fern table's seed is fixed (the reference uses time(0)); setLoopSolver() replaces the local
-//    optimiser.  reloc = true (relocalisation when lost) is not built: the constructor throws.
+//    optimiser.  reloc = true judges every tracked frame by its own statistics (:326-366): frames that are not ok are not fused, more
+//    than ten in a row and the camera is lost (getLost()) until a fern match brings the pose back (:411-413; needs closeLoops = true).
 //  * getTextures / getFeedbackBuffers / computeFeedbackBuffers / normaliseDepth are OpenGL objects and display passes in the
 //    reference and have no counterpart here.
 //  * errors throw std::runtime_error instead of assert()/exit(0).

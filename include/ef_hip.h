@@ -226,6 +226,11 @@ int ef_closure_set_fern_thresh(ef_closure* c, float fern_thresh);   /* ElasticFu
 int ef_closure_last_rows(const ef_closure* c, ef_graph_constraint* rows_or_null, int max_rows, float* error_or_null, float* mean_constraint_error_or_null);
 int ef_closure_relative(const ef_closure* c, ef_graph_constraint* rows_or_null, int max_rows);
 int ef_closure_trajectory(const ef_closure* c, double* poses16_or_null, int max_poses);
+/* a LOST camera's frame (ElasticFusion.cpp:395-413 with lost = true): Ferns::findFrame only — 1 and the registered pose when a keyframe
+ * passes the gates (ICP count > 1400), 0 otherwise; and its end (:588-589 without :601-604): the pose joins the trajectory, no keyframe */
+int ef_closure_relocalise(ef_closure* c, const uint8_t* rgb, int channels, const float* verts4, const float* norms4, const double* T_wc16, int tick,
+                          ef_fern_tracker tracker, void* user, double* T_recovery16_out);
+int ef_closure_log_pose(ef_closure* c, const double* T_wc16, int tick);
 /* ---- the GLOBAL loop closure inside ef_process_frame (ElasticFusion.cpp:392-445, 588-589, 609-618; contexts created with
  * close_loops = 1).  Creates the context's closure object (ef_closure_* above: Ferns(num_ferns, depth_cut * 1000, photo_thresh), the
  * relative constraints, the trajectory) and a third tracker instance at 1/8 resolution.  From then on every frame (tick > 1):
@@ -238,8 +243,24 @@ int ef_closure_trajectory(const ef_closure* c, double* poses16_or_null, int max_
  *                     (ef_use_builtin_loop_solver), so keyframe poses follow and a third of the new relative constraints is kept;
  *   end of the frame  the final fill-in view goes to Ferns::addFrame, the pose joins the trajectory.
  * Two stream synchronisations per frame, where the reference reads the views back (Resize.cpp:50-159).  The reference seeds its fern
- * table from time(0); here the seed is an argument (equal seeds => equal runs).  relocalisation (reloc / lost) is not built. */
+ * table from time(0); here the seed is an argument (equal seeds => equal runs). */
 int ef_enable_global_closure(ef_ctx* ctx, int num_ferns, float photo_thresh, float fern_thresh, unsigned seed);
+/* ---- relocalisation (the reference constructor's `reloc`; ElasticFusion.cpp:326-366, 402-413, 536, 601-604, 624-649).  With it on,
+ * every TRACKED frame (no injected pose) is judged by its own statistics, read back right after the tracker (one more synchronisation
+ * per frame): trackingOk = lastICPError < 1e-4 and no diagonal entry of getCovariance() above 1e-4.  A frame that is not ok is not
+ * fused; more than ten of them in a row and the camera is LOST: the fill-in passes the raw frame through, the tick stands still, no
+ * keyframe is stored, neither closure runs — but Ferns::findFrame keeps looking (ICP count gate 1400 instead of 2400) and a match
+ * becomes the pose (ef_global_loop.closest >= 0 with accepted = 0).  The frame after such a recovery is predicted from the whole model
+ * (time = 0) and, if its tracking is ok, the camera is found again.  Recovery needs the global closure (ef_enable_global_closure);
+ * without it a lost camera stays lost, as in the reference with closeLoops = false. */
+int ef_set_relocalisation(ef_ctx* ctx, int on);
+typedef struct ef_reloc_state {
+  int lost;                 /* ElasticFusion::getLost() */
+  int tracking_ok;          /* of the last frame (1 for frames with an injected pose) */
+  int tracking_count;       /* consecutive frames not ok, towards "lost" at > 10 */
+  int last_frame_recovery;  /* the last frame's pose came from a fern match while lost */
+} ef_reloc_state;
+int ef_get_relocalisation(ef_ctx* ctx, ef_reloc_state* out);
 typedef struct ef_global_loop {
   int attempted;            /* Ferns::findFrame ran in the last ef_process_frame */
   int closest;              /* matched keyframe (Ferns::lastClosest), -1: none passed the gates */

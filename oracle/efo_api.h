@@ -192,6 +192,9 @@ typedef struct efo_global_loop {
   double T_wc_recovery[16];
 } efo_global_loop;
 void efo_fusion_set_tick(efo_fusion*, int tick);
+/* relocalisation (the reference constructor's `reloc`, ElasticFusion.cpp:326-366,411-413,536,601-604,624-649) */
+void efo_fusion_set_reloc(efo_fusion*, int on);
+void efo_fusion_reloc_state(const efo_fusion*, int* out4 /* lost, trackingOk, trackingCount, lastFrameRecovery */);
 void efo_fusion_enable_ferns(efo_fusion*, int num, float photoThresh, float fernThresh, unsigned seed);
 efo_ferns* efo_fusion_ferns(efo_fusion*);
 /* the 1/8-resolution fill-in views of the last frame: which = 0 what Ferns::findFrame saw mid-frame, 1 what Ferns::addFrame saw at its end */

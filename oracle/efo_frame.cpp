@@ -1,7 +1,8 @@
 // TEST INFRASTRUCTURE — CPU oracle. Not part of the product path (see oracle/README.md).
 //
 // CPU restatement of ElasticFusion::processFrame (Core/ElasticFusion.cpp:270-607) and predict()
-// (:621-653) with reloc = false.  Open loop (closeLoops = false) by default; efo_fusion_set_close_loops adds the LOCAL loop
+// (:621-653).  Relocalisation (reloc = true, :326-366, 402-413, 536, 601-604, 624-649) is off unless efo_fusion_set_reloc turns it
+// on.  Open loop (closeLoops = false) by default; efo_fusion_set_close_loops adds the LOCAL loop
 // closure block (:447-527) with a solver callback where Deformation::constrain stands; efo_fusion_enable_ferns adds the GLOBAL one:
 // the fern branch (:391-444: Ferns::findFrame on the mid-frame fill-in, the global deformation with the relative constraints kept from
 // local closures) and Ferns::addFrame at the end of the frame (:601-619), over efo_ferns.cpp.  The deformation-graph sampling
@@ -64,6 +65,10 @@ struct efo_fusion {
   efo_deform_solver deformSolver = nullptr;
   void* deformUser = nullptr;
   efo_global_loop gloop{};
+  // relocalisation (ElasticFusion.h:283-286,311-312): the tracker's verdict on itself, the counter towards "lost", the one-frame
+  // probation after a fern brought the pose back
+  bool reloc = false, lost = false, lastFrameRecovery = false, trackingOk = true;
+  int trackingCount = 0;
   std::vector<double> relativeCons;          // rows of 10, Deformation::Constraint with relative = true
   std::vector<double> trajectory;            // t_T_wc: 16 doubles per processed frame
   std::vector<int64_t> trajectoryTimes;
@@ -194,7 +199,20 @@ struct efo_fusion {
     rows.insert(rows.end(), r, r + 10);
   }
 
-  // ElasticFusion.cpp:392-445 with lost == false: returns true when a fern was matched AND the global deformation accepted
+  // RGBDOdometry::getCovariance of the frame-to-model tracker and the gate of ElasticFusion.cpp:330-337,348-355
+  bool covarianceOk() {
+    tr("frameToModel.getCovariance");
+    double lastA[36], cov[36];
+    float st[6];
+    efo_odom_stats(frameToModel, st, lastA, nullptr);
+    lu_inverse<double, 6>(lastA, cov);
+    for (int i = 0; i < 6; ++i)
+      if (cov[i * 6 + i] > 1e-04) return false;
+    return true;
+  }
+
+  // ElasticFusion.cpp:392-445: returns true when a fern was matched AND the global deformation accepted; a lost camera takes the
+  // matched keyframe's registration as its pose instead (:411-413)
   bool fernClosure() {
     gloop = efo_global_loop{};
     gloop.attempted = 1;
@@ -205,13 +223,20 @@ struct efo_fusion {
     lastViews[0] = v;
     std::vector<double> cons((size_t)128 * 6);
     int n = 0;
-    tr("ferns.findFrame time=%d lost=0", tick);
-    const int closest = efo_ferns_find_frame(ferns, v.img.data(), 4, v.verts.data(), v.norms.data(), M, tick, 0, &fernTrack, this, E, cons.data(), 128, &n);   // :395-402
+    tr("ferns.findFrame time=%d lost=%d", tick, lost ? 1 : 0);
+    const int closest = efo_ferns_find_frame(ferns, v.img.data(), 4, v.verts.data(), v.norms.data(), M, tick, lost ? 1 : 0, &fernTrack, this, E, cons.data(), 128,
+                                             &n);   // :395-402
     tr("ferns.findFrame -> closest=%d constraints=%d", closest, n);
     gloop.closest = closest;
     gloop.n_constraints = n;
     std::memcpy(gloop.T_wc_recovery, E, sizeof(E));
     if (closest == -1) return false;                                                                          // :410
+    if (lost) {                                                                                               // :411-413
+      gloop.n_constraints = 0;   // (findFrame's surface constraints are not used on this branch)
+      T_wc = se3_from_matrix(E);
+      lastFrameRecovery = true;
+      return false;
+    }
     int fernTime = 0;
     efo_ferns_get_frame(ferns, closest, nullptr, nullptr, &fernTime, nullptr, nullptr, nullptr, nullptr);
     std::vector<double> rows;
@@ -321,17 +346,19 @@ struct efo_fusion {
 
   void pose16(double* M) const { M4d m = se3_matrix(T_wc); std::memcpy(M, m.m, sizeof(m.m)); }
 
-  // ElasticFusion::predict(), ElasticFusion.cpp:621-653 (lost == false)
+  // ElasticFusion::predict(), ElasticFusion.cpp:621-653: right after a recovery the whole model is rendered (time = 0: nothing is
+  // "inactive"); while lost the fill-in passes the raw frame through
   void predict() {
     double M[16];
     pose16(M);
-    tr("combinedPredict ACTIVE maxDepth=%g conf=%g time=%d maxTime=%d timeDelta=%d", maxDepthProcessed, p.confidence, tick, tick, p.timeDelta);
+    const int time = lastFrameRecovery ? 0 : tick;
+    tr("combinedPredict ACTIVE maxDepth=%g conf=%g time=%d maxTime=%d timeDelta=%d", maxDepthProcessed, p.confidence, time, tick, p.timeDelta);
     tr_pose("  pose", M);
-    tr("fillIn vertex passthrough=0; normal passthrough=0; image passthrough=%d", p.frameToFrameRGB ? 1 : 0);
-    efo_combined_predict(&cam, M, surfels.data(), count, maxDepthProcessed, p.confidence, tick, tick, p.timeDelta,
+    tr("fillIn vertex passthrough=%d; normal passthrough=%d; image passthrough=%d", lost ? 1 : 0, lost ? 1 : 0, (lost || p.frameToFrameRGB) ? 1 : 0);
+    efo_combined_predict(&cam, M, surfels.data(), count, maxDepthProcessed, p.confidence, time, tick, p.timeDelta,
                          image.data(), vertex.data(), normal.data(), timeMap.data());
-    efo_fill_in(&cam, image.data(), vertex.data(), normal.data(), depthFiltered.data(), rgb.data(), 0,
-                p.frameToFrameRGB ? 1 : 0, fimage.data(), fvertex.data(), fnormal.data());
+    efo_fill_in(&cam, image.data(), vertex.data(), normal.data(), depthFiltered.data(), rgb.data(), lost ? 1 : 0,
+                (lost || p.frameToFrameRGB) ? 1 : 0, fimage.data(), fvertex.data(), fnormal.data());
   }
 
   void processFrame(const uint8_t* rgb_in, const uint16_t* depth_in, int64_t, float weightMultiplier, const double* in_T_wc) {
@@ -352,6 +379,7 @@ struct efo_fusion {
       efo_odom_init_first_rgb(frameToModel, rgba.data());
     } else {
       const SE3 T_prev = T_wc;
+      trackingOk = true;                                                                                     // :300
       if (!in_T_wc) {
         bool shouldFillIn = !efo_dense_enough(&cam, image.data());  // :304-305
         double M[16];
@@ -370,6 +398,27 @@ struct efo_fusion {
         efo_odom_init_rgb(frameToModel, rgba.data());                                                        // :318
         efo_odom_track(frameToModel, M, p.rgbOnly, p.icpWeight, p.pyramid, p.fastOdom, p.so3);               // :322-323
         T_wc = se3_from_matrix(M);
+        float st[6];
+        efo_odom_stats(frameToModel, st, nullptr, nullptr);
+        trackingOk = !reloc || st[0] < 1e-04;                                                                // :326, lastICPError
+        if (reloc) {                                                                                         // :328-366
+          if (!lost) {
+            if (!covarianceOk()) trackingOk = false;
+            if (!trackingOk) {
+              trackingCount++;
+              if (trackingCount > 10) lost = true;
+            } else {
+              trackingCount = 0;
+            }
+          } else if (lastFrameRecovery) {
+            if (!covarianceOk()) trackingOk = false;
+            if (trackingOk) {
+              lost = false;
+              trackingCount = 0;
+            }
+            lastFrameRecovery = false;
+          }
+        }
       } else {
         T_wc = se3_from_matrix(in_T_wc);
       }
@@ -384,9 +433,12 @@ struct efo_fusion {
 
       predict();  // :387 (result unused when closeLoops == false; kept for fidelity)
       bool fernAccepted = false;
+      if (closeLoops) lastFrameRecovery = false;                                                             // :393
       if (closeLoops && ferns) fernAccepted = fernClosure();                                                 // :392-445
-      if (closeLoops && !(fernAccepted && !pendingGraph.empty())) localLoopClosure();                        // :447: rawGraph.size() == 0
-      if (!p.rgbOnly) {
+      if (!lost && closeLoops && !(fernAccepted && !pendingGraph.empty())) localLoopClosure();               // :447: rawGraph.size() == 0
+      else loop = efo_local_loop{};
+      const bool fuseThis = !p.rgbOnly && trackingOk && !lost;                                               // :536
+      if (fuseThis) {
         double Mt[16];
         pose16(Mt);
         tr("predictIndices time=%d maxDepth=%g timeDelta=%d", tick, maxDepthProcessed, p.timeDelta);
@@ -399,7 +451,7 @@ struct efo_fusion {
            maxDepthProcessed, pendingFern);
       }
 
-      if (!p.rgbOnly) {  // :536-585 (trackingOk && !lost always hold without reloc)
+      if (fuseThis) {  // :536-585
         double M[16];
         pose16(M);
         efo_predict_indices(&cam, M, tick, surfels.data(), count, maxDepthProcessed, p.timeDelta, indexMap.data(),
@@ -429,6 +481,8 @@ struct efo_fusion {
                                  surfelsTmp.data());
         pendingGraph.clear();
         surfels.swap(surfelsTmp);
+      } else {
+        pendingGraph.clear();   // rawGraph is a local of processFrame: a deformation accepted in a frame that does not fuse is never applied
       }
     }
     {           // :588-589
@@ -438,6 +492,7 @@ struct efo_fusion {
       trajectoryTimes.push_back(tick);
     }
     predict();  // :599
+    if (lost) return;   // :601-604: neither a keyframe nor a tick while the camera is lost
     if (ferns) {   // processFerns, :609-618
       double Mt[16];
       pose16(Mt);
@@ -446,7 +501,7 @@ struct efo_fusion {
       const int kept = efo_ferns_add_frame(ferns, v.img.data(), 4, v.verts.data(), v.norms.data(), Mt, tick, fernThresh);
       tr("ferns.addFrame time=%d -> %d", tick, kept);
     }
-    tick++;     // :603 (lost is never set without reloc)
+    tick++;     // :603
   }
 };
 
@@ -492,6 +547,11 @@ void efo_fusion_set_close_loops(efo_fusion* f, int on, int icpCountThresh, float
 }
 void efo_fusion_set_loop_solver(efo_fusion* f, efo_loop_solver fn, void* user) { f->solver = fn; f->solverUser = user; }
 void efo_fusion_set_tick(efo_fusion* f, int tick) { f->tick = tick; }
+void efo_fusion_set_reloc(efo_fusion* f, int on) { f->reloc = on != 0; }
+// {lost, trackingOk of the last frame, trackingCount, lastFrameRecovery}
+void efo_fusion_reloc_state(const efo_fusion* f, int* out4) {
+  out4[0] = f->lost; out4[1] = f->trackingOk; out4[2] = f->trackingCount; out4[3] = f->lastFrameRecovery;
+}
 void efo_fusion_enable_ferns(efo_fusion* f, int num, float photoThresh, float fernThresh, unsigned seed) {
   const efo_fusion_params& p = f->p;
   f->ferns = efo_ferns_create(num, (int)(p.depthCut * 1000), photoThresh, p.width, p.height, p.fx, p.fy, p.cx, p.cy, seed);   // ElasticFusion.cpp:53

@@ -140,15 +140,17 @@ const char* take(Frame* f) { f->out.swap(glrec::S().log); glrec::S().log.clear()
 }  // namespace
 
 extern "C" {
-void* efe_create(int w, int h, float fx, float fy, float cx, float cy, int timeDelta, int countThresh, float errThresh, float covThresh, int closeLoops,
+// flags: bit 0 = closeLoops, bit 1 = reloc (the constructor's relocalisation mode, ElasticFusion.cpp:29,79)
+void* efe_create(int w, int h, float fx, float fy, float cx, float cy, int timeDelta, int countThresh, float errThresh, float covThresh, int flags,
                  float confidence, float depthCut, float icpThresh, int fastOdom, int so3, int frameToFrameRGB, const char* fileName) {
   Resolution::getInstance(w, h);
   Intrinsics::getInstance(fx, fy, cx, cy);
   Frame* f = new Frame();
-  f->ef = new ElasticFusion(timeDelta, countThresh, errThresh, covThresh, closeLoops != 0, false, false, 115, confidence, depthCut, icpThresh,
+  f->ef = new ElasticFusion(timeDelta, countThresh, errThresh, covThresh, (flags & 1) != 0, false, (flags & 2) != 0, 115, confidence, depthCut, icpThresh,
                             fastOdom != 0, 0.3095f, so3 != 0, frameToFrameRGB != 0, fileName);
   return f;
 }
+int efe_lost(void* p) { return ((Frame*)p)->ef->getLost() ? 1 : 0; }
 const char* efe_take_log(void* p) { return take((Frame*)p); }
 void efe_destroy(void* p) { Frame* f = (Frame*)p; delete f->ef; delete f; }   // the destructor writes <fileName>.freiburg
 const char* efe_process_frame(void* p, const unsigned char* rgb, const unsigned short* depth, long long timestamp, float weightMultiplier, const double* T16) {

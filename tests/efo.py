@@ -590,6 +590,16 @@ class Fusion:
     def set_tick(self, tick):
         lib().efo_fusion_set_tick(self.h_, c_i(int(tick)))
 
+    # ---- relocalisation (ElasticFusion.cpp:326-366,411-413,536,601-604,624-649) ----
+    def set_reloc(self, on=True):
+        lib().efo_fusion_set_reloc(self.h_, c_i(int(on)))
+
+    def reloc_state(self):
+        """dict(lost, trackingOk, trackingCount, lastFrameRecovery) after the last frame"""
+        out = np.zeros(4, np.int32)
+        lib().efo_fusion_reloc_state(self.h_, ptr(out))
+        return dict(lost=bool(out[0]), trackingOk=bool(out[1]), trackingCount=int(out[2]), lastFrameRecovery=bool(out[3]))
+
     def enable_ferns(self, num=500, photoThresh=115.0, fernThresh=0.3095, seed=0):
         lib().efo_fusion_enable_ferns(self.h_, c_i(num), c_f(photoThresh), c_f(fernThresh), C.c_uint(seed))
 

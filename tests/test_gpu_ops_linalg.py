@@ -53,6 +53,29 @@ def test_ldlt6_bit_exact(ops):
             assert np.array_equal(x.view(np.uint64), x_r.view(np.uint64)), (which, t, x, x_r)
 
 
+def test_ldlt6_degenerate_systems(ops):
+    """what a frame without correspondences hands the solver (a covered lens: A = 0, b = 0), a rank-one system, and a system with a zero
+    block: Eigen::LDLT's zero-pivot branch leaves the factorisation where it stands and the solve sets those components to 0"""
+    rng = np.random.RandomState(5)
+    cases = []
+    cases.append((np.zeros((6, 6)), np.zeros(6)))
+    cases.append((np.zeros((6, 6)), rng.randn(6)))
+    v = rng.randn(6)
+    cases.append((np.outer(v, v), rng.randn(6)))
+    J = rng.randn(30, 3)
+    A = np.zeros((6, 6))
+    A[3:, 3:] = J.T @ J                                            # rotation constrained, translation not at all
+    cases.append((A, rng.randn(6)))
+    for t, (A, b) in enumerate(cases):
+        A = np.ascontiguousarray(A, np.float64)
+        x_r = np.zeros(6)
+        efo.lib().efo_ldlt6(_p(A), _p(b), _p(x_r))
+        for which in ("ldlt6", "ldlt6_wave"):
+            x = ops.linalg(which, np.concatenate([A.reshape(-1), b]), 6)
+            assert np.array_equal(x.view(np.uint64), x_r.view(np.uint64)), (which, t, x, x_r)
+    assert not np.any(x_r[:3]) and np.all(np.isfinite(x_r))
+
+
 def test_ldlt3f_bit_exact(ops):
     rng = np.random.RandomState(1)
     for _ in range(20):
