@@ -236,6 +236,19 @@ EFL_HD void polar3(const double* Ain, double* R) {
 // ---- Sophus::SE3d stand-in: unit quaternion (x,y,z,w) + translation ----
 struct SE3 { double q[4]; double t[3]; };
 
+// the branch of Eigen::Quaternion(Matrix3) for a non-positive trace, largest diagonal entry I: every index a compile-time constant (a
+// run-time i put q[] into scratch memory on gfx950 — 64 bytes per lane, the only private segment of the whole library — and a kernel
+// with a private segment pays for its set-up at every dispatch)
+template <int I>
+EFL_HD void mat_to_quat_diag(const double* m, double* q) {
+  constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+  double t = sqrt(m[I * 3 + I] - m[J * 3 + J] - m[K * 3 + K] + 1.0);
+  q[I] = 0.5 * t;
+  t = 0.5 / t;
+  q[3] = (m[K * 3 + J] - m[J * 3 + K]) * t;
+  q[J] = (m[J * 3 + I] + m[I * 3 + J]) * t;
+  q[K] = (m[K * 3 + I] + m[I * 3 + K]) * t;
+}
 EFL_HD void mat_to_quat(const double* m, double* q) {  // Eigen::Quaternion(Matrix3)
   double t = m[0] + m[4] + m[8];
   if (t > 0.0) {
@@ -246,6 +259,13 @@ EFL_HD void mat_to_quat(const double* m, double* q) {  // Eigen::Quaternion(Matr
     q[1] = (m[2] - m[6]) * t;
     q[2] = (m[3] - m[1]) * t;
   } else {
+#ifndef EF_R02K_BASELINE
+    const bool one = m[4] > m[0];
+    const bool two = m[8] > (one ? m[4] : m[0]);
+    if (two) mat_to_quat_diag<2>(m, q);
+    else if (one) mat_to_quat_diag<1>(m, q);
+    else mat_to_quat_diag<0>(m, q);
+#else   // A/B only (tools/gpu_ab.sh): the run-time index that put q[] into scratch memory
     int i = 0;
     if (m[4] > m[0]) i = 1;
     if (m[8] > m[i * 3 + i]) i = 2;
@@ -256,6 +276,7 @@ EFL_HD void mat_to_quat(const double* m, double* q) {  // Eigen::Quaternion(Matr
     q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
     q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
     q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+#endif
   }
 }
 template <typename T>

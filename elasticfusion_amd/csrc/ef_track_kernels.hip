@@ -419,6 +419,105 @@ __device__ __forceinline__ void store_planar(float* m, int cols, int rows, int x
     }
   }
 }
+#ifndef EF_R02K_BASELINE
+// Four lanes share a 4x4 block: lane j of the quad owns COLUMN j of it, so that every load and every level-0 store of a wavefront
+// covers 64 consecutive pixels of one row (1 KB of float4s per load instruction, four times as many workgroups as one thread per
+// block gave: 300 instead of 75 at 640x480).  The 2x2 boxes of level 1 need the neighbouring column (quad_perm xor 1), the one of
+// level 2 the neighbouring pair (xor 2); both lanes of a pair / all lanes of the quad evaluate the same expressions on the same
+// operands in the reference's order ((a + b) + c) + d, one of them stores.
+__device__ __forceinline__ float qx1(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float qx2(float x) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ f3 qx1(f3 v) { return f3{qx1(v.x), qx1(v.y), qx1(v.z)}; }
+__device__ __forceinline__ f3 qx2(f3 v) { return f3{qx2(v.x), qx2(v.y), qx2(v.z)}; }
+__device__ __forceinline__ f3 box4(f3 a, f3 b, f3 c, f3 d) {
+  return f3{(a.x + b.x + c.x + d.x) / 4, (a.y + b.y + c.y + d.y) / 4, (a.z + b.z + c.z + d.z) / 4};
+}
+__global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const TrackState* __restrict__ st) {
+  const int gx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
+  const int cols = A.cols, rows = A.rows;
+  if (gx >= cols || by * 4 >= rows) return;   // cols is a multiple of 4: a quad is in or out as a whole
+  const int j = gx & 3, bx = gx >> 2;
+  const bool even = (j & 1) == 0, leftpair = j < 2;
+  const bool fill = use_fill_in(st);
+  const float4* __restrict__ vsrc = fill ? A.fill_vertex : A.pred_vertex;
+  const float4* __restrict__ nsrc = fill ? A.fill_normal : A.pred_normal;
+  const m33 R = m33_load(st->R_wc_f);
+  const f3 t{st->t_wc_f[0], st->t_wc_f[1], st->t_wc_f[2]};
+  const bool cf = A.camera_frame;
+  const int c1 = cols / 2, r1 = rows / 2, c2 = cols / 4, r2 = rows / 4;
+  float4 vs[4], ns[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    vs[r] = vsrc[(by * 4 + r) * cols + gx];
+    ns[r] = nsrc[(by * 4 + r) * cols + gx];
+  }
+  f3 v0[4], n0[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = by * 4 + r;
+    const bool ok = !(vs[r].z == 0);
+    v0[r] = {vs[r].x, vs[r].y, vs[r].z};
+    n0[r] = {ns[r].x, ns[r].y, ns[r].z};
+    A.depth0[y * cols + gx] = (vs[r].z > A.maxDepthRGB || vs[r].z <= 0) ? qnan() : vs[r].z;
+    // level 0: copyMaps NaNs all planes where z == 0, transform propagates NaN via the x-plane
+    const bool nok = ok && !isnan(ns[r].x);
+    if (cf) {   // copyMaps alone: the NaN test of tranformMaps is not applied, an empty texel NaNs all planes
+      store_planar<true>(A.vmap[0], cols, rows, gx, y, ok, v0[r]);
+      store_planar<true>(A.nmap[0], cols, rows, gx, y, ok, n0[r]);
+    } else {
+      store_planar<true>(A.vmap[0], cols, rows, gx, y, ok && !isnan(vs[r].x), mul(R, v0[r]) + t);
+      store_planar<true>(A.nmap[0], cols, rows, gx, y, nok, mul(R, n0[r]));
+    }
+  }
+  // level 1: 2x2 box of the camera-frame level-0 maps (x-plane NaN test only); this lane's pair of columns, both box rows
+  f3 v1[2], n1[2];
+  bool v1ok[2], n1ok[2];
+#pragma unroll
+  for (int qy = 0; qy < 2; ++qy) {
+    const f3 pv0 = qx1(v0[2 * qy]), pv1 = qx1(v0[2 * qy + 1]), pn0 = qx1(n0[2 * qy]), pn1 = qx1(n0[2 * qy + 1]);
+    // [sy][sx] of the one-thread-per-block form: [0][0], [0][1], [1][0], [1][1]
+    const f3 va = even ? v0[2 * qy] : pv0, vb = even ? pv0 : v0[2 * qy], vc = even ? v0[2 * qy + 1] : pv1, vd = even ? pv1 : v0[2 * qy + 1];
+    const f3 na_ = even ? n0[2 * qy] : pn0, nb = even ? pn0 : n0[2 * qy], nc = even ? n0[2 * qy + 1] : pn1, nd = even ? pn1 : n0[2 * qy + 1];
+    const bool oka = !(va.z == 0), okb = !(vb.z == 0), okc = !(vc.z == 0), okd = !(vd.z == 0);
+    const bool vok = oka && okb && okc && okd && !isnan(va.x) && !isnan(vb.x) && !isnan(vc.x) && !isnan(vd.x);
+    const bool nok = oka && okb && okc && okd && !isnan(na_.x) && !isnan(nb.x) && !isnan(nc.x) && !isnan(nd.x);
+    const f3 vavg = box4(va, vb, vc, vd);
+    const f3 navg = normalized(box4(na_, nb, nc, nd));
+    v1[qy] = vavg; n1[qy] = navg;
+    // a valid-flagged average can still be NaN in x (NaN y/z never matter: only x is tested downstream)
+    v1ok[qy] = vok; n1ok[qy] = nok;
+    if (even) {
+      const int x1 = bx * 2 + (j >> 1), y1 = by * 2 + qy;
+      if (cf) {   // resizeMapKernel alone: x-plane NaN where a source x is NaN, else the three averages as they come
+        store_planar<false>(A.vmap[1], c1, r1, x1, y1, vok, vavg);
+        store_planar<false>(A.nmap[1], c1, r1, x1, y1, nok, navg);
+      } else {
+        store_planar<false>(A.vmap[1], c1, r1, x1, y1, vok && !isnan(vavg.x), mul(R, vavg) + t);
+        store_planar<false>(A.nmap[1], c1, r1, x1, y1, nok && !isnan(navg.x), mul(R, navg));
+      }
+    }
+  }
+  // level 2: [qy][qx] = this pair's and the other pair's level-1 values
+  const f3 ov0 = qx2(v1[0]), ov1 = qx2(v1[1]), on0 = qx2(n1[0]), on1 = qx2(n1[1]);
+  const bool ovok0 = qx2(v1ok[0] ? 1.0f : 0.0f) != 0.0f, ovok1 = qx2(v1ok[1] ? 1.0f : 0.0f) != 0.0f;
+  const bool onok0 = qx2(n1ok[0] ? 1.0f : 0.0f) != 0.0f, onok1 = qx2(n1ok[1] ? 1.0f : 0.0f) != 0.0f;
+  const f3 v00 = leftpair ? v1[0] : ov0, v01 = leftpair ? ov0 : v1[0], v10 = leftpair ? v1[1] : ov1, v11 = leftpair ? ov1 : v1[1];
+  const f3 n00 = leftpair ? n1[0] : on0, n01 = leftpair ? on0 : n1[0], n10 = leftpair ? n1[1] : on1, n11 = leftpair ? on1 : n1[1];
+  const bool vok2 = v1ok[0] && ovok0 && v1ok[1] && ovok1 && !isnan(v00.x) && !isnan(v01.x) && !isnan(v10.x) && !isnan(v11.x);
+  const bool nok2 = n1ok[0] && onok0 && n1ok[1] && onok1 && !isnan(n00.x) && !isnan(n01.x) && !isnan(n10.x) && !isnan(n11.x);
+  const f3 va = box4(v00, v01, v10, v11);
+  const f3 na = normalized(box4(n00, n01, n10, n11));
+  if (j == 0) {
+    if (cf) {
+      store_planar<false>(A.vmap[2], c2, r2, bx, by, vok2, va);
+      store_planar<false>(A.nmap[2], c2, r2, bx, by, nok2, na);
+    } else {
+      store_planar<false>(A.vmap[2], c2, r2, bx, by, vok2 && !isnan(va.x), mul(R, va) + t);
+      store_planar<false>(A.nmap[2], c2, r2, bx, by, nok2 && !isnan(na.x), mul(R, na));
+    }
+  }
+}
+#else
 __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const TrackState* __restrict__ st) {
   const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
   const int cols = A.cols, rows = A.rows;
@@ -501,6 +600,7 @@ __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const
   }
 }
 
+#endif
 // ------------------------------------------------------------------------------------------
 // per-pixel Jacobian rows
 // ------------------------------------------------------------------------------------------
@@ -1885,6 +1985,14 @@ void init_icp(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cu
   hipLaunchKernelGGL(k_vmap_nmap_levels, g, tile_block(), 0, s, L);
 }
 
+// k_model_maps: one lane per level-0 column of a 4-row band (a quad of lanes per 4x4 block)
+static inline dim3 model_maps_grid(const Pyramid& p) {
+#ifndef EF_R02K_BASELINE
+  return dim3(ceil_div(p.W(0), 64), ceil_div(p.H(0) / 4, 4));
+#else
+  return dim3(ceil_div(p.W(0) / 4, 64), ceil_div(p.H(0) / 4, 4));
+#endif
+}
 void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
                     const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s) {
   ModelMapsArgs A;
@@ -1895,9 +2003,7 @@ void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pre
   A.cols = p.W(0); A.rows = p.H(0);
   A.maxDepthRGB = maxDepthRGB;
   A.camera_frame = false;
-  dim3 block(64, 4);
-  dim3 grid(ceil_div(p.W(0) / 4, 64), ceil_div(p.H(0) / 4, 4));
-  hipLaunchKernelGGL(k_model_maps, grid, block, 0, s, A, st);
+  hipLaunchKernelGGL(k_model_maps, model_maps_grid(p), dim3(64, 4), 0, s, A, st);
 }
 
 namespace {
@@ -1931,7 +2037,7 @@ void init_icp_maps(const Pyramid& p, const float* vertex, const float* normal, c
   A.cols = p.W(0); A.rows = p.H(0);
   A.maxDepthRGB = maxDepthRGB;
   A.camera_frame = true;
-  hipLaunchKernelGGL(k_model_maps, dim3(ceil_div(p.W(0) / 4, 64), ceil_div(p.H(0) / 4, 4)), dim3(64, 4), 0, s, A, st);
+  hipLaunchKernelGGL(k_model_maps, model_maps_grid(p), dim3(64, 4), 0, s, A, st);
   const int n = p.W(0) * p.H(0);
   for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_gauss_f(p.nextDepth[i], p.W(i), p.H(i), p.nextDepth[i + 1], s);
   hipLaunchKernelGGL(k_model_intensity, dim3(ceil_div(n, 256)), dim3(256), 0, s, image_rgba, image_rgba, true, st, n, p.nextImage[0]);
