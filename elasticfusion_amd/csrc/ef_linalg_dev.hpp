@@ -259,24 +259,11 @@ EFL_HD void mat_to_quat(const double* m, double* q) {  // Eigen::Quaternion(Matr
     q[1] = (m[2] - m[6]) * t;
     q[2] = (m[3] - m[1]) * t;
   } else {
-#ifndef EF_R02K_BASELINE
     const bool one = m[4] > m[0];
     const bool two = m[8] > (one ? m[4] : m[0]);
     if (two) mat_to_quat_diag<2>(m, q);
     else if (one) mat_to_quat_diag<1>(m, q);
     else mat_to_quat_diag<0>(m, q);
-#else   // A/B only (tools/gpu_ab.sh): the run-time index that put q[] into scratch memory
-    int i = 0;
-    if (m[4] > m[0]) i = 1;
-    if (m[8] > m[i * 3 + i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
-    q[i] = 0.5 * t;
-    t = 0.5 / t;
-    q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
-    q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
-    q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
-#endif
   }
 }
 template <typename T>

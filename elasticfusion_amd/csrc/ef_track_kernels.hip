@@ -419,7 +419,7 @@ __device__ __forceinline__ void store_planar(float* m, int cols, int rows, int x
     }
   }
 }
-#ifndef EF_R02K_BASELINE
+#ifdef EF_MODEL_MAPS_QUAD   // built, NOT yet validated on a GPU (round 2 ran out of GPU time): python -m elasticfusion_amd.build --variant quadmaps -DEF_MODEL_MAPS_QUAD
 // Four lanes share a 4x4 block: lane j of the quad owns COLUMN j of it, so that every load and every level-0 store of a wavefront
 // covers 64 consecutive pixels of one row (1 KB of float4s per load instruction, four times as many workgroups as one thread per
 // block gave: 300 instead of 75 at 640x480).  The 2x2 boxes of level 1 need the neighbouring column (quad_perm xor 1), the one of
@@ -1987,7 +1987,7 @@ void init_icp(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cu
 
 // k_model_maps: one lane per level-0 column of a 4-row band (a quad of lanes per 4x4 block)
 static inline dim3 model_maps_grid(const Pyramid& p) {
-#ifndef EF_R02K_BASELINE
+#ifdef EF_MODEL_MAPS_QUAD
   return dim3(ceil_div(p.W(0), 64), ceil_div(p.H(0) / 4, 4));
 #else
   return dim3(ceil_div(p.W(0) / 4, 64), ceil_div(p.H(0) / 4, 4));
