@@ -56,7 +56,9 @@ def test_klg_replay_with_close_loops(tmp_path, seq):
         opened += info.gates_ok
     log = str(tmp_path / "loops.klg")
     synth.write_klg(log, frames)
-    r = subprocess.run([exe, "-l", log, "-cl", "-t", "3", "-c", "2", "-all"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # (the front-end's own defaults are MainController's -ic 40000 -ie 4e-05; the oracle above runs on the constructor's)
+    r = subprocess.run([exe, "-l", log, "-cl", "-t", "3", "-c", "2", "-all", "-ic", "35000", "-ie", "5e-05"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("local loop closure")][0].split()
     assert int(line[line.index("attempts") + 1]) == attempts == n - 1 and int(line[line.index("open") + 1]) == opened

@@ -6,9 +6,13 @@
 //
 //   efusion_replay -l seq.klg [-w 640 -h 480] [-cal fx fy cx cy] [-d depthCut] [-c confidence] [-t timeDelta]
 //                  [-fo] [-nso] [-ftf] [-i icpWeight] [-e endFrame] [-ply] [-dev N] [-q]
+//                  [-cl [-ic icpCountThresh] [-ie icpErrThresh] [-cv covThresh] [-pt photoThresh] [-ft fernThresh] [-rl]] [-icl] [-f]
 //
-// Open loop (the reference's -o) unless -cl is given (closed loop: fern database, global and local closures, built-in optimiser).  Like the reference's run loop, the last frame of a log is not
-// processed (RawLogReader::hasMore, see include/efusion_klg.hpp); -all processes every frame.
+// The flags and their defaults are MainController's (MainController.cpp:69-104: -c 10, -d 3, -i 10, -ie 4e-05, -cv 1e-05, -pt 115,
+// -ft 0.3095, -t 200, -ic 40000; -rl relocalisation, -icl the ICL-NUIM conventions, -f flipped colours, -fo, -nso, -ftf, -e, -q) with one
+// difference: open loop (the reference's -o) is the default here and -cl selects the closed loop (fern database, global and local
+// closures, built-in optimiser).  Like the reference's run loop, the last frame of a log is not processed (RawLogReader::hasMore, see
+// include/efusion_klg.hpp); -all processes every frame.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -26,7 +30,10 @@ int main(int argc, char** argv) {
   std::string log;
   int w = 640, h = 480, timeDelta = 200, end = -1, dev = 0;
   float fx = 528, fy = 528, cx = 320, cy = 240, depthCut = 3, confidence = 10, icp = 10;
+  float icpErrThresh = 4e-05f, covThresh = 1e-05f, photoThresh = 115, fernThresh = 0.3095f;   // MainController.cpp:72-75
+  int icpCountThresh = 40000;                                                                 // :78
   bool fastOdom = false, so3 = true, ftf = false, ply = false, quiet = false, closeLoops = false, allFrames = false, solve = false;
+  bool reloc = false, iclnuim = false, flipColors = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&](int n = 1) { if (i + n >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -40,6 +47,14 @@ int main(int argc, char** argv) {
     else if (a == "-i") icp = std::atof(next());
     else if (a == "-e") end = std::atoi(next());
     else if (a == "-dev") dev = std::atoi(next());
+    else if (a == "-ic") icpCountThresh = std::atoi(next());
+    else if (a == "-ie") icpErrThresh = (float)std::atof(next());
+    else if (a == "-cv") covThresh = (float)std::atof(next());
+    else if (a == "-pt") photoThresh = (float)std::atof(next());
+    else if (a == "-ft") fernThresh = (float)std::atof(next());
+    else if (a == "-rl") reloc = true;        // relocalisation (needs -cl to find its way back, as in the reference)
+    else if (a == "-icl") iclnuim = true;     // PLY dump and raw timestamps in the destructor (ElasticFusion.cpp:108-128)
+    else if (a == "-f") flipColors = true;    // LogReader::flipColors (RawLogReader.cpp:88-98)
     else if (a == "-fo") fastOdom = true;
     else if (a == "-nso") so3 = false;
     else if (a == "-ftf") ftf = true;
@@ -57,9 +72,10 @@ int main(int argc, char** argv) {
     Intrinsics::getInstance(fx, fy, cx, cy);
     KlgReader reader(log, w, h);
     reader.deliverLastFrame = allFrames;
+    reader.flipColors = flipColors;
     // open loop: timeDelta = INT_MAX / 2 exactly as MainController does for -o (MainController.cpp:179-183)
-    ElasticFusion eFusion(closeLoops ? timeDelta : 2147483647 / 2, 35000, 5e-05f, 1e-05f, closeLoops, false, false, 115, confidence, depthCut,
-                          icp, fastOdom, 0.3095f, so3, ftf, log, dev);
+    ElasticFusion eFusion(closeLoops ? timeDelta : 2147483647 / 2, icpCountThresh, icpErrThresh, covThresh, closeLoops, iclnuim, reloc, photoThresh,
+                          confidence, depthCut, icp, fastOdom, fernThresh, so3, ftf, log, dev);
     (void)solve;
     int attempts = 0, opened = 0;
     const auto t0 = std::chrono::steady_clock::now();
@@ -77,6 +93,7 @@ int main(int argc, char** argv) {
     if (!quiet)
       std::printf("frames %d  %.1f fps  surfels %u  icp %g/%g  t_wc %.9g %.9g %.9g\n", n, n / dt, eFusion.getGlobalModel().lastCount(),
                   (double)eFusion.getModelToModel().lastICPError, (double)eFusion.getModelToModel().lastICPCount, M[3], M[7], M[11]);
+    if (!quiet && reloc) std::printf("relocalisation: lost %d  tick %d\n", (int)eFusion.getLost(), eFusion.getTick());
     if (!quiet && closeLoops) {
       std::printf("local loop closure: attempts %d  gates open %d  deformations %d\n", attempts, opened, eFusion.getDeforms());
       const efusion::FernsView& F = eFusion.getFerns();
