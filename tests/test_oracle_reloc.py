@@ -59,7 +59,11 @@ def wild(lines):
     return out
 
 
-def test_relocalisation_flow_matches_the_compiled_reference(tmp_path, seq):
+@pytest.mark.parametrize("mode", ["close_loops", "open_loop"])
+def test_relocalisation_flow_matches_the_compiled_reference(tmp_path, seq, mode):
+    """close_loops: lost and found again through the fern database.  open_loop (the reference's -o -rl): the same verdicts, but nothing
+    ever looks for the way back — the camera stays lost, the tick frozen, nothing fused, whatever the frames show afterwards."""
+    close = mode == "close_loops"
     so = lib()
     so.efe_queue_readpixels.argtypes = [P, C.c_long]
     so.efe_set_tick.argtypes = [P, C.c_int]
@@ -67,14 +71,15 @@ def test_relocalisation_flow_matches_the_compiled_reference(tmp_path, seq):
     so.efe_ferns_last_closest.argtypes = [P]
     efo.lib().efo_set_threads(min(16, os.cpu_count() or 1))
     o = efo.Fusion(timeDelta=TD, confidence=CONF)
-    o.set_close_loops(True)
-    o.enable_ferns(seed=7)
+    if close:
+        o.set_close_loops(True)
+        o.enable_ferns(seed=7)
+        o.set_deform_solver(lambda *a: None)                   # the optimiser rejects (as the reference's scripted one does below)
     o.set_reloc(True)
-    o.set_deform_solver(lambda *a: None)                       # the optimiser rejects (as the reference's scripted one does below)
     efo.lib().efo_fusion_trace(o.h_, 1)
     take = efo.lib().efo_fusion_take_trace
     take.restype = C.c_char_p
-    ref = Ref(so, str(tmp_path / "ref"), timeDelta=TD, closeLoops=3, confidence=CONF)     # bit 0: closeLoops, bit 1: reloc
+    ref = Ref(so, str(tmp_path / "ref"), timeDelta=TD, closeLoops=3 if close else 2, confidence=CONF)     # bit 0: closeLoops, bit 1: reloc
     key = fernscene.place(2)
     blank = tuple(np.zeros_like(a) for a in key)
     dense = np.zeros(32 * 24 * 3, np.uint8)                    # Resize::image for denseEnough (ElasticFusion.cpp:304): 1/20 resolution
@@ -109,7 +114,9 @@ def test_relocalisation_flow_matches_the_compiled_reference(tmp_path, seq):
             # local closure's gate (35000) shut
             so.efe_script_tracker(D.ctypes.data, 1e-6 if stats[0] < 1e-4 else 1e-3, 3000.0 if matched else 1000.0, 1e-3 if cov_bad else 1e-7, 0)
         view = key if proposed else blank                      # what Ferns::findFrame reads back: the stored keyframe's view again, or nothing
-        if k == 0:
+        if not close:
+            queue(dense)                                       # open loop: only denseEnough reads pixels back (the fern database is idle)
+        elif k == 0:
             queue(*key)                                        # first frame: Ferns::addFrame only -> keyframe 0
         elif st["lost"]:
             queue(dense, *view)                                # denseEnough, findFrame; a lost camera stores no keyframe (:601-604)
@@ -119,7 +126,7 @@ def test_relocalisation_flow_matches_the_compiled_reference(tmp_path, seq):
         assert got == want, (k, what, "\n".join(got), "----", "\n".join(want))
         assert bool(so.efe_lost(ref.h)) == st["lost"], (k, what)
         assert so.efe_tick(ref.h) == o.tick(), (k, what)
-        assert (so.efe_ferns_last_closest(ref.h) >= 0) == bool(matched) or k == 0, (k, what)
+        assert not close or (so.efe_ferns_last_closest(ref.h) >= 0) == bool(matched) or k == 0, (k, what)
         if st["lost"]:                                         # (lost at the end of the frame: lost all the way through it)
             assert not any(l.startswith(("fuse", "predictIndices", "clean", "modelToModel")) for l in got), (k, what)
     so.efe_clear_queues()
@@ -135,6 +142,9 @@ def test_relocalisation_flow_matches_the_compiled_reference(tmp_path, seq):
     ticks = [h[6] for h in history]
     assert all(ticks[k] == ticks[first_lost - 1] for k in range(first_lost, len(history)) if lost[k])   # the tick stands still while lost
     back = whats.index("back")
+    if not close:
+        assert all(lost[first_lost:]) and ticks[-1] == ticks[first_lost - 1]                 # lost for good
+        return
     assert lost[back] and history[back][5] >= 0 and history[back][4]                     # lost, keyframe matched, pose taken: probation next
     assert not lost[back + 1] and history[back + 1][2] and not history[back + 1][4]      # found again
     assert ticks[back + 1] == ticks[back] + 1 and ticks[back + 2] == ticks[back] + 2
