@@ -398,6 +398,36 @@ class Closure:
             _chk(rc)
         return rc == 1, Tr, g[:n.value].copy()
 
+    def relocalise(self, rgb, verts, norms, T_wc, tick, tracker):
+        """a LOST camera's mid-frame step (ef_closure_relocalise: Ferns::findFrame with lost = true) -> (found, T_recovery [4, 4])"""
+        rgb, verts, norms = self._view(rgb, verts, norms)
+        T = np.ascontiguousarray(T_wc, np.float64).reshape(4, 4)
+        px = self.w * self.h * 4
+
+        def tramp(_user, fv, fn, Tf, cv, cn, Tio, err, cnt):
+            A = lambda p, n, dt: np.ctypeslib.as_array(p, shape=(n,)).astype(dt).copy()
+            Te, e, k = tracker(A(fv, px, np.float32).reshape(self.h, self.w, 4), A(fn, px, np.float32).reshape(self.h, self.w, 4),
+                               A(Tf, 16, np.float64).reshape(4, 4), A(cv, px, np.float32).reshape(self.h, self.w, 4),
+                               A(cn, px, np.float32).reshape(self.h, self.w, 4), A(Tio, 16, np.float64).reshape(4, 4))
+            Te = np.ascontiguousarray(Te, np.float64).reshape(16)
+            for i in range(16):
+                Tio[i] = Te[i]
+            err[0], cnt[0] = float(e), float(k)
+
+        cb = FERN_TRACKER(tramp)
+        Tr = np.zeros((4, 4), np.float64)
+        lib().ef_closure_relocalise.argtypes = [P, P, c_i, P, P, P, c_i, FERN_TRACKER, P, P]
+        rc = lib().ef_closure_relocalise(self._h, _ptr(rgb), rgb.shape[2], _ptr(verts), _ptr(norms), _ptr(T), int(tick), cb, None, _ptr(Tr))
+        if rc < 0:
+            _chk(rc)
+        return rc == 1, Tr
+
+    def logPose(self, T_wc, tick):
+        """the end of a lost camera's frame (ef_closure_log_pose): the pose joins the trajectory, no keyframe is stored"""
+        T = np.ascontiguousarray(T_wc, np.float64).reshape(4, 4)
+        lib().ef_closure_log_pose.argtypes = [P, P, c_i]
+        _chk(lib().ef_closure_log_pose(self._h, _ptr(T), int(tick)))
+
     def localClosure(self, constraints8, tick, nodes4):
         cons = np.ascontiguousarray(constraints8, np.float64).reshape(-1, 8)
         nodes4 = np.ascontiguousarray(nodes4, np.float32).reshape(-1, 4)

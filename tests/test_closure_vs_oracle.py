@@ -136,3 +136,51 @@ def test_local_closure_decisions():
     assert len(rel) >= 3 and np.abs(rel - o.relative_constraints()).max() < 1e-12 and set(rel[:, 8]) == {1.0}
     assert c.counts()["deforms"] == closures and c.counts()["fernDeforms"] == 0
     c.close()
+
+
+def test_lost_camera_decisions():
+    """relocalisation (ElasticFusion.cpp:395-413, 601-604 with lost = true): while the oracle's camera is lost the closure object is fed
+    what the device side feeds it — the mid-frame view (the raw frame: pass-through fill-in), the pose, the fern tracker's answer — and
+    has to decide like the oracle: no match on the patch-only frames, the keyframe matched (count gate 1400) when the known view is back,
+    the registered pose handed over; the pose joins the trajectory every frame, no keyframe is stored while lost"""
+    from test_oracle_reloc import CONF, N_GOOD, TD, scenario
+    seq = synth.Sequence(seed=0xEF0001)
+    o = efo.Fusion(timeDelta=TD, confidence=CONF)
+    o.set_close_loops(True)
+    o.enable_ferns(seed=7)
+    o.set_reloc(True)
+    o.set_deform_solver(lambda *a: None)
+    c = api.Closure(seed=7)
+    frames = scenario(seq)
+    found_while_lost = 0
+    for k, (rgb, depth, what) in enumerate(frames):
+        if k == N_GOOD:
+            o.set_tick(o.tick() + 400)
+        tick = o.tick()
+        o.process_frame(rgb, depth, k * 33333)
+        st, g = o.reloc_state(), o.global_loop()
+        lost_mid = st["lost"]                  # `lost` is set (:343) or cleared (:359) before the mid-frame step, never after it
+        rec = np.array(g.T_wc_recovery).reshape(4, 4)
+        answer = lambda fv, fn, Tf, cv, cn, Tin: (rec, g.icp_error, g.icp_count)      # the device's 80x60 registration: here the oracle's
+        if k > 0 and g.attempted:
+            # the pose findFrame saw: the tracker's estimate, which the recovery (if any) then replaced
+            T_mid = o.trajectory()[-1] if not (lost_mid and g.closest >= 0) else None
+            if lost_mid:
+                ok, Tr = c.relocalise(*o.fern_view(0), T_mid if T_mid is not None else rec, tick, answer)
+                assert ok == (g.closest >= 0), (k, what)
+                assert c.ferns.lastClosest == g.closest, (k, what)
+                if ok:
+                    found_while_lost += 1
+                    assert np.abs(Tr - rec).max() < 1e-12 and np.abs(o.pose() - rec).max() < 1e-12 and st["lastFrameRecovery"]
+            else:
+                acc, _, _ = c.globalClosure(*o.fern_view(0), T_mid, tick, answer, np.zeros((0, 4), np.float32))
+                assert not acc and c.ferns.lastClosest == g.closest, (k, what)
+        if st["lost"]:
+            c.logPose(o.pose(), tick)
+        else:
+            c.endFrame(*o.fern_view(1), o.pose(), tick)
+        assert len(c.ferns) == len(o.ferns()), (k, what)
+        assert len(c.trajectory()) == len(o.trajectory()) == k + 1
+    assert found_while_lost == 1 and not o.reloc_state()["lost"]
+    assert np.abs(c.trajectory() - o.trajectory()).max() < 1e-12
+    c.close()
