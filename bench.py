@@ -269,8 +269,17 @@ def main():
         ks = KT()
         if lib.ef_get_splat_timing(ef.h, C.byref(ks)) == 0 and ks.launches > 0:
             ach = ks.bytes_per_launch / (ks.avg_us * 1e-6) / 1e9
+            straffic, ssource = None, None
+            try:   # the committed PMC measurement of this kernel on the default workload (see roofline.traffic_source)
+                if (w, h) == (W, H):
+                    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                        pj = json.load(f)
+                    straffic = int(pj["also"]["k_index_splat"]["traffic_bytes_per_launch"])
+                    ssource = "committed PMC measurement (profiles/pmc_traffic.json: " + str(pj.get("source", "tools/pmc_traffic.sh")) + "), not measured in this run"
+            except Exception:
+                straffic, ssource = None, None
             roofline_splat = {"bound": "hbm", "kernel": ks.name.decode(), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_us": round(float(ks.avg_us), 3),
+                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": straffic, "traffic_source": ssource, "avg_us": round(float(ks.avg_us), 3),
                               "launches_sampled": int(ks.launches), "algorithmic_bytes_per_launch": int(ks.bytes_per_launch)}
     out = {
         "metric": f"frames/s per GPU, {w}x{h} 3-level ICP+fuse",
