@@ -31,6 +31,16 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+// broadcast from a lane known at compile time (the diagonal of the 6x6 system): v_readlane (a few cycles) instead of the LDS crossbar
+// (ds_bpermute, a round trip of >100 cycles, 27 of them on the factorisation's critical path).  Built, NOT yet validated on a GPU:
+// python -m elasticfusion_amd.build --variant readlane -DEF_SOLVE_READLANE
+#ifdef EF_SOLVE_READLANE
+__device__ __forceinline__ double bcast_d(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+#else
+__device__ __forceinline__ double bcast_d(double v, int src) { return shfl_d(v, src); }
+#endif
 
 struct SolveScratch {     // LDS, one per workgroup that runs a solve
   double A[36];           // factorised matrix: D on the diagonal, L below
@@ -95,10 +105,10 @@ __device__ __forceinline__ void ldlt6_wave(double a, SolveScratch& S) {
   for (int k = 0; k < 6; ++k) {
     // pivot: largest |diagonal| of the trailing block, first one wins
     int p = k;
-    double best = fabs(shfl_d(a, k * 7));
+    double best = fabs(bcast_d(a, k * 7));
 #pragma unroll
     for (int m = k + 1; m < 6; ++m) {
-      const double v = fabs(shfl_d(a, m * 7));
+      const double v = fabs(bcast_d(a, m * 7));
       const bool gt = v > best;
       best = gt ? v : best;
       p = gt ? m : p;
@@ -114,7 +124,7 @@ __device__ __forceinline__ void ldlt6_wave(double a, SolveScratch& S) {
       perm[k] = sw ? pm : pk;
       perm[m] = sw ? pk : pm;
     }
-    const double d = shfl_d(a, k * 7);
+    const double d = bcast_d(a, k * 7);
     const double c_hi = shfl_d(a, hi * 6 + k), c_lo = shfl_d(a, lo * 6 + k);
     if (!(d == 0.0)) {
       const double l = c_hi / d;
