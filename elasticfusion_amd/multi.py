@@ -54,3 +54,70 @@ def aggregate(allstats: np.ndarray):
     frames = float(allstats[:, 1].sum())
     return {"value": frames / t_max, "t_max": t_max, "frames": frames,
             "per_rank_fps": [float(r[1] / r[0]) for r in allstats]}
+
+
+def shard_logs(logs, rank: int, world: int):
+    """BASELINE.json configs[3]: independent .klg sequences, one per GPU — log k goes to rank k mod world (a rank with several logs
+    replays them one after the other, each in a fresh context)."""
+    return [log for k, log in enumerate(logs) if k % world == rank]
+
+
+class KlgFile:
+    """the .klg reader of libefusion.so (include/efusion_klg.hpp: raw / zlib depth, raw / JPEG colour, the reference's frame protocol)
+    through its C entry points; host-only, no GPU"""
+
+    def __init__(self, path: str, width: int = 640, height: int = 480, all_frames: bool = False, flip_colors: bool = False):
+        import ctypes as C
+        here = os.path.dirname(os.path.abspath(__file__))
+        self._so = C.CDLL(os.path.join(here, "libefusion.so"))
+        self._so.efk_open.restype = C.c_void_p
+        self._so.efk_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        self._so.efk_last_error.restype = C.c_char_p
+        for f in (self._so.efk_close, self._so.efk_num_frames, self._so.efk_has_more):
+            f.argtypes = [C.c_void_p]
+        self._so.efk_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.w, self.h = width, height
+        self._h = self._so.efk_open(path.encode(), width, height, int(all_frames), int(flip_colors))
+        if not self._h:
+            raise IOError(self._so.efk_last_error().decode())
+
+    def __len__(self):
+        return self._so.efk_num_frames(self._h)
+
+    def __iter__(self):
+        import ctypes as C
+        while self._so.efk_has_more(self._h):
+            ts = C.c_int64(0)
+            depth = np.zeros((self.h, self.w), np.uint16)
+            rgb = np.zeros((self.h, self.w, 3), np.uint8)
+            if self._so.efk_next(self._h, C.byref(ts), depth.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p)) != 1:
+                raise IOError(self._so.efk_last_error().decode())
+            yield ts.value, rgb, depth
+
+    def close(self):
+        if self._h:
+            self._so.efk_close(self._h)
+            self._h = None
+
+
+def replay_logs(logs, make_engine, rank: int, world: int, width: int = 640, height: int = 480, on_done=None):
+    """rank's share of `logs` through make_engine() objects (processFrame(rgb, depth, timestamp), synchronize(), close()): decoding is
+    host work done up front per log, the clock runs around the frames only.  -> [seconds, frames, logs] for gather_stats"""
+    import time
+    seconds, frames, done = 0.0, 0, 0
+    for log in shard_logs(logs, rank, world):
+        reader = KlgFile(log, width, height)
+        decoded = list(reader)
+        reader.close()
+        eng = make_engine()
+        t0 = time.perf_counter()
+        for ts, rgb, depth in decoded:
+            eng.processFrame(rgb, depth, ts)
+        eng.synchronize()
+        seconds += time.perf_counter() - t0
+        frames += len(decoded)
+        done += 1
+        if on_done:
+            on_done(log, eng)
+        eng.close()
+    return [seconds, float(frames), float(done)]
