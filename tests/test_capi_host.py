@@ -200,3 +200,21 @@ def test_klg_reader_decodes_jpeg_colour(tmp_path):
     h = so.efk_open(str(tmp_path / "bad.klg").encode(), W, H, 1, 0)
     assert so.efk_next(C.c_void_p(h), None, None, None) == 0 and b"JPEG" in so.efk_last_error()
     so.efk_close(C.c_void_p(h))
+
+
+def test_every_context_entry_point_refuses_a_null_context():
+    """error behaviour at the boundary: every `int ef_*(ef_ctx*, ...)` of include/ef_hip.h returns EF_EINVAL for a NULL context — no
+    crash, no GPU touched (run in a child process, so that a crash would be a failed test and not a dead session)"""
+    import re
+    import subprocess
+    import sys
+    from elasticfusion_amd import api
+    hdr = open(os.path.join(ROOT, "include", "ef_hip.h")).read()
+    names = sorted(set(re.findall(r"^int (ef_[a-z_0-9]*)\(ef_ctx\*", hdr, re.M)) | {"ef_process_frame", "ef_process_frame_dev"})
+    assert len(names) >= 40
+    code = ("import ctypes as C\nL = C.CDLL(%r)\nz = C.c_void_p(None)\nfor n in %r:\n    f = getattr(L, n)\n    f.restype = C.c_int\n"
+            "    print(n, f(z, z, z, z, z, z, z, z), flush=True)\n") % (api.LIB_PATH, names)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-500:])
+    got = dict(ln.split() for ln in r.stdout.splitlines())
+    assert sorted(got) == names and all(int(v) == -1 for v in got.values()), got   # EF_EINVAL
