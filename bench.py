@@ -53,12 +53,12 @@ def generate_frames(seed: int, n: int, w: int = W, h: int = H, ranks_on_host: in
         return list(ex.map(_gen_frame, [(seed, k, w, h) for k in range(n)], chunksize=4))
 
 
-def cpu_baseline(frames, budget_s: float = 20.0, w: int = W, h: int = H):
+def cpu_baseline(frames, budget_s: float = 20.0, w: int = W, h: int = H, poses_out=None):
     """Times the CPU oracle (the reference restated; the reference itself has no CPU path and cannot be built here)
     on the same frames, single thread, bounded to ~budget_s of CPU work.  Checker code used as a *baseline leg* only."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import efo
-    def run(threads, budget):
+    def run(threads, budget, keep=None):
         efo.set_threads(threads)
         o = efo.Fusion(width=w, height=h, fx=528.0 * w / 640, fy=528.0 * w / 640, cx=320.0 * w / 640, cy=240.0 * w / 640)
         t0 = time.perf_counter()
@@ -66,6 +66,8 @@ def cpu_baseline(frames, budget_s: float = 20.0, w: int = W, h: int = H):
         for rgb, depth, _ in frames:
             o.process_frame(rgb, depth, n)
             n += 1
+            if keep is not None:
+                keep.append(o.pose())     # (a 16-double copy per frame: nothing next to the ~0.5 s the frame took)
             if time.perf_counter() - t0 > budget and n >= 3:
                 break
         return n, time.perf_counter() - t0
@@ -87,7 +89,7 @@ def cpu_baseline(frames, budget_s: float = 20.0, w: int = W, h: int = H):
         od.h_ = None   # the handle belongs to the Fusion object
         return reps, time.perf_counter() - t0
 
-    n, dt = run(1, budget_s * 0.6)
+    n, dt = run(1, budget_s * 0.6, poses_out)
     nt, dtt = run_tracking_only(budget_s * 0.15)
     cores = min(os.cpu_count() or 1, 32)   # threads are created per parallel loop; beyond ~32 the spawn cost eats the gain
     nm, dtm = run(cores, budget_s * 0.4) if cores > 1 else (n, dt)
@@ -308,7 +310,20 @@ def main():
         "roofline_index_splat": roofline_splat,
     }
     if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (the scaling runs reuse the N=1 figure)
-        out["cpu_baseline"] = cpu_baseline(frames[: min(len(frames), 40)], w=w, h=h)
+        oracle_poses = []
+        out["cpu_baseline"] = cpu_baseline(frames[: min(len(frames), 40)], w=w, h=h, poses_out=oracle_poses)
+        # BASELINE.json's metric names "ATE vs reference pose": the CPU leg above ran the reference's restatement over the first frames
+        # of this very replay, so the GPU run's logged trajectory can be held against it frame by frame (bit-identical expected: 0.0)
+        try:
+            gpu_poses, _ = ef.trajectory()
+            m = min(len(oracle_poses), len(gpu_poses))
+            if m > 0 and not a.close_loops:
+                d = np.array([gpu_poses[k][:3, 3] - oracle_poses[k][:3, 3] for k in range(m)])
+                rot = max(float(np.abs(gpu_poses[k][:3, :3] - oracle_poses[k][:3, :3]).max()) for k in range(m))
+                out["ate_vs_oracle"] = {"rmse_m": float(np.sqrt((d * d).sum(1).mean())), "max_m": float(np.abs(d).max()), "max_rotation_entry_diff": rot,
+                                        "frames": m, "what": "logged GPU poses of the first frames of this run against the CPU oracle's poses on the same frames"}
+        except Exception as e:   # never let the side figure cost the line
+            out["ate_vs_oracle"] = {"error": repr(e)}
     out["config"]["stable_surfels_end"] = int(stable)
     print(json.dumps(out), flush=True)
     ef.close()
