@@ -4,11 +4,22 @@ localLoopClosure / processFerns, itself equal to the compiled ElasticFusion.cpp)
 object is fed what the device side will feed it — the 1/8-resolution views, the poses, the graph nodes, the fern tracker's answer — and
 has to take the same decisions: keyframes kept, fern matched, rows handed to the optimiser, recovered pose, graph, keyframe and
 trajectory poses after the deformation, relative constraints kept."""
+import os
+
 import numpy as np
+import pytest
 
 import efo
 import loopscene
 from elasticfusion_amd import api, synth
+
+
+@pytest.fixture(autouse=True)
+def oracle_threads():
+    """the oracle's frame loop on several host threads (its parallel loops are block-partitioned: same results, a third of the time)"""
+    efo.lib().efo_set_threads(min(16, os.cpu_count() or 1))
+    yield
+    efo.lib().efo_set_threads(1)
 
 
 def rows_of(rows):
