@@ -77,9 +77,10 @@ def test_tracking_and_fusion_sequence(hip, seq):
         assert np.abs(ef.get_T_wc() - o.pose()).max() <= 1e-15, (k, np.abs(ef.get_T_wc() - o.pose()).max())
         assert np.array_equal(ef.get_T_wc().astype(np.float32), o.pose().astype(np.float32)), k
         assert ef.lastCount() == o.map_count(), k
-    # and both stay close to the generating trajectory (known-answer guard on the oracle itself)
+    # and both stay close to the generating trajectory (known-answer guard on the oracle itself): 5.65 mm / 1.04 mrad after 16 frames at the
+    # default confidence of 10 — frame-to-frame odometry while the map has no stable surfel yet (2.7 mm with confidence 1)
     dt, da = pose_err(ef.get_T_wc(), seq.pose(n - 1))
-    assert dt < 0.01 and da < 0.01, (dt, da)
+    assert dt < 0.007 and da < 0.002, (dt, da)
     m, mr = ef.downloadMap(), o.map()
     assert m.shape == mr.shape
     assert compare_maps(m, mr) == 1.0
