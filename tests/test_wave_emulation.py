@@ -79,3 +79,43 @@ def test_quad_of_lanes_model_maps_equals_the_validated_kernel(tmp_path, cols, ro
             # quirk Q3: the resized levels only get an x-plane NaN; y/z of an invalid texel keep what was there (the -7 canary)
             lvl1 = want[1]
             assert (lvl1[rows // 2:] == -7.0).any()
+
+
+def build_solve(tmp, readlane):
+    so = os.path.join(tmp, "solve_%s.so" % ("readlane" if readlane else "shipped"))
+    cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-I" + EMU, "-I" + CSRC] + \
+          (["-DEF_SOLVE_READLANE"] if readlane else []) + [os.path.join(EMU, "solve_host.cpp"), "-o", so]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    return C.CDLL(so)
+
+
+def test_wave_parallel_ldlt_equals_the_scalar_statement_and_its_readlane_variant(tmp_path):
+    """the 6x6 LDL^T of the update step as the tracker runs it (one matrix element per lane, 64 emulated lanes) against the scalar
+    restatement of Eigen::LDLT it mirrors (which tests/test_oracle_linalg.py and the GPU operator tests tie to the oracle), on
+    well-conditioned, pivoting-heavy and degenerate systems — and the same for the -DEF_SOLVE_READLANE variant (diagonal broadcasts
+    through v_readlane), which has to agree before it is ever tried on a GPU"""
+    shipped, readlane = build_solve(str(tmp_path), False), build_solve(str(tmp_path), True)
+    rng = np.random.RandomState(0)
+    cases = []
+    for t in range(12):
+        J = rng.randn(40, 6) * np.array([100, 100, 100, 1, 1, 1.0])
+        A = J.T @ J
+        if t % 4 == 3:
+            A[2, :] = 0; A[:, 2] = 0                            # a singular direction
+        if t % 4 == 2:
+            A = A[::-1, ::-1].copy()                            # largest pivots last: every step swaps
+        cases.append((A, rng.randn(6)))
+    cases.append((np.zeros((6, 6)), rng.randn(6)))              # a frame without correspondences
+    v = rng.randn(6)
+    cases.append((np.outer(v, v), rng.randn(6)))                # rank one
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    for k, (A, b) in enumerate(cases):
+        A = np.ascontiguousarray((A + A.T) / 2 if k < 12 else A, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        want = np.zeros(6)
+        shipped.run_ldlt6_scalar(P(A), P(b), P(want))
+        for name, lib in (("shipped", shipped), ("readlane", readlane)):
+            got = np.zeros(6)
+            lib.run_ldlt6_wave(P(A), P(b), P(got))
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (name, k, got, want)

@@ -54,3 +54,31 @@ inline void __syncthreads() { std::abort(); }
 inline int __shfl_down(int, int, int) { std::abort(); }
 inline float __shfl_down(float, int, int) { std::abort(); }
 inline int atomicAdd(int*, int) { std::abort(); }
+
+// ---- a whole wavefront: 64 host threads that meet at every cross-lane operation (emu::wave) ----
+namespace emu {
+struct Wave {
+  std::barrier<>* barrier = nullptr;     // 64 participants
+  unsigned long long* slots = nullptr;   // 64 x 8 bytes
+  int lane = 0;
+};
+inline thread_local Wave wave;
+inline unsigned long long exchange(unsigned long long v, int src) {
+  Wave& W = wave;
+  if (!W.barrier) std::abort();
+  W.slots[W.lane] = v;
+  W.barrier->arrive_and_wait();
+  const unsigned long long r = W.slots[src & 63];
+  W.barrier->arrive_and_wait();
+  return r;
+}
+}  // namespace emu
+inline double __shfl(double v, int src, int width) { if (width != 64) std::abort(); unsigned long long b; std::memcpy(&b, &v, 8); b = emu::exchange(b, src); std::memcpy(&v, &b, 8); return v; }
+inline int __shfl(int v, int src, int width) { if (width != 64) std::abort(); return (int)(unsigned)emu::exchange((unsigned)v, src); }
+inline float __shfl(float v, int src, int width) { return __int_as_float(__shfl(__float_as_int(v), src, width)); }
+inline int __builtin_amdgcn_readlane(int v, int src) { return (int)(unsigned)emu::exchange((unsigned)v, src); }   // src is wave-uniform
+inline void __builtin_amdgcn_wave_barrier() { emu::wave.barrier->arrive_and_wait(); }
+#define __builtin_amdgcn_fence(...) ((void)0)   /* the barrier of the emulation orders the lanes' memory accesses */
+inline int __double2hiint(double d) { unsigned long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }
+inline int __double2loint(double d) { unsigned long long b; std::memcpy(&b, &d, 8); return (int)(b & 0xffffffffu); }
+inline double __hiloint2double(int hi, int lo) { const unsigned long long b = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo; double d; std::memcpy(&d, &b, 8); return d; }
