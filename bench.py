@@ -142,6 +142,8 @@ def main():
                     "frames: every frame also runs the global closure (fern match on the mid-frame view, keyframe store at the end: two "
                     "synchronisations) and the local one (inactive-model prediction, second tracker, gates, built-in optimiser: one "
                     "synchronisation).  NOT the headline metric, which is open loop (-o)")
+    ap.add_argument("--per-step-tracker", action="store_true", help="development (A/B): the round-2 tracker script, one launch per step, instead "
+                    "of the persistent small-level launch (ef_set_persistent_tracker(ctx, 0)); results are bit-identical")
     a = ap.parse_args()
     w, h = a.width, a.height
 
@@ -181,6 +183,8 @@ def main():
     sc = w / 640.0
     ef = api.ElasticFusion(width=w, height=h, fx=528.0 * sc, fy=528.0 * sc, cx=320.0 * sc, cy=240.0 * sc, device=local_rank, stream=stream,
                            maxSurfels=max(4 * 1024 * 1024, 6 * w * h), **(dict(closeLoops=True, timeDelta=200) if a.close_loops else {}))
+    if a.per_step_tracker:
+        ef.setPersistentTracker(False)
     if a.close_loops:   # the reference's closed-loop mode: fern database + global closure, then the local closure, built-in optimiser
         ef.useBuiltinLoopSolver(True)
         ef.enableGlobalClosure(seed=0)

@@ -134,6 +134,14 @@ def default_config(**kw) -> ef_config:
     return cfg
 
 
+def write_freiburg(path: str, T_wc, timestamps):
+    """ef_write_freiburg on host arrays (no GPU): the reference's trajectory dump (ElasticFusion.cpp:112-139)"""
+    T = np.ascontiguousarray(T_wc, np.float64).reshape(-1, 16)
+    ts = np.ascontiguousarray(timestamps, np.int64)
+    assert len(T) == len(ts)
+    _chk(lib().ef_write_freiburg(path.encode(), _ptr(T), _ptr(ts), c_i(len(T))))
+
+
 class GlobalLoop(C.Structure):   # ef_global_loop
     _fields_ = [("attempted", c_i), ("closest", c_i), ("n_constraints", c_i), ("accepted", c_i), ("graph_nodes", c_i), ("icp_error", c_f),
                 ("icp_count", c_f), ("T_wc_recovery", C.c_double * 16)]
@@ -618,6 +626,10 @@ class ElasticFusion:
     def predict(self):
         _chk(lib().ef_predict(self.h), self.h)
 
+    def setPersistentTracker(self, on=True):
+        """small pyramid levels + SO(3) in one persistent launch (default) or one launch per step (ef_set_persistent_tracker)"""
+        _chk(lib().ef_set_persistent_tracker(self.h, c_i(int(on))), self.h)
+
     def synchronize(self):
         _chk(lib().ef_synchronize(self.h), self.h)
 
@@ -686,6 +698,23 @@ class ElasticFusion:
     def uploadMap(self, surfels: np.ndarray):
         s = np.ascontiguousarray(surfels, np.float32).reshape(-1, 12)
         _chk(lib().ef_map_upload(self.h, _ptr(s), c_u32(len(s))), self.h)
+
+    def getPoseQT(self) -> np.ndarray:
+        """T_wc as the engine holds it: unit quaternion x y z w + translation (7 doubles), no matrix round trip (ef_get_pose_qt)"""
+        qt = np.zeros(7, np.float64)
+        _chk(lib().ef_get_pose_qt(self.h, _ptr(qt)), self.h)
+        return qt
+
+    def checkpoint(self, last_rgb, last_depth) -> dict:
+        """what a replay carries from one processFrame to the next: map, tick, pose and the frame processed last"""
+        return dict(map=self.downloadMap(), tick=self.getTick(), qt=self.getPoseQT(), rgb=np.ascontiguousarray(last_rgb, np.uint8).copy(),
+                    depth=np.ascontiguousarray(last_depth, np.uint16).copy())
+
+    def restore(self, ck: dict):
+        """resume from ``checkpoint()`` in a fresh context (ef_map_upload + ef_restore_state): the next processFrame continues the replay"""
+        self.uploadMap(ck["map"])
+        qt = np.ascontiguousarray(ck["qt"], np.float64).reshape(7)
+        _chk(lib().ef_restore_state(self.h, c_i(int(ck["tick"])), _ptr(qt), _ptr(ck["rgb"]), _ptr(ck["depth"])), self.h)
 
     def savePly(self, path: str):
         _chk(lib().ef_save_ply(self.h, path.encode()), self.h)

@@ -136,6 +136,7 @@ struct ef_ctx {
   // hipGraph replay of the tracker (BASELINE.json configs[4]): the ~70 launches of getIncrementalTransformation are
   // captured once per pyramid parity (the SO(3) reference / frame intensity buffers swap every frame) and replayed
   bool use_graph = false;
+  bool persistent = true;        // ef_set_persistent_tracker: small pyramid levels + SO(3) in one persistent launch (k_track_small)
   struct TrackGraph { hipGraphExec_t exec = nullptr; const void* key = nullptr; eft::TrackParams tp{}; eft::TrackTail tail{}; };
   TrackGraph tgraph[2];
   // HIP-event sampling of the dominant kernel (ef_kernel_timing)
@@ -332,6 +333,7 @@ void fern_tracker_device(void* user, const float* fv, const float* fn, const dou
   eft::init_icp_maps(c->pyr3, (const float*)d_cv, (const float*)d_cn, zero_image, c->st3, 6.0f, s);
   eft::TrackParams tp;
   tp.rgbOnly = false; tp.pyramid = false; tp.fastOdom = false; tp.so3 = false; tp.icpWeight = 100.f;
+  tp.persistent = c->persistent ? 1 : 0;
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
   const eft::TrackTail tail = eft::track(c->pyr3, c->st3, c->intr3, tp, s, nullptr);
@@ -422,6 +424,7 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
   eft::init_rgb_sobel(c->pyr2, s);
   eft::TrackParams tp;
   tp.rgbOnly = false; tp.pyramid = c->cfg.pyramid != 0; tp.fastOdom = c->cfg.fast_odom != 0; tp.so3 = false; tp.icpWeight = 10.f;   // :471
+  tp.persistent = c->persistent ? 1 : 0;
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
   const eft::TrackTail tail2 = eft::track(c->pyr2, c->st2, c->intr, tp, s, nullptr);
@@ -585,6 +588,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       tp.fastOdom = c->cfg.fast_odom != 0;
       tp.so3 = c->cfg.so3 != 0;
       tp.icpWeight = c->cfg.icp_weight;
+      tp.persistent = c->persistent ? 1 : 0;
       tp.distThres = 0.10f;                                   // RGBDOdometry.h:41
       tp.angleThres = sinf(20.f * 3.14159254f / 180.f);       // RGBDOdometry.h:42
       const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
@@ -779,7 +783,7 @@ int ctx_init(ef_ctx* c) {
     EF_ALLOC(c, c->pyr.corres[i], n);
     EF_ALLOC(c, c->pyr.rgbMask[i], n);
   }
-  EF_ALLOC(c, c->pyr.partials, (size_t)eft::PARTIAL_FLOATS);
+  EF_ALLOC(c, c->pyr.partials, (size_t)eft::PARTIAL_ALLOC_FLOATS);
   EF_ALLOC(c, c->st, 1);
   // prediction images
   EF_ALLOC(c, c->im.index, P);
@@ -836,7 +840,7 @@ int ctx_init(ef_ctx* c) {
       EF_ALLOC(c, c->pyr2.corres[i], n);
       EF_ALLOC(c, c->pyr2.rgbMask[i], n);
     }
-    EF_ALLOC(c, c->pyr2.partials, (size_t)eft::PARTIAL_FLOATS);
+    EF_ALLOC(c, c->pyr2.partials, (size_t)eft::PARTIAL_ALLOC_FLOATS);
     EF_ALLOC(c, c->st2, 1);
     EF_ALLOC(c, c->old.image, P);
     EF_ALLOC(c, c->old.vertex, P);
@@ -959,6 +963,15 @@ int ef_synchronize(ef_ctx* c) {
   if (!c) return EF_EINVAL;
   DeviceGuard dg_(c);
   EF_HIP(c, hipStreamSynchronize(c->stream));
+  for (const eft::Pyramid* p : {&c->pyr, &c->pyr2, &c->pyr3}) {
+    const int a = eft::tracker_aborted(*p, c->stream);
+    if (a != 0) {
+      c->err = a > 0 ? "the persistent tracker launch timed out in a grid barrier (its 128 workgroups were not resident together): results "
+                       "since then are invalid; recreate the context, or run it with ef_set_persistent_tracker(ctx, 0)"
+                     : "hipMemcpy (tracker status)";
+      return EF_EHIP;
+    }
+  }
   return check_capacity(c);
 }
 
@@ -1087,7 +1100,7 @@ int ef_enable_global_closure(ef_ctx* c, int num_ferns, float photo_thresh, float
     EF_ALLOC(c, c->pyr3.corres[i], m);
     EF_ALLOC(c, c->pyr3.rgbMask[i], m);
   }
-  EF_ALLOC(c, c->pyr3.partials, (size_t)eft::PARTIAL_FLOATS);
+  EF_ALLOC(c, c->pyr3.partials, (size_t)eft::PARTIAL_ALLOC_FLOATS);
   EF_ALLOC(c, c->st3, 1);
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, c->stream, c->st3, 1, c->fern_w * c->fern_h);
   EF_HIP(c, hipStreamSynchronize(c->stream));
@@ -1140,6 +1153,13 @@ int ef_sample_graph(ef_ctx* c, float* nodes4, int max_nodes, int* n_out) {
   return EF_OK;
 }
 int ef_set_graph_replay(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->use_graph = on != 0; return EF_OK; }
+int ef_set_persistent_tracker(ef_ctx* c, int on) {
+  if (!c) return EF_EINVAL;
+  c->persistent = on != 0;
+  for (auto& g : c->tgraph)   // captured tracker graphs hold the other script
+    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+  return EF_OK;
+}
 int ef_predict(ef_ctx* c) {
   if (!c) return EF_EINVAL;
   DeviceGuard dg_(c);
@@ -1198,6 +1218,18 @@ int ef_get_trajectory(ef_ctx* c, double* T16s, int64_t* stamps, int max_frames, 
   if (T16s && n) {
     EF_HIP(c, hipMemcpyAsync(T16s, c->traj, (size_t)n * 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     EF_HIP(c, hipStreamSynchronize(c->stream));
+    // "Output deformed pose graph" (ElasticFusion.cpp:107-139): every accepted Deformation::constrain moves the poses logged so far
+    // (DeformationGraph::applyGraphToPoses), so with loop closures on the log to hand out is the closure object's copy of t_T_wc — the
+    // device log holds each frame's pose as it was when the frame ended.  The closure object logs one pose per frame from the frame
+    // ef_enable_global_closure was called before: it covers the LAST `m` frames.
+    if (c->closure) {
+      const int total = (int)c->stamps.size(), m = ef_closure_trajectory(c->closure, nullptr, 0), first = total - m;
+      if (m > 0 && first >= 0 && first < n) {
+        std::vector<double> P((size_t)m * 16);
+        ef_closure_trajectory(c->closure, P.data(), m);
+        memcpy(T16s + (size_t)first * 16, P.data(), (size_t)(n - first) * 16 * sizeof(double));
+      }
+    }
   }
   if (stamps) for (int i = 0; i < n; ++i) stamps[i] = c->stamps[i];
   *n_frames = n;
@@ -1272,6 +1304,42 @@ int ef_map_upload(ef_ctx* c, const float* surfels, uint32_t count) {
   }
   hipLaunchKernelGGL(k_set_count, dim3(1), dim3(64), 0, c->stream, &c->st->map_counts[c->cur], count);
   return EF_OK;
+}
+int ef_get_pose_qt(ef_ctx* c, double* q4_t3) {
+  if (!c || !q4_t3) return EF_EINVAL;
+  DeviceGuard dg_(c);
+  eft::TrackState h;
+  EF_HIP(c, hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 4; ++i) q4_t3[i] = h.q[i];
+  for (int i = 0; i < 3; ++i) q4_t3[4 + i] = h.t[i];
+  return EF_OK;
+}
+// Resume from a checkpoint (include/ef_hip.h): the end-of-frame state of the frame `rgb_prev` / `depth_prev` was, on the uploaded map
+int ef_restore_state(ef_ctx* c, int tick, const double* q4_t3, const uint8_t* rgb_prev, const uint16_t* depth_prev) {
+  if (!c || !q4_t3 || !rgb_prev || !depth_prev || tick < 2) return EF_EINVAL;
+  DeviceGuard dg_(c);
+  hipStream_t s = c->stream;
+  const int W = c->cam.cols, H = c->cam.rows;
+  EF_HIP(c, hipMemcpyAsync(c->rgb, rgb_prev, (size_t)W * H * 3, hipMemcpyHostToDevice, s));
+  EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_prev, (size_t)W * H * 2, hipMemcpyHostToDevice, s));
+  EF_HIP(c, hipStreamSynchronize(s));   // the caller's buffers are pageable and only borrowed
+  efm::preprocess_depth(c->depth_raw, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, s, 0u);
+  // the frame's intensity pyramid where the next frame's SO(3) pre-alignment looks for it (lastNextImage: initFirstRGB's target and,
+  // after every tracked frame, the swapped-in nextImage, RGBDOdometry.cpp:246-257,284-288)
+  eft::init_first_rgb(c->pyr, c->rgb, s);
+  efl::SE3 T;
+  for (int i = 0; i < 4; ++i) T.q[i] = q4_t3[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = q4_t3[4 + i];
+  eft::pose_restored(c->st, T.q, T.t, s);
+  c->tick = tick;
+  c->lost = c->last_frame_recovery = false;
+  c->tracking_ok = true;
+  c->tracking_count = 0;
+  c->graph_nodes = 0;
+  const int r = do_predict(c);
+  EF_HIP(c, hipGetLastError());
+  return r;
 }
 // Host-only writers (no context, no GPU): the two dumps of the reference, byte for byte.
 //   trajectory: ~ElasticFusion, ElasticFusion.cpp:112-139 — "timestamp tx ty tz qx qy qz qw" per pose, the timestamp as microseconds / 1e6

@@ -32,15 +32,11 @@ __device__ __forceinline__ void wave_sync() {
 }
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 // broadcast from a lane known at compile time (the diagonal of the 6x6 system): v_readlane (a few cycles) instead of the LDS crossbar
-// (ds_bpermute, a round trip of >100 cycles, 27 of them on the factorisation's critical path).  Built, NOT yet validated on a GPU:
-// python -m elasticfusion_amd.build --variant readlane -DEF_SOLVE_READLANE
-#ifdef EF_SOLVE_READLANE
+// (ds_bpermute, a round trip of >100 cycles, 27 of them on the factorisation's critical path).  Validated on the GPU in round 3 (full
+// -m gpu suite) and adopted: profiles/r03a_ab.log.
 __device__ __forceinline__ double bcast_d(double v, int src) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
-#else
-__device__ __forceinline__ double bcast_d(double v, int src) { return shfl_d(v, src); }
-#endif
 
 struct SolveScratch {     // LDS, one per workgroup that runs a solve
   double A[36];           // factorised matrix: D on the diagonal, L below
@@ -183,8 +179,10 @@ struct SolveInputs {
 // The update step proper.  sums: 58 floats in LDS (ICP members 0..28, RGB members 29..57).  Called by ONE converged
 // wavefront (lanes 0..63).  Leaves resultRt, Rcurr/tcurr, krkinv/kt in S; with `publish` also writes them into `next`
 // and lastA/lastb into st.
+// `stats`: also leave lastA / lastb in st (one workgroup does; in the persistent small-level kernel every workgroup publishes into its own
+// LDS copy of the state but only workgroup 0 writes the TrackState)
 __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, eft::GNState* next, bool publish, const float* sums,
-                                                         const SolveInputs in, SolveScratch& S) {
+                                                         const SolveInputs in, SolveScratch& S, bool stats) {
   const int lane = threadIdx.x & 63;
   // ---- A = A_rgb + w^2 A_icp, b = b_rgb + w b_icp (RGBDOdometry.cpp:522-534), one element per lane ----
   double a = 0.0;
@@ -205,8 +203,8 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, ef
     } else {
       v = (double)sums[eft::SE3_ACCS + m];
     }
-    if (lane < 36) { a = v; if (publish) st->lastA[lane] = v; }
-    else if (lane < 42) { S.b[lane - 36] = v; if (publish) st->lastb[lane - 36] = v; }
+    if (lane < 36) { a = v; if (stats) st->lastA[lane] = v; }
+    else if (lane < 42) { S.b[lane - 36] = v; if (stats) st->lastb[lane - 36] = v; }
   }
   wave_sync();
   EF_STAMP(st, 4);
@@ -269,9 +267,9 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, ef
     const float* Rp = S.prevPose;
     if (lane < 9) {
       const int r = lane / 3, c = lane - r * 3;
-      float i0 = iR[0], i1 = iR[3], i2 = iR[6];
-      if (c == 1) { i0 = iR[1]; i1 = iR[4]; i2 = iR[7]; }
-      if (c == 2) { i0 = iR[2]; i1 = iR[5]; i2 = iR[8]; }
+      // column c of iR = row c of float(resultRt), read from LDS with the lane's own index (selecting among the register copies
+      // makes the compiler index a private array, which lands in scratch when the alloca is not promoted to LDS)
+      const float i0 = (float)S.Rt[c * 4], i1 = (float)S.Rt[c * 4 + 1], i2 = (float)S.Rt[c * 4 + 2];
       const float v = Rp[r * 3] * i0 + Rp[r * 3 + 1] * i1 + Rp[r * 3 + 2] * i2;
       S.Rcurr[lane] = v;
       if (publish) next->Rcurr[lane] = v;

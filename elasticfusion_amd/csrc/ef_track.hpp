@@ -23,6 +23,11 @@ constexpr int SO3_ACCS = 11;         // JtJJtrSO3, types.cuh:145-168
 // the SO(3) kernel leaves one partial per accumulator and virtual warp, layout [acc][warp]
 constexpr int SE3_PAIRS = VWARPS / 2;
 constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * SE3_PAIRS > SO3_ACCS * VWARPS ? 2 * SE3_ACCS * SE3_PAIRS : SO3_ACCS * VWARPS;
+// The persistent small-level tracker (k_track_small, round 3): 128 co-resident workgroups of 512 threads run k_track_begin, the SO(3)
+// loop and every Gauss-Newton iteration of the levels with <= PT_MAX_PIXELS pixels in ONE launch; hand-overs between workgroups
+// alternate between two partial regions, and a small synchronisation record (PtSync) sits behind them.
+constexpr int PT_WGS = 128, PT_BLOCK = 512, PT_MAX_ITER = 16, PT_MAX_PIXELS = 8 * VTHREADS, PT_SYNC_FLOATS = 1024;
+constexpr int PARTIAL_ALLOC_FLOATS = 2 * PARTIAL_FLOATS + PT_SYNC_FLOATS;
 
 struct Intr { float fx, fy, cx, cy; };
 __host__ __device__ inline Intr intr_level(const Intr& k, int level) {  // CameraModel::operator()(level), types.cuh:92-95
@@ -103,7 +108,7 @@ struct Pyramid {               // one RGBDOdometry instance's device buffers (RG
   // DataTerm (types.cuh:81-86): bit31 valid | (diff+255) << 22 | v0 << 11 | u0 ("one" is the pixel itself)
   uint32_t* corres[NUM_PYRS];
   uint8_t* rgbMask[NUM_PYRS];      // iteration-invariant part of residualKernel's gates, built once per frame
-  float* partials;                 // PARTIAL_FLOATS
+  float* partials;                 // PARTIAL_ALLOC_FLOATS: region 0 (what the per-step kernels use), region 1, PtSync (zero-filled at allocation)
   int W(int l) const { return width >> l; }
   int H(int l) const { return height >> l; }
 };
@@ -121,6 +126,7 @@ struct TrackParams {           // host-side knobs of getIncrementalTransformatio
   bool rgbOnly, pyramid, fastOdom, so3;
   float icpWeight;
   float distThres, angleThres; // RGBDOdometry.h:41-42
+  int persistent = 1;          // (int: the struct is compared with memcmp, no tail padding) small levels + SO(3) in one persistent launch (k_track_small); false = one launch per step (round 2)
 };
 
 // ---- operator-tier launchers (raw device pointers) ----
@@ -198,6 +204,9 @@ struct TrackTail {
   const float* pairs;
 };
 TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe = nullptr);
+// 1 when a persistent launch of this tracker instance gave up waiting in a grid barrier (its workgroups were not co-resident), 0
+// otherwise, < 0 on a HIP error; synchronises the stream
+int tracker_aborted(const Pyramid& p, hipStream_t s);
 void track_swap(Pyramid& p, const TrackParams& tp);   // the pointer swap track() ends with (for hipGraph replay)
 // tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +
 // velocity weighting (ElasticFusion.cpp:369-383) + the float matrices of the map passes
@@ -208,6 +217,9 @@ void track_end(TrackState* st, const TrackTail& tail, bool rgb, float weightMult
 void pose_injected(TrackState* st, const double* T_wc16, bool save_prev, float weightMultiplier, bool with_weighting, double* traj,
                    int slot, hipStream_t s);
 void log_pose(const TrackState* st, double* traj, int slot, hipStream_t s);
+// checkpoint restore (ef_restore_state): the pose exactly as a context held it (quaternion xyzw + translation), float matrices published,
+// the denseEnough() tally re-armed for the predict() that follows
+void pose_restored(TrackState* st, const double* q4, const double* t3, hipStream_t s);
 // local loop closure plumbing (ElasticFusion.cpp:469-527): T_wc_est := T_wc_curr before the model-to-model tracker runs;
 // T_wc_curr := T_wc_est after an accepted deformation; the (W/20)x(H/20) constraint samples {x, y, z, inactive time}
 void copy_pose(TrackState* dst, const TrackState* src, hipStream_t s);

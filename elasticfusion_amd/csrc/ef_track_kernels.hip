@@ -419,7 +419,6 @@ __device__ __forceinline__ void store_planar(float* m, int cols, int rows, int x
     }
   }
 }
-#ifdef EF_MODEL_MAPS_QUAD   // built, NOT yet validated on a GPU (round 2 ran out of GPU time): python -m elasticfusion_amd.build --variant quadmaps -DEF_MODEL_MAPS_QUAD
 // Four lanes share a 4x4 block: lane j of the quad owns COLUMN j of it, so that every load and every level-0 store of a wavefront
 // covers 64 consecutive pixels of one row (1 KB of float4s per load instruction, four times as many workgroups as one thread per
 // block gave: 300 instead of 75 at 640x480).  The 2x2 boxes of level 1 need the neighbouring column (quad_perm xor 1), the one of
@@ -517,90 +516,6 @@ __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const
     }
   }
 }
-#else
-__global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const TrackState* __restrict__ st) {
-  const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
-  const int cols = A.cols, rows = A.rows;
-  if (bx * 4 >= cols || by * 4 >= rows) return;
-  const bool fill = use_fill_in(st);
-  const float4* __restrict__ vsrc = fill ? A.fill_vertex : A.pred_vertex;
-  const float4* __restrict__ nsrc = fill ? A.fill_normal : A.pred_normal;
-  const m33 R = m33_load(st->R_wc_f);
-  const f3 t{st->t_wc_f[0], st->t_wc_f[1], st->t_wc_f[2]};
-  const bool cf = A.camera_frame;
-  const int c1 = cols / 2, r1 = rows / 2, c2 = cols / 4, r2 = rows / 4;
-  f3 v1[2][2], n1[2][2];
-  bool v1ok[2][2], n1ok[2][2];
-#pragma unroll
-  for (int qy = 0; qy < 2; ++qy)
-#pragma unroll
-    for (int qx = 0; qx < 2; ++qx) {
-      f3 v0[2][2], n0[2][2];
-      bool ok0[2][2];
-#pragma unroll
-      for (int sy = 0; sy < 2; ++sy)
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-          const int x = bx * 4 + qx * 2 + sx, y = by * 4 + qy * 2 + sy;
-          const float4 vs = vsrc[y * cols + x];
-          const float4 ns = nsrc[y * cols + x];
-          const bool ok = !(vs.z == 0);
-          ok0[sy][sx] = ok;
-          v0[sy][sx] = {vs.x, vs.y, vs.z};
-          n0[sy][sx] = {ns.x, ns.y, ns.z};
-          A.depth0[y * cols + x] = (vs.z > A.maxDepthRGB || vs.z <= 0) ? qnan() : vs.z;
-          // level 0: copyMaps NaNs all planes where z == 0, transform propagates NaN via the x-plane
-          const bool nok = ok && !isnan(ns.x);
-          if (cf) {   // copyMaps alone: the NaN test of tranformMaps is not applied, an empty texel NaNs all planes
-            store_planar<true>(A.vmap[0], cols, rows, x, y, ok, v0[sy][sx]);
-            store_planar<true>(A.nmap[0], cols, rows, x, y, ok, n0[sy][sx]);
-          } else {
-            store_planar<true>(A.vmap[0], cols, rows, x, y, ok && !isnan(vs.x), mul(R, v0[sy][sx]) + t);
-            store_planar<true>(A.nmap[0], cols, rows, x, y, nok, mul(R, n0[sy][sx]));
-          }
-        }
-      // level 1: 2x2 box of the camera-frame level-0 maps (x-plane NaN test only)
-      const bool vok = ok0[0][0] && ok0[0][1] && ok0[1][0] && ok0[1][1] && !isnan(v0[0][0].x) && !isnan(v0[0][1].x) &&
-                       !isnan(v0[1][0].x) && !isnan(v0[1][1].x);
-      const bool nok = ok0[0][0] && ok0[0][1] && ok0[1][0] && ok0[1][1] && !isnan(n0[0][0].x) && !isnan(n0[0][1].x) &&
-                       !isnan(n0[1][0].x) && !isnan(n0[1][1].x);
-      f3 va{(v0[0][0].x + v0[0][1].x + v0[1][0].x + v0[1][1].x) / 4, (v0[0][0].y + v0[0][1].y + v0[1][0].y + v0[1][1].y) / 4,
-            (v0[0][0].z + v0[0][1].z + v0[1][0].z + v0[1][1].z) / 4};
-      f3 na{(n0[0][0].x + n0[0][1].x + n0[1][0].x + n0[1][1].x) / 4, (n0[0][0].y + n0[0][1].y + n0[1][0].y + n0[1][1].y) / 4,
-            (n0[0][0].z + n0[0][1].z + n0[1][0].z + n0[1][1].z) / 4};
-      na = normalized(na);
-      v1[qy][qx] = va; n1[qy][qx] = na;
-      // a valid-flagged average can still be NaN in x (NaN y/z never matter: only x is tested downstream)
-      v1ok[qy][qx] = vok; n1ok[qy][qx] = nok;
-      const int x1 = bx * 2 + qx, y1 = by * 2 + qy;
-      if (cf) {   // resizeMapKernel alone: x-plane NaN where a source x is NaN, else the three averages as they come
-        store_planar<false>(A.vmap[1], c1, r1, x1, y1, vok, va);
-        store_planar<false>(A.nmap[1], c1, r1, x1, y1, nok, na);
-      } else {
-        store_planar<false>(A.vmap[1], c1, r1, x1, y1, vok && !isnan(va.x), mul(R, va) + t);
-        store_planar<false>(A.nmap[1], c1, r1, x1, y1, nok && !isnan(na.x), mul(R, na));
-      }
-    }
-  // level 2
-  const bool vok2 = v1ok[0][0] && v1ok[0][1] && v1ok[1][0] && v1ok[1][1] && !isnan(v1[0][0].x) && !isnan(v1[0][1].x) &&
-                    !isnan(v1[1][0].x) && !isnan(v1[1][1].x);
-  const bool nok2 = n1ok[0][0] && n1ok[0][1] && n1ok[1][0] && n1ok[1][1] && !isnan(n1[0][0].x) && !isnan(n1[0][1].x) &&
-                    !isnan(n1[1][0].x) && !isnan(n1[1][1].x);
-  f3 va{(v1[0][0].x + v1[0][1].x + v1[1][0].x + v1[1][1].x) / 4, (v1[0][0].y + v1[0][1].y + v1[1][0].y + v1[1][1].y) / 4,
-        (v1[0][0].z + v1[0][1].z + v1[1][0].z + v1[1][1].z) / 4};
-  f3 na{(n1[0][0].x + n1[0][1].x + n1[1][0].x + n1[1][1].x) / 4, (n1[0][0].y + n1[0][1].y + n1[1][0].y + n1[1][1].y) / 4,
-        (n1[0][0].z + n1[0][1].z + n1[1][0].z + n1[1][1].z) / 4};
-  na = normalized(na);
-  if (cf) {
-    store_planar<false>(A.vmap[2], c2, r2, bx, by, vok2, va);
-    store_planar<false>(A.nmap[2], c2, r2, bx, by, nok2, na);
-  } else {
-    store_planar<false>(A.vmap[2], c2, r2, bx, by, vok2 && !isnan(va.x), mul(R, va) + t);
-    store_planar<false>(A.nmap[2], c2, r2, bx, by, nok2 && !isnan(na.x), mul(R, na));
-  }
-}
-
-#endif
 // ------------------------------------------------------------------------------------------
 // per-pixel Jacobian rows
 // ------------------------------------------------------------------------------------------
@@ -831,8 +746,8 @@ struct StepArgs {
   bool level_changes;         // this iteration runs at another level than the one whose update the head evaluates
 };
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* prev, GNState* next, bool publish, const float* sums,
-                                                const StepArgs& A, efs::SolveScratch& S, const efs::SolvePrefetch& PF);
-template <int BLOCK>
+                                                const StepArgs& A, efs::SolveScratch& S, const efs::SolvePrefetch& PF, bool stats);
+template <int BLOCK, bool COHERENT = false>
 __device__ __forceinline__ void pair_partials_tree(const float* __restrict__ pairs, bool icp, bool rgb, float* sums_s);
 
 template <int PPT>
@@ -865,7 +780,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_track_step(const ResidualPacke
     if (t < 64) PF = efs::solve_prefetch(st, prev, slots_prev);
     pair_partials_tree<REDUCE_BLOCK>(pairs, A.icp, A.rgb, sums_s);
     __syncthreads();
-    if (t < 64) solve_step_wave(st, prev, next, blockIdx.x == 0, sums_s, A, S, PF);
+    if (t < 64) solve_step_wave(st, prev, next, blockIdx.x == 0, sums_s, A, S, PF, blockIdx.x == 0);
     __syncthreads();
     K = m33_load(S.krkinv);
     kt = f3{S.kt[0], S.kt[1], S.kt[2]};
@@ -970,7 +885,7 @@ constexpr int ROW_STRIDE = 8 * 32;   // floats per pass in LDS (SO(3) kernel): 8
 //            lo x lo, lo x hi, hi x hi with lo = (r0..r3), hi = (r4, r5, r6, found).  Duplicate (i > j) and unused
 //            outputs are simply not stored.  The VALU sees only the 32 transposition moves per step; the 12 MFMAs run
 //            beside the other wave's phase A.  (EF_NO_FMA builds, where every product is rounded before it is added,
-//            and EF_ACCUM_VALU builds do the same outer products with quad broadcasts on the VALU.)
+//            do the same outer products with quad broadcasts on the VALU.)
 //   tree     warpReduceSum (reduce.cu:57-95): offset 16 is the other half's wave (one LDS exchange, the only barrier of the
 //            kernel), offsets 8..1 are lane shuffles by 32..4.
 // A workgroup is two virtual warps x {ICP, RGB} x two halves = 8 waves; waves i and i + 4 share a SIMD, so every SIMD
@@ -1010,7 +925,7 @@ __device__ __forceinline__ void quad_transpose(float (&m)[4], int j) {
 }
 // c[i] (lane j of the quad) = fma(a of lane i, b of lane j, c[i]): sixteen 4x4 rank-1 updates per wavefront
 __device__ __forceinline__ f32x4 quad_outer(float a, float b, f32x4 c) {
-#if defined(EF_NO_FMA) || defined(EF_ACCUM_VALU)
+#ifdef EF_NO_FMA
   c.x = EF_FMA(quad_bcast<0>(a), b, c.x);
   c.y = EF_FMA(quad_bcast<1>(a), b, c.y);
   c.z = EF_FMA(quad_bcast<2>(a), b, c.z);
@@ -1193,17 +1108,12 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
   const int S = (K + 3) >> 2;
   const int lane = threadIdx.x & 63;
   const int j = lane & 3;                    // quad layout (phase B): lane = 4 v + j
-#ifdef EF_ACCUM_QUAD_LOADS
-  const int jl = j, g = gbase + (lane >> 2); // phase A in the quad layout too: a quarter-wave touches four 16-byte segments per load
-  const int gather_from = lane;
-#else
   // Phase A runs in the LOAD layout, lane = 16 jl + vl: a quarter-wave (16 lanes) covers 16 consecutive pixels of ONE pass, so
   // every planar load touches one 64-byte segment per quarter-wave (four 16-byte pieces of four different rows in the quad
   // layout: 4x the tag look-ups of the CU's one address pipe).  The rows then move to the quad layout through the LDS crossbar
   // (ds_bpermute: lane 4 v + j takes lane 16 j + v's), 8 moves per step.
   const int jl = lane >> 4, g = gbase + (lane & 15);
   const int gather_from = (16 * j + (lane >> 2)) * 4;
-#endif
   IcpPose P;
   if (ICP) {
     P.Rcurr = m33_load(in.Rcurr);
@@ -1267,10 +1177,8 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
       if (s0 + u < S) {   // uniform
-#ifndef EF_ACCUM_QUAD_LOADS
 #pragma unroll
         for (int q = 0; q < 8; ++q) rows[u][q] = __int_as_float(__builtin_amdgcn_ds_bpermute(gather_from, __float_as_int(rows[u][q])));
-#endif
         float lo[4] = {rows[u][0], rows[u][1], rows[u][2], rows[u][3]};
         float hi[4] = {rows[u][4], rows[u][5], rows[u][6], rows[u][7]};
         quad_transpose(lo, j);
@@ -1279,13 +1187,79 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
         for (int q = 0; q < 4; ++q) {
           if (4 * (s0 + u) + q < K) {   // uniform; passes in order: the chain of every accumulator is the reference thread's
             c[0] = quad_outer(lo[q], lo[q], c[0]);
-#ifdef EF_MFMA_SWAP_AB   // development: the cross term with A and B exchanged (were the instruction's output indexed [b][a])
-            c[1] = quad_outer(hi[q], lo[q], c[1]);
-#else
             c[1] = quad_outer(lo[q], hi[q], c[1]);
-#endif
             c[2] = quad_outer(hi[q], hi[q], c[2]);
           }
+        }
+      }
+    }
+  }
+}
+
+// accum_quads for BOTH halves of one virtual warp in ONE wavefront, for the small levels (K <= 8 passes: at most two steps per half):
+// the persistent kernel (k_track_small) gives a wavefront the 32 virtual threads of a warp, so that 8 wavefronts (2 per SIMD, 256
+// registers each) cover what 16 cover in k_se3_accum.  All four (half, step) visits have their loads in flight together; each half
+// accumulates into its own c[half][0..2] in pass order, so every accumulator sees the chain of additions accum_quads gives it.
+template <bool ICP>
+__device__ __forceinline__ void accum_quads_halves(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int wbase, int N, int K,
+                                                   int slot_a, int slot_b, bool with_slots, f32x4 (&c)[2][3]) {
+  constexpr int SU = 2, CH = 2 * SU;
+  const int S = (K + 3) >> 2;   // <= SU
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 3;
+  const int jl = lane >> 4, vl = lane & 15;                 // load layout, see accum_quads
+  const int gather_from = (16 * j + (lane >> 2)) * 4;
+  IcpPose P;
+  if (ICP) {
+    P.Rcurr = m33_load(in.Rcurr);
+    P.tcurr = {in.tcurr[0], in.tcurr[1], in.tcurr[2]};
+    P.Rprev_inv = m33_load(in.Rprev_inv);
+    P.tprev = {in.tprev[0], in.tprev[1], in.tprev[2]};
+  }
+  VisitLoads L[CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    const int hf = u / SU, sp = u % SU, k = 4 * sp + jl;
+    L[u] = visit_stage1<ICP, !ICP>(IV, RV, (sp < S && k < K) ? k * VTHREADS + wbase + 16 * hf + vl : N, N);
+  }
+  float sigma = in.sigma_fixed;
+  if (!ICP && with_slots) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      slot_a += __shfl_down(slot_a, off, 64);
+      slot_b += __shfl_down(slot_b, off, 64);
+    }
+    sigma = sigma_from_sums(__shfl(slot_b, 0, 64), __shfl(slot_a, 0, 64), in.rgbOnly);
+  }
+  VisitGathers G[CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) G[u] = visit_stage2a<ICP, !ICP>(IV, RV, P, L[u]);
+  float rows[CH][8];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    float irow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, grow[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float ifound, gfound;
+    visit_stage2b<ICP, !ICP>(IV, RV, P, sigma, L[u], G[u], irow, ifound, grow, gfound);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) rows[u][q] = ICP ? irow[q] : grow[q];
+    rows[u][7] = ICP ? ifound : gfound;
+  }
+#pragma unroll
+  for (int u = 0; u < CH; ++u) {
+    const int hf = u / SU, sp = u % SU;
+    if (sp < S) {   // uniform
+#pragma unroll
+      for (int q = 0; q < 8; ++q) rows[u][q] = __int_as_float(__builtin_amdgcn_ds_bpermute(gather_from, __float_as_int(rows[u][q])));
+      float lo[4] = {rows[u][0], rows[u][1], rows[u][2], rows[u][3]};
+      float hi[4] = {rows[u][4], rows[u][5], rows[u][6], rows[u][7]};
+      quad_transpose(lo, j);
+      quad_transpose(hi, j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (4 * sp + q < K) {   // uniform; passes in order
+          c[hf][0] = quad_outer(lo[q], lo[q], c[hf][0]);
+          c[hf][1] = quad_outer(lo[q], hi[q], c[hf][1]);
+          c[hf][2] = quad_outer(hi[q], hi[q], c[hf][2]);
         }
       }
     }
@@ -1378,14 +1352,14 @@ k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, const Se3Out
 // All loads of a thread are issued before the first shuffle (NA is a compile-time count): one memory round trip, not NA.
 template <int BLOCK, int NA, bool COHERENT>
 __device__ __forceinline__ void final_tree(const float* partials, float* bs, float* out) {
-  static_assert((NA * VWARPS) % BLOCK == 0 && BLOCK % 64 == 0, "whole waves, whole passes");
-  constexpr int PASSES = NA * VWARPS / BLOCK;
+  static_assert((NA * VWARPS) % 64 == 0 && BLOCK % 64 == 0, "whole waves");
+  constexpr int TOTAL = NA * VWARPS, PASSES = (TOTAL + BLOCK - 1) / BLOCK;   // the last pass may be ragged (whole waves are in or out)
   const int t = threadIdx.x;
   float v[PASSES];
 #pragma unroll
   for (int j = 0; j < PASSES; ++j) {
-    const int idx = t + j * BLOCK;
-    v[j] = COHERENT ? __hip_atomic_load(partials + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials[idx];
+    const int idx = t + j * BLOCK, q = idx < TOTAL ? idx : 0;
+    v[j] = COHERENT ? __hip_atomic_load(partials + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partials[q];
   }
 #pragma unroll
   for (int j = 0; j < PASSES; ++j) {
@@ -1394,7 +1368,7 @@ __device__ __forceinline__ void final_tree(const float* partials, float* bs, flo
     x += __shfl_down(x, 4, 8);
     x += __shfl_down(x, 2, 8);
     x += __shfl_down(x, 1, 8);
-    if ((idx & 7) == 0) bs[idx >> 3] = x;   // [acc][block]
+    if (idx < TOTAL && (idx & 7) == 0) bs[idx >> 3] = x;   // [acc][block]
   }
   __syncthreads();
   for (int idx = t; idx < NA * 64; idx += BLOCK) {
@@ -1487,7 +1461,7 @@ constexpr int SOLVE_BLOCK = 512;
 // calling workgroup needs (krkinv, kt, Rcurr, tcurr, broken); with `publish` the whole GNState goes to `next` and the
 // statistics to st.
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* prev, GNState* next, bool publish, const float* sums,
-                                                const StepArgs& A, efs::SolveScratch& S, const efs::SolvePrefetch& PF) {
+                                                const StepArgs& A, efs::SolveScratch& S, const efs::SolvePrefetch& PF, bool stats) {
   const int lane = threadIdx.x & 63;
   int sigma = PF.slot_b, rgbSize = PF.slot_a;   // {count, sum diff^2} slots of the residual pass, prefetched
 #pragma unroll
@@ -1530,6 +1504,8 @@ __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* p
     if (publish) {
       next->rgb_broken = 0;
       next->lastRGBErrorLevel = A.level_changes ? 3.402823466e+38f : rgbError;
+    }
+    if (stats) {
       st->lastRGBError = rgbError;
       st->lastRGBCount = (float)rgbSize;
       if (A.icp) {
@@ -1545,13 +1521,15 @@ __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* p
   }
   EF_STAMP(st, 3);
   efs::SolveInputs in{A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes};
-  efs::gauss_newton_update_wave(st, next, publish, sums, in, S);
+  efs::gauss_newton_update_wave(st, next, publish, sums, in, S, stats);
 }
 // reduceSum over what k_se3_accum leaves: pairs[term][acc][block][pair] -> the rest of blockReduceSum's 8-warp tree (offsets 2, 1
 // over the four pair sums of a block: (p0 + p2) + (p1 + p3)), then reduceSum<<<1,1024>>> over the 64 block partials (two warp32
 // trees + one add).  sums_s[term * SE3_ACCS + acc]; call with the whole workgroup (BLOCK threads), follow with __syncthreads().
 // One 16-byte load per (acc, block), all of a thread's loads in flight together, one wavefront per accumulator.
-template <int BLOCK>
+// COHERENT: the partials were written by other workgroups of the SAME launch (agent-scope stores, drained, then a grid barrier): read
+// them with agent-scope loads, which no CU's L1 serves (two 8-byte loads per float4)
+template <int BLOCK, bool COHERENT>
 __device__ __forceinline__ void pair_partials_tree(const float* __restrict__ pairs, bool icp, bool rgb, float* sums_s) {
   static_assert(BLOCK % 64 == 0, "one wavefront per accumulator");
   const int t = threadIdx.x;
@@ -1561,7 +1539,18 @@ __device__ __forceinline__ void pair_partials_tree(const float* __restrict__ pai
 #pragma unroll
   for (int q = 0; q < PASSES; ++q) {
     const int idx = t + q * BLOCK;
-    v[q] = idx < na * 64 ? ((const float4*)pairs)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (COHERENT) {
+      unsigned long long lo = 0ull, hi = 0ull;
+      if (idx < na * 64) {
+        const unsigned long long* src = (const unsigned long long*)pairs + (size_t)idx * 2;
+        lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      v[q] = make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
+                         __uint_as_float((unsigned)(hi >> 32)));
+    } else {
+      v[q] = idx < na * 64 ? ((const float4*)pairs)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 #pragma unroll
   for (int q = 0; q < PASSES; ++q) {
@@ -1622,7 +1611,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_track_end(TrackState* st, cons
     if (t < 64) PF = efs::solve_prefetch(st, prev, slots_prev);
     pair_partials_tree<REDUCE_BLOCK>(pairs, A.icp, A.rgb, sums_s);
     __syncthreads();
-    if (t < 64) solve_step_wave(st, prev, next, true, sums_s, A, S, PF);
+    if (t < 64) solve_step_wave(st, prev, next, true, sums_s, A, S, PF, true);
     __syncthreads();
   } else if (t == 0) {
     for (int i = 0; i < 9; ++i) S.Rcurr[i] = prev->Rcurr[i];
@@ -1715,6 +1704,7 @@ __device__ __forceinline__ void so3_chains(const float* __restrict__ R, int l, i
   }
 }
 // phase A + B of so3Step for the virtual warps of this workgroup; leaves partials[acc * VWARPS + warp]
+template <int BLOCK = SO3_BLOCK>
 __device__ __forceinline__ void so3_accumulate(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, int cols,
                                                int rows, const m33& IB, const m33& KI, const m33& KR, float* lds_rows,
                                                float* __restrict__ partials) {
@@ -1729,7 +1719,7 @@ __device__ __forceinline__ void so3_accumulate(const uint8_t* __restrict__ lastI
   for (int i = 0; i < SO3_ACCS; ++i) acc[i] = 0.f;
   for (int k0 = 0; k0 < K; k0 += SO3_KC) {
     const int kc = min(SO3_KC, K - k0);
-    for (int s = t; s < SO3_WPB * kc * 32; s += SO3_BLOCK) {
+    for (int s = t; s < SO3_WPB * kc * 32; s += BLOCK) {
       const int sl = s & 31, q = s >> 5, k = q % kc, sw = q / kc;
       const int p = (k0 + k) * VTHREADS + (blockIdx.x * SO3_WPB + sw) * 32 + sl;
       float row[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1856,6 +1846,454 @@ __global__ void __launch_bounds__(SOLVE_BLOCK) k_final_tree_op(const float* __re
     final_tree<SOLVE_BLOCK, SO3_ACCS, false>(partials, bs, sums);
   }
   if ((int)threadIdx.x < na) out[threadIdx.x] = sums[threadIdx.x];
+}
+
+
+// ------------------------------------------------------------------------------------------
+// The SMALL pyramid levels in ONE launch (round 3): k_track_begin, the <= 10 SO(3) iterations and every Gauss-Newton iteration of the
+// levels with at most PT_MAX_PIXELS pixels (levels 2 and 1 at 640x480: 4 + 5 iterations) — 1 + 10 + 27 dependent launches of the
+// launch-per-step script — as one persistent kernel of PT_WGS co-resident workgroups.
+//
+//   * Every workgroup keeps its OWN copy of the Gauss-Newton state in LDS and evaluates every update step redundantly (the same
+//     wave-parallel solve, ef_solve_dev.hpp): nothing is broadcast, the only traffic between workgroups is what the reference
+//     reduces globally — the pair partials of the normal equations (all-gathered: 59 KB, read by every workgroup) and the two
+//     integers of the correspondence search.
+//   * Hand-over = agent-scope (write-through) stores, drained, then ONE counter barrier; readers use agent-scope loads, which no
+//     CU's L1 serves.  Placement-independent: nothing assumes which XCD a workgroup runs on (HIP promises no mapping).  Payloads
+//     alternate between two regions by iteration parity, so a workgroup that runs ahead never overwrites what a slow one still reads.
+//   * Two barriers per SE(3) iteration: A after the correspondence search (the photometric rows need the global count: sigma,
+//     quirk Q2) — its latency is hidden behind the ICP wavefronts, which do not depend on it — and B after the accumulation.
+//     One barrier per SO(3) iteration; the loop leaves at convergence (no post-convergence no-op launches).
+//   * Summation order, arithmetic and device functions are those of the per-step kernels (accum_quads, pair_partials_tree,
+//     solve_step_wave, so3_accumulate, final_tree), so every result is bit-identical to the launch-per-step script
+//     (tests/test_gpu_frame.py, test_gpu_steady.py run both).
+//   * Every spin is bounded (PT_SPIN polls); a barrier that times out (the grid was not co-resident: only possible when other work
+//     occupies the chip's wave slots for ever) raises PtSync::abort and the launch runs to its end without waiting any more; later
+//     launches on that tracker instance return at once and ef_synchronize reports EF_EHIP.
+// Work split: workgroup w = 2 b + h owns pairs h and h + 2 of reference block b, i.e. virtual warps 8 b + {h, h + 4, h + 2, h + 6}
+// (SE(3)), and virtual warps 4 w .. 4 w + 3 (SO(3), as k_so3_iteration).  8 wavefronts = 2 pair tasks x {ICP, RGB} x 2 virtual
+// warps, each wavefront working through BOTH halves of its warp (accum_quads_halves; two wavefronts per SIMD leave each 256 registers:
+// with 16 wavefronts the update step spilled); the correspondence search runs two pixels per thread over exactly the pixels the
+// workgroup's own RGB wavefronts visit afterwards, so the packed correspondences never cross a workgroup.
+// ------------------------------------------------------------------------------------------
+constexpr int PT_SPIN = 1 << 20;
+struct PtSync {                   // behind the partial regions (Pyramid::partials + 2 * PARTIAL_FLOATS), zero-filled at allocation
+  unsigned count, pad0[31];       // arrivals of the barrier in flight (its atomics do not share a cache line with the pollers' word)
+  unsigned gen, pad1[31];         // generations completed, monotonic across launches
+  unsigned abort, pad2[31];       // sticky: a wait timed out
+  int wg_sums[2][PT_WGS][2];      // {count, sum diff^2} of each workgroup's share of a correspondence search, by iteration parity
+};
+static_assert(sizeof(PtSync) <= PT_SYNC_FLOATS * sizeof(float), "PtSync fits its reservation");
+struct PtLevel {
+  const float* vmap_curr; const float* nmap_curr; const float* vmap_g_prev; const float* nmap_g_prev;
+  const uint8_t* mask; const float* lastDepth; const float* nextDepth; const uint8_t* lastImage; const uint8_t* nextImage;
+  uint32_t* corres; const int16_t* dIdx; const int16_t* dIdy;
+  int cols, rows;
+  Intr k;
+};
+struct PtArgs {
+  PtLevel L[NUM_PYRS];
+  int n_iter;
+  unsigned levels;                // level of iteration i in bits 2 i, 2 i + 1 (a kernel argument indexed at run time would live in scratch)
+  bool so3;
+  const uint8_t* so3_last; const uint8_t* so3_next;
+  int so3_cols, so3_rows;
+  Intr kso3, kfirst;
+  float icpWeight, distThres, angleThres;
+  float* partials;                // two regions of PARTIAL_FLOATS + the PtSync
+  int out_cur;                    // TrackState::gn buffer the launches that follow read
+};
+struct So3Loop {                  // k_so3_iteration's state, per workgroup in LDS
+  double resR[9], lastResR[9];
+  float R_lr[9], mats[27];
+  float lastError, lastCount, err, cnt;
+  int done, iterations;
+};
+__device__ __forceinline__ unsigned pt_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int pt_loadi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one thread per workgroup, after the workgroup's agent-scope stores were drained and a __syncthreads()
+__device__ __forceinline__ void pt_arrive(PtSync* Y) {
+  const unsigned old = __hip_atomic_fetch_add(&Y->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old == PT_WGS - 1) {   // last arriver: re-arm the counter, then open the generation
+    __hip_atomic_store(&Y->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    drain_stores();
+    __hip_atomic_fetch_add(&Y->gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// one lane; returns true when the wait was abandoned (time-out here or in another workgroup)
+__device__ __forceinline__ bool pt_wait(PtSync* Y, unsigned target, bool dead) {
+  if (dead) return true;
+  for (int i = 0; i < PT_SPIN; ++i) {
+    if ((int)(pt_load(&Y->gen) - target) >= 0) return false;
+    if ((i & 255) == 255 && pt_load(&Y->abort)) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __hip_atomic_store(&Y->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+__device__ __forceinline__ int pt_level_of(const PtArgs& A, int it) { return (int)((A.levels >> (2 * it)) & 3u); }
+// The level descriptors are read from the kernel-argument segment AS MEMORY (scalar loads at a run-time offset), one level at a time:
+// taken from the by-value argument they would all have to sit in SGPRs at once (3 x 30: spilled), or, indexed at run time, be copied
+// into a private array (scratch).
+typedef const __attribute__((address_space(4))) PtArgs* PtArgsK;
+__device__ __forceinline__ PtLevel pt_load_level(PtArgsK Ak, int lvl) {
+  PtLevel L;
+  L.vmap_curr = Ak->L[lvl].vmap_curr; L.nmap_curr = Ak->L[lvl].nmap_curr;
+  L.vmap_g_prev = Ak->L[lvl].vmap_g_prev; L.nmap_g_prev = Ak->L[lvl].nmap_g_prev;
+  L.mask = Ak->L[lvl].mask; L.lastDepth = Ak->L[lvl].lastDepth; L.nextDepth = Ak->L[lvl].nextDepth;
+  L.lastImage = Ak->L[lvl].lastImage; L.nextImage = Ak->L[lvl].nextImage;
+  L.corres = Ak->L[lvl].corres; L.dIdx = Ak->L[lvl].dIdx; L.dIdy = Ak->L[lvl].dIdy;
+  L.cols = Ak->L[lvl].cols; L.rows = Ak->L[lvl].rows;
+  L.k.fx = Ak->L[lvl].k.fx; L.k.fy = Ak->L[lvl].k.fy; L.k.cx = Ak->L[lvl].k.cx; L.k.cy = Ak->L[lvl].k.cy;
+  return L;
+}
+// virtual warp of slot 0..3 of workgroup wg: slot = 2 * task + wl; task 0 / 1 = pairs h / h + 2 of reference block b, wl = upper warp of the pair
+__device__ __forceinline__ int pt_vwarp(int wg, int slot) {
+  const int b = wg >> 1, h = wg & 1;
+  return 8 * b + h + 2 * (slot >> 1) + 4 * (slot & 1);
+}
+// the update of one SO(3) iteration (k_so3_iteration's tail) on the workgroup's own state; returns true when the loop is over
+__device__ __forceinline__ bool so3_update(So3Loop& Z, const float* red, int it, Intr k, Intr kfirst, GNState& g0) {
+  float jtj[9], jtr[3];
+  int shift = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i; j < 4; ++j) {
+      const float value = red[shift++];
+      if (j == 3) jtr[i] = value;
+      else jtj[j * 3 + i] = jtj[i * 3 + j] = value;
+    }
+  float err = sqrtf(red[9]) / red[10];
+  float cnt = red[10];
+  bool done = false;
+  double resR[9];
+  for (int i = 0; i < 9; ++i) resR[i] = Z.resR[i];
+  if (err < Z.lastError && Z.lastCount == cnt) {
+    done = true;
+  } else if ((double)err > (double)Z.lastError + 0.001) {
+    err = Z.lastError; cnt = Z.lastCount;
+    for (int i = 0; i < 9; ++i) { resR[i] = Z.lastResR[i]; Z.resR[i] = resR[i]; }
+    done = true;
+  } else {
+    Z.lastError = err; Z.lastCount = cnt;
+    for (int i = 0; i < 9; ++i) Z.lastResR[i] = resR[i];
+    float delta[3];
+    efl::ldlt_solve<float, 3>(jtj, jtr, delta);
+    const double dv[3] = {(double)delta[0], (double)delta[1], (double)delta[2]};
+    double ru[9];
+    efl::rodrigues(dv, ru);
+    float ruf[9], nR[9], Rlr[9];
+    for (int i = 0; i < 9; ++i) { ruf[i] = (float)ru[i]; Rlr[i] = Z.R_lr[i]; }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        float s = 0;
+        for (int kk = 0; kk < 3; ++kk) s += ruf[r * 3 + kk] * Rlr[kk * 3 + c];
+        nR[r * 3 + c] = s;
+      }
+    for (int i = 0; i < 9; ++i) { Z.R_lr[i] = nR[i]; resR[i] = (double)nR[i]; Z.resR[i] = resR[i]; }
+  }
+  Z.err = err;
+  Z.cnt = cnt;
+  Z.iterations = it + 1;
+  if (done || it == 9) {
+    double Rt[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int x = 0; x < 3; ++x)
+      for (int y = 0; y < 3; ++y) { Rt[x * 4 + y] = resR[x * 3 + y]; g0.resultRt[x * 4 + y] = resR[x * 3 + y]; }
+    compute_krk(Rt, kfirst, g0.krkinv, g0.kt);
+    return true;
+  }
+  so3_matrices(resR, k, Z.mats);
+  return false;
+}
+
+template <bool HAS_ICP, bool HAS_RGB>
+__global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackState* st) {
+  constexpr int NT = (HAS_ICP && HAS_RGB) ? 2 : 1;
+  static_assert(PT_BLOCK == 64 * 2 * 2 * ACC_NW && PT_MAX_PIXELS == 2 * PT_BLOCK * PT_WGS && PT_WGS * 128 == VTHREADS,
+                "8 wavefronts: 2 tasks x 2 terms x 2 warps; 128 virtual threads per workgroup; <= 2 pixels per thread in the search");
+  __shared__ GNState gs[2];
+  __shared__ efs::SolveScratch S;
+  __shared__ float sums_s[2 * SE3_ACCS];
+  __shared__ float bg[24];   // Rprev[9] | tprev[3] | Rprev_inv[9]: constants of the call (k_track_begin)
+  __shared__ float lds_rows[SO3_WPB * SO3_KC * ROW_STRIDE];
+  __shared__ float pairx[2 * 2 * 12 * 4];   // [task][term][12][4]
+  __shared__ float red[SO3_ACCS];
+  __shared__ So3Loop Z;
+  __shared__ int ired[2 * PT_BLOCK / 64];
+  __shared__ unsigned sync_s[2];
+  __shared__ int flag_s;
+  __shared__ unsigned seen_a[2];   // barrier A relay: {generation the workgroup's polling wavefront has seen complete, wait abandoned}
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wg = blockIdx.x;
+  PtSync* Y = (PtSync*)(A.partials + 2 * PARTIAL_FLOATS);
+  // ---- k_track_begin, by every workgroup for itself; workgroup 0 also leaves the global side of it ----
+  if (t == 0) {
+    sync_s[0] = pt_load(&Y->gen) + 1u;   // the generation that ends this launch's first barrier
+    sync_s[1] = pt_load(&Y->abort);
+    seen_a[0] = sync_s[0] - 1u;
+    seen_a[1] = 0u;
+    double R[9];
+    efl::quat_to_mat<double>(st->q, R);
+    GNState& g = gs[0];
+    for (int i = 0; i < 9; ++i) bg[i] = g.Rcurr[i] = (float)R[i];
+    for (int i = 0; i < 3; ++i) bg[9 + i] = g.tcurr[i] = (float)st->t[i];
+    efl::m3_inverse<float>(bg, bg + 12);
+    efl::m4_identity(g.resultRt);
+    g.rgb_broken = 0;
+    g.lastRGBErrorLevel = 3.402823466e+38f;
+    if (!A.so3) compute_krk(g.resultRt, A.kfirst, g.krkinv, g.kt);
+    if (wg == 0) {
+      for (int i = 0; i < 9; ++i) { st->Rprev[i] = bg[i]; st->Rprev_inv[i] = bg[12 + i]; }
+      for (int i = 0; i < 3; ++i) st->tprev[i] = bg[9 + i];
+      for (int i = 0; i < 4; ++i) st->q_prev[i] = st->q[i];
+      for (int i = 0; i < 3; ++i) st->t_prev[i] = st->t[i];
+      for (int i = 0; i < RGB_SLOTS; ++i) st->rgb_slots[0][i][0] = st->rgb_slots[0][i][1] = st->rgb_slots[1][i][0] = st->rgb_slots[1][i][1] = 0;
+      st->so3_iterations = 0;
+      st->so3_ticket = 0;
+      st->so3_done = 1;
+      st->dense_count = 0;
+    }
+  }
+  __syncthreads();
+  if (sync_s[1]) return;   // an earlier launch of this tracker instance timed out in a barrier
+  unsigned gen_next = sync_s[0];
+  bool dead = false;
+  // ---- SO(3) pre-alignment, RGBDOdometry.cpp:284-369 ----
+  if (A.so3) {
+    if (t == 0) {
+      efl::m3_identity(Z.resR);
+      efl::m3_identity(Z.lastResR);
+      for (int i = 0; i < 9; ++i) Z.R_lr[i] = (i % 4 == 0) ? 1.f : 0.f;
+      Z.lastError = 3.402823466e+38f / 2;
+      Z.lastCount = 3.402823466e+38f / 2;
+      Z.done = 0;
+      so3_matrices(Z.resR, A.kso3, Z.mats);
+    }
+    __syncthreads();
+    for (int it = 0; it < 10; ++it) {
+      float* region = A.partials + (size_t)(it & 1) * PARTIAL_FLOATS;
+      {
+        const m33 IB = m33_load(Z.mats), KI = m33_load(Z.mats + 9), KR = m33_load(Z.mats + 18);
+        so3_accumulate<PT_BLOCK>(A.so3_last, A.so3_next, A.so3_cols, A.so3_rows, IB, KI, KR, lds_rows, region);   // agent-scope stores, drained
+      }
+      __syncthreads();
+      if (t == 0) {
+        pt_arrive(Y);
+        flag_s = pt_wait(Y, gen_next, dead) ? 1 : 0;
+      }
+      __syncthreads();
+      dead = flag_s != 0;
+      ++gen_next;
+      final_tree<PT_BLOCK, SO3_ACCS, true>(region, lds_rows, red);
+      if (t == 0) Z.done = so3_update(Z, red, it, A.kso3, A.kfirst, gs[0]) ? 1 : 0;
+      __syncthreads();
+      if (Z.done) break;   // every workgroup computes the same bits, so every workgroup leaves in the same iteration
+    }
+    if (wg == 0 && t == 0) {
+      st->lastSO3Error = Z.err;
+      st->lastSO3Count = Z.cnt;
+      st->so3_iterations = Z.iterations;
+    }
+  }
+  // ---- the Gauss-Newton iterations of the small levels, RGBDOdometry.cpp:371-553 ----
+  int cur = 0;
+  for (int it = 0; it < A.n_iter; ++it) {
+    const int lvl = pt_level_of(A, it);
+    const PtLevel Lv = pt_load_level((PtArgsK)__builtin_amdgcn_kernarg_segment_ptr(), lvl);   // PtArgs is the kernel's FIRST argument
+    const int cols = Lv.cols, rows = Lv.rows, N = cols * rows;
+    const int K = (N + VTHREADS - 1) / VTHREADS;
+    float* region = A.partials + (size_t)((A.n_iter - 1 - it) & 1) * PARTIAL_FLOATS;   // the last iteration's partials land in region 0
+    if (it > 0) {
+      // head: the update step of iteration it - 1 (k_track_step's head), by every workgroup on its own state
+      const float* prev_region = A.partials + (size_t)((A.n_iter - it) & 1) * PARTIAL_FLOATS;
+      StepArgs H{true, false, HAS_ICP, HAS_RGB, false, A.icpWeight, Lv.k, lvl != pt_level_of(A, it - 1)};
+      efs::SolvePrefetch PF{};
+      if (t < 64) {
+        const GNState& g = gs[cur];
+        PF.rt = g.resultRt[lane & 15];
+        PF.pose = bg[lane < 12 ? lane : 0];
+        PF.slot_a = PF.slot_b = 0;
+        if (HAS_RGB) {
+          const int (*ws)[2] = Y->wg_sums[(it - 1) & 1];
+          PF.slot_a = pt_loadi(&ws[lane][0]) + pt_loadi(&ws[lane + 64][0]);
+          PF.slot_b = pt_loadi(&ws[lane][1]) + pt_loadi(&ws[lane + 64][1]);
+        }
+        PF.lastRGBErrorLevel = g.lastRGBErrorLevel;
+        PF.broken = g.rgb_broken;
+      }
+      pair_partials_tree<PT_BLOCK, true>(prev_region, HAS_ICP, HAS_RGB, sums_s);
+      __syncthreads();
+      if (t < 64) solve_step_wave(st, &gs[cur], &gs[cur ^ 1], true, sums_s, H, S, PF, wg == 0);
+      __syncthreads();
+      cur ^= 1;
+    }
+    const GNState& G = gs[cur];
+    // correspondence search (k_track_step's body, two pixels per thread, their loads in flight together) over exactly the pixels this
+    // workgroup's RGB wavefronts visit
+    if (HAS_RGB) {
+      const m33 Km = m33_load(G.krkinv);
+      const f3 kt{G.kt[0], G.kt[1], G.kt[2]};
+      int qs[2];
+      uint8_t m[2];
+      float d1s[2];
+      int nis[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int idx = t + e * PT_BLOCK, kpass = idx >> 7, vt = idx & 127;
+        const int q = kpass * VTHREADS + pt_vwarp(wg, vt >> 5) * 32 + (vt & 31);
+        const bool in = kpass < K && q < N;
+        const int qq = in ? q : N - 1;
+        qs[e] = q;
+        m[e] = in ? Lv.mask[qq] : (uint8_t)0;
+        d1s[e] = Lv.nextDepth[qq];
+        nis[e] = Lv.nextImage[qq];
+      }
+      int gi[2], u0s[2], v0s[2], lis[2];
+      float td1[2], d0s[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int q = qs[e];
+        const int y = q / cols, x = q - y * cols;
+        const float d1 = d1s[e];
+        td1[e] = (float)(d1 * (Km.r[2].x * x + Km.r[2].y * y + Km.r[2].z) + kt.z);
+        u0s[e] = f2i_rn((d1 * (Km.r[0].x * x + Km.r[0].y * y + Km.r[0].z) + kt.x) / td1[e]);
+        v0s[e] = f2i_rn((d1 * (Km.r[1].x * x + Km.r[1].y * y + Km.r[1].z) + kt.y) / td1[e]);
+        gi[e] = (m[e] && u0s[e] >= 0 && v0s[e] >= 0 && u0s[e] < cols && v0s[e] < rows) ? v0s[e] * cols + u0s[e] : -1;
+        d0s[e] = 0.f;
+        lis[e] = 0;
+        if (gi[e] >= 0) { d0s[e] = Lv.lastDepth[gi[e]]; lis[e] = Lv.lastImage[gi[e]]; }
+      }
+      int cnt = 0, sq = 0;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (!m[e]) continue;
+        uint32_t packed = 0u;
+        if (gi[e] >= 0 && d0s[e] > 0 && fabsf(td1[e] - d0s[e]) <= 0.07f /* maxDepthDeltaRGB, RGBDOdometry.cpp:41 */ && lis[e] != 0) {
+          const int idiff = nis[e] - lis[e];
+          packed = pack_corres(u0s[e], v0s[e], idiff);
+          cnt += 1;
+          sq += idiff * idiff;
+        }
+        Lv.corres[qs[e]] = packed;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off, 64);
+        sq += __shfl_down(sq, off, 64);
+      }
+      if (lane == 0) { ired[wave * 2] = cnt; ired[wave * 2 + 1] = sq; }
+      __syncthreads();   // also: the workgroup's packed correspondences are visible to its RGB wavefronts
+      if (t == 0) {
+        int sa = 0, sb = 0;
+        for (int w = 0; w < PT_BLOCK / 64; ++w) { sa += ired[w * 2]; sb += ired[w * 2 + 1]; }
+        int (*ws)[2] = Y->wg_sums[it & 1];
+        __hip_atomic_store(&ws[wg][0], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws[wg][1], sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        drain_stores();
+        pt_arrive(Y);   // barrier A: arrive now, the RGB wavefronts wait below
+      }
+    }
+    // normal equations of the workgroup's two pair tasks: one wavefront per (task, term, warp of the pair), both halves of the warp
+    const int task = wave / (2 * NT), w4 = wave % (2 * NT);
+    const bool active = task < 2;
+    const int tix = w4 >> 1, wl = w4 & 1;
+    const bool rgb_wave = HAS_RGB && (!HAS_ICP || tix == 1);
+    const int v = lane >> 2, j = lane & 3;
+    f32x4 c[2][3];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) c[hf][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      const int wbase = pt_vwarp(wg, 2 * task + wl) * 32;
+      const IcpView IV{Lv.vmap_curr, Lv.nmap_curr, Lv.vmap_g_prev, Lv.nmap_g_prev, cols, rows, Lv.k, A.distThres, A.angleThres};
+      const RgbView RV{Lv.corres, Lv.lastDepth, nullptr, Lv.dIdx, Lv.dIdy, cols, rows, Lv.k, 1.0f / 8.0f};
+      Se3Inputs in{G.Rcurr, G.tcurr, bg + 12, bg + 9, nullptr, nullptr, 0.f, false};
+      if (HAS_ICP && !rgb_wave) accum_quads_halves<true>(IV, RV, in, wbase, N, K, 0, 0, false, c);
+      if (HAS_RGB && rgb_wave) {
+        // barrier A: ONE wavefront of the workgroup polls the global word, the other RGB wavefronts watch its relay in LDS
+        bool gone = false;
+        if (lane == 0) {
+          if (task == 0 && wl == 0) {
+            gone = pt_wait(Y, gen_next, dead);
+            if (gone) __hip_atomic_store(&seen_a[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&seen_a[0], gen_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          } else {
+            int spins = 0;
+            while ((int)(__hip_atomic_load(&seen_a[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen_next) < 0 && ++spins < 4 * PT_SPIN)
+              __builtin_amdgcn_s_sleep(1);
+            gone = dead || spins >= 4 * PT_SPIN || __hip_atomic_load(&seen_a[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+          }
+        }
+        dead = __shfl((int)gone, 0, 64) != 0;
+        const int (*ws)[2] = Y->wg_sums[it & 1];
+        const int slot_a = pt_loadi(&ws[lane][0]) + pt_loadi(&ws[lane + 64][0]);
+        const int slot_b = pt_loadi(&ws[lane][1]) + pt_loadi(&ws[lane + 64][1]);
+        accum_quads_halves<false>(IV, RV, in, wbase, N, K, slot_a, slot_b, true, c);
+      }
+    }
+    if (HAS_RGB) ++gen_next;
+    // warpReduceSum (offset 16 = the other half, here in the same wavefront) + the first level of blockReduceSum's 8-warp tree
+    float r[12];
+    float* pw = pairx + (size_t)((active ? task : 0) * 2 + tix) * 12 * 4;
+    if (active) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        r[q * 4 + 0] = c[0][q].x + c[1][q].x; r[q * 4 + 1] = c[0][q].y + c[1][q].y;
+        r[q * 4 + 2] = c[0][q].z + c[1][q].z; r[q * 4 + 3] = c[0][q].w + c[1][q].w;
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        r[i] += down32(r[i]);
+        r[i] += down16(r[i]);
+        r[i] += row_down<8>(r[i]);
+        r[i] += row_down<4>(r[i]);
+      }
+      if (wl == 1 && v == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) pw[i * 4 + j] = r[i];
+      }
+    }
+    __syncthreads();
+    if (active && wl == 0 && v == 0) {
+      const int pair_index = 4 * (wg >> 1) + (wg & 1) + 2 * task;   // 4 * reference block + pair, k_se3_accum's `wg`
+      float* dst = region + (size_t)tix * SE3_ACCS * SE3_PAIRS + pair_index;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int a = quad_member(q, i, j);
+          if (a >= 0) coherent_store(dst + (size_t)a * SE3_PAIRS, r[q * 4 + i] + pw[(q * 4 + i) * 4 + j]);
+        }
+      drain_stores();
+    }
+    __syncthreads();
+    if (t == 0) {   // barrier B: every pair partial of this iteration is out
+      pt_arrive(Y);
+      flag_s = pt_wait(Y, gen_next, dead) ? 1 : 0;
+    }
+    __syncthreads();
+    dead = dead || flag_s != 0;
+    ++gen_next;
+  }
+  // ---- what the launches that follow read: the Gauss-Newton state and the last search's sums (update of iteration n_iter - 1
+  //      at the head of the next k_track_step / k_track_end) ----
+  if (wg == 0 && t == 0) {
+    const GNState& g = gs[cur];
+    GNState& o = st->gn[A.out_cur];
+    for (int i = 0; i < 9; ++i) { o.Rcurr[i] = g.Rcurr[i]; o.krkinv[i] = g.krkinv[i]; }
+    for (int i = 0; i < 3; ++i) { o.tcurr[i] = g.tcurr[i]; o.kt[i] = g.kt[i]; }
+    for (int i = 0; i < 16; ++i) o.resultRt[i] = g.resultRt[i];
+    o.lastRGBErrorLevel = g.lastRGBErrorLevel;
+    o.rgb_broken = g.rgb_broken;
+    if (HAS_RGB && A.n_iter > 0) {
+      const int set = (A.n_iter - 1) & 1;
+      int sa = 0, sb = 0;
+      for (int w = 0; w < PT_WGS; ++w) { sa += pt_loadi(&Y->wg_sums[set][w][0]); sb += pt_loadi(&Y->wg_sums[set][w][1]); }
+      st->rgb_slots[set][0][0] = sa;
+      st->rgb_slots[set][0][1] = sb;
+    }
+  }
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -1987,11 +2425,7 @@ void init_icp(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cu
 
 // k_model_maps: one lane per level-0 column of a 4-row band (a quad of lanes per 4x4 block)
 static inline dim3 model_maps_grid(const Pyramid& p) {
-#ifdef EF_MODEL_MAPS_QUAD
   return dim3(ceil_div(p.W(0), 64), ceil_div(p.H(0) / 4, 4));
-#else
-  return dim3(ceil_div(p.W(0) / 4, 64), ceil_div(p.H(0) / 4, 4));
-#endif
 }
 void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
                     const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s) {
@@ -2140,11 +2574,9 @@ int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const
   const bool sample = probe && level == 0 && probe->used < probe->capacity;
   const int sp = it & 1;
   StepArgs A{it > 0, rgb, icp, rgb, tp.rgbOnly, tp.icpWeight, kl, level_changes};
-#ifndef EF_TRACK_FUSED
   // The update step as its own ONE-workgroup launch (head only), then the correspondence search alone (body only): three launches
-  // per iteration.  Evaluating the update redundantly at the head of every workgroup of the correspondence kernel instead (two launches,
-  // -DEF_TRACK_FUSED) was built and measured on one box: 888 vs 1322 frames/s — 600 concurrent copies of a 6 us fp64 chain cost far
-  // more than the kernel boundary they save.
+  // per iteration.  Evaluating the update redundantly at the head of every workgroup of the correspondence kernel instead (two
+  // launches) was built and measured in round 2: 888 vs 1322 frames/s; dropped from the source in round 3.
   if (A.has_head) {
     StepArgs H = A;
     H.has_body = false;
@@ -2158,13 +2590,6 @@ int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const
     if (N >= 256 * 1024) launch_step<2>(p, st, level, cur, sp, B, s);
     else launch_step<1>(p, st, level, cur, sp, B, s);
   }
-#else
-  if (A.has_head || A.has_body) {
-    if (N >= 256 * 1024) launch_step<2>(p, st, level, cur, sp, A, s);
-    else launch_step<1>(p, st, level, cur, sp, A, s);
-  }
-  if (A.has_head) cur ^= 1;
-#endif
   const GNState* g = &st->gn[cur];
   IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres};
   RgbView GV{p.corres[level], p.lastDepth[level], nullptr, p.dIdx[level], p.dIdy[level], cols, rows, kl, 1.0f / 8.0f};
@@ -2191,17 +2616,57 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
   for (int i = NUM_PYRS - 1; i >= 0; --i)
     if (iterations[i] > 0) { first_level = i; break; }
   const int so3_level = 2;
-  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st, tp.so3, intr_level(k, so3_level), intr_level(k, first_level));
-  if (tp.so3) {
-    for (int it = 0; it < 10; ++it)
-      hipLaunchKernelGGL(k_so3_iteration, dim3(VWARPS / SO3_WPB), dim3(SO3_BLOCK), 0, s, (const uint8_t*)p.lastNextImage[so3_level],
-                         (const uint8_t*)p.nextImage[so3_level], p.W(so3_level), p.H(so3_level), intr_level(k, so3_level),
-                         intr_level(k, first_level), it, st, p.partials);
+  // The persistent launch takes k_track_begin, the SO(3) loop and the leading iterations whose level fits (coarse to fine: once a
+  // level is too large, it and everything after it run one launch per step).  rgbOnly keeps the per-step script (its per-level
+  // "break" bookkeeping is not in the persistent kernel).
+  int n_small = 0;
+  PtArgs PA{};
+  if (tp.persistent && !tp.rgbOnly) {
+    bool fits = true;
+    for (int i = NUM_PYRS - 1; i >= 0 && fits; --i) {
+      if (iterations[i] == 0) continue;
+      fits = p.W(i) * p.H(i) <= PT_MAX_PIXELS && n_small + iterations[i] <= PT_MAX_ITER;
+      for (int j = 0; fits && j < iterations[i]; ++j) PA.levels |= (unsigned)i << (2 * n_small++);
+    }
   }
   int it = 0, cur = 0, prev_level = first_level;
+  if (tp.persistent && !tp.rgbOnly && (n_small > 0 || tp.so3)) {
+    for (int i = 0; i < NUM_PYRS; ++i)
+      PA.L[i] = PtLevel{p.vmap_curr[i], p.nmap_curr[i], p.vmap_g_prev[i], p.nmap_g_prev[i], p.rgbMask[i], p.lastDepth[i], p.nextDepth[i],
+                        p.lastImage[i], p.nextImage[i], p.corres[i], p.dIdx[i], p.dIdy[i], p.W(i), p.H(i), intr_level(k, i)};
+    PA.n_iter = n_small;
+    PA.so3 = tp.so3;
+    PA.so3_last = p.lastNextImage[so3_level];
+    PA.so3_next = p.nextImage[so3_level];
+    PA.so3_cols = p.W(so3_level);
+    PA.so3_rows = p.H(so3_level);
+    PA.kso3 = intr_level(k, so3_level);
+    PA.kfirst = intr_level(k, first_level);
+    PA.icpWeight = tp.icpWeight;
+    PA.distThres = tp.distThres;
+    PA.angleThres = tp.angleThres;
+    PA.partials = p.partials;
+    PA.out_cur = 0;
+    if (icp && rgb) hipLaunchKernelGGL((k_track_small<true, true>), dim3(PT_WGS), dim3(PT_BLOCK), 0, s, PA, st);
+    else if (icp) hipLaunchKernelGGL((k_track_small<true, false>), dim3(PT_WGS), dim3(PT_BLOCK), 0, s, PA, st);
+    else hipLaunchKernelGGL((k_track_small<false, true>), dim3(PT_WGS), dim3(PT_BLOCK), 0, s, PA, st);
+    it = n_small;
+    if (n_small > 0) prev_level = (int)((PA.levels >> (2 * (n_small - 1))) & 3u);
+  } else {
+    n_small = 0;
+    hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st, tp.so3, intr_level(k, so3_level), intr_level(k, first_level));
+    if (tp.so3) {
+      for (int i = 0; i < 10; ++i)
+        hipLaunchKernelGGL(k_so3_iteration, dim3(VWARPS / SO3_WPB), dim3(SO3_BLOCK), 0, s, (const uint8_t*)p.lastNextImage[so3_level],
+                           (const uint8_t*)p.nextImage[so3_level], p.W(so3_level), p.H(so3_level), intr_level(k, so3_level),
+                           intr_level(k, first_level), i, st, p.partials);
+    }
+  }
+  int done = 0;
   for (int i = NUM_PYRS - 1; i >= 0; --i) {
     const Intr kl = intr_level(k, i);
     for (int j = 0; j < iterations[i]; ++j) {
+      if (done++ < n_small) continue;   // ran inside the persistent launch
       cur = launch_iteration(p, st, i, kl, tp, icp, rgb, it, cur, i != prev_level, s, probe);
       prev_level = i;
       ++it;
@@ -2213,6 +2678,13 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
 }
 // host-side tail of getIncrementalTransformation: the frame's intensity pyramid becomes the SO(3) reference of the next
 // (RGBDOdometry.cpp:284-288 swaps lastNextImage / nextImage); separate so that a replayed hipGraph can do it without launching
+int tracker_aborted(const Pyramid& p, hipStream_t s) {
+  if (!p.partials) return 0;
+  PtSync h;
+  if (hipMemcpyAsync(&h, p.partials + 2 * PARTIAL_FLOATS, offsetof(PtSync, wg_sums), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  return h.abort != 0 ? 1 : 0;
+}
 void track_swap(Pyramid& p, const TrackParams& tp) {
   if (tp.so3)
     for (int i = 0; i < NUM_PYRS; ++i) { uint8_t* tmp = p.lastNextImage[i]; p.lastNextImage[i] = p.nextImage[i]; p.nextImage[i] = tmp; }
@@ -2228,6 +2700,12 @@ void pose_injected(TrackState* st, const double* T_wc16, bool save_prev, float w
                    hipStream_t s) {
   hipLaunchKernelGGL(k_pose_injected, dim3(1), dim3(64), 0, s, st, efl::se3_from_matrix(T_wc16), save_prev, weightMultiplier, with_weighting,
                      traj, slot);
+}
+void pose_restored(TrackState* st, const double* q4, const double* t3, hipStream_t s) {
+  efl::SE3 T;
+  for (int i = 0; i < 4; ++i) T.q[i] = q4[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = t3[i];
+  hipLaunchKernelGGL(k_pose_injected, dim3(1), dim3(64), 0, s, st, T, false, 1.0f, false, (double*)nullptr, 0);
 }
 void copy_pose(TrackState* dst, const TrackState* src, hipStream_t s) { hipLaunchKernelGGL(k_copy_pose, dim3(1), dim3(64), 0, s, dst, src); }
 void adopt_pose(TrackState* st, const TrackState* est, double* traj, int slot, hipStream_t s) {

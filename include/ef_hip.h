@@ -82,6 +82,13 @@ int ef_set_input_overlap(ef_ctx* ctx, int on);
  * (RGBDOdometry.cpp:259-571) are captured once per pyramid parity and replayed with one hipGraphLaunch per frame.
  * Identical results; it only trims host-side launch work (BASELINE.json configs[4]). */
 int ef_set_graph_replay(ef_ctx* ctx, int on);
+/* The tracker's small pyramid levels (every level of at most 131072 pixels: levels 2 and 1 at 640x480), its SO(3) pre-alignment and
+ * its first kernel as ONE persistent launch of 128 co-resident workgroups (default, on) instead of one launch per step (off: the
+ * round-2 script, 38 launches more per frame).  Same arithmetic in the same order: results are bit-identical either way
+ * (RGBDOdometry.cpp:259-553; tests/test_gpu_frame.py runs both).  The persistent launch needs its 128 workgroups resident at the same
+ * time (512 threads, 36 KB of LDS each: half the CUs of one MI355X); every wait in it is bounded, and a launch whose grid could not
+ * become resident (other work holding the chip's wave slots for ever) makes ef_synchronize return EF_EHIP instead of hanging. */
+int ef_set_persistent_tracker(ef_ctx* ctx, int on);
 /* Device half of a loop closure: hands a deformation graph (HOST pointer, nodes x 16 floats sorted by time, layout of
  * GlobalModel::clean's rawGraph, GlobalModel.cpp:536-546) to the NEXT ef_process_frame, whose clean pass applies it to the
  * whole map exactly as ElasticFusion.cpp:558-585 does (synthesizeDepth first unless is_fern).  For a caller that finds loop closures
@@ -284,6 +291,16 @@ int ef_get_trajectory(ef_ctx* ctx, double* T_wc16_array, int64_t* timestamps, in
 int ef_map_count(ef_ctx* ctx, uint32_t* count);               /* GlobalModel::lastCount(); synchronises */
 int ef_map_download(ef_ctx* ctx, float* surfels, uint32_t max_surfels, uint32_t* count); /* downloadMap(), 12 floats each */
 int ef_map_upload(ef_ctx* ctx, const float* surfels, uint32_t count);  /* test/bench seeding */
+/* Checkpoint / resume of a replay.  What ElasticFusion carries from one processFrame to the next is the map, the tick,
+ * T_wc and the previous frame (its intensity pyramid is the SO(3) reference of RGBDOdometry.cpp:284-288, its filtered depth and colour
+ * feed FillIn, ElasticFusion.cpp:621-653); everything else is re-derived.  ef_get_pose_qt returns T_wc exactly as the engine holds it
+ * (unit quaternion x y z w + translation, doubles: no round trip through a matrix).  ef_restore_state, called on a context whose map
+ * was brought in with ef_map_upload, sets tick and pose, takes the frame that was processed LAST before the checkpoint (host pointers,
+ * W*H*3 bytes and W*H uint16), rebuilds its pre-processing and SO(3) reference and runs predict(): the next ef_process_frame then tracks
+ * and fuses exactly as the checkpointed context's next frame does (tests/test_gpu_one_frame.py).  The velocity weighting needs no extra
+ * state: it compares the pose before and after the tracker of the same frame. */
+int ef_get_pose_qt(ef_ctx* ctx, double* q4_t3);
+int ef_restore_state(ef_ctx* ctx, int tick, const double* q4_t3, const uint8_t* rgb_prev, const uint16_t* depth_prev);
 /* Which buffer ef_map_download / ef_save_ply read.  0 (default): model(), the map as it stands after the frame's clean pass.
  * 1: what GlobalModel::downloadMap really reads (GlobalModel.cpp:673-706, quirk Q14): vbos[renderSource], i.e. the buffer the frame's
  * UPDATE pass wrote (the map before clean) truncated to the count AFTER clean — entries beyond the pre-clean count are whatever older

@@ -117,6 +117,31 @@ def test_pipelined_frames_match_oracle(hip, seq):
         assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
 
 
+@pytest.mark.parametrize("cfg", [dict(), dict(icpThresh=100.0), dict(so3=False), dict(fastOdom=True)], ids=["default", "icp_only", "no_so3", "fastOdom"])
+def test_persistent_and_per_step_tracker_scripts_agree(hip, seq, cfg):
+    """The small pyramid levels + SO(3) as ONE persistent launch (k_track_small, the default since round 3) and as one launch per step
+    (ef_set_persistent_tracker(ctx, 0), the round-2 script) are the same arithmetic in the same order: statistics, pose, trajectory
+    and map must be bit-identical, frame after frame — whichever of the two the oracle comparisons of this file ran."""
+    n = 14
+    runs = []
+    for persistent in (True, False):
+        ef = hip.ElasticFusion(**cfg)
+        ef.setPersistentTracker(persistent)
+        rec = []
+        for k in range(n):
+            rgb, depth, _ = seq.frame(k)
+            ef.processFrame(rgb, depth, k * 33333)
+            st, A, b = ef.trackingStats()
+            rec.append((np.asarray(st, np.float32).view(np.uint32).copy(), A.copy(), b.copy(), ef.getPoseQT()))
+        ef.synchronize()                      # also: no barrier of the persistent launches timed out
+        runs.append((rec, ef.downloadMap()))
+        ef.close()
+    for k in range(1, n):
+        for x, y in zip(runs[0][0][k], runs[1][0][k]):
+            assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), (k, x, y)
+    assert np.array_equal(runs[0][1].view(np.uint32), runs[1][1].view(np.uint32))
+
+
 VARIANTS = {
     "fastOdom": (dict(fastOdom=True), dict(fastOdom=1), None),
     "no_so3": (dict(so3=False), dict(so3=0), None),

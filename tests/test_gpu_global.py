@@ -99,7 +99,7 @@ def test_keyframes_revisit_registration_and_rejection(hip_api, seq):
     ef.close()
 
 
-def test_accepted_global_closure_replaces_pose_and_deforms_as_fern_match(hip_api, seq):
+def test_accepted_global_closure_replaces_pose_and_deforms_as_fern_match(hip_api, seq, tmp_path):
     """The reference's gates on a global deformation (entry: mean constraint error >= 0.06 m; acceptance: optimised mean error < 3e-4 m,
     energy < 0.12) were tuned on room-scale trajectories and never open on a map of a dozen frames; with the gates relaxed on both
     sides (ef_closure_set_gates / the same optimiser behind the oracle's solver hook) an 8 mm drift is closed: the pose becomes the
@@ -132,6 +132,12 @@ def test_accepted_global_closure_replaces_pose_and_deforms_as_fern_match(hip_api
     assert not ef.localLoop()[0].attempted                                                            # skipped (:447)
     assert np.abs(ef.get_T_wc() - np.array(go.T_wc_recovery).reshape(4, 4)).max() <= 1e-15
     assert np.abs(ef.closure().trajectory() - o.trajectory()).max() <= 1e-12                          # trajectory deformed along
+    # ... and it is the DEFORMED log that ef_get_trajectory / the .freiburg dump hand out ("Output deformed pose graph",
+    # ElasticFusion.cpp:107-139), not the per-frame device log
+    Ts, _ = ef.trajectory()
+    assert len(Ts) == n0 + 1 and np.abs(Ts - o.trajectory()).max() <= 1e-12
+    moved = np.abs(Ts[:n0, :3, 3] - np.array([seq.frame(2 * k)[2][:3, 3] for k in range(n0)])).max()
+    assert moved > 1e-4, moved                                                                        # the closure really moved earlier poses
     assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
     # two more frames: the database and the map carry on identically
     for k in range(2):
@@ -140,4 +146,11 @@ def test_accepted_global_closure_replaces_pose_and_deforms_as_fern_match(hip_api
         o.process_frame(rgb, depth, 101 + k)
         same_frame_state(ef, o, n0 + 1 + k)
     assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
+    Ts, ts = ef.trajectory()
+    assert np.abs(Ts - o.trajectory()).max() <= 1e-12
+    path = str(tmp_path / "closed.freiburg")
+    ef.saveFreiburg(path)
+    want = str(tmp_path / "want.freiburg")
+    api.write_freiburg(want, o.trajectory(), ts)
+    assert open(path).read() == open(want).read()
     ef.close()

@@ -1,7 +1,7 @@
 """Device code that leans on cross-lane operations, executed WITHOUT a GPU: the text of a kernel is cut out of the product's source and
 compiled for the host over tests/wave_emu/hip/hip_runtime.h (execution-space keywords, thread indices, DPP quad permutes with one host
-thread per lane).  Used for k_model_maps, whose quad-of-lanes form (-DEF_MODEL_MAPS_QUAD: coalesced loads, 2x2 boxes through quad_perm
-exchanges) has to write bit for bit what the one-thread-per-block form writes — the form every GPU parity test has validated — on maps
+thread per lane).  Used for k_model_maps, whose quad-of-lanes form (coalesced loads, 2x2 boxes through quad_perm exchanges; shipped since
+round 3) has to write bit for bit what the one-thread-per-block form of rounds 1-2 wrote (archived as tests/wave_emu/model_maps_block.inc) on maps
 with holes, NaNs, both sources (prediction / fill-in) and both modes (world frame / camera frame).  This pins the LOGIC of the variant
 (indexing, pairing, the reference's order of additions); what the GPU compiler makes of it is the GPU suite's business."""
 import ctypes as C
@@ -16,19 +16,25 @@ CSRC = os.path.join(ROOT, "elasticfusion_amd", "csrc")
 EMU = os.path.join(ROOT, "tests", "wave_emu")
 
 
-def cut_model_maps(tmp):
+def cut_model_maps(tmp, quad):
+    """quad: the product's kernel as shipped; otherwise the product's helpers (argument struct, fill-in choice, planar stores) followed
+    by the archived one-thread-per-block kernel of rounds 1-2 (tests/wave_emu/model_maps_block.inc), the form every GPU parity test of
+    those rounds validated"""
     src = open(os.path.join(CSRC, "ef_track_kernels.hip")).read()
     a = src.index("// !denseEnough(): float(sum)")
     b = src.index("// ------------------------------------------------------------------------------------------\n// per-pixel Jacobian rows")
     text = src[a:b]
-    assert "k_model_maps" in text and "EF_MODEL_MAPS_QUAD" in text and "__builtin_amdgcn_mov_dpp" in text
-    path = os.path.join(tmp, "model_maps_cut.inc")
+    assert "k_model_maps" in text and "__builtin_amdgcn_mov_dpp" in text and text.count("__global__") == 1
+    if not quad:
+        text = text[:text.index("// Four lanes share a 4x4 block")] + open(os.path.join(EMU, "model_maps_block.inc")).read()
+        assert text.count("__global__") == 1 and "__builtin_amdgcn_mov_dpp" not in text
+    path = os.path.join(tmp, "model_maps_cut_%s.inc" % ("quad" if quad else "block"))
     open(path, "w").write(text)
     return path
 
 
 def build(tmp, quad):
-    cut = cut_model_maps(tmp)
+    cut = cut_model_maps(tmp, quad)
     so = os.path.join(tmp, "model_maps_%s.so" % ("quad" if quad else "block"))
     cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-I" + EMU, "-I" + CSRC,
            '-DMODEL_MAPS_SOURCE="%s"' % cut] + (["-DEF_MODEL_MAPS_QUAD"] if quad else []) + [os.path.join(EMU, "model_maps_host.cpp"), "-o", so]
@@ -81,21 +87,19 @@ def test_quad_of_lanes_model_maps_equals_the_validated_kernel(tmp_path, cols, ro
             assert (lvl1[rows // 2:] == -7.0).any()
 
 
-def build_solve(tmp, readlane):
-    so = os.path.join(tmp, "solve_%s.so" % ("readlane" if readlane else "shipped"))
-    cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-I" + EMU, "-I" + CSRC] + \
-          (["-DEF_SOLVE_READLANE"] if readlane else []) + [os.path.join(EMU, "solve_host.cpp"), "-o", so]
+def build_solve(tmp):
+    so = os.path.join(tmp, "solve_shipped.so")
+    cmd = ["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-I" + EMU, "-I" + CSRC, os.path.join(EMU, "solve_host.cpp"), "-o", so]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     return C.CDLL(so)
 
 
-def test_wave_parallel_ldlt_equals_the_scalar_statement_and_its_readlane_variant(tmp_path):
-    """the 6x6 LDL^T of the update step as the tracker runs it (one matrix element per lane, 64 emulated lanes) against the scalar
-    restatement of Eigen::LDLT it mirrors (which tests/test_oracle_linalg.py and the GPU operator tests tie to the oracle), on
-    well-conditioned, pivoting-heavy and degenerate systems — and the same for the -DEF_SOLVE_READLANE variant (diagonal broadcasts
-    through v_readlane), which has to agree before it is ever tried on a GPU"""
-    shipped, readlane = build_solve(str(tmp_path), False), build_solve(str(tmp_path), True)
+def test_wave_parallel_ldlt_equals_the_scalar_statement(tmp_path):
+    """the 6x6 LDL^T of the update step as the tracker runs it (one matrix element per lane, 64 emulated lanes, diagonal broadcasts
+    through v_readlane) against the scalar restatement of Eigen::LDLT it mirrors (which tests/test_oracle_linalg.py and the GPU operator
+    tests tie to the oracle), on well-conditioned, pivoting-heavy and degenerate systems"""
+    shipped = build_solve(str(tmp_path))
     rng = np.random.RandomState(0)
     cases = []
     for t in range(12):
@@ -113,9 +117,7 @@ def test_wave_parallel_ldlt_equals_the_scalar_statement_and_its_readlane_variant
     for k, (A, b) in enumerate(cases):
         A = np.ascontiguousarray((A + A.T) / 2 if k < 12 else A, np.float64)
         b = np.ascontiguousarray(b, np.float64)
-        want = np.zeros(6)
+        want, got = np.zeros(6), np.zeros(6)
         shipped.run_ldlt6_scalar(P(A), P(b), P(want))
-        for name, lib in (("shipped", shipped), ("readlane", readlane)):
-            got = np.zeros(6)
-            lib.run_ldlt6_wave(P(A), P(b), P(got))
-            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (name, k, got, want)
+        shipped.run_ldlt6_wave(P(A), P(b), P(got))
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (k, got, want)

@@ -1,6 +1,6 @@
-// TEST INFRASTRUCTURE — host execution of the product's k_model_maps (both forms: one thread per 4x4 block, and a quad of lanes per block
-// behind EF_MODEL_MAPS_QUAD), compiled from the text tests/test_wave_emulation.py cuts out of elasticfusion_amd/csrc/ef_track_kernels.hip
-// (MODEL_MAPS_SOURCE) over the stand-in <hip/hip_runtime.h> beside this file.  Each lane of a quad is a host thread.
+// TEST INFRASTRUCTURE — host execution of the product's k_model_maps (a quad of lanes per 4x4 block; the harness is built with
+// -DEF_MODEL_MAPS_QUAD for its grid) and of the archived one-thread-per-block form of rounds 1-2 (model_maps_block.inc), compiled from
+// the text tests/test_wave_emulation.py cuts out of elasticfusion_amd/csrc/ef_track_kernels.hip (MODEL_MAPS_SOURCE) over the stand-in <hip/hip_runtime.h> beside this file.  Each lane of a quad is a host thread.
 #include <hip/hip_runtime.h>
 #include <thread>
 #include <vector>

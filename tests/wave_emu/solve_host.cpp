@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE — the product's wave-parallel 6x6 LDL^T (efs::ldlt6_wave, elasticfusion_amd/csrc/ef_solve_dev.hpp: one matrix
 // element per lane, pivot search and row/column swaps through cross-lane shuffles) executed on the host: 64 host threads are the 64
-// lanes (tests/wave_emu/hip/hip_runtime.h).  Built twice by tests/test_wave_emulation.py: as shipped, and with -DEF_SOLVE_READLANE.
+// lanes (tests/wave_emu/hip/hip_runtime.h).  Built by tests/test_wave_emulation.py.
 #include <hip/hip_runtime.h>
 #include <thread>
 #include <vector>

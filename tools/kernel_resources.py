@@ -3,7 +3,7 @@
 import re, subprocess, sys
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-c", src,
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", *sys.argv[3:], "-c", src,
        "-o", "/tmp/_kr.o", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
 rows, cur = [], None
