@@ -119,10 +119,129 @@ def _leave():
     os._exit(0)
 
 
+KT_FIELDS = None
+
+
+def _kernel_time_struct():
+    global KT_FIELDS
+    if KT_FIELDS is None:
+        class KT(C.Structure):
+            _fields_ = [("name", C.c_char_p), ("avg_us", C.c_float), ("launches", C.c_int), ("bytes_per_launch", C.c_double),
+                        ("bytes_per_launch_survey", C.c_double)]
+        KT_FIELDS = KT
+    return KT_FIELDS
+
+
+def rooflines(lib, ef, w, h, where):
+    """(roofline of the level-0 normal-equation kernel, roofline of the IndexMap splat) from the engine's own dispatch-timestamp samples"""
+    KT = _kernel_time_struct()
+    roofline = roofline_splat = None
+    kt = KT()
+    if lib.ef_get_kernel_timing(ef.h, C.byref(kt)) == 0 and kt.launches > 0:
+        # avg_us: the dispatches' own begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of the sampled launches
+        # -- the duration rocprofv3 --kernel-trace reports for the same kernel (profiles/)
+        achieved = kt.bytes_per_launch / (kt.avg_us * 1e-6) / 1e9
+        achieved_survey = kt.bytes_per_launch_survey / (kt.avg_us * 1e-6) / 1e9
+        # HBM-side bytes per launch: rocprofv3 PMC passes cannot run inside this process, so this is the measurement
+        # COMMITTED under profiles/ by tools/pmc_traffic.sh for this kernel and workload (see traffic_source), not a live value
+        traffic, traffic_source, straffic, ssource = None, None, None, None
+        try:
+            if (w, h) != (W, H):
+                raise KeyError("the committed PMC measurement is for the default workload")
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pj = json.load(f)
+            src = "committed PMC measurement (profiles/pmc_traffic.json: " + str(pj.get("source", "tools/pmc_traffic.sh")) + "), not measured in this run"
+            traffic, traffic_source = int(pj["traffic_bytes_per_launch"]), src
+            straffic, ssource = int(pj["also"]["k_index_splat"]["traffic_bytes_per_launch"]), src
+        except Exception:
+            pass
+        roofline = {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                    "avg_us": round(float(kt.avg_us), 3), "timer": "dispatch begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of every level-0 launch of the " + where,
+                    "launches_sampled": int(kt.launches), "algorithmic_bytes_per_launch": int(kt.bytes_per_launch),
+                    "algorithmic_bytes_per_launch_survey_48B": int(kt.bytes_per_launch_survey),
+                    "frac_survey_48B": round(achieved_survey / HBM_PEAK_GBS, 4), "frac_of_achievable_6300": round(achieved / 6300.0, 4)}
+        ks = KT()
+        if lib.ef_get_splat_timing(ef.h, C.byref(ks)) == 0 and ks.launches > 0:
+            ach = ks.bytes_per_launch / (ks.avg_us * 1e-6) / 1e9
+            roofline_splat = {"bound": "hbm", "kernel": ks.name.decode(), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": straffic, "traffic_source": ssource, "avg_us": round(float(ks.avg_us), 3),
+                              "launches_sampled": int(ks.launches), "algorithmic_bytes_per_launch": int(ks.bytes_per_launch)}
+    return roofline, roofline_splat
+
+
+def make_engine(api, w, h, device, stream, close_loops=False, graph=False, per_step=False):
+    sc = w / 640.0
+    ef = api.ElasticFusion(width=w, height=h, fx=528.0 * sc, fy=528.0 * sc, cx=320.0 * sc, cy=240.0 * sc, device=device, stream=stream,
+                           maxSurfels=max(4 * 1024 * 1024, 6 * w * h), **(dict(closeLoops=True, timeDelta=200) if close_loops else {}))
+    if per_step:
+        ef.setPersistentTracker(False)
+    if graph:
+        ef.setGraphReplay(True)
+    if close_loops:   # the reference's closed-loop mode: fern database + global closure, then the local closure, built-in optimiser
+        ef.useBuiltinLoopSolver(True)
+        ef.enableGlobalClosure(seed=0)
+    return ef
+
+
+def preseed(ef, seed, w, h, n, frame0):
+    """a map of ~n surfels sampled on the scene's surfaces instead of the first frame's seeding"""
+    from elasticfusion_amd import synth
+    m = synth.sample_surfels(synth.Sequence(seed, width=w, height=h), n)
+    ef.restore(dict(map=m, tick=2, qt=np.array([0, 0, 0, 1, 0, 0, 0], np.float64), rgb=frame0[0], depth=frame0[1]))
+    return len(m)
+
+
+def side_leg(torch, api, frames, dev, w, h, device, stream, steps, warmup, preroll, *, host_frames=False, close_loops=False, graph=False,
+             track_only=False, per_step=False, seed=None, preseed_n=0, probe_frames=0):
+    """one extra, separately timed replay of the same frames on a fresh engine (never the headline value) -> dict"""
+    ef = make_engine(api, w, h, device, stream, close_loops=close_loops, graph=graph, per_step=per_step)
+    k0 = 0
+    if preseed_n:
+        surfels = preseed(ef, seed, w, h, preseed_n, frames[0])
+        k0 = 1
+
+    def step(k):
+        if host_frames:
+            ef.processFrame(frames[k][0], frames[k][1], k * 33333)
+        else:
+            ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
+
+    first = k0 + (0 if preseed_n else 1) + preroll + warmup
+    for k in range(k0, first):
+        step(k)
+    if track_only:
+        ef.setTrackOnly(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(first, first + steps):
+        step(k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"value": round(steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps}
+    if probe_frames:
+        lib = api.lib()
+        lib.ef_kernel_timing(ef.h, C.c_int(1))
+        for k in range(first + steps, first + steps + probe_frames):
+            step(k)
+        torch.cuda.synchronize()
+        r, rs = rooflines(lib, ef, w, h, f"{probe_frames} frames that follow the timed region")
+        out["roofline"], out["roofline_index_splat"] = r, rs
+    T = ef.get_T_wc()
+    Tgt = frames[first + steps + probe_frames - 1][2]
+    out["pose_err_vs_generating_traj_m"] = round(float(np.linalg.norm(T[:3, 3] - Tgt[:3, 3])), 5)
+    out["surfels_end"] = int(ef.lastCount())
+    if preseed_n:
+        out["surfels_preseeded"] = int(surfels)
+    ef.close()
+    return out
+
+
 def main():
     import faulthandler
     faulthandler.enable()
-    # a wedged GPU runtime must not hold the caller for ever: after 9 minutes dump every thread's stack and leave
+    # a wedged GPU runtime must not hold the caller for ever: 9 minutes for the GPU sections, then every thread's stack and out
+    # (cancelled before the CPU baseline legs, which are bounded by their own budgets)
     faulthandler.dump_traceback_later(540, exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,16 +251,26 @@ def main():
     ap.add_argument("--probe-inside", action="store_true", help="development: sample the roofline kernels inside the timed region (1 frame in 8) "
                     "instead of on the frames that follow it")
     ap.add_argument("--frames-cache", default=None, help="development: keep the generated synthetic frames in this .npz between runs "
-                    "(A/B runs of library variants on one GPU box, tools/gpu_r2.sh); never used by the driver")
-    ap.add_argument("--width", type=int, default=W, help="1280 (with --height 960) = BASELINE.json configs[2]: the first frame seeds "
-                    "~1.2 M surfels, i.e. the 1 M-surfel HBM-bound map; NOT the headline metric")
+                    "(A/B runs of library variants on one GPU box, tools/gpu_ab.sh); never used by the driver")
+    ap.add_argument("--width", type=int, default=W, help="1280 (with --height 960) = BASELINE.json configs[2]; NOT the headline metric")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--host-frames", action="store_true", help="hand the frames over as HOST buffers (ef_process_frame: copy into pinned "
                     "staging + PCIe upload inside the timed region) - the PCIe-inclusive rate of DESIGN.md, never the headline value")
     ap.add_argument("--close-loops", action="store_true", help="closeLoops = true with the reference's default time window of 200 "
-                    "frames: every frame also runs the global closure (fern match on the mid-frame view, keyframe store at the end: two "
-                    "synchronisations) and the local one (inactive-model prediction, second tracker, gates, built-in optimiser: one "
-                    "synchronisation).  NOT the headline metric, which is open loop (-o)")
+                    "frames: every frame also runs the global closure (fern match on the mid-frame view, keyframe store at the end) and the "
+                    "local one (inactive-model prediction, second tracker, gates, built-in optimiser).  NOT the headline metric, which is "
+                    "open loop (-o)")
+    ap.add_argument("--graph", action="store_true", help="BASELINE.json configs[4]: the tracker's launches captured once into a hipGraph and "
+                    "replayed (ef_set_graph_replay); bit-identical results, NOT the headline (measured: no faster, the host is not the limit)")
+    ap.add_argument("--track-only", action="store_true", help="BASELINE.json configs[4]: odometry only on the map the pre-roll built "
+                    "(ef_set_track_only during the timed region: pre-process, track, predict; no fusion) -> pairs/s")
+    ap.add_argument("--library", default=None, help="'nofma' = libefusion_hip_nofma.so, the reference-rounding build (bit for bit the "
+                    "reference's own sources compiled without contraction), or a path; default: the shipped libefusion_hip.so")
+    ap.add_argument("--preseed", type=int, default=0, help="SURVEY 8(d) config 3: start from a map of about this many surfels sampled on the "
+                    "scene's surfaces (radius 4 mm, confidence 12) brought in with ef_map_upload + ef_restore_state instead of seeding from "
+                    "the first frame; with --width 1280 --height 960 --preseed 1048576 = BASELINE.json configs[2], the HBM-bound map")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the extra keys of the N = 1 line (host-frame path, reference-rounding "
+                    "build, closed loop, odometry only, hipGraph replay, configs[2])")
     ap.add_argument("--per-step-tracker", action="store_true", help="development (A/B): the round-2 tracker script, one launch per step, instead "
                     "of the persistent small-level launch (ef_set_persistent_tracker(ctx, 0)); results are bit-identical")
     a = ap.parse_args()
@@ -151,19 +280,34 @@ def main():
     rank, local_rank, world = multi.rank_info()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    plain = not (a.host_frames or a.close_loops or a.graph or a.track_only or a.library or a.preseed or a.per_step_tracker or a.probe_inside)
+    side = world == 1 and plain and (w, h) == (W, H) and not a.no_side_legs   # the extra keys ride on the default N = 1 line only
 
     # synthetic frames first: the generator forks worker processes, which must happen before HIP / RCCL are initialised
     # frame 0 seeds the map (tick 1); pre-roll and warm-up are never timed; the last PROBE_FRAMES frames continue the same replay with
     # the per-kernel sampling switched on (a sampled launch carries profiling timestamps, which the timed region is kept free of)
     n_frames = 1 + PREROLL + a.warmup + a.steps + PROBE_FRAMES
+    seed = multi.sequence_seed(rank)
     cache = f"{a.frames_cache}.{rank}.{w}x{h}.{n_frames}.npz" if a.frames_cache else None
     if cache and os.path.exists(cache):
         z = np.load(cache)
         frames = [(z["rgb"][k], z["depth"][k], z["T"][k]) for k in range(n_frames)]
     else:
-        frames = generate_frames(multi.sequence_seed(rank), n_frames, w, h, ranks_on_host=world)
+        frames = generate_frames(seed, n_frames, w, h, ranks_on_host=world)
         if cache:
             np.savez(cache, rgb=np.stack([f[0] for f in frames]), depth=np.stack([f[1] for f in frames]), T=np.stack([f[2] for f in frames]))
+    big = None
+    BIG = dict(w=1280, h=960, preroll=16, warmup=4, steps=40, probe=8, preseed=1 << 20)
+    if side:   # configs[2] for the extra key: 1280x960, ~1 M pre-seeded surfels (fewer frames: the map is mature from the start)
+        nb = 1 + BIG["preroll"] + BIG["warmup"] + BIG["steps"] + BIG["probe"]
+        bcache = f"{a.frames_cache}.{rank}.1280x960.{nb}.npz" if a.frames_cache else None
+        if bcache and os.path.exists(bcache):
+            z = np.load(bcache)
+            big = [(z["rgb"][k], z["depth"][k], z["T"][k]) for k in range(nb)]
+        else:
+            big = generate_frames(seed, nb, BIG["w"], BIG["h"])
+            if bcache:
+                np.savez(bcache, rgb=np.stack([f[0] for f in big]), depth=np.stack([f[1] for f in big]), T=np.stack([f[2] for f in big]))
 
     import torch
     import torch.distributed as dist
@@ -173,22 +317,22 @@ def main():
     if world > 1:
         multi.init_process_group("nccl", local_rank)
 
-    from elasticfusion_amd import api
+    from elasticfusion_amd import api, build
+    if a.library:
+        api.use_library(build.NOFMA_LIB if a.library == "nofma" else a.library)
 
     # a real (non-null) stream, made torch's current one: the engine enqueues on it, torch.cuda.synchronize() covers it,
-    # and it can be captured into a hipGraph (EF_GRAPH=1), which the legacy null stream cannot
+    # and it can be captured into a hipGraph (--graph), which the legacy null stream cannot
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    sc = w / 640.0
-    ef = api.ElasticFusion(width=w, height=h, fx=528.0 * sc, fy=528.0 * sc, cx=320.0 * sc, cy=240.0 * sc, device=local_rank, stream=stream,
-                           maxSurfels=max(4 * 1024 * 1024, 6 * w * h), **(dict(closeLoops=True, timeDelta=200) if a.close_loops else {}))
-    if a.per_step_tracker:
-        ef.setPersistentTracker(False)
-    if a.close_loops:   # the reference's closed-loop mode: fern database + global closure, then the local closure, built-in optimiser
-        ef.useBuiltinLoopSolver(True)
-        ef.enableGlobalClosure(seed=0)
+    ef = make_engine(api, w, h, local_rank, stream, close_loops=a.close_loops, graph=a.graph, per_step=a.per_step_tracker)
     dev = [(api.DevBuf.from_array(r), api.DevBuf.from_array(d)) for r, d, _ in frames]
+    k0 = 0
+    n_pre = 0
+    if a.preseed:
+        n_pre = preseed(ef, seed, w, h, a.preseed, frames[0])
+        k0 = 1
 
     def step(k):
         if a.host_frames:
@@ -197,12 +341,13 @@ def main():
             ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
 
     first_timed = 1 + PREROLL + a.warmup
-    for k in range(first_timed):
+    for k in range(k0, first_timed):
         step(k)
+    if a.track_only:
+        ef.setTrackOnly(True)
     # per-kernel HIP-event sampling of the dominant kernel inside the timed region (1 frame in 8)
     lib = api.lib()
-    have_ktime = hasattr(lib, "ef_kernel_timing")
-    if have_ktime and a.probe_inside:
+    if a.probe_inside:
         lib.ef_kernel_timing(ef.h, C.c_int(8))
     torch.cuda.synchronize()
     if world > 1:
@@ -216,7 +361,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if have_ktime and not a.probe_inside:   # the same replay goes on; every level-0 accumulation launch and every first index splat is sampled
+    if not a.probe_inside:   # the same replay goes on; every level-0 accumulation launch and every first index splat is sampled
         lib.ef_kernel_timing(ef.h, C.c_int(1))
         for k in range(first_timed + a.steps, first_timed + a.steps + PROBE_FRAMES):
             step(k)
@@ -239,54 +384,14 @@ def main():
         return
     agg = multi.aggregate(allstats)
     t_max, value = agg["t_max"], agg["value"]
-
-    roofline = None
-    if have_ktime:
-        class KT(C.Structure):
-            _fields_ = [("name", C.c_char_p), ("avg_us", C.c_float), ("launches", C.c_int), ("bytes_per_launch", C.c_double),
-                        ("bytes_per_launch_survey", C.c_double)]
-        kt = KT()
-        if lib.ef_get_kernel_timing(ef.h, C.byref(kt)) == 0 and kt.launches > 0:
-            # avg_us: the dispatches' own begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of the sampled launches
-            # inside the timed region -- the duration rocprofv3 --kernel-trace reports for the same kernel (profiles/)
-            achieved = kt.bytes_per_launch / (kt.avg_us * 1e-6) / 1e9
-            achieved_survey = kt.bytes_per_launch_survey / (kt.avg_us * 1e-6) / 1e9
-            # HBM-side bytes per launch: rocprofv3 PMC passes cannot run inside this process, so this is the measurement
-            # COMMITTED under profiles/ by tools/pmc_traffic.sh for this kernel and workload (see traffic_source), not a live value
-            traffic, traffic_source = None, None
-            try:
-                if (w, h) != (W, H):
-                    raise KeyError("the committed PMC measurement is for the default workload")
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    pj = json.load(f)
-                traffic = int(pj["traffic_bytes_per_launch"])
-                traffic_source = "committed PMC measurement (profiles/pmc_traffic.json: " + str(pj.get("source", "tools/pmc_traffic.sh")) + "), not measured in this run"
-            except Exception:
-                pass
-            roofline = {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                        "avg_us": round(float(kt.avg_us), 3), "timer": "dispatch begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of every level-0 launch of the "
-                        + (f"{PROBE_FRAMES} frames that follow the timed region (same replay, same map)" if not a.probe_inside else "sampled frames inside the timed region"),
-                        "launches_sampled": int(kt.launches), "algorithmic_bytes_per_launch": int(kt.bytes_per_launch),
-                        "algorithmic_bytes_per_launch_survey_48B": int(kt.bytes_per_launch_survey),
-                        "frac_survey_48B": round(achieved_survey / HBM_PEAK_GBS, 4), "frac_of_achievable_6300": round(achieved / 6300.0, 4)}
-    roofline_splat = None
-    if have_ktime and hasattr(lib, "ef_get_splat_timing"):
-        ks = KT()
-        if lib.ef_get_splat_timing(ef.h, C.byref(ks)) == 0 and ks.launches > 0:
-            ach = ks.bytes_per_launch / (ks.avg_us * 1e-6) / 1e9
-            straffic, ssource = None, None
-            try:   # the committed PMC measurement of this kernel on the default workload (see roofline.traffic_source)
-                if (w, h) == (W, H):
-                    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                        pj = json.load(f)
-                    straffic = int(pj["also"]["k_index_splat"]["traffic_bytes_per_launch"])
-                    ssource = "committed PMC measurement (profiles/pmc_traffic.json: " + str(pj.get("source", "tools/pmc_traffic.sh")) + "), not measured in this run"
-            except Exception:
-                straffic, ssource = None, None
-            roofline_splat = {"bound": "hbm", "kernel": ks.name.decode(), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": straffic, "traffic_source": ssource, "avg_us": round(float(ks.avg_us), 3),
-                              "launches_sampled": int(ks.launches), "algorithmic_bytes_per_launch": int(ks.bytes_per_launch)}
+    roofline, roofline_splat = rooflines(lib, ef, w, h, (f"{PROBE_FRAMES} frames that follow the timed region (same replay, same map)"
+                                                         if not a.probe_inside else "sampled frames inside the timed region"))
+    mode = ("HOST frames (pinned staging + PCIe upload timed), " if a.host_frames else "") + \
+           ("closeLoops (fern database + global closure + local closure every frame, timeDelta 200), " if a.close_loops else "open loop, ") + \
+           ("tracker replayed from a hipGraph, " if a.graph else "") + ("ODOMETRY ONLY in the timed region (no fusion), " if a.track_only else "") + \
+           ("one launch per tracker step (round-2 script), " if a.per_step_tracker else "") + \
+           (f"reference-rounding build ({os.path.basename(api.LIB_PATH)}), " if a.library else "") + \
+           (f"map pre-seeded with {n_pre} surfels sampled on the scene (radius 4 mm, confidence 12), " if a.preseed else "")
     out = {
         "metric": f"frames/s per GPU, {w}x{h} 3-level ICP+fuse",
         "value": round(value, 2),
@@ -300,12 +405,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{w}x{h} synthetic RGB-D replay (box+spheres, Lissajous trajectory), "
-                               + ("HOST frames (pinned staging + PCIe upload timed), " if a.host_frames else "")
-                               + ("closeLoops (fern database + global closure + local closure every frame, timeDelta 200), " if a.close_loops else "open loop, ") +
+        "config": {"workload": f"{w}x{h} synthetic RGB-D replay (box+spheres, Lissajous trajectory), " + mode +
                                "SO(3)+ICP+RGB 3-level tracking (10/5/4 its) + surfel fuse/clean/predict; "
                                + ("stand-in for configs[1] (dyson_lab.klg is not available offline)" if (w, h) == (W, H) else
-                                  "configs[2]: 1280x960 stream, ~1.2 M-surfel map"),
+                                  "configs[2]: 1280x960 stream"),
                    "resolution": [w, h], "sequences": world, "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
                    "preroll_frames": PREROLL, "surfels_end": int(count),
                    "pose_err_vs_generating_traj_m": round(err_t, 5),
@@ -313,24 +416,68 @@ def main():
         "roofline": roofline,
         "roofline_index_splat": roofline_splat,
     }
+    out["config"]["stable_surfels_end"] = int(stable)
+    gpu_poses = None
+    try:
+        gpu_poses, _ = ef.trajectory()
+    except Exception:
+        pass
+    ef.close()
+    if side:
+        # Extra keys of the N = 1 line: the same frames replayed on fresh engines in the other modes a reader of the headline asks
+        # about.  Each leg is timed on its own after the headline's clock has stopped; none of them is `value`.
+        legs = {}
+        common = dict(steps=a.steps, warmup=a.warmup, preroll=PREROLL)
+        try:
+            legs["host_frames_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, host_frames=True, **common)
+            legs["host_frames_fps"]["what"] = "the B1 signature: frames handed over as HOST pointers (ef_process_frame: pinned staging + PCIe upload inside the timed region)"
+            legs["graph_replay_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, graph=True, **common)
+            legs["graph_replay_fps"]["what"] = "BASELINE configs[4]: the tracker's launches replayed from a hipGraph (ef_set_graph_replay), full frame"
+            legs["track_only_pairs_per_s"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, track_only=True, **common)
+            legs["track_only_pairs_per_s"]["what"] = ("BASELINE configs[4] / configs[0] on the GPU: odometry only (pre-process + SO(3) + 19 ICP+RGB iterations + "
+                                                      "prediction at the new pose) on the mature map, no fusion; beside cpu_baseline.tracking_only")
+            legs["per_step_tracker_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, per_step=True, **common)
+            legs["per_step_tracker_fps"]["what"] = "the round-2 tracker script (one launch per step) on this box, for the persistent launch's A/B"
+            legs["close_loops_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, close_loops=True, **common)
+            legs["close_loops_fps"]["what"] = "the reference's DEFAULT mode (closeLoops = true, timeDelta 200): fern database + global closure + local closure every frame"
+        except Exception as e:   # never let a side figure cost the line
+            legs["error"] = repr(e)
+        try:
+            bdev = [(api.DevBuf.from_array(r), api.DevBuf.from_array(d)) for r, d, _ in big]
+            leg = side_leg(torch, api, big, bdev, BIG["w"], BIG["h"], local_rank, stream, BIG["steps"], BIG["warmup"], BIG["preroll"],
+                           seed=seed, preseed_n=BIG["preseed"], probe_frames=BIG["probe"])
+            leg["what"] = ("BASELINE configs[2] as SURVEY 8(d) defines it: 1280x960 stream on a map pre-seeded with ~1 M surfels (ef_map_upload of "
+                           "surfels sampled on the scene, radius 4 mm, confidence 12); rooflines by the engine's dispatch-timestamp events")
+            legs["config2_1280x960_1M"] = leg
+            del bdev
+        except Exception as e:
+            legs["config2_1280x960_1M"] = {"error": repr(e)}
+        try:   # the build whose every result is bit-identical to the reference's own sources (compiled without contraction)
+            api.use_library(build.NOFMA_LIB)
+            legs["reference_rounding_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, **common)
+            legs["reference_rounding_fps"]["what"] = ("libefusion_hip_nofma.so (INTEGRATION.md 'reference rounding'): no fused multiply-add anywhere, bit for bit the "
+                                                     "reference's .cu / .cpp / GLSL arithmetic (tests/test_gpu_vs_reference.py, test_gpu_steady.py)")
+        except Exception as e:
+            legs["reference_rounding_fps"] = {"error": repr(e)}
+        finally:
+            api.use_library(None)
+        out["side_legs"] = legs
+    faulthandler.cancel_dump_traceback_later()
     if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (the scaling runs reuse the N=1 figure)
         oracle_poses = []
         out["cpu_baseline"] = cpu_baseline(frames[: min(len(frames), 40)], w=w, h=h, poses_out=oracle_poses)
         # BASELINE.json's metric names "ATE vs reference pose": the CPU leg above ran the reference's restatement over the first frames
         # of this very replay, so the GPU run's logged trajectory can be held against it frame by frame (bit-identical expected: 0.0)
         try:
-            gpu_poses, _ = ef.trajectory()
-            m = min(len(oracle_poses), len(gpu_poses))
-            if m > 0 and not a.close_loops:
+            m = min(len(oracle_poses), len(gpu_poses)) if gpu_poses is not None else 0
+            if m > 0 and not a.close_loops and not a.preseed and not a.library:
                 d = np.array([gpu_poses[k][:3, 3] - oracle_poses[k][:3, 3] for k in range(m)])
                 rot = max(float(np.abs(gpu_poses[k][:3, :3] - oracle_poses[k][:3, :3]).max()) for k in range(m))
                 out["ate_vs_oracle"] = {"rmse_m": float(np.sqrt((d * d).sum(1).mean())), "max_m": float(np.abs(d).max()), "max_rotation_entry_diff": rot,
                                         "frames": m, "what": "logged GPU poses of the first frames of this run against the CPU oracle's poses on the same frames"}
         except Exception as e:   # never let the side figure cost the line
             out["ate_vs_oracle"] = {"error": repr(e)}
-    out["config"]["stable_surfels_end"] = int(stable)
     print(json.dumps(out), flush=True)
-    ef.close()
     del dev
     torch.cuda.synchronize()
     if world > 1:

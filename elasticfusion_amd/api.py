@@ -586,9 +586,14 @@ class ElasticFusion:
 
     def getFerns(self):
         """the fern database of the context (Ferns view: len() = frames.size(), lastClosest(), frame(i))"""
-        return self._closure.ferns
+        return self.closure().ferns
 
     def closure(self):
+        # every look at the closure object goes through ef_get_closure: the engine defers the end-of-frame bookkeeping (keyframe decision,
+        # trajectory entry) to its next synchronisation point, and ef_get_closure is one
+        lib().ef_get_closure.restype = P
+        lib().ef_get_closure.argtypes = [P]
+        lib().ef_get_closure(self.h)
         return self._closure
 
     def globalLoop(self) -> GlobalLoop:
@@ -625,6 +630,10 @@ class ElasticFusion:
 
     def predict(self):
         _chk(lib().ef_predict(self.h), self.h)
+
+    def setTrackOnly(self, on=True):
+        """odometry on a frozen map: track + predict, no fusion (ef_set_track_only; BASELINE.json configs[4])"""
+        _chk(lib().ef_set_track_only(self.h, c_i(int(on))), self.h)
 
     def setPersistentTracker(self, on=True):
         """small pyramid levels + SO(3) in one persistent launch (default) or one launch per step (ef_set_persistent_tracker)"""

@@ -102,7 +102,7 @@ struct ef_ctx {
   efm::PredictMaps old{};                  // IndexMap's oldImage/oldVertex/oldNormal/oldTime textures (IndexMap.h:114-128)
   float* cons_dev = nullptr;               // (W/20) x (H/20) x {x, y, z, inactive time}
   float* h_cons = nullptr;                 // pinned
-  eft::TrackState* h_states = nullptr;     // pinned: [0] frame-to-model, [1] model-to-model
+  eft::TrackState* h_states = nullptr;     // pinned: [0] frame-to-model, [1] model-to-model / fern tracker, [2] frame-to-model at the end of the frame
   ef_loop_solver solver = nullptr;
   void* solver_user = nullptr;
   bool builtin_solver = false;             // ef_use_builtin_loop_solver: efd::solve_local where Deformation::constrain stands
@@ -127,6 +127,18 @@ struct ef_ctx {
   eft::Intr intr3{};
   float4* fern_maps_dev = nullptr;         // fern vertices | fern normals | view vertices | view normals (+ a zero image)
   float* h_nodes_pinned = nullptr;         // graph nodes sampled at the end of the previous frame (Deformation::sampleGraphModel, :593)
+  // fern coding on the device (k_fern_codes): the table, the codes of the view just coded (num bytes, padded to 512, + their count),
+  // pinned landing zones for the mid-frame codes and for the END-of-frame record (codes, view, pose, nodes), which is only looked at
+  // at the next frame's first synchronisation (Ferns::addFrame's verdict matters to nobody before the next findFrame)
+  int* fern_table_dev = nullptr;
+  int fern_num = 0, fern_table_version = -1;
+  uint8_t* fern_codes_dev = nullptr;       // FERN_CODES_BYTES
+  uint8_t* h_codes = nullptr;              // pinned, mid-frame
+  uint8_t* h_codes_end = nullptr;          // pinned, end of frame
+  uint8_t* h_view_end = nullptr;           // pinned, end of frame: image | vertices | normals
+  hipEvent_t ev_end_record = nullptr;
+  bool end_pending = false, end_lost = false;
+  int end_tick = 0;
   int n_nodes_host = 0;
   double h_pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   // relocalisation (ef_set_relocalisation; ElasticFusion.h:283-286,311-312)
@@ -136,6 +148,7 @@ struct ef_ctx {
   // hipGraph replay of the tracker (BASELINE.json configs[4]): the ~70 launches of getIncrementalTransformation are
   // captured once per pyramid parity (the SO(3) reference / frame intensity buffers swap every frame) and replayed
   bool use_graph = false;
+  bool track_only = false;       // ef_set_track_only: odometry on a frozen map (BASELINE.json configs[4])
   bool persistent = true;        // ef_set_persistent_tracker: small pyramid levels + SO(3) in one persistent launch (k_track_small)
   struct TrackGraph { hipGraphExec_t exec = nullptr; const void* key = nullptr; eft::TrackParams tp{}; eft::TrackTail tail{}; };
   TrackGraph tgraph[2];
@@ -224,6 +237,36 @@ __global__ void k_resize_nearest(const T* __restrict__ src, int cols, int dw, in
   const int b = i / dw, a = i - b * dw;
   dst[i] = src[(size_t)(b * factor + factor / 2) * cols + (a * factor + factor / 2)];
 }
+// Ferns.cpp:97-118 / :186-208 on the device: the 4-bit code of every fern on the view Resize::image / Resize::vertex would produce
+// (NEAREST, texel (f x + f / 2, f y + f / 2) of the full-resolution fill-in maps), 255 where the depth is not positive, and the number
+// of valid codes behind them.  One workgroup of FERN_CODES_PAD threads; table6 rows {x, y, r, g, b, d}.
+constexpr int FERN_CODES_PAD = 512, FERN_CODES_BYTES = FERN_CODES_PAD + 16;
+__global__ void __launch_bounds__(FERN_CODES_PAD) k_fern_codes(const uchar4* __restrict__ image, const float4* __restrict__ vertex, int cols, int factor,
+                                                              const int* __restrict__ table6, int num, uint8_t* __restrict__ codes) {
+  __shared__ int wsum[FERN_CODES_PAD / 64];
+  const int i = threadIdx.x;
+  uint8_t code = 255;
+  int good = 0;
+  if (i < num) {
+    const int x = table6[i * 6], y = table6[i * 6 + 1];
+    const size_t texel = (size_t)(y * factor + factor / 2) * cols + (x * factor + factor / 2);
+    const float z = vertex[texel].z;
+    if (z > 0) {
+      const uchar4 p = image[texel];
+      code = (uint8_t)((p.x > table6[i * 6 + 2]) << 3 | (p.y > table6[i * 6 + 3]) << 2 | (p.z > table6[i * 6 + 4]) << 1 | ((int)(z * 1000.0f) > table6[i * 6 + 5]));
+      good = 1;
+    }
+  }
+  codes[i] = code;
+  for (int off = 32; off > 0; off >>= 1) good += __shfl_down(good, off, 64);
+  if ((i & 63) == 0) wsum[i >> 6] = good;
+  __syncthreads();
+  if (i == 0) {
+    int g = 0;
+    for (int w = 0; w < FERN_CODES_PAD / 64; ++w) g += wsum[w];
+    *(int*)(codes + FERN_CODES_PAD) = g;
+  }
+}
 __global__ void k_set_count(unsigned* count_dev, unsigned v) {
   if (threadIdx.x == 0) *count_dev = v;
 }
@@ -279,34 +322,96 @@ bool reloc_covariance_ok(const eft::TrackState& h) {
   return true;
 }
 
-// The 1/8-resolution views of the fill-in maps the fern database works on (Ferns.cpp:91-93,178-180: Resize::image / Resize::vertex x2),
-// the current pose and (optionally) a fresh sample of the graph nodes, brought to the host with ONE synchronisation.
-int read_fern_view(ef_ctx* c, bool with_nodes) {
+// The 1/8-resolution views of the fill-in maps (Ferns.cpp:91-93,178-180: Resize::image / Resize::vertex x2) into a pinned buffer
+// (image | vertices | normals); enqueued only, the caller synchronises
+int enqueue_fern_view(ef_ctx* c, uint8_t* h_dst) {
   hipStream_t s = c->stream;
   const int W = c->cam.cols, dw = c->fern_w, dh = c->fern_h, n = dw * dh;
   const dim3 g((unsigned)((n + 255) / 256));
   hipLaunchKernelGGL(k_resize_nearest<uint32_t>, g, dim3(256), 0, s, (const uint32_t*)c->fm.image, W, dw, dh, 8, (uint32_t*)c->view_img_dev);
   hipLaunchKernelGGL(k_resize_nearest<float4>, g, dim3(256), 0, s, (const float4*)c->fm.vertex, W, dw, dh, 8, c->view_vert_dev);
   hipLaunchKernelGGL(k_resize_nearest<float4>, g, dim3(256), 0, s, (const float4*)c->fm.normal, W, dw, dh, 8, c->view_norm_dev);
-  EF_HIP(c, hipMemcpyAsync(c->h_view, c->view_img_dev, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-  EF_HIP(c, hipMemcpyAsync(c->h_view + (size_t)n * 4, c->view_vert_dev, (size_t)n * 16, hipMemcpyDeviceToHost, s));
-  EF_HIP(c, hipMemcpyAsync(c->h_view + (size_t)n * 20, c->view_norm_dev, (size_t)n * 16, hipMemcpyDeviceToHost, s));
-  EF_HIP(c, hipMemcpyAsync(&c->h_states[0], c->st, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
-  if (with_nodes) {   // Deformation::sampleGraphModel at the end of the frame (ElasticFusion.cpp:593): every 5000th surfel of the new map
-    unsigned* n_dev = (unsigned*)(c->nodes_dev + (size_t)1024 * 4);
-    efm::sample_graph(c->maps[c->cur], &c->st->map_counts[c->cur], 5000, 1023, c->nodes_dev, n_dev, s);
-    EF_HIP(c, hipMemcpyAsync(c->h_nodes_pinned, c->nodes_dev, ((size_t)1024 * 4 + 1) * sizeof(float), hipMemcpyDeviceToHost, s));
+  EF_HIP(c, hipMemcpyAsync(h_dst, c->view_img_dev, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  EF_HIP(c, hipMemcpyAsync(h_dst + (size_t)n * 4, c->view_vert_dev, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+  EF_HIP(c, hipMemcpyAsync(h_dst + (size_t)n * 20, c->view_norm_dev, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+  return EF_OK;
+}
+// the fern codes of the current fill-in maps (k_fern_codes) into a pinned buffer; enqueued only
+int enqueue_fern_codes(ef_ctx* c, uint8_t* h_dst) {
+  hipStream_t s = c->stream;
+  ef_ferns* F = ef_closure_ferns(c->closure);
+  if (ef_ferns_table_version(F) != c->fern_table_version) {   // first use, or ef_ferns_set_table since: (rare) synchronous upload
+    std::vector<int> t((size_t)c->fern_num * 6);
+    if (ef_ferns_get_table(F, t.data()) != EF_OK) { c->err = "ef_ferns_get_table failed"; return EF_EINVAL; }
+    EF_HIP(c, hipStreamSynchronize(s));
+    EF_HIP(c, hipMemcpy(c->fern_table_dev, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->fern_table_version = ef_ferns_table_version(F);
   }
-  EF_HIP(c, hipStreamSynchronize(s));
+  hipLaunchKernelGGL(k_fern_codes, dim3(1), dim3(FERN_CODES_PAD), 0, s, (const uchar4*)c->fm.image, (const float4*)c->fm.vertex, c->cam.cols, 8,
+                     (const int*)c->fern_table_dev, c->fern_num, c->fern_codes_dev);
+  EF_HIP(c, hipMemcpyAsync(h_dst, c->fern_codes_dev, FERN_CODES_BYTES, hipMemcpyDeviceToHost, s));
+  return EF_OK;
+}
+void pose_of_state(const eft::TrackState& h, double* T16) {
   efl::SE3 T;
-  for (int i = 0; i < 4; ++i) T.q[i] = c->h_states[0].q[i];
-  for (int i = 0; i < 3; ++i) T.t[i] = c->h_states[0].t[i];
-  efl::se3_matrix(T, c->h_pose);
-  if (with_nodes) {
-    unsigned nn = 0;
-    memcpy(&nn, c->h_nodes_pinned + (size_t)1024 * 4, sizeof(unsigned));
-    c->n_nodes_host = (int)nn;
+  for (int i = 0; i < 4; ++i) T.q[i] = h.q[i];
+  for (int i = 0; i < 3; ++i) T.t[i] = h.t[i];
+  efl::se3_matrix(T, T16);
+}
+// ef_view_fetch of the mid-frame view: Ferns::findFrame asks for it only when a keyframe passed the code gates (one more synchronisation,
+// in those frames only); the fill-in maps still hold the mid-frame prediction
+int fetch_mid_view(void* user, const uint8_t** rgb, int* ch, const float** verts, const float** norms) {
+  ef_ctx* c = (ef_ctx*)user;
+  const int r = enqueue_fern_view(c, c->h_view);
+  if (r != EF_OK) return r;
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  const size_t n = (size_t)c->fern_w * c->fern_h;
+  *rgb = c->h_view; *ch = 4; *verts = (const float*)(c->h_view + n * 4); *norms = (const float*)(c->h_view + n * 20);
+  return EF_OK;
+}
+// ... and of the end-of-frame view, which was copied with the end-of-frame record
+int fetch_end_view(void* user, const uint8_t** rgb, int* ch, const float** verts, const float** norms) {
+  ef_ctx* c = (ef_ctx*)user;
+  const size_t n = (size_t)c->fern_w * c->fern_h;
+  *rgb = c->h_view_end; *ch = 4; *verts = (const float*)(c->h_view_end + n * 4); *norms = (const float*)(c->h_view_end + n * 20);
+  return EF_OK;
+}
+// End of a frame (ElasticFusion.cpp:588-589, 593, 609-618) — ENQUEUED: fern codes and 1/8 view of the final fill-in maps, the pose, a
+// fresh sample of the graph nodes, all into pinned memory behind one event.  Nothing waits for them here.
+int enqueue_end_record(ef_ctx* c) {
+  hipStream_t s = c->stream;
+  int r = enqueue_fern_codes(c, c->h_codes_end);
+  if (r != EF_OK) return r;
+  if (!c->lost) {   // a lost camera stores no keyframe (:601-604): its view is never asked for
+    r = enqueue_fern_view(c, c->h_view_end);
+    if (r != EF_OK) return r;
   }
+  EF_HIP(c, hipMemcpyAsync(&c->h_states[2], c->st, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
+  unsigned* n_dev = (unsigned*)(c->nodes_dev + (size_t)1024 * 4);   // Deformation::sampleGraphModel (:593): every 5000th surfel of the new map
+  efm::sample_graph(c->maps[c->cur], &c->st->map_counts[c->cur], 5000, 1023, c->nodes_dev, n_dev, s);
+  EF_HIP(c, hipMemcpyAsync(c->h_nodes_pinned, c->nodes_dev, ((size_t)1024 * 4 + 1) * sizeof(float), hipMemcpyDeviceToHost, s));
+  EF_HIP(c, hipEventRecord(c->ev_end_record, s));
+  c->end_pending = true;
+  c->end_lost = c->lost;
+  c->end_tick = c->tick;
+  return EF_OK;
+}
+// ... and looked at: pose -> trajectory, codes (+ view, if the frame is kept) -> Ferns::addFrame, the node count.  Called at the next
+// point where the host waits for the stream anyway (the next frame's closures) and by every getter that shows closure state.
+int flush_end_record(ef_ctx* c) {
+  if (!c->closure || !c->end_pending) return EF_OK;
+  EF_HIP(c, hipEventSynchronize(c->ev_end_record));
+  c->end_pending = false;
+  double T[16];
+  pose_of_state(c->h_states[2], T);
+  int good = 0;
+  memcpy(&good, c->h_codes_end + FERN_CODES_PAD, sizeof(int));
+  const int r = c->end_lost ? ef_closure_log_pose(c->closure, T, c->end_tick)
+                            : ef_closure_end_frame_coded(c->closure, c->h_codes_end, good, &fetch_end_view, c, T, c->end_tick);
+  unsigned nn = 0;
+  memcpy(&nn, c->h_nodes_pinned + (size_t)1024 * 4, sizeof(unsigned));
+  c->n_nodes_host = (int)nn;
+  if (r < 0) { c->err = "ef_closure_end_frame failed"; return r; }
   return EF_OK;
 }
 
@@ -359,14 +464,25 @@ int global_loop_closure(ef_ctx* c, int log_slot, int* accepted_with_graph) {
   memset(&G, 0, sizeof(G));
   G.attempted = 1;
   G.closest = -1;
-  const int r0 = read_fern_view(c, false);
+  for (int i = 0; i < 16; ++i) G.T_wc_recovery[i] = (i % 5 == 0) ? 1.0 : 0.0;   // Sophus::SE3d T_wc_est; (Ferns.cpp:236)
+  ef_ferns* F = ef_closure_ferns(c->closure);
+  // Ferns::findFrame only considers keyframes stored more than 300 ticks ago (Ferns.cpp:225).  While there is none — the host knows: it
+  // keeps the database — the answer is -1 whatever the view shows, and nothing has to come back from the device: no synchronisation.
+  if (!ef_closure_candidate_possible(c->closure, c->tick)) return EF_OK;
+  // otherwise: the view's fern codes, computed on the device, + the pose — one small read-back (0.5 KB + the state)
+  int r0 = enqueue_fern_codes(c, c->h_codes);
   if (r0 != EF_OK) return r0;
-  const size_t n = (size_t)c->fern_w * c->fern_h;
+  EF_HIP(c, hipMemcpyAsync(&c->h_states[0], c->st, sizeof(eft::TrackState), hipMemcpyDeviceToHost, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  r0 = flush_end_record(c);   // the previous frame's keyframe decision first: the database findFrame walks must be complete
+  if (r0 != EF_OK) return r0;
+  pose_of_state(c->h_states[0], c->h_pose);
+  int good = 0;
+  memcpy(&good, c->h_codes + FERN_CODES_PAD, sizeof(int));
   if (c->lost) {
-    const int r = ef_closure_relocalise(c->closure, c->h_view, 4, (const float*)(c->h_view + n * 4), (const float*)(c->h_view + n * 20), c->h_pose, c->tick,
-                                        &fern_tracker_device, c, G.T_wc_recovery);
+    const int r = ef_closure_relocalise_coded(c->closure, c->h_codes, good, &fetch_mid_view, c, c->h_pose, c->tick, &fern_tracker_device, c, G.T_wc_recovery);
     if (r < 0) { c->err = "ef_closure_relocalise failed"; return r; }
-    G.closest = ef_ferns_last_closest(ef_closure_ferns(c->closure));
+    G.closest = ef_ferns_last_closest(F);
     if (r == 1) {
       eft::pose_injected(c->st, G.T_wc_recovery, false, 1.0f, false, log_slot >= 0 ? c->traj : nullptr, log_slot, c->stream);
       c->last_frame_recovery = true;
@@ -375,8 +491,8 @@ int global_loop_closure(ef_ctx* c, int log_slot, int* accepted_with_graph) {
   }
   c->loop_graph.assign((size_t)1024 * 16, 0.f);
   int nodes = 0;
-  const int r = ef_closure_global(c->closure, c->h_view, 4, (const float*)(c->h_view + n * 4), (const float*)(c->h_view + n * 20), c->h_pose, c->tick,
-                                  &fern_tracker_device, c, c->h_nodes_pinned, c->n_nodes_host, G.T_wc_recovery, c->loop_graph.data(), &nodes);
+  const int r = ef_closure_global_coded(c->closure, c->h_codes, good, &fetch_mid_view, c, c->h_pose, c->tick, &fern_tracker_device, c, c->h_nodes_pinned,
+                                        c->n_nodes_host, G.T_wc_recovery, c->loop_graph.data(), &nodes);
   if (r < 0) { c->err = "ef_closure_global failed"; return r; }
   G.closest = ef_ferns_last_closest(ef_closure_ferns(c->closure));   // Ferns::lastClosest: -1 unless a keyframe passed every gate
   if (G.closest >= 0) {   // the rows handed to the optimiser: two per fern constraint (the constraint and its pin) + the kept relative ones
@@ -434,6 +550,10 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
   EF_HIP(c, hipMemcpyAsync(&c->h_states[1], c->st2, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
   EF_HIP(c, hipMemcpyAsync(c->h_cons, c->cons_dev, (size_t)cw * ch * 4 * sizeof(float), hipMemcpyDeviceToHost, s));
   EF_HIP(c, hipStreamSynchronize(s));
+  {
+    const int rf = flush_end_record(c);   // the previous frame's end-of-frame record (keyframe decision, graph nodes) has landed by now
+    if (rf != EF_OK) return rf;
+  }
   ef_local_loop& L = c->loop;
   memset(&L, 0, sizeof(L));
   c->loop_constraints.clear();
@@ -689,7 +809,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
         memset(&c->loop, 0, sizeof(c->loop));
       }
     }
-    if (!rgbOnly && c->tracking_ok && !c->lost) {  // ElasticFusion.cpp:536-585
+    if (!rgbOnly && c->tracking_ok && !c->lost && !c->track_only) {  // ElasticFusion.cpp:536-585
       timer_begin(c, "indexMap");
       const bool sample_splat = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0 && c->probe_splat.start;
       efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
@@ -726,14 +846,10 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   timer_end(c, "IndexMap::ACTIVE");
   if (c->closure) {   // :588-589, 593, 609-618: pose -> trajectory, graph nodes re-sampled, final fill-in view -> Ferns::addFrame
     timer_begin(c, "ferns");
-    const int r0 = read_fern_view(c, true);
-    if (r0 != EF_OK) return r0;
-    const size_t n = (size_t)c->fern_w * c->fern_h;
-    const int r = c->lost ? ef_closure_log_pose(c->closure, c->h_pose, c->tick)   // :601-604: no keyframe while lost
-                          : ef_closure_end_frame(c->closure, c->h_view, 4, (const float*)(c->h_view + n * 4), (const float*)(c->h_view + n * 20), c->h_pose,
-                                                 c->tick);
+    int r = flush_end_record(c);           // (normally long done: the frame's closures synchronised)
+    if (r == EF_OK) r = enqueue_end_record(c);   // no synchronisation: looked at when the next frame first waits for the stream
     timer_end(c, "ferns");
-    if (r < 0) { c->err = "ef_closure_end_frame failed"; return r; }
+    if (r != EF_OK) return r;
   }
   EF_HIP(c, hipEventRecord(c->ev_frame_done[c->frame_parity], s));
   if (!c->lost) c->tick++;   // :601-604
@@ -849,7 +965,7 @@ int ctx_init(ef_ctx* c) {
     EF_ALLOC(c, c->cons_dev, (size_t)(W / 20) * (H / 20) * 4 + 4);
     EF_ALLOC(c, c->nodes_dev, (size_t)1024 * 4 + 4);
     EF_HIP(c, hipHostMalloc((void**)&c->h_cons, ((size_t)(W / 20) * (H / 20) * 4 + 4) * sizeof(float)));
-    EF_HIP(c, hipHostMalloc((void**)&c->h_states, 2 * sizeof(eft::TrackState)));
+    EF_HIP(c, hipHostMalloc((void**)&c->h_states, 3 * sizeof(eft::TrackState)));
     hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->st2, (W / 20) * (H / 20), W * H);
   }
   c->traj_cap = 1 << 10;   // doubled on demand (grow_trajectory)
@@ -875,6 +991,10 @@ void ctx_free(ef_ctx* c) {
   if (c->h_cons) (void)hipHostFree(c->h_cons);
   if (c->h_states) (void)hipHostFree(c->h_states);
   if (c->h_view) (void)hipHostFree(c->h_view);
+  if (c->h_view_end) (void)hipHostFree(c->h_view_end);
+  if (c->h_codes) (void)hipHostFree(c->h_codes);
+  if (c->h_codes_end) (void)hipHostFree(c->h_codes_end);
+  if (c->ev_end_record) (void)hipEventDestroy(c->ev_end_record);
   if (c->h_nodes_pinned) (void)hipHostFree(c->h_nodes_pinned);
   if (c->closure) ef_closure_destroy(c->closure);
   for (auto& t : c->timers) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -963,6 +1083,10 @@ int ef_synchronize(ef_ctx* c) {
   if (!c) return EF_EINVAL;
   DeviceGuard dg_(c);
   EF_HIP(c, hipStreamSynchronize(c->stream));
+  {
+    const int rf = flush_end_record(c);
+    if (rf != EF_OK) return rf;
+  }
   for (const eft::Pyramid* p : {&c->pyr, &c->pyr2, &c->pyr3}) {
     const int a = eft::tracker_aborted(*p, c->stream);
     if (a != 0) {
@@ -1078,6 +1202,14 @@ int ef_enable_global_closure(ef_ctx* c, int num_ferns, float photo_thresh, float
   EF_ALLOC(c, c->view_norm_dev, n);
   EF_ALLOC(c, c->fern_maps_dev, 5 * n);   // 4 maps + a zero image (the 1/8 tracker never reads colour: icpWeight = 100)
   EF_HIP(c, hipHostMalloc((void**)&c->h_view, n * 36));
+  EF_HIP(c, hipHostMalloc((void**)&c->h_view_end, n * 36));
+  EF_HIP(c, hipHostMalloc((void**)&c->h_codes, FERN_CODES_BYTES));
+  EF_HIP(c, hipHostMalloc((void**)&c->h_codes_end, FERN_CODES_BYTES));
+  if (num_ferns > FERN_CODES_PAD) { c->err = "ef_enable_global_closure: at most 512 ferns"; return EF_EINVAL; }
+  c->fern_num = num_ferns;
+  EF_ALLOC(c, c->fern_table_dev, (size_t)num_ferns * 6);
+  EF_ALLOC(c, c->fern_codes_dev, (size_t)FERN_CODES_BYTES);
+  EF_HIP(c, hipEventCreateWithFlags(&c->ev_end_record, hipEventDisableTiming));
   EF_HIP(c, hipHostMalloc((void**)&c->h_nodes_pinned, ((size_t)1024 * 4 + 4) * sizeof(float)));
   memset(c->h_nodes_pinned, 0, ((size_t)1024 * 4 + 4) * sizeof(float));
   c->intr3 = eft::Intr{c->cfg.fx / 8, c->cfg.fy / 8, c->cfg.cx / 8, c->cfg.cy / 8};   // Ferns.cpp:31-36
@@ -1126,7 +1258,12 @@ int ef_get_global_loop(ef_ctx* c, ef_global_loop* info) {
   *info = c->gloop;
   return EF_OK;
 }
-ef_closure* ef_get_closure(ef_ctx* c) { return c ? c->closure : nullptr; }
+ef_closure* ef_get_closure(ef_ctx* c) {
+  if (!c) return nullptr;
+  DeviceGuard dg_(c);
+  (void)flush_end_record(c);   // the last frame's keyframe decision and trajectory entry are part of what the caller will look at
+  return c->closure;
+}
 int ef_get_local_loop(ef_ctx* c, ef_local_loop* info, double* constraints, int max_constraints, int* n_out) {
   if (!c || !info) return EF_EINVAL;
   *info = c->loop;
@@ -1153,6 +1290,7 @@ int ef_sample_graph(ef_ctx* c, float* nodes4, int max_nodes, int* n_out) {
   return EF_OK;
 }
 int ef_set_graph_replay(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->use_graph = on != 0; return EF_OK; }
+int ef_set_track_only(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->track_only = on != 0; return EF_OK; }
 int ef_set_persistent_tracker(ef_ctx* c, int on) {
   if (!c) return EF_EINVAL;
   c->persistent = on != 0;
@@ -1201,6 +1339,12 @@ int ef_get_covariance(ef_ctx* c, double* cov36) {
   efl::lu_inverse<double, 6>(h.lastA, cov36);   // host side, like the reference (Eigen on the CPU)
   return EF_OK;
 }
+// developer instrumentation: per-phase clocks of the persistent small-level launch (-DEF_STAGE_CLOCKS builds; tools/small_clocks.py)
+int ef_debug_small_clocks(ef_ctx* c, unsigned long long* out24) {
+  if (!c || !out24) return EF_EINVAL;
+  DeviceGuard dg_(c);
+  return eft::tracker_small_clocks(c->pyr, out24, c->stream) == 0 ? EF_OK : EF_EHIP;
+}
 int ef_debug_clocks(ef_ctx* c, unsigned long long* out16) {
   if (!c || !out16) return EF_EINVAL;
   DeviceGuard dg_(c);
@@ -1216,6 +1360,8 @@ int ef_get_trajectory(ef_ctx* c, double* T16s, int64_t* stamps, int max_frames, 
   int n = (int)c->stamps.size();
   if (n > max_frames) n = max_frames;
   if (T16s && n) {
+    const int rf = flush_end_record(c);
+    if (rf != EF_OK) return rf;
     EF_HIP(c, hipMemcpyAsync(T16s, c->traj, (size_t)n * 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     EF_HIP(c, hipStreamSynchronize(c->stream));
     // "Output deformed pose graph" (ElasticFusion.cpp:107-139): every accepted Deformation::constrain moves the poses logged so far

@@ -57,6 +57,7 @@ struct ef_ferns {
   float photoThresh;
   float fx, fy, cx, cy;   // full-resolution intrinsics
   int lastClosest = -1;
+  int tableVersion = 0;   // bumped by ef_ferns_set_table (a device-side copy of the table knows when to refresh)
   std::vector<Fern> conservatory;
   std::vector<std::unique_ptr<StoredFrame>> frames;
 
@@ -64,18 +65,23 @@ struct ef_ferns {
   void encode(const View& v, std::vector<uint8_t>& codes, int& good, std::vector<int>& coOccurrences) const {
     codes.assign(num, BAD_CODE);
     good = 0;
-    coOccurrences.assign(frames.size(), 0);
     for (int i = 0; i < num; ++i) {
       const Fern& f = conservatory[i];
       const float z = v.z(f.x, f.y);
       if (z > 0) {
         const uint8_t* p = v.px(f.x, f.y);
-        const uint8_t code = (uint8_t)((p[0] > f.rgbd[0]) << 3 | (p[1] > f.rgbd[1]) << 2 | (p[2] > f.rgbd[2]) << 1 | (int(z * 1000.0f) > f.rgbd[3]));
+        codes[i] = (uint8_t)((p[0] > f.rgbd[0]) << 3 | (p[1] > f.rgbd[1]) << 2 | (p[2] > f.rgbd[2]) << 1 | (int(z * 1000.0f) > f.rgbd[3]));
         ++good;
-        for (int id : f.ids[code]) ++coOccurrences[id];
-        codes[i] = code;
       }
     }
+    cooccur(codes, coOccurrences);
+  }
+  // the inverted-list walk alone, for codes that were computed elsewhere (on the device: k_fern_codes, ef_context.hip)
+  void cooccur(const std::vector<uint8_t>& codes, std::vector<int>& coOccurrences) const {
+    coOccurrences.assign(frames.size(), 0);
+    for (int i = 0; i < num; ++i)
+      if (codes[i] != BAD_CODE)
+        for (int id : conservatory[i].ids[codes[i]]) ++coOccurrences[id];
   }
   float dissimilarity(int good, const StoredFrame& s, int co) const {
     const float maxCo = (float)(good < s.goodCodes ? good : s.goodCodes);
@@ -175,16 +181,38 @@ int ef_ferns_set_table(ef_ferns* f, const int* t) {
     e.x = t[i * 6]; e.y = t[i * 6 + 1];
     for (int k = 0; k < 4; ++k) e.rgbd[k] = t[i * 6 + 2 + k];
   }
+  ++f->tableVersion;
   return EF_OK;
 }
+int ef_ferns_table_version(const ef_ferns* f) { return f ? f->tableVersion : EF_EINVAL; }
 
-int ef_ferns_add_frame(ef_ferns* f, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int src_time,
-                       float threshold) {
-  if (!f || !rgb || !verts4 || !norms4 || !T_wc16 || (ch != 3 && ch != 4)) return EF_EINVAL;
-  const View v{rgb, ch, verts4, f->width};
-  std::unique_ptr<StoredFrame> frame(new StoredFrame());
-  std::vector<int> co;
-  f->encode(v, frame->codes, frame->goodCodes, co);
+}  // extern "C"
+
+namespace {
+// where a view comes from: handed over by the caller, or fetched on demand (a device read-back) the first time it is needed
+struct ViewSource {
+  View v{nullptr, 0, nullptr, 0};
+  const float* norms = nullptr;
+  ef_view_fetch fetch = nullptr;
+  void* user = nullptr;
+  bool have = false;
+  bool get(int width) {
+    if (have) return true;
+    if (!fetch) return false;
+    const uint8_t* rgb = nullptr;
+    const float *verts = nullptr, *nrm = nullptr;
+    int ch = 0;
+    if (fetch(user, &rgb, &ch, &verts, &nrm) != EF_OK || !rgb || !verts || !nrm || (ch != 3 && ch != 4)) return false;
+    v = View{rgb, ch, verts, width};
+    norms = nrm;
+    have = true;
+    return true;
+  }
+};
+
+// Ferns::addFrame from the codes on (Ferns.cpp:120-159)
+int add_frame_core(ef_ferns* f, std::unique_ptr<StoredFrame>& frame, const std::vector<int>& co, ViewSource& src, const double* T_wc16, int src_time,
+                   float threshold) {
   float minimum = std::numeric_limits<float>::max();
   if (frame->goodCodes > 0)
     for (size_t i = 0; i < f->frames.size(); ++i) {
@@ -192,32 +220,25 @@ int ef_ferns_add_frame(ef_ferns* f, const uint8_t* rgb, int ch, const float* ver
       if (d < minimum) minimum = d;
     }
   if (!((minimum > threshold || f->frames.empty()) && frame->goodCodes > 0)) return 0;
+  if (!src.get(f->width)) return EF_EINVAL;   // the frame is kept: now its images are needed
   const size_t px = (size_t)f->width * f->height;
   frame->id = (int)f->frames.size();
   frame->T_wc = efl::se3_from_matrix(T_wc16);
   frame->srcTime = src_time;
   frame->rgb.resize(px * 3);
   for (size_t i = 0; i < px; ++i)
-    for (int k = 0; k < 3; ++k) frame->rgb[i * 3 + k] = rgb[i * ch + k];
-  frame->verts.assign(verts4, verts4 + px * 4);
-  frame->norms.assign(norms4, norms4 + px * 4);
+    for (int k = 0; k < 3; ++k) frame->rgb[i * 3 + k] = src.v.rgb[i * src.v.ch + k];
+  frame->verts.assign(src.v.verts, src.v.verts + px * 4);
+  frame->norms.assign(src.norms, src.norms + px * 4);
   for (int i = 0; i < f->num; ++i)
     if (frame->codes[i] != BAD_CODE) f->conservatory[i].ids[frame->codes[i]].push_back(frame->id);
   f->frames.push_back(std::move(frame));
   return 1;
 }
 
-int ef_ferns_find_frame(ef_ferns* f, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int time, int lost,
-                        ef_fern_tracker tracker, void* user, double* T_est16_out, double* cons, int max_cons, int* n_out) {
-  if (!f || !rgb || !verts4 || !norms4 || !T_wc16 || !T_est16_out || (ch != 3 && ch != 4)) return EF_EINVAL;
-  f->lastClosest = -1;
-  if (n_out) *n_out = 0;
-  identity16(T_est16_out);                       // Sophus::SE3d T_wc_est; (Ferns.cpp:236)
-  const View v{rgb, ch, verts4, f->width};
-  std::vector<uint8_t> codes;
-  std::vector<int> co;
-  int good = 0;
-  f->encode(v, codes, good, co);
+// Ferns::findFrame from the codes on (Ferns.cpp:210-299)
+int find_frame_core(ef_ferns* f, const std::vector<uint8_t>& codes, int good, const std::vector<int>& co, ViewSource& src, const double* T_wc16, int time,
+                    int lost, ef_fern_tracker tracker, void* user, double* T_est16_out, double* cons, int max_cons, int* n_out) {
   float minimum = std::numeric_limits<float>::max();
   int minId = -1;
   for (size_t i = 0; i < f->frames.size(); ++i) {
@@ -229,13 +250,15 @@ int ef_ferns_find_frame(ef_ferns* f, const uint8_t* rgb, int ch, const float* ve
   }
   if (minId == -1 || !(f->blockHDAware(codes, f->frames[minId]->codes) > 0.3)) return -1;
   if (!tracker) return EF_EINVAL;
+  if (!src.get(f->width)) return EF_EINVAL;   // a candidate passed the code gates: the registration needs the view itself
+  const View& v = src.v;
   const StoredFrame& s = *f->frames[minId];
   double T_fern[16];
   efl::se3_matrix(s.T_wc, T_fern);
   std::memcpy(T_est16_out, T_fern, sizeof(T_fern));
   float icpError = 0, icpCount = 0;
   // rgbd.initICPModel(fern) / initICP(current) / getIncrementalTransformation(T, false, 100, false, false, false) (Ferns.cpp:243-258)
-  tracker(user, s.verts.data(), s.norms.data(), T_fern, verts4, norms4, T_est16_out, &icpError, &icpCount);
+  tracker(user, s.verts.data(), s.norms.data(), T_fern, v.verts, src.norms, T_est16_out, &icpError, &icpCount);
   const efl::SE3 T_est = efl::se3_from_matrix(T_est16_out);
   const float photoError = f->photometricCheck(v, T_est, s);
   const int icpCountThresh = lost ? 1400 : 2400;
@@ -259,6 +282,85 @@ int ef_ferns_find_frame(ef_ferns* f, const uint8_t* rgb, int ch, const float* ve
     if (n_out) *n_out = n;
   }
   return f->lastClosest;
+}
+bool codes_ok(const ef_ferns* f, const uint8_t* codes, int good) {
+  if (!f || !codes || good < 0 || good > f->num) return false;
+  int g = 0;
+  for (int i = 0; i < f->num; ++i) {
+    if (codes[i] != BAD_CODE && codes[i] > 15) return false;
+    g += codes[i] != BAD_CODE;
+  }
+  return g == good;
+}
+}  // namespace
+
+extern "C" {
+
+int ef_ferns_add_frame(ef_ferns* f, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int src_time,
+                       float threshold) {
+  if (!f || !rgb || !verts4 || !norms4 || !T_wc16 || (ch != 3 && ch != 4)) return EF_EINVAL;
+  ViewSource src;
+  src.v = View{rgb, ch, verts4, f->width};
+  src.norms = norms4;
+  src.have = true;
+  std::unique_ptr<StoredFrame> frame(new StoredFrame());
+  std::vector<int> co;
+  f->encode(src.v, frame->codes, frame->goodCodes, co);
+  return add_frame_core(f, frame, co, src, T_wc16, src_time, threshold);
+}
+int ef_ferns_add_frame_coded(ef_ferns* f, const uint8_t* codes, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int src_time,
+                             float threshold) {
+  if (!f || !fetch || !T_wc16 || !codes_ok(f, codes, good_codes)) return EF_EINVAL;
+  ViewSource src;
+  src.fetch = fetch;
+  src.user = fetch_user;
+  std::unique_ptr<StoredFrame> frame(new StoredFrame());
+  frame->codes.assign(codes, codes + f->num);
+  frame->goodCodes = good_codes;
+  std::vector<int> co;
+  f->cooccur(frame->codes, co);
+  return add_frame_core(f, frame, co, src, T_wc16, src_time, threshold);
+}
+
+int ef_ferns_find_frame(ef_ferns* f, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int time, int lost,
+                        ef_fern_tracker tracker, void* user, double* T_est16_out, double* cons, int max_cons, int* n_out) {
+  if (!f || !rgb || !verts4 || !norms4 || !T_wc16 || !T_est16_out || (ch != 3 && ch != 4)) return EF_EINVAL;
+  f->lastClosest = -1;
+  if (n_out) *n_out = 0;
+  identity16(T_est16_out);                       // Sophus::SE3d T_wc_est; (Ferns.cpp:236)
+  ViewSource src;
+  src.v = View{rgb, ch, verts4, f->width};
+  src.norms = norms4;
+  src.have = true;
+  std::vector<uint8_t> codes;
+  std::vector<int> co;
+  int good = 0;
+  f->encode(src.v, codes, good, co);
+  return find_frame_core(f, codes, good, co, src, T_wc16, time, lost, tracker, user, T_est16_out, cons, max_cons, n_out);
+}
+int ef_ferns_find_frame_coded(ef_ferns* f, const uint8_t* codes_in, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int time,
+                              int lost, ef_fern_tracker tracker, void* user, double* T_est16_out, double* cons, int max_cons, int* n_out) {
+  if (!f || !fetch || !T_wc16 || !T_est16_out || !codes_ok(f, codes_in, good_codes)) return EF_EINVAL;
+  f->lastClosest = -1;
+  if (n_out) *n_out = 0;
+  identity16(T_est16_out);
+  ViewSource src;
+  src.fetch = fetch;
+  src.user = fetch_user;
+  const std::vector<uint8_t> codes(codes_in, codes_in + f->num);
+  std::vector<int> co;
+  f->cooccur(codes, co);
+  return find_frame_core(f, codes, good_codes, co, src, T_wc16, time, lost, tracker, user, T_est16_out, cons, max_cons, n_out);
+}
+// can any stored frame close a loop at `time` (Ferns.cpp:225: only frames stored more than 300 ticks ago are candidates)?  0 => findFrame
+// returns -1 whatever the view looks like, and a caller may skip bringing the view (or its codes) to the host: lastClosest is reset here
+// as findFrame would have reset it
+int ef_ferns_candidate_possible(ef_ferns* f, int time) {
+  if (!f) return EF_EINVAL;
+  for (const auto& s : f->frames)
+    if (time - s->srcTime > 300) return 1;
+  f->lastClosest = -1;   // what findFrame would have left (Ferns.cpp:169)
+  return 0;
 }
 
 int ef_ferns_count(const ef_ferns* f) { return f ? (int)f->frames.size() : EF_EINVAL; }
@@ -340,15 +442,9 @@ void ef_closure_destroy(ef_closure* c) {
 }
 ef_ferns* ef_closure_ferns(ef_closure* c) { return c ? c->ferns : nullptr; }
 
-// ElasticFusion.cpp:392-445 (lost == false; ef_closure_relocalise is the other branch)
-int ef_closure_global(ef_closure* c, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int tick,
-                      ef_fern_tracker tracker, void* user, const float* nodes4, int n_nodes, double* T_recovery16_out, float* graph16_out, int* nodes_out) {
-  if (!c || !T_recovery16_out || !graph16_out || !nodes_out || n_nodes < 0 || (n_nodes > 0 && !nodes4)) return EF_EINVAL;
-  *nodes_out = 0;
-  c->lastRows.clear();
-  double cons[128 * 6];   // at most 99 constraints: every (num / 50)-th fern, Ferns.cpp:268
-  int n = 0;
-  const int closest = ef_ferns_find_frame(c->ferns, rgb, ch, verts4, norms4, T_wc16, tick, 0, tracker, user, T_recovery16_out, cons, 128, &n);   // :395-402
+// ElasticFusion.cpp:410-445 once Ferns::findFrame has answered (closest = its return value, cons / n its constraints)
+static int closure_global_after_find(ef_closure* c, int closest, const double* cons, int n, int tick, const float* nodes4, int n_nodes, float* graph16_out,
+                                     int* nodes_out) {
   if (closest < -1) return closest;
   if (closest == -1) return 0;                                                                     // :410
   const int64_t fernTime = c->ferns->frames[closest]->srcTime;
@@ -376,6 +472,30 @@ int ef_closure_global(ef_closure* c, const uint8_t* rgb, int ch, const float* ve
   c->fernDeforms += gn > 0;                                                                        // :439
   *nodes_out = gn;
   return 1;
+}
+// ElasticFusion.cpp:392-445 (lost == false; ef_closure_relocalise is the other branch)
+int ef_closure_global(ef_closure* c, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int tick,
+                      ef_fern_tracker tracker, void* user, const float* nodes4, int n_nodes, double* T_recovery16_out, float* graph16_out, int* nodes_out) {
+  if (!c || !T_recovery16_out || !graph16_out || !nodes_out || n_nodes < 0 || (n_nodes > 0 && !nodes4)) return EF_EINVAL;
+  *nodes_out = 0;
+  c->lastRows.clear();
+  double cons[128 * 6];   // at most 99 constraints: every (num / 50)-th fern, Ferns.cpp:268
+  int n = 0;
+  const int closest = ef_ferns_find_frame(c->ferns, rgb, ch, verts4, norms4, T_wc16, tick, 0, tracker, user, T_recovery16_out, cons, 128, &n);   // :395-402
+  return closure_global_after_find(c, closest, cons, n, tick, nodes4, n_nodes, graph16_out, nodes_out);
+}
+// the same with the view's fern codes computed by the caller (on the device) and the view itself fetched only if a keyframe passes the
+// code gates
+int ef_closure_global_coded(ef_closure* c, const uint8_t* codes, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int tick,
+                            ef_fern_tracker tracker, void* user, const float* nodes4, int n_nodes, double* T_recovery16_out, float* graph16_out,
+                            int* nodes_out) {
+  if (!c || !T_recovery16_out || !graph16_out || !nodes_out || n_nodes < 0 || (n_nodes > 0 && !nodes4)) return EF_EINVAL;
+  *nodes_out = 0;
+  c->lastRows.clear();
+  double cons[128 * 6];
+  int n = 0;
+  const int closest = ef_ferns_find_frame_coded(c->ferns, codes, good_codes, fetch, fetch_user, T_wc16, tick, 0, tracker, user, T_recovery16_out, cons, 128, &n);
+  return closure_global_after_find(c, closest, cons, n, tick, nodes4, n_nodes, graph16_out, nodes_out);
 }
 
 // ElasticFusion.cpp:488-526 once the gates are open: constraints8 as ef_get_local_loop returns them (pin flag = deforms == 0 is the caller's)
@@ -413,6 +533,31 @@ int ef_closure_end_frame(ef_closure* c, const uint8_t* rgb, int ch, const float*
   c->trajectory.insert(c->trajectory.end(), T_wc16, T_wc16 + 16);
   c->trajectoryTimes.push_back(tick);
   return ef_ferns_add_frame(c->ferns, rgb, ch, verts4, norms4, T_wc16, tick, c->fernThresh);
+}
+
+// Can this frame's Ferns::findFrame match at all (ef_ferns_candidate_possible)?  Answering 0 it leaves the closure object as the
+// ef_closure_global / ef_closure_relocalise that was not needed would have: no rows, lastClosest = -1.
+int ef_closure_candidate_possible(ef_closure* c, int tick) {
+  if (!c) return EF_EINVAL;
+  const int r = ef_ferns_candidate_possible(c->ferns, tick);
+  if (r == 0) c->lastRows.clear();
+  return r;
+}
+int ef_closure_end_frame_coded(ef_closure* c, const uint8_t* codes, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int tick) {
+  if (!c || !T_wc16) return EF_EINVAL;
+  c->trajectory.insert(c->trajectory.end(), T_wc16, T_wc16 + 16);
+  c->trajectoryTimes.push_back(tick);
+  return ef_ferns_add_frame_coded(c->ferns, codes, good_codes, fetch, fetch_user, T_wc16, tick, c->fernThresh);
+}
+int ef_closure_relocalise_coded(ef_closure* c, const uint8_t* codes, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int tick,
+                                ef_fern_tracker tracker, void* user, double* T_recovery16_out) {
+  if (!c || !T_recovery16_out) return EF_EINVAL;
+  c->lastRows.clear();
+  double cons[128 * 6];
+  int n = 0;
+  const int closest = ef_ferns_find_frame_coded(c->ferns, codes, good_codes, fetch, fetch_user, T_wc16, tick, 1, tracker, user, T_recovery16_out, cons, 128, &n);
+  if (closest < -1) return closest;
+  return closest == -1 ? 0 : 1;
 }
 
 // ElasticFusion.cpp:395-413 for a lost camera: the match itself is the answer (no deformation)

@@ -27,7 +27,10 @@ constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * SE3_PAIRS > SO3_ACCS * VWARPS ? 2 
 // loop and every Gauss-Newton iteration of the levels with <= PT_MAX_PIXELS pixels in ONE launch; hand-overs between workgroups
 // alternate between two partial regions, and a small synchronisation record (PtSync) sits behind them.
 constexpr int PT_WGS = 128, PT_BLOCK = 512, PT_MAX_ITER = 16, PT_MAX_PIXELS = 8 * VTHREADS, PT_SYNC_FLOATS = 1024;
-constexpr int PARTIAL_ALLOC_FLOATS = 2 * PARTIAL_FLOATS + PT_SYNC_FLOATS;
+// behind the two float regions and the PtSync: two regions of tagged 8-byte granules {value, epoch} for the pair sums the SE(3)
+// iterations of the persistent launch exchange, and two sets of {count, sum} granules of the correspondence search (PT_WGS x 2 each)
+constexpr int PT_GRANULES = 2 * SE3_ACCS * 64 * 2;   // [term][acc][block][h]
+constexpr int PARTIAL_ALLOC_FLOATS = 2 * PARTIAL_FLOATS + PT_SYNC_FLOATS + 2 * (2 * PT_GRANULES) + 2 * (2 * 2 * PT_WGS);
 
 struct Intr { float fx, fy, cx, cy; };
 __host__ __device__ inline Intr intr_level(const Intr& k, int level) {  // CameraModel::operator()(level), types.cuh:92-95
@@ -108,7 +111,7 @@ struct Pyramid {               // one RGBDOdometry instance's device buffers (RG
   // DataTerm (types.cuh:81-86): bit31 valid | (diff+255) << 22 | v0 << 11 | u0 ("one" is the pixel itself)
   uint32_t* corres[NUM_PYRS];
   uint8_t* rgbMask[NUM_PYRS];      // iteration-invariant part of residualKernel's gates, built once per frame
-  float* partials;                 // PARTIAL_ALLOC_FLOATS: region 0 (what the per-step kernels use), region 1, PtSync (zero-filled at allocation)
+  float* partials;                 // PARTIAL_ALLOC_FLOATS: region 0 (what the per-step kernels use), region 1, PtSync, granule regions (zero-filled at allocation)
   int W(int l) const { return width >> l; }
   int H(int l) const { return height >> l; }
 };
@@ -207,6 +210,7 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
 // 1 when a persistent launch of this tracker instance gave up waiting in a grid barrier (its workgroups were not co-resident), 0
 // otherwise, < 0 on a HIP error; synchronises the stream
 int tracker_aborted(const Pyramid& p, hipStream_t s);
+int tracker_small_clocks(const Pyramid& p, unsigned long long* out24, hipStream_t s);   // developer instrumentation (-DEF_STAGE_CLOCKS)
 void track_swap(Pyramid& p, const TrackParams& tp);   // the pointer swap track() ends with (for hipGraph replay)
 // tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +
 // velocity weighting (ElasticFusion.cpp:369-383) + the float matrices of the map passes

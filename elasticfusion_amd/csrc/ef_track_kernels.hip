@@ -1200,9 +1200,12 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
 // the persistent kernel (k_track_small) gives a wavefront the 32 virtual threads of a warp, so that 8 wavefronts (2 per SIMD, 256
 // registers each) cover what 16 cover in k_se3_accum.  All four (half, step) visits have their loads in flight together; each half
 // accumulates into its own c[half][0..2] in pass order, so every accumulator sees the chain of additions accum_quads gives it.
-template <bool ICP>
+// `before_rows(slot_a, slot_b)`: called once every load and gather is issued and before anything needs sigma — the photometric wavefronts of
+// the persistent kernel wait THERE for the correspondence search's global count, with their memory round trips already under way.
+struct NoWait { __device__ __forceinline__ void operator()(int&, int&) const {} };
+template <bool ICP, typename Hook = NoWait>
 __device__ __forceinline__ void accum_quads_halves(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int wbase, int N, int K,
-                                                   int slot_a, int slot_b, bool with_slots, f32x4 (&c)[2][3]) {
+                                                   int slot_a, int slot_b, bool with_slots, f32x4 (&c)[2][3], Hook before_rows = Hook()) {
   constexpr int SU = 2, CH = 2 * SU;
   const int S = (K + 3) >> 2;   // <= SU
   const int lane = threadIdx.x & 63;
@@ -1222,6 +1225,10 @@ __device__ __forceinline__ void accum_quads_halves(const IcpView& IV, const RgbV
     const int hf = u / SU, sp = u % SU, k = 4 * sp + jl;
     L[u] = visit_stage1<ICP, !ICP>(IV, RV, (sp < S && k < K) ? k * VTHREADS + wbase + 16 * hf + vl : N, N);
   }
+  VisitGathers G[CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) G[u] = visit_stage2a<ICP, !ICP>(IV, RV, P, L[u]);
+  before_rows(slot_a, slot_b);
   float sigma = in.sigma_fixed;
   if (!ICP && with_slots) {
 #pragma unroll
@@ -1231,9 +1238,6 @@ __device__ __forceinline__ void accum_quads_halves(const IcpView& IV, const RgbV
     }
     sigma = sigma_from_sums(__shfl(slot_b, 0, 64), __shfl(slot_a, 0, 64), in.rgbOnly);
   }
-  VisitGathers G[CH];
-#pragma unroll
-  for (int u = 0; u < CH; ++u) G[u] = visit_stage2a<ICP, !ICP>(IV, RV, P, L[u]);
   float rows[CH][8];
 #pragma unroll
   for (int u = 0; u < CH; ++u) {
@@ -1529,6 +1533,31 @@ __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* p
 // One 16-byte load per (acc, block), all of a thread's loads in flight together, one wavefront per accumulator.
 // COHERENT: the partials were written by other workgroups of the SAME launch (agent-scope stores, drained, then a grid barrier): read
 // them with agent-scope loads, which no CU's L1 serves (two 8-byte loads per float4)
+// pair_partials_tree for the persistent kernel's own iterations: slot 0 of a block holds p0 + p2 and slot 1 holds p1 + p3 already (each
+// workgroup owns pairs h and h + 2 of a reference block and adds them before it publishes), so the gather is one 8-byte agent-scope
+// load per (accumulator, block) — half the bytes and half the publishing stores — and x = s02 + s13 is the same (p0 + p2) + (p1 + p3).
+template <int BLOCK>
+__device__ __forceinline__ void half_partials_tree(const float* __restrict__ pairs, bool icp, bool rgb, float* sums_s) {
+  static_assert(BLOCK % 64 == 0, "one wavefront per accumulator");
+  const int t = threadIdx.x;
+  const int na = (icp ? SE3_ACCS : 0) + (rgb ? SE3_ACCS : 0);
+  constexpr int PASSES = (2 * SE3_ACCS * 64 + BLOCK - 1) / BLOCK;
+  unsigned long long v[PASSES];
+#pragma unroll
+  for (int q = 0; q < PASSES; ++q) {
+    const int idx = t + q * BLOCK;
+    v[q] = idx < na * 64 ? __hip_atomic_load((const unsigned long long*)pairs + (size_t)idx * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+  }
+#pragma unroll
+  for (int q = 0; q < PASSES; ++q) {
+    const int idx = t + q * BLOCK;
+    float x = __uint_as_float((unsigned)v[q]) + __uint_as_float((unsigned)(v[q] >> 32));
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, 32);
+    const float w1 = __shfl(x, 32, 64);
+    if (idx < na * 64 && (idx & 63) == 0) sums_s[(icp ? 0 : SE3_ACCS) + (idx >> 6)] = x + w1;
+  }
+}
 template <int BLOCK, bool COHERENT>
 __device__ __forceinline__ void pair_partials_tree(const float* __restrict__ pairs, bool icp, bool rgb, float* sums_s) {
   static_assert(BLOCK % 64 == 0, "one wavefront per accumulator");
@@ -1745,6 +1774,74 @@ __device__ __forceinline__ void so3_accumulate(const uint8_t* __restrict__ lastI
   }
 }
 
+// so3_accumulate for the persistent kernel: workgroup 2 b + h owns virtual warps 8 b + {h, h + 4, h + 2, h + 6} (pt_vwarp), so that the
+// first two levels of blockReduceSum's 8-warp tree — (x_h + x_{h+4}) + (x_{h+2} + x_{h+6}) — are added here, and ONE value per
+// accumulator and workgroup is published: partials[(acc * 64 + b) * 2 + h], 5.6 KB for the whole grid instead of 22 KB.
+template <int BLOCK>
+__device__ __forceinline__ void so3_accumulate_halves(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage, int cols, int rows,
+                                                      const m33& IB, const m33& KI, const m33& KR, float* lds_rows, float* wsum /* [4][SO3_ACCS] */,
+                                                      float* __restrict__ partials) {
+  const int t = threadIdx.x, N = cols * rows, wg = blockIdx.x;
+  const int K = (N + VTHREADS - 1) / VTHREADS;
+  const int l = t & 31, w = t >> 5;   // phase-B identity (t < 32 * SO3_WPB)
+  const int W = (8 * (wg >> 1) + (wg & 1)) + 2 * ((w & 3) >> 1) + 4 * (w & 1);   // pt_vwarp(wg, w)
+  const int g = W * 32 + l;
+  const int nk = g < N ? (N - g + VTHREADS - 1) / VTHREADS : 0;
+  float acc[SO3_ACCS];
+#pragma unroll
+  for (int i = 0; i < SO3_ACCS; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += SO3_KC) {
+    const int kc = min(SO3_KC, K - k0);
+    for (int s = t; s < SO3_WPB * kc * 32; s += BLOCK) {
+      const int sl = s & 31, q = s >> 5, k = q % kc, sw = q / kc;
+      const int Ws = (8 * (wg >> 1) + (wg & 1)) + 2 * (sw >> 1) + 4 * (sw & 1);
+      const int p = (k0 + k) * VTHREADS + Ws * 32 + sl;
+      float row[4] = {0.f, 0.f, 0.f, 0.f};
+      float found = 0.f;
+      if (p < N && so3_row(lastImage, nextImage, cols, rows, IB, KI, KR, p, row)) found = 1.f;
+      float* r = lds_rows + (sw * SO3_KC + k) * ROW_STRIDE + sl;
+      r[0] = row[0]; r[32] = row[1]; r[64] = row[2]; r[96] = row[3]; r[128] = found;
+    }
+    __syncthreads();
+    if (t < 32 * SO3_WPB) so3_chains(lds_rows + w * SO3_KC * ROW_STRIDE, l, min(kc, nk - k0), acc);
+    __syncthreads();
+  }
+  if (t < 32 * SO3_WPB) {
+#pragma unroll
+    for (int i = 0; i < SO3_ACCS; ++i)
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) acc[i] += __shfl_down(acc[i], off, 32);
+    if (l == 0) {
+#pragma unroll
+      for (int i = 0; i < SO3_ACCS; ++i) wsum[w * SO3_ACCS + i] = acc[i];
+    }
+  }
+  __syncthreads();
+  if (t < SO3_ACCS) {
+    const float z = (wsum[t] + wsum[SO3_ACCS + t]) + (wsum[2 * SO3_ACCS + t] + wsum[3 * SO3_ACCS + t]);
+    coherent_store(partials + ((size_t)t * 64 + (wg >> 1)) * 2 + (wg & 1), z);
+    drain_stores();
+  }
+}
+// ... and the rest of the tree over those: z_0 + z_1 per block (8-byte agent-scope loads), then reduceSum's 64-block tree as final_tree
+template <int BLOCK, int NA>
+__device__ __forceinline__ void final_tree_halves(const float* partials, float* bs, float* out) {
+  const int t = threadIdx.x;
+  for (int idx = t; idx < NA * 64; idx += BLOCK) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)partials + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bs[idx] = __uint_as_float((unsigned)v) + __uint_as_float((unsigned)(v >> 32));
+  }
+  __syncthreads();
+  for (int idx = t; idx < NA * 64; idx += BLOCK) {
+    float x = bs[idx];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, 32);
+    const float w1 = __shfl(x, 32, 64);
+    if ((idx & 63) == 0) out[idx >> 6] = x + w1;
+  }
+  __syncthreads();
+}
+
 __global__ void __launch_bounds__(SO3_BLOCK) k_so3_iteration(const uint8_t* __restrict__ lastImage, const uint8_t* __restrict__ nextImage,
                                                               int cols, int rows, Intr k, Intr kfirst, int it, TrackState* st,
                                                               float* __restrict__ partials) {
@@ -1881,8 +1978,21 @@ struct PtSync {                   // behind the partial regions (Pyramid::partia
   unsigned count, pad0[31];       // arrivals of the barrier in flight (its atomics do not share a cache line with the pollers' word)
   unsigned gen, pad1[31];         // generations completed, monotonic across launches
   unsigned abort, pad2[31];       // sticky: a wait timed out
+  unsigned epoch, pad3[31];       // tag base of the granule exchange: read by every workgroup at its start, advanced by workgroup 0 at its end
   int wg_sums[2][PT_WGS][2];      // {count, sum diff^2} of each workgroup's share of a correspondence search, by iteration parity
+  unsigned long long clk[24];     // developer instrumentation (-DEF_STAGE_CLOCKS builds): 10 ns ticks per phase, summed over launches
 };
+// -DEF_STAGE_CLOCKS: workgroup 0 adds the time since its last stamp to PtSync::clk[i] (thread 0: the phases of an ICP wavefront; PT_CLK2:
+// lane 0 of the polling RGB wavefront).  tools/small_clocks.py reads them through ef_debug_small_clocks.
+#ifdef EF_STAGE_CLOCKS
+#define PT_CLK(i) do { if (wg == 0 && t == 0) { const unsigned long long now_ = wall_clock64(); Y->clk[i] += now_ - clk_last; clk_last = now_; } } while (0)
+#define PT_CLK2(i) do { if (wg == 0 && lane == 0) { const unsigned long long now_ = wall_clock64(); Y->clk[i] += now_ - clk_last2; clk_last2 = now_; } } while (0)
+#define PT_COUNT(i) do { if (wg == 0 && t == 0) Y->clk[i] += 1; } while (0)
+#else
+#define PT_CLK(i) do { } while (0)
+#define PT_CLK2(i) do { } while (0)
+#define PT_COUNT(i) do { } while (0)
+#endif
 static_assert(sizeof(PtSync) <= PT_SYNC_FLOATS * sizeof(float), "PtSync fits its reservation");
 struct PtLevel {
   const float* vmap_curr; const float* nmap_curr; const float* vmap_g_prev; const float* nmap_g_prev;
@@ -1952,6 +2062,65 @@ __device__ __forceinline__ int pt_vwarp(int wg, int slot) {
   const int b = wg >> 1, h = wg & 1;
   return 8 * b + h + 2 * (slot >> 1) + 4 * (slot & 1);
 }
+// ---- tagged granules: one naturally aligned 8-byte {value, epoch tag} written by ONE agent-scope store and read by agent-scope loads until
+// the tag is the expected one.  No fence, no drain, no counter: a granule is its own "ready" flag (MI355X_MICROARCH.md price list,
+// handoff-1to1), and the data dependence from iteration to iteration orders every re-use of a region (see k_track_small).
+__device__ __forceinline__ void pt_put(unsigned long long* g, unsigned value_bits, unsigned tag) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | value_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long pt_get(const unsigned long long* g) {
+  return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// half_partials_tree over granules: G[(acc * 64 + block) * 2 + h] = {s_h, tag}; polls until every granule of the thread carries `tag`
+// (bounded; `dead`: a wait was abandoned somewhere, stop waiting).  Follow with __syncthreads().
+template <int BLOCK>
+__device__ __forceinline__ bool granule_partials_tree(const unsigned long long* __restrict__ G, unsigned tag, PtSync* Y, bool dead, bool icp, bool rgb,
+                                                      float* sums_s) {
+  static_assert(BLOCK % 64 == 0, "one wavefront per accumulator");
+  const int t = threadIdx.x;
+  const int na = (icp ? SE3_ACCS : 0) + (rgb ? SE3_ACCS : 0);
+  constexpr int PASSES = (2 * SE3_ACCS * 64 + BLOCK - 1) / BLOCK, CHUNK = 4;   // in chunks: 2 x CHUNK granules per thread in flight / in registers
+#pragma unroll 1
+  for (int q0 = 0; q0 < PASSES; q0 += CHUNK) {
+    unsigned long long v0[CHUNK], v1[CHUNK];
+#pragma unroll
+    for (int q = 0; q < CHUNK; ++q) {
+      const int idx = t + (q0 + q) * BLOCK;
+      const bool in = q0 + q < PASSES && idx < na * 64;
+      v0[q] = in ? pt_get(G + (size_t)idx * 2) : ((unsigned long long)tag << 32);
+      v1[q] = in ? pt_get(G + (size_t)idx * 2 + 1) : ((unsigned long long)tag << 32);
+    }
+    if (!dead) {
+      for (int spin = 0;; ++spin) {
+        bool pending = false;
+#pragma unroll
+        for (int q = 0; q < CHUNK; ++q) {
+          const int idx = t + (q0 + q) * BLOCK;
+          if ((unsigned)(v0[q] >> 32) != tag) { v0[q] = pt_get(G + (size_t)idx * 2); pending = true; }
+          if ((unsigned)(v1[q] >> 32) != tag) { v1[q] = pt_get(G + (size_t)idx * 2 + 1); pending = true; }
+        }
+        if (!__any(pending)) break;
+        const unsigned ab = (spin & 255) == 255 ? (unsigned)__builtin_amdgcn_readfirstlane((int)pt_load(&Y->abort)) : 0u;   // wave-uniform
+        if (spin >= PT_SPIN || ab) {
+          if (spin >= PT_SPIN) __hip_atomic_store(&Y->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dead = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CHUNK; ++q) {
+      const int idx = t + (q0 + q) * BLOCK;
+      float x = __uint_as_float((unsigned)v0[q]) + __uint_as_float((unsigned)v1[q]);
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, 32);
+      const float w1 = __shfl(x, 32, 64);
+      if (q0 + q < PASSES && idx < na * 64 && (idx & 63) == 0) sums_s[(icp ? 0 : SE3_ACCS) + (idx >> 6)] = x + w1;
+    }
+  }
+  return dead;
+}
 // the update of one SO(3) iteration (k_so3_iteration's tail) on the workgroup's own state; returns true when the loop is over
 __device__ __forceinline__ bool so3_update(So3Loop& Z, const float* red, int it, Intr k, Intr kfirst, GNState& g0) {
   float jtj[9], jtr[3];
@@ -2018,19 +2187,27 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
   __shared__ float bg[24];   // Rprev[9] | tprev[3] | Rprev_inv[9]: constants of the call (k_track_begin)
   __shared__ float lds_rows[SO3_WPB * SO3_KC * ROW_STRIDE];
   __shared__ float pairx[2 * 2 * 12 * 4];   // [task][term][12][4]
+  __shared__ float tsum[2 * 12 * 4];        // [term][12][4]: task 1's pair sums on their way to task 0's storing lanes
+  __shared__ float wsum[SO3_WPB * SO3_ACCS];
   __shared__ float red[SO3_ACCS];
   __shared__ So3Loop Z;
   __shared__ int ired[2 * PT_BLOCK / 64];
-  __shared__ unsigned sync_s[2];
+  __shared__ unsigned sync_s[3];
+  __shared__ int tot_s[2][2];               // {count, sum diff^2} of the correspondence search, by iteration parity (relay of the polling wavefront)
   __shared__ int flag_s;
   __shared__ unsigned seen_a[2];   // barrier A relay: {generation the workgroup's polling wavefront has seen complete, wait abandoned}
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wg = blockIdx.x;
   PtSync* Y = (PtSync*)(A.partials + 2 * PARTIAL_FLOATS);
+#ifdef EF_STAGE_CLOCKS
+  unsigned long long clk_last = wall_clock64(), clk_last2 = clk_last;
+  const unsigned long long clk_start = clk_last;
+#endif
   // ---- k_track_begin, by every workgroup for itself; workgroup 0 also leaves the global side of it ----
   if (t == 0) {
     sync_s[0] = pt_load(&Y->gen) + 1u;   // the generation that ends this launch's first barrier
     sync_s[1] = pt_load(&Y->abort);
-    seen_a[0] = sync_s[0] - 1u;
+    sync_s[2] = pt_load(&Y->epoch) + 1u;   // tag of this launch's first iteration (never 0: fresh granules carry tag 0)
+    seen_a[0] = sync_s[2] - 1u;            // no iteration of this launch carries that tag
     seen_a[1] = 0u;
     double R[9];
     efl::quat_to_mat<double>(st->q, R);
@@ -2055,6 +2232,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
     }
   }
   __syncthreads();
+  PT_CLK(0);   // begin
   if (sync_s[1]) return;   // an earlier launch of this tracker instance timed out in a barrier
   unsigned gen_next = sync_s[0];
   bool dead = false;
@@ -2074,19 +2252,24 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
       float* region = A.partials + (size_t)(it & 1) * PARTIAL_FLOATS;
       {
         const m33 IB = m33_load(Z.mats), KI = m33_load(Z.mats + 9), KR = m33_load(Z.mats + 18);
-        so3_accumulate<PT_BLOCK>(A.so3_last, A.so3_next, A.so3_cols, A.so3_rows, IB, KI, KR, lds_rows, region);   // agent-scope stores, drained
+        so3_accumulate_halves<PT_BLOCK>(A.so3_last, A.so3_next, A.so3_cols, A.so3_rows, IB, KI, KR, lds_rows, wsum, region);   // agent-scope stores, drained
       }
       __syncthreads();
+      PT_CLK(1);   // SO(3): rows, chains, publish
       if (t == 0) {
         pt_arrive(Y);
         flag_s = pt_wait(Y, gen_next, dead) ? 1 : 0;
       }
       __syncthreads();
+      PT_CLK(2);   // SO(3): barrier
       dead = flag_s != 0;
       ++gen_next;
-      final_tree<PT_BLOCK, SO3_ACCS, true>(region, lds_rows, red);
+      final_tree_halves<PT_BLOCK, SO3_ACCS>(region, lds_rows, red);
+      PT_CLK(3);   // SO(3): gather + tree
       if (t == 0) Z.done = so3_update(Z, red, it, A.kso3, A.kfirst, gs[0]) ? 1 : 0;
       __syncthreads();
+      PT_CLK(4);   // SO(3): update
+      PT_COUNT(20);
       if (Z.done) break;   // every workgroup computes the same bits, so every workgroup leaves in the same iteration
     }
     if (wg == 0 && t == 0) {
@@ -2096,35 +2279,40 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
     }
   }
   // ---- the Gauss-Newton iterations of the small levels, RGBDOdometry.cpp:371-553 ----
+  // No barrier in this loop: the pair sums and the search's {count, sum} travel as tagged granules (tag = epoch + iteration), each reader
+  // polls exactly the granules it needs, and every re-use of a granule slot is ordered by the data dependence itself — a workgroup writes
+  // iteration i + 2's granules only after its update step consumed iteration i + 1's granules of EVERY workgroup, which those published
+  // after they were done reading iteration i's.
+  unsigned long long* GR = (unsigned long long*)((char*)Y + PT_SYNC_FLOATS * sizeof(float));   // [2 regions][PT_GRANULES]
+  unsigned long long* WS = GR + 2 * PT_GRANULES;                                               // [2 sets][PT_WGS][2]
+  const unsigned epoch = sync_s[2];
   int cur = 0;
   for (int it = 0; it < A.n_iter; ++it) {
     const int lvl = pt_level_of(A, it);
     const PtLevel Lv = pt_load_level((PtArgsK)__builtin_amdgcn_kernarg_segment_ptr(), lvl);   // PtArgs is the kernel's FIRST argument
     const int cols = Lv.cols, rows = Lv.rows, N = cols * rows;
     const int K = (N + VTHREADS - 1) / VTHREADS;
-    float* region = A.partials + (size_t)((A.n_iter - 1 - it) & 1) * PARTIAL_FLOATS;   // the last iteration's partials land in region 0
+    const unsigned tag = epoch + (unsigned)it;
+    const bool last = it == A.n_iter - 1;
     if (it > 0) {
       // head: the update step of iteration it - 1 (k_track_step's head), by every workgroup on its own state
-      const float* prev_region = A.partials + (size_t)((A.n_iter - it) & 1) * PARTIAL_FLOATS;
       StepArgs H{true, false, HAS_ICP, HAS_RGB, false, A.icpWeight, Lv.k, lvl != pt_level_of(A, it - 1)};
       efs::SolvePrefetch PF{};
       if (t < 64) {
         const GNState& g = gs[cur];
         PF.rt = g.resultRt[lane & 15];
         PF.pose = bg[lane < 12 ? lane : 0];
-        PF.slot_a = PF.slot_b = 0;
-        if (HAS_RGB) {
-          const int (*ws)[2] = Y->wg_sums[(it - 1) & 1];
-          PF.slot_a = pt_loadi(&ws[lane][0]) + pt_loadi(&ws[lane + 64][0]);
-          PF.slot_b = pt_loadi(&ws[lane][1]) + pt_loadi(&ws[lane + 64][1]);
-        }
+        PF.slot_a = lane == 0 ? tot_s[(it - 1) & 1][0] : 0;   // the search's totals, as this workgroup's polling wavefront saw them
+        PF.slot_b = lane == 0 ? tot_s[(it - 1) & 1][1] : 0;
         PF.lastRGBErrorLevel = g.lastRGBErrorLevel;
         PF.broken = g.rgb_broken;
       }
-      pair_partials_tree<PT_BLOCK, true>(prev_region, HAS_ICP, HAS_RGB, sums_s);
+      dead = granule_partials_tree<PT_BLOCK>(GR + (size_t)((it - 1) & 1) * PT_GRANULES, tag - 1u, Y, dead, HAS_ICP, HAS_RGB, sums_s);
       __syncthreads();
+      PT_CLK(5);   // SE(3) head: poll + gather + trees
       if (t < 64) solve_step_wave(st, &gs[cur], &gs[cur ^ 1], true, sums_s, H, S, PF, wg == 0);
       __syncthreads();
+      PT_CLK(6);   // SE(3) head: solve
       cur ^= 1;
     }
     const GNState& G = gs[cur];
@@ -2186,12 +2374,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
       if (t == 0) {
         int sa = 0, sb = 0;
         for (int w = 0; w < PT_BLOCK / 64; ++w) { sa += ired[w * 2]; sb += ired[w * 2 + 1]; }
-        int (*ws)[2] = Y->wg_sums[it & 1];
-        __hip_atomic_store(&ws[wg][0], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ws[wg][1], sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        drain_stores();
-        pt_arrive(Y);   // barrier A: arrive now, the RGB wavefronts wait below
+        unsigned long long* ws = WS + ((size_t)(it & 1) * PT_WGS + wg) * 2;
+        pt_put(ws, (unsigned)sa, tag);
+        pt_put(ws + 1, (unsigned)sb, tag);
       }
+      PT_CLK(7);   // SE(3): correspondence search + publish its sums
     }
     // normal equations of the workgroup's two pair tasks: one wavefront per (task, term, warp of the pair), both halves of the warp
     const int task = wave / (2 * NT), w4 = wave % (2 * NT);
@@ -2210,29 +2397,72 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
       const RgbView RV{Lv.corres, Lv.lastDepth, nullptr, Lv.dIdx, Lv.dIdy, cols, rows, Lv.k, 1.0f / 8.0f};
       Se3Inputs in{G.Rcurr, G.tcurr, bg + 12, bg + 9, nullptr, nullptr, 0.f, false};
       if (HAS_ICP && !rgb_wave) accum_quads_halves<true>(IV, RV, in, wbase, N, K, 0, 0, false, c);
+      if (HAS_ICP && !rgb_wave) PT_CLK(8);   // SE(3): ICP accumulation (wavefront 0)
       if (HAS_RGB && rgb_wave) {
-        // barrier A: ONE wavefront of the workgroup polls the global word, the other RGB wavefronts watch its relay in LDS
-        bool gone = false;
-        if (lane == 0) {
-          if (task == 0 && wl == 0) {
-            gone = pt_wait(Y, gen_next, dead);
-            if (gone) __hip_atomic_store(&seen_a[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&seen_a[0], gen_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef EF_STAGE_CLOCKS
+        if (task == 0 && wl == 0 && lane == 0 && wg == 0) clk_last2 = wall_clock64();
+#endif
+        // The global {count, sum diff^2} of the search (sigma, quirk Q2): ONE wavefront of the workgroup polls the 2 x PT_WGS granules
+        // (four per lane) and relays the totals through LDS; the others watch the relay.  All of them wait with their loads and
+        // gathers already issued (accum_quads_halves' hook).
+        const unsigned long long* ws = WS + (size_t)(it & 1) * PT_WGS * 2;
+        const bool leader = task == 0 && wl == 0;
+        bool gone = dead;
+        auto wait_totals = [&](int& slot_a, int& slot_b) {
+          if (leader) {
+            unsigned long long g4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g4[e] = pt_get(ws + (size_t)(lane + 64 * (e >> 1)) * 2 + (e & 1));
+            if (!gone) {
+              for (int spin = 0;; ++spin) {
+                bool pending = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if ((unsigned)(g4[e] >> 32) != tag) { g4[e] = pt_get(ws + (size_t)(lane + 64 * (e >> 1)) * 2 + (e & 1)); pending = true; }
+                if (!__any(pending)) break;
+                const unsigned ab = (spin & 255) == 255 ? (unsigned)__builtin_amdgcn_readfirstlane((int)pt_load(&Y->abort)) : 0u;
+                if (spin >= PT_SPIN || ab) {
+                  if (spin >= PT_SPIN) __hip_atomic_store(&Y->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  gone = true;
+                  break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+              }
+            }
+            int sa = (int)(unsigned)g4[0] + (int)(unsigned)g4[2], sb = (int)(unsigned)g4[1] + (int)(unsigned)g4[3];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+              sa += __shfl_down(sa, off, 64);
+              sb += __shfl_down(sb, off, 64);
+            }
+            if (lane == 0) {
+              tot_s[it & 1][0] = sa;
+              tot_s[it & 1][1] = sb;
+              if (gone) __hip_atomic_store(&seen_a[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              __hip_atomic_store(&seen_a[0], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            slot_a = lane == 0 ? sa : 0;
+            slot_b = lane == 0 ? sb : 0;
           } else {
-            int spins = 0;
-            while ((int)(__hip_atomic_load(&seen_a[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen_next) < 0 && ++spins < 4 * PT_SPIN)
-              __builtin_amdgcn_s_sleep(1);
-            gone = dead || spins >= 4 * PT_SPIN || __hip_atomic_load(&seen_a[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+            if (lane == 0) {
+              int spins = 0;
+              while (__hip_atomic_load(&seen_a[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != tag && ++spins < 8 * PT_SPIN) __builtin_amdgcn_s_sleep(1);
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              gone = gone || spins >= 8 * PT_SPIN || __hip_atomic_load(&seen_a[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+            }
+            gone = __shfl((int)gone, 0, 64) != 0;
+            const volatile int* tv = &tot_s[it & 1][0];
+            slot_a = lane == 0 ? tv[0] : 0;
+            slot_b = lane == 0 ? tv[1] : 0;
           }
-        }
-        dead = __shfl((int)gone, 0, 64) != 0;
-        const int (*ws)[2] = Y->wg_sums[it & 1];
-        const int slot_a = pt_loadi(&ws[lane][0]) + pt_loadi(&ws[lane + 64][0]);
-        const int slot_b = pt_loadi(&ws[lane][1]) + pt_loadi(&ws[lane + 64][1]);
-        accum_quads_halves<false>(IV, RV, in, wbase, N, K, slot_a, slot_b, true, c);
+          if (leader) PT_CLK2(12);   // SE(3): wait for the search's totals (polling RGB wavefront; its own loads are in flight)
+        };
+        accum_quads_halves<false>(IV, RV, in, wbase, N, K, 0, 0, true, c, wait_totals);
+        dead = dead || gone;
+        if (leader) PT_CLK2(13);   // SE(3): RGB rows + outer products after the totals
       }
     }
-    if (HAS_RGB) ++gen_next;
     // warpReduceSum (offset 16 = the other half, here in the same wavefront) + the first level of blockReduceSum's 8-warp tree
     float r[12];
     float* pw = pairx + (size_t)((active ? task : 0) * 2 + tix) * 12 * 4;
@@ -2255,26 +2485,44 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
       }
     }
     __syncthreads();
+    // second level of the 8-warp tree inside the workgroup: pair h (task 0) + pair h + 2 (task 1): s_h = p_h + p_{h+2}, so that a reader's
+    // s_0 + s_1 is blockReduceSum's (p0 + p2) + (p1 + p3)
     if (active && wl == 0 && v == 0) {
-      const int pair_index = 4 * (wg >> 1) + (wg & 1) + 2 * task;   // 4 * reference block + pair, k_se3_accum's `wg`
-      float* dst = region + (size_t)tix * SE3_ACCS * SE3_PAIRS + pair_index;
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
+      for (int i = 0; i < 12; ++i) r[i] = r[i] + pw[i * 4 + j];
+      if (task == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int a = quad_member(q, i, j);
-          if (a >= 0) coherent_store(dst + (size_t)a * SE3_PAIRS, r[q * 4 + i] + pw[(q * 4 + i) * 4 + j]);
-        }
-      drain_stores();
+        for (int i = 0; i < 12; ++i) tsum[(tix * 12 + i) * 4 + j] = r[i];
+      }
     }
     __syncthreads();
-    if (t == 0) {   // barrier B: every pair partial of this iteration is out
-      pt_arrive(Y);
-      flag_s = pt_wait(Y, gen_next, dead) ? 1 : 0;
+    if (active && task == 0 && wl == 0 && v == 0) {
+      const int b = wg >> 1, h = wg & 1;
+      if (!last) {   // to every workgroup's next update step: tagged granules
+        unsigned long long* g = GR + (size_t)(it & 1) * PT_GRANULES;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int a = quad_member(q, i, j);
+            if (a >= 0) pt_put(g + ((size_t)(tix * SE3_ACCS + a) * 64 + b) * 2 + h, __float_as_uint(r[q * 4 + i] + tsum[(tix * 12 + q * 4 + i) * 4 + j]), tag);
+          }
+      } else {       // to the per-step kernel that follows the launch: region 0 in k_se3_accum's pair layout, slot h = s_h, slot h + 2 = 0
+        float* dst = A.partials + (size_t)tix * SE3_ACCS * SE3_PAIRS + 4 * b + h;   // ((s + 0) + (s' + 0) = s + s' to the bit)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int a = quad_member(q, i, j);
+            if (a >= 0) {
+              dst[(size_t)a * SE3_PAIRS] = r[q * 4 + i] + tsum[(tix * 12 + q * 4 + i) * 4 + j];
+              dst[(size_t)a * SE3_PAIRS + 2] = 0.f;
+            }
+          }
+      }
     }
-    __syncthreads();
-    dead = dead || flag_s != 0;
-    ++gen_next;
+    PT_CLK(9);   // SE(3): join, trees, publish
+    PT_COUNT(21);
   }
   // ---- what the launches that follow read: the Gauss-Newton state and the last search's sums (update of iteration n_iter - 1
   //      at the head of the next k_track_step / k_track_end) ----
@@ -2286,13 +2534,16 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
     for (int i = 0; i < 16; ++i) o.resultRt[i] = g.resultRt[i];
     o.lastRGBErrorLevel = g.lastRGBErrorLevel;
     o.rgb_broken = g.rgb_broken;
-    if (HAS_RGB && A.n_iter > 0) {
+    if (HAS_RGB && A.n_iter > 0) {   // the last search's totals, where the next update step's head looks for them
       const int set = (A.n_iter - 1) & 1;
-      int sa = 0, sb = 0;
-      for (int w = 0; w < PT_WGS; ++w) { sa += pt_loadi(&Y->wg_sums[set][w][0]); sb += pt_loadi(&Y->wg_sums[set][w][1]); }
-      st->rgb_slots[set][0][0] = sa;
-      st->rgb_slots[set][0][1] = sb;
+      st->rgb_slots[set][0][0] = tot_s[set][0];
+      st->rgb_slots[set][0][1] = tot_s[set][1];
     }
+    __hip_atomic_store(&Y->epoch, epoch + (unsigned)A.n_iter + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch's tags
+#ifdef EF_STAGE_CLOCKS
+    Y->clk[11] += wall_clock64() - clk_start;   // whole launch
+    Y->clk[22] += 1;
+#endif
   }
 }
 
@@ -2678,6 +2929,14 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
 }
 // host-side tail of getIncrementalTransformation: the frame's intensity pyramid becomes the SO(3) reference of the next
 // (RGBDOdometry.cpp:284-288 swaps lastNextImage / nextImage); separate so that a replayed hipGraph can do it without launching
+// developer instrumentation: the -DEF_STAGE_CLOCKS sums of k_track_small (24 x u64, 10 ns ticks; zeros in a normal build), read and reset
+int tracker_small_clocks(const Pyramid& p, unsigned long long* out24, hipStream_t s) {
+  if (!p.partials) return -1;
+  unsigned long long* src = (unsigned long long*)((char*)(p.partials + 2 * PARTIAL_FLOATS) + offsetof(PtSync, clk));
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  if (hipMemcpy(out24, src, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return hipMemset(src, 0, 24 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 int tracker_aborted(const Pyramid& p, hipStream_t s) {
   if (!p.partials) return 0;
   PtSync h;

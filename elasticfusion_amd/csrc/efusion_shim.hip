@@ -186,20 +186,6 @@ std::vector<float> DeformationView::getGraph() {
   nodes.resize((size_t)n * 4);
   return nodes;
 }
-#ifdef EFUSION_USE_SOPHUS
-void ElasticFusion::processFrame(const uint8_t* rgb, const uint16_t* depth, const int64_t& timestamp, const float weightMultiplier,
-                                 const Sophus::SE3d* in_T_wc) {
-  if (!in_T_wc) return processFrame(rgb, depth, timestamp, weightMultiplier, (const SE3d*)nullptr);
-  SE3d T;
-  std::memcpy(T.q, in_T_wc->so3().unit_quaternion().coeffs().data(), sizeof(T.q));
-  std::memcpy(T.t, in_T_wc->translation().data(), sizeof(T.t));
-  processFrame(rgb, depth, timestamp, weightMultiplier, &T);
-}
-Sophus::SE3d ElasticFusion::get_T_wc_sophus() {
-  const SE3d& T = get_T_wc();
-  return Sophus::SE3d(Eigen::Quaterniond(T.q[3], T.q[0], T.q[1], T.q[2]), Eigen::Vector3d(T.t[0], T.t[1], T.t[2]));
-}
-#endif
 
 void ElasticFusion::predict() { chk(ef_predict(C(ctx.get())), ctx.get(), "predict"); }
 
@@ -245,7 +231,7 @@ const int& ElasticFusion::getTick() {
 }
 void ElasticFusion::setTick(const int& val) { chk(ef_set_tick(C(ctx.get()), val), ctx.get(), "setTick"); }
 
-const SE3d& ElasticFusion::get_T_wc() {
+const SE3d& ElasticFusion::get_T_wc_pod() {
   double M[16];
   chk(ef_get_pose(C(ctx.get()), M), ctx.get(), "get_T_wc");
   T_wc = SE3d::fromMatrix(M);

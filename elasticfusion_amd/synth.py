@@ -128,6 +128,47 @@ class Sequence:
         return rgb, depth, self.pose(k)
 
 
+def sample_surfels(seq: "Sequence", n: int = 1 << 20, radius: float = 0.004, conf: float = 12.0, init_time: int = 1, last_time: int = 1) -> np.ndarray:
+    """~n surfels [m, 12] float32 sampled on the scene's surfaces ("ef_map_upload of surfels sampled on the scene
+    surfaces, radius 4 mm, conf 12, times in window"), in ``seq``'s world frame (= its camera frame at k = 0), laid out as the map holds
+    them: {x, y, z, confidence} {colour, 0, initTime, lastTime} {nx, ny, nz, radius}.  Regular grids on the six walls (area-proportional) and
+    on the three spheres, wall after wall, row after row: neighbouring surfels are neighbours in memory, as in a map that grew frame by
+    frame.  Normals point away from the room's interior, the way normals computed from a depth image point away from the camera."""
+    bx, by, bz = seq.box
+    walls = []   # (origin, u axis, v axis, outward normal), absolute scene frame
+    for sgn in (-1.0, 1.0):
+        walls.append((np.array([sgn * bx, -by, -bz]), np.array([0, 2 * by, 0.0]), np.array([0, 0, 2 * bz]), np.array([sgn, 0, 0.0])))
+        walls.append((np.array([-bx, sgn * by, -bz]), np.array([2 * bx, 0, 0.0]), np.array([0, 0, 2 * bz]), np.array([0, sgn, 0.0])))
+        walls.append((np.array([-bx, -by, sgn * bz]), np.array([2 * bx, 0, 0.0]), np.array([0, 2 * by, 0.0]), np.array([0, 0, sgn])))
+    areas = [np.linalg.norm(u) * np.linalg.norm(v) for _, u, v, _ in walls] + [4 * np.pi * r * r for _, r in seq.spheres]
+    pitch = np.sqrt(sum(areas) / n)
+    P, Nn = [], []
+    for o, u, v, nrm in walls:
+        nu, nv = max(1, int(round(np.linalg.norm(u) / pitch))), max(1, int(round(np.linalg.norm(v) / pitch)))
+        a, b = np.meshgrid((np.arange(nu) + 0.5) / nu, (np.arange(nv) + 0.5) / nv, indexing="ij")
+        P.append(o + a[..., None] * u + b[..., None] * v)
+        Nn.append(np.broadcast_to(nrm, P[-1].shape))
+    for c, r in seq.spheres:
+        m = max(8, int(round(4 * np.pi * r * r / (pitch * pitch))))
+        i = np.arange(m) + 0.5
+        phi, th = np.arccos(1 - 2 * i / m), np.pi * (1 + 5 ** 0.5) * i
+        d = np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], -1)
+        P.append(c + r * d)
+        Nn.append(-d)   # the camera is outside the sphere: away from it = into the sphere
+    P = np.concatenate([x.reshape(-1, 3) for x in P])
+    Nn = np.concatenate([np.asarray(x, np.float64).reshape(-1, 3) for x in Nn])
+    rgb = seq._albedo(P).astype(np.int64)
+    R0, t0 = seq._T0_inv[:3, :3], seq._T0_inv[:3, 3]
+    out = np.zeros((len(P), 12), np.float32)
+    out[:, :3] = P @ R0.T + t0
+    out[:, 3] = conf
+    out[:, 4] = ((rgb[:, 0] << 16) + (rgb[:, 1] << 8) + rgb[:, 2]).astype(np.float32)   # color.glsl:19-34
+    out[:, 6], out[:, 7] = init_time, last_time
+    out[:, 8:11] = Nn @ R0.T
+    out[:, 11] = radius
+    return out
+
+
 def write_klg(path: str, frames, timestamps=None, compress_depth: bool = False, jpeg_quality: int | None = None) -> None:
     """Writes frames [(rgb HxWx3 u8, depth HxW u16, ...)] as a .klg log (layout of Tools/RawLogReader.cpp:29,63-109):
     int32 numFrames, then per frame int64 timestamp, int32 depthSize, int32 imageSize, depth bytes (raw little-endian

@@ -6,8 +6,8 @@
 // What is different, and why:
 //  * Sophus::SE3d / Eigen are not vendored by the reference checkout (third-party/* empty) and are absent here, so
 //    poses cross this boundary as Sophus-layout PODs (unit quaternion x,y,z,w + translation) with a row-major
-//    matrix() accessor.  When <sophus/se3.hpp> is on the include path, define EFUSION_USE_SOPHUS and the same
-//    methods take / return real Sophus::SE3d (conversion is a memcpy of 7 doubles).
+//    matrix() accessor.  When <sophus/se3.hpp> is on the include path, define EFUSION_USE_SOPHUS and processFrame / get_T_wc
+//    take / return real Sophus::SE3d, as in the reference (header-inline conversions; the library itself never sees Sophus).
 //  * getIndexMap()/getGlobalModel()/getModelToModel() return small HBM-backed facades with the members the
 //    front-end actually reads (lastCount, lastICPError, lastICPCount, downloadMap, host copies of the predicted
 //    images); there is no GL texture or VBO behind them.
@@ -152,9 +152,20 @@ class ElasticFusion {
   void processFrame(const uint8_t* rgb, const uint16_t* depth, const int64_t& timestamp, const float weightMultiplier = 1.f,
                     const SE3d* in_T_wc = 0);
 #ifdef EFUSION_USE_SOPHUS
+  // the reference's own signature (Core/ElasticFusion.h:70-75); header-inline, so that the library itself never needs Sophus.  The pose
+  // crosses as rotation matrix + translation (Sophus::SE3d::rotationMatrix() / translation(), the two accessors every Sophus has).
   void processFrame(const uint8_t* rgb, const uint16_t* depth, const int64_t& timestamp, const float weightMultiplier,
-                    const Sophus::SE3d* in_T_wc);
-  Sophus::SE3d get_T_wc_sophus();
+                    const Sophus::SE3d* in_T_wc) {
+    if (!in_T_wc) {
+      processFrame(rgb, depth, timestamp, weightMultiplier, (const SE3d*)0);
+      return;
+    }
+    const auto R = in_T_wc->rotationMatrix();
+    const auto& t = in_T_wc->translation();
+    const double M[16] = {R(0, 0), R(0, 1), R(0, 2), t(0), R(1, 0), R(1, 1), R(1, 2), t(1), R(2, 0), R(2, 1), R(2, 2), t(2), 0, 0, 0, 1};
+    const SE3d T = SE3d::fromMatrix(M);
+    processFrame(rgb, depth, timestamp, weightMultiplier, &T);
+  }
 #endif
   void predict();
 
@@ -187,7 +198,23 @@ class ElasticFusion {
   const int& getTimeDelta() { return timeDelta; }
   void setTick(const int& val);
   const float& getMaxDepthProcessed() { return maxDepthProcessed; }
-  const SE3d& get_T_wc();
+  const SE3d& get_T_wc_pod();               // the pose as the engine holds it (quaternion x,y,z,w + translation)
+#ifdef EFUSION_USE_SOPHUS
+  Sophus::SE3d get_T_wc() {                  // Core/ElasticFusion.h:196 (by value here: the class keeps no Sophus member, its layout is the library's)
+    double M[16];
+    get_T_wc_pod().matrix(M);
+    Sophus::SE3d T;
+    decltype(T.rotationMatrix()) R;
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) R(i, j) = M[i * 4 + j];
+      T.translation()(i) = M[i * 4 + 3];
+    }
+    T.setRotationMatrix(R);
+    return T;
+  }
+#else
+  const SE3d& get_T_wc() { return get_T_wc_pod(); }
+#endif
   const int& getDeforms() { return deforms; }
   const int& getFernDeforms() { return fernDeforms; }
   void savePly();                            // <fileName>.ply, binary little endian (ElasticFusion.cpp:684-781)

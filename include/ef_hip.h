@@ -89,6 +89,10 @@ int ef_set_graph_replay(ef_ctx* ctx, int on);
  * time (512 threads, 36 KB of LDS each: half the CUs of one MI355X); every wait in it is bounded, and a launch whose grid could not
  * become resident (other work holding the chip's wave slots for ever) makes ef_synchronize return EF_EHIP instead of hanging. */
 int ef_set_persistent_tracker(ef_ctx* ctx, int on);
+/* Odometry only (BASELINE.json configs[4], "open-loop odometry-only ... throughput ceiling"): frames are pre-processed, tracked against
+ * the model prediction and the prediction is renewed at the new pose, but nothing is fused (the map stays as it is: indexMap, fuse and
+ * clean of ElasticFusion.cpp:536-585 are skipped, like a frame whose tracking failed under relocalisation).  Off by default. */
+int ef_set_track_only(ef_ctx* ctx, int on);
 /* Device half of a loop closure: hands a deformation graph (HOST pointer, nodes x 16 floats sorted by time, layout of
  * GlobalModel::clean's rawGraph, GlobalModel.cpp:536-546) to the NEXT ef_process_frame, whose clean pass applies it to the
  * whole map exactly as ElasticFusion.cpp:558-585 does (synthesizeDepth first unless is_fern).  For a caller that finds loop closures
@@ -193,6 +197,20 @@ typedef void (*ef_fern_tracker)(void* user, const float* fern_verts4, const floa
 int ef_ferns_find_frame(ef_ferns* f, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16,
                         int time, int lost, ef_fern_tracker tracker, void* user, double* T_est16_out, double* constraints6_out,
                         int max_constraints, int* n_constraints_out);
+/* The same two with the view's fern codes computed by the CALLER — on the device: ef_process_frame runs one 512-thread kernel over
+ * the full-resolution fill-in maps (texel (8 x + 4, 8 y + 4) under each fern = what Resize::image / Resize::vertex would hand to
+ * Ferns.cpp:97-118) and reads back `num` code bytes (255 = no valid depth) + their count instead of three 1/8-resolution images.  The
+ * view itself is asked for through `fetch` only when it is needed: a keyframe passed the code gates (findFrame) or the frame is kept
+ * (addFrame).  fetch returns EF_OK and the three images (rgb with 3 or 4 channels); at most one call per call. */
+typedef int (*ef_view_fetch)(void* user, const uint8_t** rgb_out, int* rgb_channels_out, const float** verts4_out, const float** norms4_out);
+int ef_ferns_add_frame_coded(ef_ferns* f, const uint8_t* codes, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int src_time,
+                             float threshold);
+int ef_ferns_find_frame_coded(ef_ferns* f, const uint8_t* codes, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int time,
+                              int lost, ef_fern_tracker tracker, void* user, double* T_est16_out, double* constraints6_out, int max_constraints,
+                              int* n_constraints_out);
+/* 1 when some stored frame is more than 300 ticks older than `time` (Ferns.cpp:225), i.e. findFrame CAN match; 0: it returns -1 whatever the view */
+int ef_ferns_candidate_possible(ef_ferns* f, int time);   /* answering 0 it also resets lastClosest to -1, as the findFrame it stands for would */
+int ef_ferns_table_version(const ef_ferns* f);            /* bumped by every ef_ferns_set_table */
 int ef_ferns_count(const ef_ferns* f);          /* frames.size() */
 int ef_ferns_last_closest(const ef_ferns* f);   /* lastClosest */
 /* one stored frame: any output may be NULL.  codes_out: num bytes (255 = no valid depth under that fern). */
@@ -238,6 +256,14 @@ int ef_closure_trajectory(const ef_closure* c, double* poses16_or_null, int max_
 int ef_closure_relocalise(ef_closure* c, const uint8_t* rgb, int channels, const float* verts4, const float* norms4, const double* T_wc16, int tick,
                           ef_fern_tracker tracker, void* user, double* T_recovery16_out);
 int ef_closure_log_pose(ef_closure* c, const double* T_wc16, int tick);
+/* ef_closure_global / ef_closure_end_frame / ef_closure_relocalise on device-computed fern codes (ef_ferns_*_coded above) */
+int ef_closure_global_coded(ef_closure* c, const uint8_t* codes, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int tick,
+                            ef_fern_tracker tracker, void* user, const float* nodes4, int n_nodes, double* T_recovery16_out, float* graph16_out,
+                            int* nodes_out);
+int ef_closure_candidate_possible(ef_closure* c, int tick);   /* 0: this frame's findFrame cannot match (no keyframe older than 300 ticks); the object is left as after such a call */
+int ef_closure_end_frame_coded(ef_closure* c, const uint8_t* codes, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int tick);
+int ef_closure_relocalise_coded(ef_closure* c, const uint8_t* codes, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int tick,
+                                ef_fern_tracker tracker, void* user, double* T_recovery16_out);
 /* ---- the GLOBAL loop closure inside ef_process_frame (ElasticFusion.cpp:392-445, 588-589, 609-618; contexts created with
  * close_loops = 1).  Creates the context's closure object (ef_closure_* above: Ferns(num_ferns, depth_cut * 1000, photo_thresh), the
  * relative constraints, the trajectory) and a third tracker instance at 1/8 resolution.  From then on every frame (tick > 1):
@@ -377,6 +403,9 @@ int ef_get_splat_timing(ef_ctx* ctx, ef_kernel_time* out);
 /* developer instrumentation: the 16 wall_clock64() (100 MHz) stamps the last tracking solve left in the device state;
  * all zero unless the library was built with -DEF_STAGE_CLOCKS (EF_HIPCC_FLAGS=-DEF_STAGE_CLOCKS python -m elasticfusion_amd.build) */
 int ef_debug_clocks(ef_ctx* ctx, unsigned long long* out16);
+/* developer instrumentation of the persistent small-level launch (zeros unless the library was built with -DEF_STAGE_CLOCKS): 24 sums
+ * of 10 ns ticks per phase since the last call, tools/small_clocks.py names them */
+int ef_debug_small_clocks(ef_ctx* ctx, unsigned long long* out24);
 
 /* ---- device memory helpers (so that a non-HIP host can drive the operator tier) ---- */
 int ef_dev_alloc(void** dev, size_t bytes);

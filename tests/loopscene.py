@@ -54,3 +54,60 @@ class OneShotSolver:
             return None
         self.accepted += 1
         return graph_from_constraints(cons)
+
+
+class SweepSequence:
+    """Closed-loop steady state at the reference's DEFAULT thresholds (tests/test_gpu_closed_steady.py): dwell on view A until its surfels are
+    stable (confidence 10 takes some forty frames at a quarter of the pixels per frame), sweep away by 30 degrees, dwell on view B for longer
+    than the time window — A's surfels outside B go INACTIVE by themselves —, sweep back and dwell: the inactive surface is re-observed, the
+    model-to-model registration finds tens of thousands of inliers and the reference's own gates (35000 / 5e-5 / 1e-5) open.  No injected
+    pose, no setTick, no relaxed gate.  (A wrapper, not a subclass, so that worker processes can rebuild it from its arguments.)"""
+    PLAN = (90, 30, 30, 30, 14)     # dwell A, sweep, dwell B, sweep back, dwell A
+    A = 0.26                        # half sweep, rad
+    TIME_DELTA = 25
+
+    def __init__(self, seed=0xEF0003):
+        from elasticfusion_amd import synth
+        self.seq = synth.Sequence(seed)
+        self.seq._abs_pose = self._abs_pose
+        self.seq._T0_inv = np.linalg.inv(self._abs_pose(0))
+        self.n = sum(self.PLAN)
+
+    def _abs_pose(self, k):
+        from elasticfusion_amd import synth
+        d0, r1, d1, r2, _ = self.PLAN
+        if k < d0:
+            th = -self.A
+        elif k < d0 + r1:
+            th = -self.A + 2 * self.A * (k - d0) / r1
+        elif k < d0 + r1 + d1:
+            th = self.A
+        elif k < d0 + r1 + d1 + r2:
+            th = self.A - 2 * self.A * (k - d0 - r1 - d1) / r2
+        else:
+            th = -self.A
+        T = np.eye(4)
+        T[:3, :3] = synth._rot_xyz(0.01 * np.sin(0.21 * k), th, 0.008 * np.sin(0.13 * k))
+        T[:3, 3] = [0.03 * np.sin(0.17 * k), 0.02 * np.sin(0.11 * k), 0.02 * np.sin(0.07 * k)]
+        return T
+
+    def frame(self, k):
+        return self.seq.frame(k)
+
+
+def _sweep_frame(k):
+    s = _sweep_frame.seq
+    if s is None:
+        s = _sweep_frame.seq = SweepSequence()
+    return s.frame(k)
+
+
+_sweep_frame.seq = None
+
+
+def sweep_frames():
+    """[(rgb, depth, T_wc)] of the whole sweep, rendered by spawned workers (the parent may already hold a HIP runtime)"""
+    import multiprocessing as mp
+    import os
+    with mp.get_context("spawn").Pool(max(1, min(16, (os.cpu_count() or 2) - 1))) as pool:
+        return pool.map(_sweep_frame, range(SweepSequence().n), chunksize=4)

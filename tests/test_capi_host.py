@@ -92,7 +92,7 @@ def test_cpp_shim_library_and_replay_tool_exist_and_fail_loudly(tmp_path):
     exe = os.path.join(os.path.dirname(api.LIB_PATH), "efusion_replay")
     assert os.path.exists(shim) and os.path.exists(exe)
     syms = subprocess.run(["nm", "-DC", shim], stdout=subprocess.PIPE, text=True).stdout
-    for name in ("efusion::ElasticFusion::processFrame(", "efusion::ElasticFusion::predict()", "efusion::ElasticFusion::get_T_wc()",
+    for name in ("efusion::ElasticFusion::processFrame(", "efusion::ElasticFusion::predict()", "efusion::ElasticFusion::get_T_wc_pod()",
                  "efusion::ElasticFusion::savePly()", "Resolution::getInstance(int, int)", "Intrinsics::getInstance(float, float, float, float)",
                  "efusion::GlobalModelView::lastCount()"):
         assert name in syms, name

@@ -12,7 +12,7 @@ for rep in 1 2; do   # two passes: the first also warms the frame cache
     lib=$GRAFT_REPO_ROOT/elasticfusion_amd/libefusion_hip.so
     [ "$v" != "-" ] && lib=$GRAFT_REPO_ROOT/elasticfusion_amd/libefusion_hip_$v.so
     [ -f $lib ] || { echo "[$v] missing"; continue; }
-    EF_HIP_LIB=$lib timeout 300 python bench.py --no-cpu-baseline --steps 200 --warmup 20 --frames-cache /tmp/efframes 2>/dev/null | python -c "
+    EF_HIP_LIB=$lib timeout 300 python bench.py --no-cpu-baseline --no-side-legs --steps 200 --warmup 20 --frames-cache /tmp/efframes 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
 print('[$v]', d['value'], 'fps', r['avg_us'], 'us accum L0 (frac', r['frac'], ') splat', d['roofline_index_splat']['avg_us'], 'us')" | tee -a $out/${tag}_ab.log

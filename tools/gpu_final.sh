@@ -11,6 +11,6 @@ cat $out/${tag}_shared_gpu.jsonl; tail -3 $out/${tag}_shared_gpu.err
 timeout 300 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?"
 cat $out/${tag}_bench.json; tail -3 $out/${tag}_bench.err
 cd /tmp
-timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${tag} --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/${tag}_prof_stdout.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${tag} --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-side-legs > $out/${tag}_prof_stdout.log 2>&1
 find /tmp/prof -name "${tag}_kernel_stats.csv" -exec cp {} $out/${tag}_bench_kernel_stats.csv \;
 head -8 $out/${tag}_bench_kernel_stats.csv | cut -c1-200

@@ -14,7 +14,7 @@ cd /tmp
 for v in default both; do
   lib=$GRAFT_REPO_ROOT/elasticfusion_amd/libefusion_hip.so
   [ $v = both ] && lib=$GRAFT_REPO_ROOT/elasticfusion_amd/libefusion_hip_both.so
-  EF_HIP_LIB=$lib timeout 150 rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o ${tag}_$v --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --frames-cache /tmp/efframes > $out/${tag}_${v}_prof_stdout.log 2>&1
+  EF_HIP_LIB=$lib timeout 150 rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o ${tag}_$v --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-side-legs --frames-cache /tmp/efframes > $out/${tag}_${v}_prof_stdout.log 2>&1
   find /tmp/prof_$v -name "${tag}_${v}_kernel_stats.csv" -exec cp {} $out/${tag}_${v}_bench_kernel_stats.csv \;
   head -14 $out/${tag}_${v}_bench_kernel_stats.csv | cut -c1-150
 done

@@ -11,7 +11,7 @@ tail -25 $out/${tag}_tests.log
 for rep in 1 2; do
   for v in persistent per-step; do
     flag=""; [ $v = per-step ] && flag="--per-step-tracker"
-    timeout 200 python bench.py --no-cpu-baseline --steps 200 --warmup 20 --frames-cache /tmp/efframes $flag 2>/dev/null | python -c "
+    timeout 200 python bench.py --no-cpu-baseline --no-side-legs --steps 200 --warmup 20 --frames-cache /tmp/efframes $flag 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
 print('[$v]', d['value'], 'fps', r['avg_us'], 'us accum L0 (frac', r['frac'], ') splat', d['roofline_index_splat']['avg_us'], 'us')" | tee -a $out/${tag}_ab.log

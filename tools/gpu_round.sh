@@ -19,7 +19,7 @@ timeout 300 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; e
 cat $out/${tag}_bench.json
 tail -3 $out/${tag}_bench.err
 cd /tmp
-timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${tag} --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/${tag}_prof_stdout.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${tag} --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-side-legs > $out/${tag}_prof_stdout.log 2>&1
 find /tmp/prof -name "${tag}_kernel_stats.csv" -exec cp {} $out/${tag}_bench_kernel_stats.csv \;
 head -12 $out/${tag}_bench_kernel_stats.csv | cut -c1-200
 # the streaming probe's kernels under the same profiler (exact dispatch durations: what a kernel of this shape can reach)
@@ -28,9 +28,9 @@ find /tmp/prof2 -name "${tag}p_kernel_stats.csv" -exec cp {} $out/${tag}_stream_
 cat $out/${tag}_stream_probe_kernel_stats.csv | cut -c1-160
 # side measurements (not the headline): frames handed over as host buffers (PCIe inclusive), closed-loop mode, configs[2]
 cd $GRAFT_REPO_ROOT
-timeout 200 python bench.py --no-cpu-baseline --host-frames > $out/${tag}_hostframes_bench.json 2>/dev/null
+timeout 200 python bench.py --no-cpu-baseline --no-side-legs --host-frames > $out/${tag}_hostframes_bench.json 2>/dev/null
 cut -c1-220 $out/${tag}_hostframes_bench.json
-timeout 200 python bench.py --no-cpu-baseline --close-loops > $out/${tag}_closeloops_bench.json 2>/dev/null
+timeout 200 python bench.py --no-cpu-baseline --no-side-legs --close-loops > $out/${tag}_closeloops_bench.json 2>/dev/null
 cut -c1-220 $out/${tag}_closeloops_bench.json
-timeout 300 python bench.py --no-cpu-baseline --width 1280 --height 960 --steps 100 --warmup 10 > $out/${tag}_1280x960_bench.json 2>/dev/null
+timeout 300 python bench.py --no-cpu-baseline --no-side-legs --width 1280 --height 960 --steps 100 --warmup 10 > $out/${tag}_1280x960_bench.json 2>/dev/null
 cat $out/${tag}_1280x960_bench.json

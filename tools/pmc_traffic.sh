@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
   timeout 600 rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_$ctr -o p --output-format csv -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline --frames-cache /tmp/efframes_pmc > $out/${tag}_${ctr}_stdout.log 2>&1
+      python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-side-legs --frames-cache /tmp/efframes_pmc > $out/${tag}_${ctr}_stdout.log 2>&1
   f=$(find /tmp/pmc_$ctr -name "p_counter_collection.csv" | head -1)
   echo "$ctr -> $f"
   python - "$f" "$ctr" > $out/${tag}_${ctr}_per_kernel.csv <<'PY'
