@@ -170,12 +170,14 @@ def rooflines(lib, ef, w, h, where):
     return roofline, roofline_splat
 
 
-def make_engine(api, w, h, device, stream, close_loops=False, graph=False, per_step=False):
+def make_engine(api, w, h, device, stream, close_loops=False, graph=False, per_step=False, fused_step=False):
     sc = w / 640.0
     ef = api.ElasticFusion(width=w, height=h, fx=528.0 * sc, fy=528.0 * sc, cx=320.0 * sc, cy=240.0 * sc, device=device, stream=stream,
                            maxSurfels=max(4 * 1024 * 1024, 6 * w * h), **(dict(closeLoops=True, timeDelta=200) if close_loops else {}))
     if per_step:
         ef.setPersistentTracker(False)
+    if fused_step:
+        ef.setFusedStep(True)
     if graph:
         ef.setGraphReplay(True)
     if close_loops:   # the reference's closed-loop mode: fern database + global closure, then the local closure, built-in optimiser
@@ -271,6 +273,8 @@ def main():
                     "the first frame; with --width 1280 --height 960 --preseed 1048576 = BASELINE.json configs[2], the HBM-bound map")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the extra keys of the N = 1 line (host-frame path, reference-rounding "
                     "build, closed loop, odometry only, hipGraph replay, configs[2])")
+    ap.add_argument("--fused-step", action="store_true", help="development (A/B): level-0 update step inside the correspondence-search launch "
+                    "(ef_set_fused_step); results are bit-identical")
     ap.add_argument("--per-step-tracker", action="store_true", help="development (A/B): the round-2 tracker script, one launch per step, instead "
                     "of the persistent small-level launch (ef_set_persistent_tracker(ctx, 0)); results are bit-identical")
     a = ap.parse_args()
@@ -280,7 +284,7 @@ def main():
     rank, local_rank, world = multi.rank_info()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    plain = not (a.host_frames or a.close_loops or a.graph or a.track_only or a.library or a.preseed or a.per_step_tracker or a.probe_inside)
+    plain = not (a.host_frames or a.close_loops or a.graph or a.track_only or a.library or a.preseed or a.per_step_tracker or a.probe_inside or a.fused_step)
     side = world == 1 and plain and (w, h) == (W, H) and not a.no_side_legs   # the extra keys ride on the default N = 1 line only
 
     # synthetic frames first: the generator forks worker processes, which must happen before HIP / RCCL are initialised
@@ -326,7 +330,7 @@ def main():
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
-    ef = make_engine(api, w, h, local_rank, stream, close_loops=a.close_loops, graph=a.graph, per_step=a.per_step_tracker)
+    ef = make_engine(api, w, h, local_rank, stream, close_loops=a.close_loops, graph=a.graph, per_step=a.per_step_tracker, fused_step=a.fused_step)
     dev = [(api.DevBuf.from_array(r), api.DevBuf.from_array(d)) for r, d, _ in frames]
     k0 = 0
     n_pre = 0
@@ -389,7 +393,7 @@ def main():
     mode = ("HOST frames (pinned staging + PCIe upload timed), " if a.host_frames else "") + \
            ("closeLoops (fern database + global closure + local closure every frame, timeDelta 200), " if a.close_loops else "open loop, ") + \
            ("tracker replayed from a hipGraph, " if a.graph else "") + ("ODOMETRY ONLY in the timed region (no fusion), " if a.track_only else "") + \
-           ("one launch per tracker step (round-2 script), " if a.per_step_tracker else "") + \
+           ("one launch per tracker step (round-2 script), " if a.per_step_tracker else "") + ("level-0 update step fused into the search launch, " if a.fused_step else "") + \
            (f"reference-rounding build ({os.path.basename(api.LIB_PATH)}), " if a.library else "") + \
            (f"map pre-seeded with {n_pre} surfels sampled on the scene (radius 4 mm, confidence 12), " if a.preseed else "")
     out = {

@@ -631,6 +631,10 @@ class ElasticFusion:
     def predict(self):
         _chk(lib().ef_predict(self.h), self.h)
 
+    def setFusedStep(self, on=True):
+        """level-0 update step inside the correspondence-search launch (ef_set_fused_step)"""
+        _chk(lib().ef_set_fused_step(self.h, c_i(int(on))), self.h)
+
     def setTrackOnly(self, on=True):
         """odometry on a frozen map: track + predict, no fusion (ef_set_track_only; BASELINE.json configs[4])"""
         _chk(lib().ef_set_track_only(self.h, c_i(int(on))), self.h)

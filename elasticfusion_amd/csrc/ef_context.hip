@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -117,6 +118,7 @@ struct ef_ctx {
   // instance at 1/8 resolution for the fern-to-view registration (Ferns.cpp:243-258: RGBDOdometry rgbd(w / 8, h / 8, ...))
   ef_closure* closure = nullptr;
   ef_global_loop gloop{};
+  std::string fern_tracker_error;          // first HIP error inside the fern tracker callback (it cannot return one)
   int fern_w = 0, fern_h = 0;
   uchar4* view_img_dev = nullptr;          // Resize::image / vertex (x2) of the fill-in maps, factor 8
   float4* view_vert_dev = nullptr;
@@ -149,6 +151,7 @@ struct ef_ctx {
   // captured once per pyramid parity (the SO(3) reference / frame intensity buffers swap every frame) and replayed
   bool use_graph = false;
   bool track_only = false;       // ef_set_track_only: odometry on a frozen map (BASELINE.json configs[4])
+  bool fused_step = false;       // ef_set_fused_step: level-0 update step inside the correspondence-search launch
   bool persistent = true;        // ef_set_persistent_tracker: small pyramid levels + SO(3) in one persistent launch (k_track_small)
   struct TrackGraph { hipGraphExec_t exec = nullptr; const void* key = nullptr; eft::TrackParams tp{}; eft::TrackTail tail{}; };
   TrackGraph tgraph[2];
@@ -428,10 +431,12 @@ void fern_tracker_device(void* user, const float* fv, const float* fn, const dou
   float4* d_cv = d_fn + n;
   float4* d_cn = d_cv + n;
   const uint8_t* zero_image = (const uint8_t*)(d_cn + n);
-  (void)hipMemcpyAsync(d_fv, fv, n * 16, hipMemcpyHostToDevice, s);
-  (void)hipMemcpyAsync(d_fn, fn, n * 16, hipMemcpyHostToDevice, s);
-  (void)hipMemcpyAsync(d_cv, cv, n * 16, hipMemcpyHostToDevice, s);
-  (void)hipMemcpyAsync(d_cn, cn, n * 16, hipMemcpyHostToDevice, s);
+  // a failed copy or launch must not hand a stale pose and inlier count to Ferns::findFrame's gates: the first HIP error is kept in the
+  // context (global_loop_closure returns EF_EHIP for it) and the candidate is rejected (error = +inf, count = 0)
+  hipError_t e = hipMemcpyAsync(d_fv, fv, n * 16, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_fn, fn, n * 16, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_cv, cv, n * 16, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_cn, cn, n * 16, hipMemcpyHostToDevice, s);
   (void)Tf;   // the caller hands T_io = T_wc_fern in (Ferns.cpp:250); the model maps are transformed with it
   eft::pose_injected(c->st3, T_io, false, 1.0f, false, nullptr, 0, s);
   eft::init_icp_model(c->pyr3, (const float*)d_fv, (const float*)d_fn, (const float*)d_fv, (const float*)d_fn, c->st3, 6.0f, s);
@@ -439,12 +444,22 @@ void fern_tracker_device(void* user, const float* fv, const float* fn, const dou
   eft::TrackParams tp;
   tp.rgbOnly = false; tp.pyramid = false; tp.fastOdom = false; tp.so3 = false; tp.icpWeight = 100.f;
   tp.persistent = c->persistent ? 1 : 0;
+  tp.fused_step = c->fused_step ? 1 : 0;
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
   const eft::TrackTail tail = eft::track(c->pyr3, c->st3, c->intr3, tp, s, nullptr);
   eft::track_end(c->st3, tail, false, 1.0f, nullptr, -1, s);
-  (void)hipMemcpyAsync(&c->h_states[1], c->st3, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s);
-  (void)hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipMemcpyAsync(&c->h_states[1], c->st3, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) {
+    if (c->fern_tracker_error.empty()) c->fern_tracker_error = std::string("fern-to-view registration: ") + hipGetErrorString(e);
+    *err = std::numeric_limits<float>::infinity();
+    *cnt = 0.f;
+    c->gloop.icp_error = *err;
+    c->gloop.icp_count = 0.f;
+    return;
+  }
   const eft::TrackState& h = c->h_states[1];
   efl::SE3 T;
   for (int i = 0; i < 4; ++i) T.q[i] = h.q[i];
@@ -481,6 +496,7 @@ int global_loop_closure(ef_ctx* c, int log_slot, int* accepted_with_graph) {
   memcpy(&good, c->h_codes + FERN_CODES_PAD, sizeof(int));
   if (c->lost) {
     const int r = ef_closure_relocalise_coded(c->closure, c->h_codes, good, &fetch_mid_view, c, c->h_pose, c->tick, &fern_tracker_device, c, G.T_wc_recovery);
+    if (!c->fern_tracker_error.empty()) { c->err = c->fern_tracker_error; c->fern_tracker_error.clear(); return EF_EHIP; }
     if (r < 0) { c->err = "ef_closure_relocalise failed"; return r; }
     G.closest = ef_ferns_last_closest(F);
     if (r == 1) {
@@ -493,6 +509,7 @@ int global_loop_closure(ef_ctx* c, int log_slot, int* accepted_with_graph) {
   int nodes = 0;
   const int r = ef_closure_global_coded(c->closure, c->h_codes, good, &fetch_mid_view, c, c->h_pose, c->tick, &fern_tracker_device, c, c->h_nodes_pinned,
                                         c->n_nodes_host, G.T_wc_recovery, c->loop_graph.data(), &nodes);
+  if (!c->fern_tracker_error.empty()) { c->err = c->fern_tracker_error; c->fern_tracker_error.clear(); return EF_EHIP; }
   if (r < 0) { c->err = "ef_closure_global failed"; return r; }
   G.closest = ef_ferns_last_closest(ef_closure_ferns(c->closure));   // Ferns::lastClosest: -1 unless a keyframe passed every gate
   if (G.closest >= 0) {   // the rows handed to the optimiser: two per fern constraint (the constraint and its pin) + the kept relative ones
@@ -541,6 +558,7 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
   eft::TrackParams tp;
   tp.rgbOnly = false; tp.pyramid = c->cfg.pyramid != 0; tp.fastOdom = c->cfg.fast_odom != 0; tp.so3 = false; tp.icpWeight = 10.f;   // :471
   tp.persistent = c->persistent ? 1 : 0;
+  tp.fused_step = c->fused_step ? 1 : 0;
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
   const eft::TrackTail tail2 = eft::track(c->pyr2, c->st2, c->intr, tp, s, nullptr);
@@ -709,6 +727,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       tp.so3 = c->cfg.so3 != 0;
       tp.icpWeight = c->cfg.icp_weight;
       tp.persistent = c->persistent ? 1 : 0;
+      tp.fused_step = c->fused_step ? 1 : 0;
       tp.distThres = 0.10f;                                   // RGBDOdometry.h:41
       tp.angleThres = sinf(20.f * 3.14159254f / 180.f);       // RGBDOdometry.h:42
       const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
@@ -1290,6 +1309,13 @@ int ef_sample_graph(ef_ctx* c, float* nodes4, int max_nodes, int* n_out) {
   return EF_OK;
 }
 int ef_set_graph_replay(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->use_graph = on != 0; return EF_OK; }
+int ef_set_fused_step(ef_ctx* c, int on) {
+  if (!c) return EF_EINVAL;
+  c->fused_step = on != 0;
+  for (auto& g : c->tgraph)
+    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+  return EF_OK;
+}
 int ef_set_track_only(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->track_only = on != 0; return EF_OK; }
 int ef_set_persistent_tracker(ef_ctx* c, int on) {
   if (!c) return EF_EINVAL;

@@ -27,10 +27,7 @@ constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * SE3_PAIRS > SO3_ACCS * VWARPS ? 2 
 // loop and every Gauss-Newton iteration of the levels with <= PT_MAX_PIXELS pixels in ONE launch; hand-overs between workgroups
 // alternate between two partial regions, and a small synchronisation record (PtSync) sits behind them.
 constexpr int PT_WGS = 128, PT_BLOCK = 512, PT_MAX_ITER = 16, PT_MAX_PIXELS = 8 * VTHREADS, PT_SYNC_FLOATS = 1024;
-// behind the two float regions and the PtSync: two regions of tagged 8-byte granules {value, epoch} for the pair sums the SE(3)
-// iterations of the persistent launch exchange, and two sets of {count, sum} granules of the correspondence search (PT_WGS x 2 each)
-constexpr int PT_GRANULES = 2 * SE3_ACCS * 64 * 2;   // [term][acc][block][h]
-constexpr int PARTIAL_ALLOC_FLOATS = 2 * PARTIAL_FLOATS + PT_SYNC_FLOATS + 2 * (2 * PT_GRANULES) + 2 * (2 * 2 * PT_WGS);
+constexpr int PARTIAL_ALLOC_FLOATS = 2 * PARTIAL_FLOATS + PT_SYNC_FLOATS;
 
 struct Intr { float fx, fy, cx, cy; };
 __host__ __device__ inline Intr intr_level(const Intr& k, int level) {  // CameraModel::operator()(level), types.cuh:92-95
@@ -85,6 +82,12 @@ struct TrackState {
   unsigned dense_count;
   int dense_samples;
   int tick;
+  // Level-0 iterations with the update step INSIDE the correspondence-search launch (ef_set_fused_step): workgroup 0 evaluates the update
+  // and hands K R K^-1 / K t / the rgbOnly flag to the other workgroups of the same launch as 13 tagged 8-byte granules
+  // {value, (call_seq << 6) | iteration + 1}; call_seq counts getIncrementalTransformation calls (first kernel of the call)
+  unsigned long long step_rec[16];
+  unsigned call_seq;
+  unsigned step_timeout;      // sticky: a workgroup gave up waiting for the record (bounded spin)
   unsigned long long dbg_clock[16];   // developer instrumentation (EF_STAGE_CLOCKS builds only)
   unsigned map_counts[2];     // live surfels of the two ping-pong map buffers (clean reads one, writes the other)
   // float matrices consumed by the map kernels
@@ -111,7 +114,7 @@ struct Pyramid {               // one RGBDOdometry instance's device buffers (RG
   // DataTerm (types.cuh:81-86): bit31 valid | (diff+255) << 22 | v0 << 11 | u0 ("one" is the pixel itself)
   uint32_t* corres[NUM_PYRS];
   uint8_t* rgbMask[NUM_PYRS];      // iteration-invariant part of residualKernel's gates, built once per frame
-  float* partials;                 // PARTIAL_ALLOC_FLOATS: region 0 (what the per-step kernels use), region 1, PtSync, granule regions (zero-filled at allocation)
+  float* partials;                 // PARTIAL_ALLOC_FLOATS: region 0 (what the per-step kernels use), region 1, PtSync (zero-filled at allocation)
   int W(int l) const { return width >> l; }
   int H(int l) const { return height >> l; }
 };
@@ -129,6 +132,7 @@ struct TrackParams {           // host-side knobs of getIncrementalTransformatio
   bool rgbOnly, pyramid, fastOdom, so3;
   float icpWeight;
   float distThres, angleThres; // RGBDOdometry.h:41-42
+  int fused_step = 0;          // level-0 iterations: update step inside the correspondence-search launch (two launches per iteration)
   int persistent = 1;          // (int: the struct is compared with memcmp, no tail padding) small levels + SO(3) in one persistent launch (k_track_small); false = one launch per step (round 2)
 };
 

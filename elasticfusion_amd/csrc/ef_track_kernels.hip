@@ -744,6 +744,7 @@ struct StepArgs {
   float icpWeight;
   Intr knext;                 // intrinsics of THIS iteration's level (for the head's K R K^-1)
   bool level_changes;         // this iteration runs at another level than the one whose update the head evaluates
+  int it;                     // index of the iteration within the call (tag of the fused launch's record)
 };
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* prev, GNState* next, bool publish, const float* sums,
                                                 const StepArgs& A, efs::SolveScratch& S, const efs::SolvePrefetch& PF, bool stats);
@@ -776,12 +777,35 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_track_step(const ResidualPacke
   f3 kt;
   int skip;
   if (A.has_head) {
-    efs::SolvePrefetch PF{};
-    if (t < 64) PF = efs::solve_prefetch(st, prev, slots_prev);
-    pair_partials_tree<REDUCE_BLOCK>(pairs, A.icp, A.rgb, sums_s);
-    __syncthreads();
-    if (t < 64) solve_step_wave(st, prev, next, blockIdx.x == 0, sums_s, A, S, PF, blockIdx.x == 0);
-    __syncthreads();
+    // head + body in one launch (ef_set_fused_step): ONLY workgroup 0 evaluates the update; it hands the thirteen words the search needs
+    // to the other workgroups of the launch as tagged granules, which they poll with their pixel loads already in flight.  (Workgroups
+    // are dispatched in order, so workgroup 0 is resident whenever another one waits; the spin is bounded all the same.)
+    const unsigned tag = (st->call_seq << 6) | (unsigned)(A.it + 1);
+    if (!A.has_body || blockIdx.x == 0) {
+      efs::SolvePrefetch PF{};
+      if (t < 64) PF = efs::solve_prefetch(st, prev, slots_prev);
+      pair_partials_tree<REDUCE_BLOCK>(pairs, A.icp, A.rgb, sums_s);
+      __syncthreads();
+      if (t < 64) solve_step_wave(st, prev, next, blockIdx.x == 0, sums_s, A, S, PF, blockIdx.x == 0);
+      __syncthreads();
+      if (A.has_body && t < 13) {
+        const unsigned bits = t < 9 ? __float_as_uint(S.krkinv[t]) : (t < 12 ? __float_as_uint(S.kt[t - 9]) : (unsigned)S.broken);
+        __hip_atomic_store(&st->step_rec[t], ((unsigned long long)tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      if (t < 13) {
+        unsigned long long g = __hip_atomic_load(&st->step_rec[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; (unsigned)(g >> 32) != tag; ++spin) {
+          if (spin >= (1 << 20)) { st->step_timeout = 1u; break; }
+          __builtin_amdgcn_s_sleep(1);
+          g = __hip_atomic_load(&st->step_rec[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (t < 9) S.krkinv[t] = __uint_as_float((unsigned)g);
+        else if (t < 12) S.kt[t - 9] = __uint_as_float((unsigned)g);
+        else S.broken = (int)(unsigned)g;
+      }
+      __syncthreads();
+    }
     K = m33_load(S.krkinv);
     kt = f3{S.kt[0], S.kt[1], S.kt[2]};
     skip = S.broken;
@@ -1440,6 +1464,7 @@ __global__ void k_track_begin(TrackState* st, bool so3, Intr kso3, Intr kfirst) 
   for (int i = 0; i < RGB_SLOTS; ++i) st->rgb_slots[0][i][0] = st->rgb_slots[0][i][1] = st->rgb_slots[1][i][0] = st->rgb_slots[1][i][1] = 0;
   g.rgb_broken = 0;
   g.lastRGBErrorLevel = 3.402823466e+38f;
+  st->call_seq += 1u;
   st->so3_iterations = 0;
   st->dbg_clock[11] = ~0ull; st->dbg_clock[12] = 0;
   st->so3_ticket = 0;
@@ -1978,7 +2003,6 @@ struct PtSync {                   // behind the partial regions (Pyramid::partia
   unsigned count, pad0[31];       // arrivals of the barrier in flight (its atomics do not share a cache line with the pollers' word)
   unsigned gen, pad1[31];         // generations completed, monotonic across launches
   unsigned abort, pad2[31];       // sticky: a wait timed out
-  unsigned epoch, pad3[31];       // tag base of the granule exchange: read by every workgroup at its start, advanced by workgroup 0 at its end
   int wg_sums[2][PT_WGS][2];      // {count, sum diff^2} of each workgroup's share of a correspondence search, by iteration parity
   unsigned long long clk[24];     // developer instrumentation (-DEF_STAGE_CLOCKS builds): 10 ns ticks per phase, summed over launches
 };
@@ -2062,65 +2086,6 @@ __device__ __forceinline__ int pt_vwarp(int wg, int slot) {
   const int b = wg >> 1, h = wg & 1;
   return 8 * b + h + 2 * (slot >> 1) + 4 * (slot & 1);
 }
-// ---- tagged granules: one naturally aligned 8-byte {value, epoch tag} written by ONE agent-scope store and read by agent-scope loads until
-// the tag is the expected one.  No fence, no drain, no counter: a granule is its own "ready" flag (MI355X_MICROARCH.md price list,
-// handoff-1to1), and the data dependence from iteration to iteration orders every re-use of a region (see k_track_small).
-__device__ __forceinline__ void pt_put(unsigned long long* g, unsigned value_bits, unsigned tag) {
-  __hip_atomic_store(g, ((unsigned long long)tag << 32) | value_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long pt_get(const unsigned long long* g) {
-  return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// half_partials_tree over granules: G[(acc * 64 + block) * 2 + h] = {s_h, tag}; polls until every granule of the thread carries `tag`
-// (bounded; `dead`: a wait was abandoned somewhere, stop waiting).  Follow with __syncthreads().
-template <int BLOCK>
-__device__ __forceinline__ bool granule_partials_tree(const unsigned long long* __restrict__ G, unsigned tag, PtSync* Y, bool dead, bool icp, bool rgb,
-                                                      float* sums_s) {
-  static_assert(BLOCK % 64 == 0, "one wavefront per accumulator");
-  const int t = threadIdx.x;
-  const int na = (icp ? SE3_ACCS : 0) + (rgb ? SE3_ACCS : 0);
-  constexpr int PASSES = (2 * SE3_ACCS * 64 + BLOCK - 1) / BLOCK, CHUNK = 4;   // in chunks: 2 x CHUNK granules per thread in flight / in registers
-#pragma unroll 1
-  for (int q0 = 0; q0 < PASSES; q0 += CHUNK) {
-    unsigned long long v0[CHUNK], v1[CHUNK];
-#pragma unroll
-    for (int q = 0; q < CHUNK; ++q) {
-      const int idx = t + (q0 + q) * BLOCK;
-      const bool in = q0 + q < PASSES && idx < na * 64;
-      v0[q] = in ? pt_get(G + (size_t)idx * 2) : ((unsigned long long)tag << 32);
-      v1[q] = in ? pt_get(G + (size_t)idx * 2 + 1) : ((unsigned long long)tag << 32);
-    }
-    if (!dead) {
-      for (int spin = 0;; ++spin) {
-        bool pending = false;
-#pragma unroll
-        for (int q = 0; q < CHUNK; ++q) {
-          const int idx = t + (q0 + q) * BLOCK;
-          if ((unsigned)(v0[q] >> 32) != tag) { v0[q] = pt_get(G + (size_t)idx * 2); pending = true; }
-          if ((unsigned)(v1[q] >> 32) != tag) { v1[q] = pt_get(G + (size_t)idx * 2 + 1); pending = true; }
-        }
-        if (!__any(pending)) break;
-        const unsigned ab = (spin & 255) == 255 ? (unsigned)__builtin_amdgcn_readfirstlane((int)pt_load(&Y->abort)) : 0u;   // wave-uniform
-        if (spin >= PT_SPIN || ab) {
-          if (spin >= PT_SPIN) __hip_atomic_store(&Y->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          dead = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < CHUNK; ++q) {
-      const int idx = t + (q0 + q) * BLOCK;
-      float x = __uint_as_float((unsigned)v0[q]) + __uint_as_float((unsigned)v1[q]);
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) x += __shfl_down(x, off, 32);
-      const float w1 = __shfl(x, 32, 64);
-      if (q0 + q < PASSES && idx < na * 64 && (idx & 63) == 0) sums_s[(icp ? 0 : SE3_ACCS) + (idx >> 6)] = x + w1;
-    }
-  }
-  return dead;
-}
 // the update of one SO(3) iteration (k_so3_iteration's tail) on the workgroup's own state; returns true when the loop is over
 __device__ __forceinline__ bool so3_update(So3Loop& Z, const float* red, int it, Intr k, Intr kfirst, GNState& g0) {
   float jtj[9], jtr[3];
@@ -2192,8 +2157,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
   __shared__ float red[SO3_ACCS];
   __shared__ So3Loop Z;
   __shared__ int ired[2 * PT_BLOCK / 64];
-  __shared__ unsigned sync_s[3];
-  __shared__ int tot_s[2][2];               // {count, sum diff^2} of the correspondence search, by iteration parity (relay of the polling wavefront)
+  __shared__ unsigned sync_s[2];
   __shared__ int flag_s;
   __shared__ unsigned seen_a[2];   // barrier A relay: {generation the workgroup's polling wavefront has seen complete, wait abandoned}
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wg = blockIdx.x;
@@ -2206,8 +2170,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
   if (t == 0) {
     sync_s[0] = pt_load(&Y->gen) + 1u;   // the generation that ends this launch's first barrier
     sync_s[1] = pt_load(&Y->abort);
-    sync_s[2] = pt_load(&Y->epoch) + 1u;   // tag of this launch's first iteration (never 0: fresh granules carry tag 0)
-    seen_a[0] = sync_s[2] - 1u;            // no iteration of this launch carries that tag
+    seen_a[0] = sync_s[0] - 1u;
     seen_a[1] = 0u;
     double R[9];
     efl::quat_to_mat<double>(st->q, R);
@@ -2225,6 +2188,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
       for (int i = 0; i < 4; ++i) st->q_prev[i] = st->q[i];
       for (int i = 0; i < 3; ++i) st->t_prev[i] = st->t[i];
       for (int i = 0; i < RGB_SLOTS; ++i) st->rgb_slots[0][i][0] = st->rgb_slots[0][i][1] = st->rgb_slots[1][i][0] = st->rgb_slots[1][i][1] = 0;
+      st->call_seq += 1u;
       st->so3_iterations = 0;
       st->so3_ticket = 0;
       st->so3_done = 1;
@@ -2279,37 +2243,38 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
     }
   }
   // ---- the Gauss-Newton iterations of the small levels, RGBDOdometry.cpp:371-553 ----
-  // No barrier in this loop: the pair sums and the search's {count, sum} travel as tagged granules (tag = epoch + iteration), each reader
-  // polls exactly the granules it needs, and every re-use of a granule slot is ordered by the data dependence itself — a workgroup writes
-  // iteration i + 2's granules only after its update step consumed iteration i + 1's granules of EVERY workgroup, which those published
-  // after they were done reading iteration i's.
-  unsigned long long* GR = (unsigned long long*)((char*)Y + PT_SYNC_FLOATS * sizeof(float));   // [2 regions][PT_GRANULES]
-  unsigned long long* WS = GR + 2 * PT_GRANULES;                                               // [2 sets][PT_WGS][2]
-  const unsigned epoch = sync_s[2];
+  // Two barriers per iteration: A after the correspondence search (its latency hidden behind the ICP wavefronts), B after the
+  // accumulation.  (Round 3 also built the exchange on tagged 8-byte granules without any barrier — every reader polling exactly the
+  // granules it needs: bit-identical, and 2.5 % SLOWER end to end, profiles/r03d_ab_granules_vs_barriers.log: 7424 granule loads per
+  // workgroup cost more than one barrier + 3712 plain 8-byte loads.  Dropped.)
   int cur = 0;
   for (int it = 0; it < A.n_iter; ++it) {
     const int lvl = pt_level_of(A, it);
     const PtLevel Lv = pt_load_level((PtArgsK)__builtin_amdgcn_kernarg_segment_ptr(), lvl);   // PtArgs is the kernel's FIRST argument
     const int cols = Lv.cols, rows = Lv.rows, N = cols * rows;
     const int K = (N + VTHREADS - 1) / VTHREADS;
-    const unsigned tag = epoch + (unsigned)it;
     const bool last = it == A.n_iter - 1;
+    float* region = A.partials + (size_t)((A.n_iter - 1 - it) & 1) * PARTIAL_FLOATS;   // the last iteration's partials land in region 0
     if (it > 0) {
       // head: the update step of iteration it - 1 (k_track_step's head), by every workgroup on its own state
-      StepArgs H{true, false, HAS_ICP, HAS_RGB, false, A.icpWeight, Lv.k, lvl != pt_level_of(A, it - 1)};
+      StepArgs H{true, false, HAS_ICP, HAS_RGB, false, A.icpWeight, Lv.k, lvl != pt_level_of(A, it - 1), it};
       efs::SolvePrefetch PF{};
       if (t < 64) {
         const GNState& g = gs[cur];
         PF.rt = g.resultRt[lane & 15];
         PF.pose = bg[lane < 12 ? lane : 0];
-        PF.slot_a = lane == 0 ? tot_s[(it - 1) & 1][0] : 0;   // the search's totals, as this workgroup's polling wavefront saw them
-        PF.slot_b = lane == 0 ? tot_s[(it - 1) & 1][1] : 0;
+        PF.slot_a = PF.slot_b = 0;
+        if (HAS_RGB) {
+          const int (*ws)[2] = Y->wg_sums[(it - 1) & 1];
+          PF.slot_a = pt_loadi(&ws[lane][0]) + pt_loadi(&ws[lane + 64][0]);
+          PF.slot_b = pt_loadi(&ws[lane][1]) + pt_loadi(&ws[lane + 64][1]);
+        }
         PF.lastRGBErrorLevel = g.lastRGBErrorLevel;
         PF.broken = g.rgb_broken;
       }
-      dead = granule_partials_tree<PT_BLOCK>(GR + (size_t)((it - 1) & 1) * PT_GRANULES, tag - 1u, Y, dead, HAS_ICP, HAS_RGB, sums_s);
+      half_partials_tree<PT_BLOCK>(A.partials + (size_t)((A.n_iter - it) & 1) * PARTIAL_FLOATS, HAS_ICP, HAS_RGB, sums_s);
       __syncthreads();
-      PT_CLK(5);   // SE(3) head: poll + gather + trees
+      PT_CLK(5);   // SE(3) head: gather + trees
       if (t < 64) solve_step_wave(st, &gs[cur], &gs[cur ^ 1], true, sums_s, H, S, PF, wg == 0);
       __syncthreads();
       PT_CLK(6);   // SE(3) head: solve
@@ -2374,11 +2339,13 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
       if (t == 0) {
         int sa = 0, sb = 0;
         for (int w = 0; w < PT_BLOCK / 64; ++w) { sa += ired[w * 2]; sb += ired[w * 2 + 1]; }
-        unsigned long long* ws = WS + ((size_t)(it & 1) * PT_WGS + wg) * 2;
-        pt_put(ws, (unsigned)sa, tag);
-        pt_put(ws + 1, (unsigned)sb, tag);
+        int (*ws)[2] = Y->wg_sums[it & 1];
+        __hip_atomic_store(&ws[wg][0], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws[wg][1], sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        drain_stores();
+        pt_arrive(Y);   // barrier A: arrive now, the RGB wavefronts wait below
       }
-      PT_CLK(7);   // SE(3): correspondence search + publish its sums
+      PT_CLK(7);   // SE(3): correspondence search + arrive A
     }
     // normal equations of the workgroup's two pair tasks: one wavefront per (task, term, warp of the pair), both halves of the warp
     const int task = wave / (2 * NT), w4 = wave % (2 * NT);
@@ -2402,67 +2369,35 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
 #ifdef EF_STAGE_CLOCKS
         if (task == 0 && wl == 0 && lane == 0 && wg == 0) clk_last2 = wall_clock64();
 #endif
-        // The global {count, sum diff^2} of the search (sigma, quirk Q2): ONE wavefront of the workgroup polls the 2 x PT_WGS granules
-        // (four per lane) and relays the totals through LDS; the others watch the relay.  All of them wait with their loads and
-        // gathers already issued (accum_quads_halves' hook).
-        const unsigned long long* ws = WS + (size_t)(it & 1) * PT_WGS * 2;
+        // barrier A (the search's global {count, sum diff^2}: sigma, quirk Q2): ONE wavefront of the workgroup polls the global word, the
+        // other RGB wavefronts watch its relay in LDS; all of them wait with their loads and gathers already issued (the hook)
         const bool leader = task == 0 && wl == 0;
         bool gone = dead;
+        const int (*ws)[2] = Y->wg_sums[it & 1];
         auto wait_totals = [&](int& slot_a, int& slot_b) {
-          if (leader) {
-            unsigned long long g4[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) g4[e] = pt_get(ws + (size_t)(lane + 64 * (e >> 1)) * 2 + (e & 1));
-            if (!gone) {
-              for (int spin = 0;; ++spin) {
-                bool pending = false;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if ((unsigned)(g4[e] >> 32) != tag) { g4[e] = pt_get(ws + (size_t)(lane + 64 * (e >> 1)) * 2 + (e & 1)); pending = true; }
-                if (!__any(pending)) break;
-                const unsigned ab = (spin & 255) == 255 ? (unsigned)__builtin_amdgcn_readfirstlane((int)pt_load(&Y->abort)) : 0u;
-                if (spin >= PT_SPIN || ab) {
-                  if (spin >= PT_SPIN) __hip_atomic_store(&Y->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                  gone = true;
-                  break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-              }
-            }
-            int sa = (int)(unsigned)g4[0] + (int)(unsigned)g4[2], sb = (int)(unsigned)g4[1] + (int)(unsigned)g4[3];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-              sa += __shfl_down(sa, off, 64);
-              sb += __shfl_down(sb, off, 64);
-            }
-            if (lane == 0) {
-              tot_s[it & 1][0] = sa;
-              tot_s[it & 1][1] = sb;
+          if (lane == 0) {
+            if (leader) {
+              gone = pt_wait(Y, gen_next, gone);
               if (gone) __hip_atomic_store(&seen_a[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-              __hip_atomic_store(&seen_a[0], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            slot_a = lane == 0 ? sa : 0;
-            slot_b = lane == 0 ? sb : 0;
-          } else {
-            if (lane == 0) {
+              __hip_atomic_store(&seen_a[0], gen_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
               int spins = 0;
-              while (__hip_atomic_load(&seen_a[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != tag && ++spins < 8 * PT_SPIN) __builtin_amdgcn_s_sleep(1);
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              while ((int)(__hip_atomic_load(&seen_a[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen_next) < 0 && ++spins < 8 * PT_SPIN)
+                __builtin_amdgcn_s_sleep(1);
               gone = gone || spins >= 8 * PT_SPIN || __hip_atomic_load(&seen_a[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
             }
-            gone = __shfl((int)gone, 0, 64) != 0;
-            const volatile int* tv = &tot_s[it & 1][0];
-            slot_a = lane == 0 ? tv[0] : 0;
-            slot_b = lane == 0 ? tv[1] : 0;
           }
-          if (leader) PT_CLK2(12);   // SE(3): wait for the search's totals (polling RGB wavefront; its own loads are in flight)
+          gone = __shfl((int)gone, 0, 64) != 0;
+          if (leader) PT_CLK2(12);   // SE(3): wait for barrier A (polling RGB wavefront; its own loads are in flight)
+          slot_a = pt_loadi(&ws[lane][0]) + pt_loadi(&ws[lane + 64][0]);
+          slot_b = pt_loadi(&ws[lane][1]) + pt_loadi(&ws[lane + 64][1]);
         };
         accum_quads_halves<false>(IV, RV, in, wbase, N, K, 0, 0, true, c, wait_totals);
         dead = dead || gone;
-        if (leader) PT_CLK2(13);   // SE(3): RGB rows + outer products after the totals
+        if (leader) PT_CLK2(13);   // SE(3): RGB rows + outer products after A
       }
     }
+    if (HAS_RGB) ++gen_next;
     // warpReduceSum (offset 16 = the other half, here in the same wavefront) + the first level of blockReduceSum's 8-warp tree
     float r[12];
     float* pw = pairx + (size_t)((active ? task : 0) * 2 + tix) * 12 * 4;
@@ -2497,32 +2432,32 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
     }
     __syncthreads();
     if (active && task == 0 && wl == 0 && v == 0) {
-      const int b = wg >> 1, h = wg & 1;
-      if (!last) {   // to every workgroup's next update step: tagged granules
-        unsigned long long* g = GR + (size_t)(it & 1) * PT_GRANULES;
+      // slot h of the block receives s_h; the launch's LAST iteration, whose partials a per-step kernel reads as four pair slots, also
+      // zeroes slot h + 2 ((s + 0) + (s' + 0) = s + s' to the bit)
+      float* dst = region + (size_t)tix * SE3_ACCS * SE3_PAIRS + 4 * (wg >> 1) + (wg & 1);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+      for (int q = 0; q < 3; ++q)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int a = quad_member(q, i, j);
-            if (a >= 0) pt_put(g + ((size_t)(tix * SE3_ACCS + a) * 64 + b) * 2 + h, __float_as_uint(r[q * 4 + i] + tsum[(tix * 12 + q * 4 + i) * 4 + j]), tag);
+        for (int i = 0; i < 4; ++i) {
+          const int a = quad_member(q, i, j);
+          if (a >= 0) {
+            coherent_store(dst + (size_t)a * SE3_PAIRS, r[q * 4 + i] + tsum[(tix * 12 + q * 4 + i) * 4 + j]);
+            if (last) coherent_store(dst + (size_t)a * SE3_PAIRS + 2, 0.f);
           }
-      } else {       // to the per-step kernel that follows the launch: region 0 in k_se3_accum's pair layout, slot h = s_h, slot h + 2 = 0
-        float* dst = A.partials + (size_t)tix * SE3_ACCS * SE3_PAIRS + 4 * b + h;   // ((s + 0) + (s' + 0) = s + s' to the bit)
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int a = quad_member(q, i, j);
-            if (a >= 0) {
-              dst[(size_t)a * SE3_PAIRS] = r[q * 4 + i] + tsum[(tix * 12 + q * 4 + i) * 4 + j];
-              dst[(size_t)a * SE3_PAIRS + 2] = 0.f;
-            }
-          }
-      }
+        }
+      drain_stores();
     }
+    __syncthreads();
     PT_CLK(9);   // SE(3): join, trees, publish
+    if (t == 0) {   // barrier B: every pair partial of this iteration is out
+      pt_arrive(Y);
+      flag_s = pt_wait(Y, gen_next, dead) ? 1 : 0;
+    }
+    __syncthreads();
+    PT_CLK(10);   // SE(3): barrier B
     PT_COUNT(21);
+    dead = dead || flag_s != 0;
+    ++gen_next;
   }
   // ---- what the launches that follow read: the Gauss-Newton state and the last search's sums (update of iteration n_iter - 1
   //      at the head of the next k_track_step / k_track_end) ----
@@ -2536,10 +2471,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
     o.rgb_broken = g.rgb_broken;
     if (HAS_RGB && A.n_iter > 0) {   // the last search's totals, where the next update step's head looks for them
       const int set = (A.n_iter - 1) & 1;
-      st->rgb_slots[set][0][0] = tot_s[set][0];
-      st->rgb_slots[set][0][1] = tot_s[set][1];
+      int sa = 0, sb = 0;
+      for (int w = 0; w < PT_WGS; ++w) { sa += pt_loadi(&Y->wg_sums[set][w][0]); sb += pt_loadi(&Y->wg_sums[set][w][1]); }
+      st->rgb_slots[set][0][0] = sa;
+      st->rgb_slots[set][0][1] = sb;
     }
-    __hip_atomic_store(&Y->epoch, epoch + (unsigned)A.n_iter + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch's tags
 #ifdef EF_STAGE_CLOCKS
     Y->clk[11] += wall_clock64() - clk_start;   // whole launch
     Y->clk[22] += 1;
@@ -2604,6 +2540,10 @@ void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int
                   hipEvent_t stop = nullptr) {
   constexpr int BLOCK = 64 * 2 * ACC_NW * ((HAS_ICP && HAS_RGB) ? 2 : 1);
   const dim3 grid(VWARPS / ACC_NW), block(BLOCK);
+  // CH = steps (of four passes) a wavefront has in flight per round: 640x480 has 19 passes = 5 steps = ONE round of CH = 5; 1280x960 has
+  // 75 passes = 19 steps = four dependent rounds.  CH = 10 there (two rounds, 231 registers: the launch runs two wavefronts per SIMD
+  // anyway) was measured SLOWER: 28.4 vs 25.1 us (profiles/r03f_ab_fused_step_and_ch10.log) — twice the loads per round queue behind each
+  // other in the CU's one address pipe for longer than the two saved round trips.
   if (N > 8 * VTHREADS) hipExtLaunchKernelGGL((k_se3_accum<5, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
   else hipExtLaunchKernelGGL((k_se3_accum<2, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
 }
@@ -2824,10 +2764,16 @@ int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const
   const int cols = p.W(level), rows = p.H(level), N = cols * rows;
   const bool sample = probe && level == 0 && probe->used < probe->capacity;
   const int sp = it & 1;
-  StepArgs A{it > 0, rgb, icp, rgb, tp.rgbOnly, tp.icpWeight, kl, level_changes};
+  StepArgs A{it > 0, rgb, icp, rgb, tp.rgbOnly, tp.icpWeight, kl, level_changes, it};
   // The update step as its own ONE-workgroup launch (head only), then the correspondence search alone (body only): three launches
   // per iteration.  Evaluating the update redundantly at the head of every workgroup of the correspondence kernel instead (two
   // launches) was built and measured in round 2: 888 vs 1322 frames/s; dropped from the source in round 3.
+  if (A.has_head && A.has_body && tp.fused_step && !tp.rgbOnly) {
+    // two launches per iteration: the update step by workgroup 0 of the search launch, handed to the others in-launch (see k_track_step)
+    if (N >= 256 * 1024) launch_step<2>(p, st, level, cur, sp, A, s);
+    else launch_step<1>(p, st, level, cur, sp, A, s);
+    cur ^= 1;
+  } else {
   if (A.has_head) {
     StepArgs H = A;
     H.has_body = false;
@@ -2840,6 +2786,7 @@ int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const
     // (four times fewer, four times fatter wavefronts — PPT 8 / 4 — measured 4.5 % slower end to end: DESIGN.md 6)
     if (N >= 256 * 1024) launch_step<2>(p, st, level, cur, sp, B, s);
     else launch_step<1>(p, st, level, cur, sp, B, s);
+  }
   }
   const GNState* g = &st->gn[cur];
   IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres};
@@ -2951,7 +2898,7 @@ void track_swap(Pyramid& p, const TrackParams& tp) {
 
 // exported for the context: finishing kernels
 void track_end(TrackState* st, const TrackTail& u, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s) {
-  const StepArgs A{u.has_head, false, u.icp, u.rgb, u.rgbOnly, u.icpWeight, u.k0, true};
+  const StepArgs A{u.has_head, false, u.icp, u.rgb, u.rgbOnly, u.icpWeight, u.k0, true, 63};
   hipLaunchKernelGGL(k_track_end, dim3(1), dim3(REDUCE_BLOCK), 0, s, st, (const GNState*)&st->gn[u.cur], &st->gn[u.cur ^ 1], u.pairs,
                      (const int*)&st->rgb_slots[u.slots & 1][0][0], A, rgb, weightMultiplier, traj, slot);
 }

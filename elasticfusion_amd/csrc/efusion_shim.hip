@@ -84,7 +84,11 @@ ElasticFusion::ElasticFusion(const int timeDelta_, const int countThresh, const 
   if (closeLoops) {   // the reference's closed-loop mode: global (fern) closure, then local closure, built-in optimiser for both
     chk(ef_set_loop_thresholds(c, countThresh, errThresh, covThresh), c, "ElasticFusion::ElasticFusion");
     chk(ef_use_builtin_loop_solver(c, 1), c, "ElasticFusion::ElasticFusion");
-    chk(ef_enable_global_closure(c, 500, photoThresh, fernThresh, 0u), c, "ElasticFusion::ElasticFusion");   // Ferns(500, depthCut * 1000, photoThresh), :53
+    // Ferns(500, depthCut * 1000, photoThresh), :53.  The 1/8-resolution registration needs width and height to be multiples of 32
+    // (include/ef_hip.h); at other sizes (320x240: 40x30 views) the constructor does not throw: the context closes LOCAL loops only and
+    // keeps no fern database (getFerns() stays empty, reloc has nothing to relocalise against)
+    if (cfg.width % 32 == 0 && cfg.height % 32 == 0)
+      chk(ef_enable_global_closure(c, 500, photoThresh, fernThresh, 0u), c, "ElasticFusion::ElasticFusion");
   }
   if (reloc) chk(ef_set_relocalisation(c, 1), c, "ElasticFusion::ElasticFusion");   // :326-366, 411-413: lost / found through the fern database
   // drop-in: getGlobalModel().downloadMap() and savePly() return what the reference's return (the pre-clean buffer, quirk Q14)

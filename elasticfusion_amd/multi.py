@@ -100,22 +100,32 @@ class KlgFile:
             self._h = None
 
 
-def replay_logs(logs, make_engine, rank: int, world: int, width: int = 640, height: int = 480, on_done=None):
-    """rank's share of `logs` through make_engine() objects (processFrame(rgb, depth, timestamp), synchronize(), close()): decoding is
-    host work done up front per log, the clock runs around the frames only.  -> [seconds, frames, logs] for gather_stats"""
+def replay_logs(logs, make_engine, rank: int, world: int, width: int = 640, height: int = 480, on_done=None, chunk: int = 64):
+    """rank's share of `logs` through make_engine() objects (processFrame(rgb, depth, timestamp), synchronize(), close()).  Decoding is
+    host work and is kept off the clock, but a log is never held decoded as a whole (a real multi-thousand-frame log is ~1.5 MB per frame,
+    times 8 ranks on one host): frames are decoded `chunk` at a time, each chunk is replayed with the clock running and the engine
+    synchronised at its end.  -> [seconds, frames, logs] for gather_stats"""
     import time
     seconds, frames, done = 0.0, 0, 0
     for log in shard_logs(logs, rank, world):
         reader = KlgFile(log, width, height)
-        decoded = list(reader)
-        reader.close()
         eng = make_engine()
-        t0 = time.perf_counter()
-        for ts, rgb, depth in decoded:
-            eng.processFrame(rgb, depth, ts)
-        eng.synchronize()
-        seconds += time.perf_counter() - t0
-        frames += len(decoded)
+        it = iter(reader)
+        while True:
+            decoded = []
+            for item in it:
+                decoded.append(item)
+                if len(decoded) >= chunk:
+                    break
+            if not decoded:
+                break
+            t0 = time.perf_counter()
+            for ts, rgb, depth in decoded:
+                eng.processFrame(rgb, depth, ts)
+            eng.synchronize()
+            seconds += time.perf_counter() - t0
+            frames += len(decoded)
+        reader.close()
         done += 1
         if on_done:
             on_done(log, eng)

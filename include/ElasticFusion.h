@@ -17,6 +17,8 @@
 //    at the end of the frame.  The fern table's seed is fixed (the reference uses time(0)); setLoopSolver() replaces the local
 //    optimiser.  reloc = true judges every tracked frame by its own statistics (:326-366): frames that are not ok are not fused, more
 //    than ten in a row and the camera is lost (getLost()) until a fern match brings the pose back (:411-413; needs closeLoops = true).
+//    The global closure's 1/8-resolution registration needs width and height to be multiples of 32 (640x480, 1280x960, ...); at other
+//    sizes closeLoops = true closes local loops only (no fern database) instead of refusing to construct.
 //  * getTextures / getFeedbackBuffers / computeFeedbackBuffers / normaliseDepth are OpenGL objects and display passes in the
 //    reference and have no counterpart here.
 //  * errors throw std::runtime_error instead of assert()/exit(0).
@@ -122,6 +124,7 @@ struct PoseMatch {
 struct FernFrame {
   int id, srcTime;
   SE3d T_wc;
+  const FernFrame* operator->() const { return this; }   // the reference's frames hold Ferns::Frame*: frames.at(i)->T_wc compiles as written
 };
 struct FernsView {
   std::vector<FernFrame> frames;

@@ -89,6 +89,11 @@ int ef_set_graph_replay(ef_ctx* ctx, int on);
  * time (512 threads, 36 KB of LDS each: half the CUs of one MI355X); every wait in it is bounded, and a launch whose grid could not
  * become resident (other work holding the chip's wave slots for ever) makes ef_synchronize return EF_EHIP instead of hanging. */
 int ef_set_persistent_tracker(ef_ctx* ctx, int on);
+/* Level-0 Gauss-Newton iterations as TWO launches instead of three: the update step (one workgroup's worth of work) is evaluated by
+ * workgroup 0 of the correspondence-search launch and handed to that launch's other workgroups as tagged granules (they poll with their
+ * pixel loads in flight) instead of being a launch of its own.  Same arithmetic, bit-identical results.  Off by default (measured:
+ * DESIGN.md 6). */
+int ef_set_fused_step(ef_ctx* ctx, int on);
 /* Odometry only (BASELINE.json configs[4], "open-loop odometry-only ... throughput ceiling"): frames are pre-processed, tracked against
  * the model prediction and the prediction is renewed at the new pose, but nothing is fused (the map stays as it is: indexMap, fuse and
  * clean of ElasticFusion.cpp:536-585 are skipped, like a frame whose tracking failed under relocalisation).  Off by default. */

@@ -67,7 +67,7 @@ int front_end(int argc, char**) {
     }
     for (size_t i = 0; i < eFusion->getFerns().frames.size(); i++) {
       if ((int)i == eFusion->getFerns().lastClosest) continue;
-      const auto& T_fern = eFusion->getFerns().frames.at(i).T_wc;   // the reference's frames hold pointers: frames.at(i)->T_wc
+      const auto& T_fern = eFusion->getFerns().frames.at(i)->T_wc;   // :383, as written (the view's entries answer to -> like Ferns::Frame*)
       (void)T_fern;
     }
     const auto& graph = eFusion->getLocalDeformation().getGraph();

@@ -124,9 +124,10 @@ def test_persistent_and_per_step_tracker_scripts_agree(hip, seq, cfg):
     and map must be bit-identical, frame after frame — whichever of the two the oracle comparisons of this file ran."""
     n = 14
     runs = []
-    for persistent in (True, False):
+    for persistent, fused in ((True, False), (False, False), (True, True)):   # fused: level-0 update step inside the search launch (ef_set_fused_step)
         ef = hip.ElasticFusion(**cfg)
         ef.setPersistentTracker(persistent)
+        ef.setFusedStep(fused)
         rec = []
         for k in range(n):
             rgb, depth, _ = seq.frame(k)
@@ -136,10 +137,11 @@ def test_persistent_and_per_step_tracker_scripts_agree(hip, seq, cfg):
         ef.synchronize()                      # also: no barrier of the persistent launches timed out
         runs.append((rec, ef.downloadMap()))
         ef.close()
-    for k in range(1, n):
-        for x, y in zip(runs[0][0][k], runs[1][0][k]):
-            assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), (k, x, y)
-    assert np.array_equal(runs[0][1].view(np.uint32), runs[1][1].view(np.uint32))
+    for other in (1, 2):
+        for k in range(1, n):
+            for x, y in zip(runs[0][0][k], runs[other][0][k]):
+                assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), (other, k, x, y)
+        assert np.array_equal(runs[0][1].view(np.uint32), runs[other][1].view(np.uint32)), other
 
 
 VARIANTS = {

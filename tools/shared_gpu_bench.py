@@ -46,6 +46,9 @@ def main():
 
     for M in Ms:
         ctxs = [api.ElasticFusion() for _ in range(M)]          # each creates its own non-blocking stream
+        if M > 2:   # the persistent small-level launch needs 128 CUs to itself: two fit side by side, a third in flight at the same time can starve
+            for ef in ctxs:
+                ef.setPersistentTracker(False)
         go = threading.Barrier(M + 1)
         done = threading.Barrier(M + 1)
 

@@ -43,8 +43,8 @@ for path in libs:
            "se3_iterations_per_launch": round(se3_its / launches, 2), "whole_launch_us": us(v[11] / launches), "begin_us": us(v[0] / launches),
            "so3_per_iteration_us": {"rows_chains_publish": us(v[1] / so3_its), "barrier": us(v[2] / so3_its), "gather_tree": us(v[3] / so3_its),
                                     "update": us(v[4] / so3_its)},
-           "se3_per_iteration_us": {"head_poll_gather_trees": us(v[5] / se3_its), "head_solve": us(v[6] / se3_its), "search_publish_sums": us(v[7] / se3_its),
-                                    "icp_accumulation": us(v[8] / se3_its), "join_trees_publish": us(v[9] / se3_its),
-                                    "rgb_wave_loads_and_wait_for_totals": us(v[12] / se3_its), "rgb_wave_rows_after_totals": us(v[13] / se3_its)}}
+           "se3_per_iteration_us": {"head_gather_trees": us(v[5] / se3_its), "head_solve": us(v[6] / se3_its), "search_arrive_A": us(v[7] / se3_its),
+                                    "icp_accumulation": us(v[8] / se3_its), "join_trees_publish": us(v[9] / se3_its), "barrier_B": us(v[10] / se3_its),
+                                    "rgb_wave_loads_and_wait_A": us(v[12] / se3_its), "rgb_wave_rows_after_A": us(v[13] / se3_its)}}
     print(json.dumps(rec), flush=True)
     ef.close()
