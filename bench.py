@@ -301,7 +301,7 @@ def main():
         if cache:
             np.savez(cache, rgb=np.stack([f[0] for f in frames]), depth=np.stack([f[1] for f in frames]), T=np.stack([f[2] for f in frames]))
     big = None
-    BIG = dict(w=1280, h=960, preroll=16, warmup=4, steps=40, probe=8, preseed=1 << 20)
+    BIG = dict(w=1280, h=960, preroll=16, warmup=24, steps=60, probe=8, preseed=1 << 20)   # (a long warm-up: the GPU idles for seconds while the host samples the map)
     if side:   # configs[2] for the extra key: 1280x960, ~1 M pre-seeded surfels (fewer frames: the map is mature from the start)
         nb = 1 + BIG["preroll"] + BIG["warmup"] + BIG["steps"] + BIG["probe"]
         bcache = f"{a.frames_cache}.{rank}.1280x960.{nb}.npz" if a.frames_cache else None
