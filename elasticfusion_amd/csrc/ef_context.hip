@@ -1071,6 +1071,12 @@ int ef_create(const ef_config* cfg, ef_ctx** out) {
   }
   c->cam = efm::Cam{cfg->width, cfg->height, cfg->fx, cfg->fy, cfg->cx, cfg->cy};
   c->intr = eft::Intr{cfg->fx, cfg->fy, cfg->cx, cfg->cy};
+  {
+    // the persistent small-level launch needs its 128 workgroups resident together, one per CU: on a device (or a partition of one:
+    // CPX mode exposes 32 CUs) that cannot hold them the per-step script is the default; ef_set_persistent_tracker can still ask for it
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus < eft::PT_WGS) c->persistent = false;
+  }
   if (cfg->stream) {
     c->stream = (hipStream_t)cfg->stream;
   } else {

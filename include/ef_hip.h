@@ -87,7 +87,8 @@ int ef_set_graph_replay(ef_ctx* ctx, int on);
  * round-2 script, 38 launches more per frame).  Same arithmetic in the same order: results are bit-identical either way
  * (RGBDOdometry.cpp:259-553; tests/test_gpu_frame.py runs both).  The persistent launch needs its 128 workgroups resident at the same
  * time (512 threads, 36 KB of LDS each: half the CUs of one MI355X); every wait in it is bounded, and a launch whose grid could not
- * become resident (other work holding the chip's wave slots for ever) makes ef_synchronize return EF_EHIP instead of hanging. */
+ * become resident (other work holding the chip's wave slots for ever) makes ef_synchronize return EF_EHIP instead of hanging.  On a
+ * device that reports fewer than 128 CUs (a partition of the chip) the default is off. */
 int ef_set_persistent_tracker(ef_ctx* ctx, int on);
 /* Level-0 Gauss-Newton iterations as TWO launches instead of three: the update step (one workgroup's worth of work) is evaluated by
  * workgroup 0 of the correspondence-search launch and handed to that launch's other workgroups as tagged granules (they poll with their
