@@ -146,11 +146,11 @@ def rooflines(lib, ef, w, h, where):
         # COMMITTED under profiles/ by tools/pmc_traffic.sh for this kernel and workload (see traffic_source), not a live value
         traffic, traffic_source, straffic, ssource = None, None, None, None
         try:
-            if (w, h) != (W, H):
-                raise KeyError("the committed PMC measurement is for the default workload")
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            if (w, h) not in ((W, H), (1280, 960)):
+                raise KeyError("committed PMC measurements exist for the default workload and for configs[2]")
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json" if (w, h) == (W, H) else "pmc_traffic_1280x960.json")) as f:
                 pj = json.load(f)
-            src = "committed PMC measurement (profiles/pmc_traffic.json: " + str(pj.get("source", "tools/pmc_traffic.sh")) + "), not measured in this run"
+            src = "committed PMC measurement (profiles/" + ("pmc_traffic.json" if (w, h) == (W, H) else "pmc_traffic_1280x960.json") + ": " + str(pj.get("source", "tools/pmc_traffic.sh")) + "), not measured in this run"
             traffic, traffic_source = int(pj["traffic_bytes_per_launch"]), src
             straffic, ssource = int(pj["also"]["k_index_splat"]["traffic_bytes_per_launch"]), src
         except Exception:
@@ -273,6 +273,8 @@ def main():
                     "the first frame; with --width 1280 --height 960 --preseed 1048576 = BASELINE.json configs[2], the HBM-bound map")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the extra keys of the N = 1 line (host-frame path, reference-rounding "
                     "build, closed loop, odometry only, hipGraph replay, configs[2])")
+    ap.add_argument("--preroll", type=int, default=PREROLL, help="development (PMC passes on a pre-seeded map): untimed frames before the warm-up; "
+                    "the driver's command never sets it (100: the map's steady state)")
     ap.add_argument("--fused-step", action="store_true", help="development (A/B): level-0 update step inside the correspondence-search launch "
                     "(ef_set_fused_step); results are bit-identical")
     ap.add_argument("--per-step-tracker", action="store_true", help="development (A/B): the round-2 tracker script, one launch per step, instead "
@@ -284,13 +286,13 @@ def main():
     rank, local_rank, world = multi.rank_info()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    plain = not (a.host_frames or a.close_loops or a.graph or a.track_only or a.library or a.preseed or a.per_step_tracker or a.probe_inside or a.fused_step)
+    plain = not (a.host_frames or a.close_loops or a.graph or a.track_only or a.library or a.preseed or a.per_step_tracker or a.probe_inside or a.fused_step or a.preroll != PREROLL)
     side = world == 1 and plain and (w, h) == (W, H) and not a.no_side_legs   # the extra keys ride on the default N = 1 line only
 
     # synthetic frames first: the generator forks worker processes, which must happen before HIP / RCCL are initialised
     # frame 0 seeds the map (tick 1); pre-roll and warm-up are never timed; the last PROBE_FRAMES frames continue the same replay with
     # the per-kernel sampling switched on (a sampled launch carries profiling timestamps, which the timed region is kept free of)
-    n_frames = 1 + PREROLL + a.warmup + a.steps + PROBE_FRAMES
+    n_frames = 1 + a.preroll + a.warmup + a.steps + PROBE_FRAMES
     seed = multi.sequence_seed(rank)
     cache = f"{a.frames_cache}.{rank}.{w}x{h}.{n_frames}.npz" if a.frames_cache else None
     if cache and os.path.exists(cache):
@@ -344,7 +346,7 @@ def main():
         else:
             ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
 
-    first_timed = 1 + PREROLL + a.warmup
+    first_timed = 1 + a.preroll + a.warmup
     for k in range(k0, first_timed):
         step(k)
     if a.track_only:
@@ -414,7 +416,7 @@ def main():
                                + ("stand-in for configs[1] (dyson_lab.klg is not available offline)" if (w, h) == (W, H) else
                                   "configs[2]: 1280x960 stream"),
                    "resolution": [w, h], "sequences": world, "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
-                   "preroll_frames": PREROLL, "surfels_end": int(count),
+                   "preroll_frames": a.preroll, "surfels_end": int(count),
                    "pose_err_vs_generating_traj_m": round(err_t, 5),
                    "per_rank_fps": [round(x, 2) for x in agg["per_rank_fps"]]},
         "roofline": roofline,
@@ -431,7 +433,7 @@ def main():
         # Extra keys of the N = 1 line: the same frames replayed on fresh engines in the other modes a reader of the headline asks
         # about.  Each leg is timed on its own after the headline's clock has stopped; none of them is `value`.
         legs = {}
-        common = dict(steps=a.steps, warmup=a.warmup, preroll=PREROLL)
+        common = dict(steps=a.steps, warmup=a.warmup, preroll=a.preroll)
         try:
             legs["host_frames_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, host_frames=True, **common)
             legs["host_frames_fps"]["what"] = "the B1 signature: frames handed over as HOST pointers (ef_process_frame: pinned staging + PCIe upload inside the timed region)"
