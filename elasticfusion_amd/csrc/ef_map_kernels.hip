@@ -479,10 +479,10 @@ constexpr int SPLAT_LANES = EF_SPLAT_LANES;
 // against 1472 frames/s (profiles/r03e_ab_tiled_vs_global_splat.log, profiles/r03e_tiled_splat_bench_kernel_stats.csv): three barriers, the
 // tile's clear and sweep and the box atomics per 128 surfels cost more than the overdraw they keep out of HBM, whose 64-bit atomics on
 // neighbouring pixels already coalesce in L2.  Not the default.
-constexpr int SPLAT_ROUNDS = 2, SPLAT_CHUNK = SPLAT_ROUNDS * (BLK / SPLAT_LANES), SPLAT_TILE = 4096;
 #ifndef EF_SPLAT_TILED
 constexpr int SPLAT_GRID = SURFEL_GRID * SPLAT_LANES;
 #else
+constexpr int SPLAT_ROUNDS = 2, SPLAT_CHUNK = SPLAT_ROUNDS * (BLK / SPLAT_LANES), SPLAT_TILE = 4096;
 constexpr int SPLAT_GRID = 4096;   // workgroups; each strides over chunks of SPLAT_CHUNK ids (the count lives on the device)
 #endif
 __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const float* __restrict__ T16, SurfelSoA map,
