@@ -157,7 +157,7 @@ struct Graph {
       for (int r = 0; r < 9; ++r) nd.R[r] = (r % 4 == 0) ? 1.0 : 0.0;
       nd.time = (uint64_t)nodes4[i * 4 + 3];
       nd.enabled = nd.time > last_deform_time;
-      int c = 0;   // sequence neighbours (DeformationGraph.cpp:226-251)
+      int c = 0;   // sequence neighbours (DeformationGraph.cpp:239-266)
       if (i < K / 2) { for (int q = 0; q < K + 1; ++q) if (q != i) nd.nb[c++] = q; }
       else if (i >= n - K / 2) { for (int q = n - (K + 1); q < n; ++q) if (q != i) nd.nb[c++] = q; }
       else { for (int q = 0; q < K / 2; ++q) { nd.nb[c++] = i - (q + 1); nd.nb[c++] = i + (q + 1); } }

@@ -94,6 +94,7 @@ ElasticFusion::ElasticFusion(const int timeDelta_, const int countThresh, const 
   // drop-in: getGlobalModel().downloadMap() and savePly() return what the reference's return (the pre-clean buffer, quirk Q14)
   chk(ef_set_reference_download(c, 1), c, "ElasticFusion::ElasticFusion");
   indexMap.ctx = globalModel.ctx = localDeformation.ctx = c;
+  localDeformation.closeLoops = closeLoops;
   indexMap.w = cfg.width;
   indexMap.h = cfg.height;
   if (!saveFilename.empty()) {  // the reference truncates <file>.freiburg in its constructor (ElasticFusion.cpp:97-102)
@@ -183,12 +184,37 @@ const FernsView& ElasticFusion::getFerns() {
   return fernsView;
 }
 
-std::vector<float> DeformationView::getGraph() {
-  std::vector<float> nodes((size_t)1024 * 4);
+void DeformationView::getRawGraph(std::vector<float>& nodes4) {
+  nodes4.assign((size_t)1024 * 4, 0.f);
   int n = 0;
-  chk(ef_sample_graph(C(ctx), nodes.data(), 1023, &n), ctx, "getGraph");
-  nodes.resize((size_t)n * 4);
-  return nodes;
+  chk(ef_sample_graph(C(ctx), nodes4.data(), 1023, &n), ctx, "getRawGraph");
+  nodes4.resize((size_t)n * 4);
+}
+
+const std::vector<GraphNode*>& DeformationView::getGraph() {
+  constexpr int K = 4;   // DeformationGraph's k (Deformation.cpp:23)
+  nodes.clear();
+  node_ptrs.clear();
+  if (!closeLoops) return node_ptrs;            // sampleGraphModel only runs in closed-loop mode (ElasticFusion.cpp:592-594)
+  std::vector<float> raw;
+  getRawGraph(raw);
+  const int n = (int)(raw.size() / 4);
+  if (n <= K) return node_ptrs;                 // Deformation.cpp:283: no graph from k samples or fewer
+  nodes.resize((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    GraphNode& g = nodes[(size_t)i];
+    g.id = i;
+    g.enabled = true;
+    for (int r = 0; r < 3; ++r) { g.position(r) = raw[(size_t)i * 4 + r]; g.translation(r) = 0.0; }
+    for (int r = 0; r < 9; ++r) g.rotation.m[r] = (r % 4 == 0) ? 1.0 : 0.0;
+    // sequence neighbours (DeformationGraph.cpp:239-266): the first K/2 and last K/2 nodes take the K others of the first / last K + 1,
+    // everyone else K/2 on either side
+    if (i < K / 2) { for (int q = 0; q < K + 1; ++q) if (q != i) g.neighbours.push_back(q); }
+    else if (i >= n - K / 2) { for (int q = n - (K + 1); q < n; ++q) if (q != i) g.neighbours.push_back(q); }
+    else { for (int q = 0; q < K / 2; ++q) { g.neighbours.push_back(i - (q + 1)); g.neighbours.push_back(i + (q + 1)); } }
+  }
+  for (GraphNode& g : nodes) node_ptrs.push_back(&g);
+  return node_ptrs;
 }
 
 void ElasticFusion::predict() { chk(ef_predict(C(ctx.get())), ctx.get(), "predict"); }

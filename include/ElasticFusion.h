@@ -24,9 +24,25 @@
 //  * errors throw std::runtime_error instead of assert()/exit(0).
 #ifndef EFUSION_ELASTICFUSION_H_
 #define EFUSION_ELASTICFUSION_H_
+// This header stands where the reference's Core/ElasticFusion.h stands.  It takes that header's include guard, so a front end that
+// still has the old file on its include path (MainController.h:20 includes "Core/ElasticFusion.h" next to itself) gets this class and
+// an inert old header when this one comes first (g++ -include ElasticFusion.h: tests/test_front_end_compiles.py compiles the
+// reference's MainController.cpp where it lies that way), and a loud error instead of two classes when it comes second.
+#ifdef ELASTICFUSION_H_
+#error "the reference's Core/ElasticFusion.h was included before include/ElasticFusion.h: include this one first, or remove the old one"
+#endif
+#define ELASTICFUSION_H_
 
+// what the reference's header brings along and its front end relies on (MainController.cpp: std::stringstream, std::isnan,
+// std::numeric_limits, std::map, memcpy, std::setprecision)
+#include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <iomanip>
+#include <limits>
+#include <map>
 #include <memory>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -36,7 +52,11 @@
 #include <sophus/se3.hpp>
 #endif
 
-// ---- process-wide singletons of the reference (Core/Utils/Resolution.h:25-58, Intrinsics.h:25-51) ----
+// ---- process-wide singletons of the reference (Core/Utils/Resolution.h:25-58, Intrinsics.h:25-51), under the reference's own include
+// guards: the front end's headers include those files themselves (Tools/GUI.h:29, LogReader.h:27), and whichever definition comes first is
+// the one the translation unit sees — same members, same layout, getInstance() in libefusion.so either way ----
+#ifndef RESOLUTION_H_
+#define RESOLUTION_H_
 class Resolution {
  public:
   static const Resolution& getInstance(int width = 0, int height = 0);
@@ -50,7 +70,10 @@ class Resolution {
   Resolution(int width, int height);
   const int imgWidth, imgHeight, imgNumPixels;
 };
+#endif  // RESOLUTION_H_
 
+#ifndef INTRINSICS_H_
+#define INTRINSICS_H_
 class Intrinsics {
  public:
   static const Intrinsics& getInstance(float fx = 0, float fy = 0, float cx = 0, float cy = 0);
@@ -63,9 +86,46 @@ class Intrinsics {
   Intrinsics(float fx, float fy, float cx, float cy);
   const float fx_, fy_, cx_, cy_;
 };
+#endif  // INTRINSICS_H_
+
+// Core/Shaders/Vertex.h: the stride of one surfel in bytes — three float4 rows, the layout downloadMap() returns and a viewer's vertex
+// attribute pointers step by (Tools/GUI.h:325-343)
+#ifndef VERTEX_H_
+#define VERTEX_H_
+class Vertex {
+ public:
+  static constexpr int SIZE = 12 * (int)sizeof(float);
+};
+#endif  // VERTEX_H_
 
 namespace efusion {
 
+// small fixed-size values with Eigen's element access — v(i), v[i], m(r, c), data() — for the members the front end reads coefficient by
+// coefficient (MainController.cpp:389-441: graph.at(i)->position(0), constraints.at(j).sourcePoint(1), ...); plain arrays underneath
+struct Vec3d {
+  double v[3];
+  double& operator()(int i) { return v[i]; }
+  const double& operator()(int i) const { return v[i]; }
+  double& operator[](int i) { return v[i]; }
+  const double& operator[](int i) const { return v[i]; }
+  double* data() { return v; }
+  const double* data() const { return v; }
+};
+struct Mat3d {       // row major
+  double m[9];
+  double& operator()(int r, int c) { return m[r * 3 + c]; }
+  const double& operator()(int r, int c) const { return m[r * 3 + c]; }
+};
+template <typename S>
+struct Mat4 {        // column major like Eigen's default, so that data() can be handed to whatever takes Eigen::Matrix4f::data()
+  S m[16];
+  S& operator()(int r, int c) { return m[c * 4 + r]; }
+  const S& operator()(int r, int c) const { return m[c * 4 + r]; }
+  S* data() { return m; }
+  const S* data() const { return m; }
+};
+
+template <typename S> struct SE3Cast;
 // Sophus::SE3d's data layout: Eigen::Quaterniond (x, y, z, w) followed by Eigen::Vector3d
 struct SE3d {
   double q[4] = {0, 0, 0, 1};
@@ -74,7 +134,33 @@ struct SE3d {
   static SE3d fromMatrix(const double* T_wc16_rowmajor);
   void matrix(double* out16_rowmajor) const;      // Sophus::SE3d::matrix()
   const double* translation() const { return t; } // Sophus::SE3d::translation()
+  // Sophus::SE3d::cast<float>(), as far as the front end uses it: frames.at(i)->T_wc.cast<float>().matrix() (MainController.cpp:383,411)
+  template <typename S> SE3Cast<S> cast() const;
 };
+template <typename S>
+struct SE3Cast {
+  SE3d pose;
+#ifdef EFUSION_USE_SOPHUS
+  Eigen::Matrix<S, 4, 4> matrix() const {
+    double M[16];
+    pose.matrix(M);
+    Eigen::Matrix<S, 4, 4> r;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) r(i, j) = (S)M[i * 4 + j];
+    return r;
+  }
+#else
+  Mat4<S> matrix() const {
+    double M[16];
+    pose.matrix(M);
+    Mat4<S> r;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) r(i, j) = (S)M[i * 4 + j];
+    return r;
+  }
+#endif
+};
+template <typename S> SE3Cast<S> SE3d::cast() const { return SE3Cast<S>{*this}; }
 
 struct ef_ctx_deleter { void operator()(void* p) const; };
 
@@ -112,7 +198,7 @@ class IndexMapView {
 
 // Ferns::SurfaceConstraint (Core/Ferns.h) and PoseMatch (Core/PoseMatch.h): what getPoseMatches() hands to the front-end's drawing code
 struct SurfaceConstraint {
-  double sourcePoint[3], targetPoint[3];
+  Vec3d sourcePoint, targetPoint;
 };
 struct PoseMatch {
   int firstId, secondId;
@@ -130,13 +216,30 @@ struct FernsView {
   std::vector<FernFrame> frames;
   int lastClosest = -1;
 };
-// Deformation facade: getGraph() = the sampled graph nodes {x, y, z, time} of the current model (Deformation::sampleGraphModel)
+// Core/Utils/GraphNode.h: a node of the embedded deformation graph as the front end draws it (MainController.cpp:388-404)
+struct GraphNode {
+  int id;
+  Vec3d position;
+  Mat3d rotation;
+  Vec3d translation;
+  std::vector<int> neighbours;
+  bool enabled;
+};
+// Deformation facade.  getGraph() (Deformation.cpp:65-67): the graph Deformation::sampleGraphModel builds at the end of every closed-loop
+// frame (ElasticFusion.cpp:593) — every 5000th surfel of the current model in time order, identity rotation, zero translation, each node
+// joined to its four sequence neighbours (DeformationGraph.cpp:239-266) — sampled from the map as it stands when the call is made;
+// empty while the map yields no more than four nodes (Deformation.cpp:283) and in open loop.  getRawGraph(): the same nodes as rows
+// {x, y, z, time}.
 class DeformationView {
  public:
-  std::vector<float> getGraph();
+  const std::vector<GraphNode*>& getGraph();
+  void getRawGraph(std::vector<float>& nodes4);
  private:
   friend class ::efusion::ElasticFusion;
   void* ctx = nullptr;
+  bool closeLoops = false;
+  std::vector<GraphNode> nodes;
+  std::vector<GraphNode*> node_ptrs;
 };
 
 class ElasticFusion {
@@ -251,8 +354,10 @@ class ElasticFusion {
 
 }  // namespace efusion
 
-// the reference's class lives in the global namespace
+// the reference's classes live in the global namespace
 using efusion::ElasticFusion;
+using efusion::GraphNode;
+using efusion::PoseMatch;
 #ifndef EFUSION_USE_SOPHUS
 namespace Sophus { using SE3d = efusion::SE3d; }
 #endif

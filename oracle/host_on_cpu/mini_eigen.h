@@ -16,6 +16,7 @@
 #include <fstream>
 #include <iostream>
 #include <limits>
+#include <memory>
 #include <vector>
 #include "../efo_linalg.h"
 
@@ -140,6 +141,33 @@ class Matrix {
       for (int j = 0; j < C; ++j) (*this)(i, j) += o(i, j);
     return *this;
   }
+  template <int O2>
+  Matrix& operator-=(const Matrix<T, R, C, O2>& o) {
+    for (int i = 0; i < R; ++i)
+      for (int j = 0; j < C; ++j) (*this)(i, j) -= o(i, j);
+    return *this;
+  }
+  // ---- only used by the reference's display code (MainController.cpp:262-286, compiled but never run: tests/test_front_end_compiles.py) ----
+  Matrix normalized() const {
+    Matrix r;
+    const T n = norm();
+    for (int i = 0; i < R * C; ++i) r.m[i] = m[i] / n;
+    return r;
+  }
+  template <int O2>
+  Matrix cross(const Matrix<T, R, C, O2>& o) const {
+    static_assert(R * C == 3, "3-vectors");
+    return Matrix(m[1] * o.m[2] - m[2] * o.m[1], m[2] * o.m[0] - m[0] * o.m[2], m[0] * o.m[1] - m[1] * o.m[0]);
+  }
+  // m << a, b, c, ...: coefficients in ROW order
+  struct CommaInit {
+    Matrix& dst;
+    int n;
+    template <typename U>
+    CommaInit& operator,(const U& v) { dst(n / C, n % C) = (T)v; ++n; return *this; }
+  };
+  template <typename U>
+  CommaInit operator<<(const U& v) { (*this)(0, 0) = (T)v; return CommaInit{*this, 1}; }
   Matrix<T, R, 1> col(int j) const {
     Matrix<T, R, 1> r;
     for (int i = 0; i < R; ++i) r.m[i] = (*this)(i, j);
@@ -308,6 +336,19 @@ class Quaterniond {
  private:
   double q[4];
 };
+// display code only (MainController.cpp:265-270): the camera's rotation applied to the view axes
+class Quaternionf {
+ public:
+  template <int O>
+  explicit Quaternionf(const Matrix<float, 3, 3, O>& R) : Rm(R) {}
+  Matrix<float, 3, 1> operator*(const Matrix<float, 3, 1>& v) const { return Rm * v; }
+
+ private:
+  Matrix<float, 3, 3> Rm;
+};
+// std::map<..., Eigen::aligned_allocator<...>> (Tools/GroundTruthOdometry.h:50)
+template <typename T>
+using aligned_allocator = std::allocator<T>;
 // run-time sized vector (only declared by the reference's deformation-graph headers here)
 class VectorXd {
  public:

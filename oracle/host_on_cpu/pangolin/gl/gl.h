@@ -19,6 +19,7 @@ struct GlTexture {
   void Unbind() const { glBindTexture(GL_TEXTURE_2D, 0); }
   void Upload(const void*, GLenum fmt, GLenum type) { rec("GlTexture::Upload %u fmt=%#x type=%#x", tid, fmt, type); }
   void Download(void*, GLenum fmt, GLenum type) const { rec("GlTexture::Download %u fmt=%#x type=%#x", tid, fmt, type); }
+  void RenderToViewport(bool flip = false) const { rec("GlTexture::RenderToViewport %u flip=%d", tid, (int)flip); }   // display only (Tools/GUI.h:256)
 };
 struct GlRenderBuffer {
   GLint width = 0, height = 0;

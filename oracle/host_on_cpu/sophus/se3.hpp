@@ -24,6 +24,14 @@ class SE3d {
  public:
   SE3d() : T(efo::se3_identity()) { sync_t(); }
   explicit SE3d(const efo::SE3& s) : T(s) { sync_t(); }
+  template <int O>
+  explicit SE3d(const Eigen::Matrix<double, 4, 4, O>& M) {   // Sophus::SE3d(Matrix4d): MainController.cpp:238-239 (ground-truth poses)
+    double m[16];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) m[i * 4 + j] = M(i, j);
+    T = efo::se3_from_matrix(m);
+    sync_t();
+  }
   Eigen::Matrix3d rotationMatrix() const {
     const efo::M3d R = efo::se3_rotation(T);
     Eigen::Matrix3d r;

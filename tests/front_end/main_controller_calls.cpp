@@ -67,18 +67,26 @@ int front_end(int argc, char**) {
     }
     for (size_t i = 0; i < eFusion->getFerns().frames.size(); i++) {
       if ((int)i == eFusion->getFerns().lastClosest) continue;
-      const auto& T_fern = eFusion->getFerns().frames.at(i)->T_wc;   // :383, as written (the view's entries answer to -> like Ferns::Frame*)
-      (void)T_fern;
+      const auto M_fern = eFusion->getFerns().frames.at(i)->T_wc.cast<float>().matrix();   // :383, as written (the view's entries answer to -> like Ferns::Frame*)
+      (void)M_fern(0, 3);
     }
-    const auto& graph = eFusion->getLocalDeformation().getGraph();
-    (void)graph;
-    const std::vector<efusion::PoseMatch>& poseMatches = eFusion->getPoseMatches();
+    const std::vector<GraphNode*>& graph = eFusion->getLocalDeformation().getGraph();        // :389-403, as written
+    for (size_t i = 0; i < graph.size(); i++) {
+      double x = graph.at(i)->position(0) + graph.at(i)->position(1) + graph.at(i)->position(2);
+      for (size_t j = 0; j < graph.at(i)->neighbours.size(); j++) x += graph.at(graph.at(i)->neighbours.at(j))->position(0);
+      (void)x;
+    }
+    const std::vector<PoseMatch>& poseMatches = eFusion->getPoseMatches();                    // :416-441, as written
+    int maxDiff = 0;
     for (size_t i = 0; i < poseMatches.size(); i++) {
+      if (poseMatches.at(i).secondId - poseMatches.at(i).firstId > maxDiff) maxDiff = poseMatches.at(i).secondId - poseMatches.at(i).firstId;
       if (poseMatches.at(i).fern) {
       }
       for (size_t j = 0; j < poseMatches.at(i).constraints.size(); j++) {
-        (void)poseMatches.at(i).constraints.at(j).sourcePoint;
-        (void)poseMatches.at(i).constraints.at(j).targetPoint;
+        const double d = poseMatches.at(i).constraints.at(j).sourcePoint(0) + poseMatches.at(i).constraints.at(j).sourcePoint(1) +
+                         poseMatches.at(i).constraints.at(j).sourcePoint(2) - poseMatches.at(i).constraints.at(j).targetPoint(0) -
+                         poseMatches.at(i).constraints.at(j).targetPoint(1) - poseMatches.at(i).constraints.at(j).targetPoint(2);
+        (void)d;
       }
     }
     // :455-458 draw from getIndexMap()'s GL textures; what a GL-free front-end reads instead are the same images as host copies

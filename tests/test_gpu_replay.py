@@ -68,6 +68,14 @@ def test_klg_replay_with_close_loops(tmp_path, seq):
     assert int(words[words.index("surfels") + 1]) == o.map_count(), r.stdout
     traj = np.loadtxt(log + ".freiburg")
     assert np.abs(traj[-1, 1:4] - o.pose()[:3, 3]).max() <= 1e-6
+    # getLocalDeformation().getGraph() as MainController draws it (:388-404): Deformation::sampleGraphModel's nodes of the final map, four
+    # sequence neighbours each
+    import efo
+    nodes = efo.sample_graph(o.map())
+    g = [ln for ln in r.stdout.splitlines() if ln.startswith("deformation graph")][0].split()
+    assert int(g[g.index("nodes") + 1]) == len(nodes) > 4 and int(g[g.index("links") + 1]) == 4 * len(nodes), (g, len(nodes))
+    first = [float(x) for x in g[g.index("first") + 1:g.index("first") + 4]]
+    assert np.abs(np.asarray(first) - nodes[0, :3]).max() <= 1e-6 * max(1.0, float(np.abs(nodes[0, :3]).max())), (first, nodes[0])
 
 
 def test_jpeg_klg_replay(tmp_path, seq):

@@ -99,6 +99,20 @@ int main(int argc, char** argv) {
       const efusion::FernsView& F = eFusion.getFerns();
       std::printf("fern database: keyframes %d  global deformations %d  pose matches %d\n", (int)F.frames.size(), eFusion.getFernDeforms(),
                   (int)eFusion.getPoseMatches().size());
+      // MainController.cpp:388-404,465-468: the deformation graph as the GUI draws and counts it
+      const std::vector<GraphNode*>& graph = eFusion.getLocalDeformation().getGraph();
+      size_t links = 0;
+      double reach = 0;   // longest link
+      for (size_t g = 0; g < graph.size(); g++)
+        for (size_t j = 0; j < graph.at(g)->neighbours.size(); j++, links++) {
+          const GraphNode* o = graph.at(graph.at(g)->neighbours.at(j));
+          double d = 0;
+          for (int k = 0; k < 3; k++) d += (graph.at(g)->position(k) - o->position(k)) * (graph.at(g)->position(k) - o->position(k));
+          reach = d > reach ? d : reach;
+        }
+      std::printf("deformation graph: nodes %d  links %d  longest %.6f", (int)graph.size(), (int)links, std::sqrt(reach));
+      if (!graph.empty()) std::printf("  first %.9g %.9g %.9g", graph.at(0)->position(0), graph.at(0)->position(1), graph.at(0)->position(2));
+      std::printf("\n");
     }
     if (ply) eFusion.savePly();
   } catch (const std::exception& e) {
