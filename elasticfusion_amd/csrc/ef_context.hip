@@ -550,10 +550,9 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
                         c->cfg.time_delta, c->zbuf, c->old, none, nullptr, nullptr, false, nullptr, s);
   eft::copy_pose(c->st2, c->st, s);                                                              // :469
   const float maxDepthRGB = 6.0f;                                                                // RGBDOdometry.cpp:42
-  eft::init_icp_model(c->pyr2, (const float*)c->old.vertex, (const float*)c->old.normal, (const float*)c->old.vertex,
-                      (const float*)c->old.normal, c->st2, maxDepthRGB, s);                      // :463
-  eft::init_rgb_model(c->pyr2, (const uint8_t*)c->old.image, (const uint8_t*)c->old.image, false, c->st2, s);   // :464
-  eft::init_icp_maps(c->pyr2, (const float*)c->pm.vertex, (const float*)c->pm.normal, (const uint8_t*)c->pm.image, c->st2, maxDepthRGB, s);  // :466-467
+  // :463 initICPModel(inactive view) + :464 initRGBModel(its image) + :466-467 initICP / initRGB(active view), fused (eft::init_model_pair)
+  eft::init_model_pair(c->pyr2, (const float*)c->old.vertex, (const float*)c->old.normal, (const uint8_t*)c->old.image, (const float*)c->pm.vertex,
+                       (const float*)c->pm.normal, (const uint8_t*)c->pm.image, c->st2, maxDepthRGB, s);
   eft::init_rgb_sobel(c->pyr2, s);
   eft::TrackParams tp;
   tp.rgbOnly = false; tp.pyramid = c->cfg.pyramid != 0; tp.fastOdom = c->cfg.fast_odom != 0; tp.so3 = false; tp.icpWeight = 10.f;   // :471

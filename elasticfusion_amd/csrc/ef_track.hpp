@@ -194,6 +194,10 @@ void init_rgb_frame(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
 void init_icp_maps(const Pyramid& p, const float* vertex4, const float* normal4, const uint8_t* image_rgba, const TrackState* st,
                    float maxDepthRGB, hipStream_t s);
 void init_rgb_sobel(const Pyramid& p, hipStream_t s);
+// init_icp_model + init_rgb_model (model view, its own image, no fill-in) + init_icp_maps (current view) of a model-to-model tracker in five launches
+void init_model_pair(const Pyramid& p, const float* model_vertex4, const float* model_normal4, const uint8_t* model_image_rgba,
+                     const float* cur_vertex4, const float* cur_normal4, const uint8_t* cur_image_rgba, const TrackState* st, float maxDepthRGB,
+                     hipStream_t s);
 // init_icp + init_rgb_model + init_rgb_frame in three launches (single-stream frame script; needs init_icp_model first)
 void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, const uint8_t* pred_image_rgba,
                     const uint8_t* fill_image_rgba, bool frameToFrameRGB, const uint8_t* rgb3, const TrackState* st, hipStream_t s,

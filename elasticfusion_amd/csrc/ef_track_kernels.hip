@@ -2668,6 +2668,52 @@ void init_icp_maps(const Pyramid& p, const float* vertex, const float* normal, c
   hipLaunchKernelGGL(k_model_intensity, dim3(ceil_div(n, 256)), dim3(256), 0, s, image_rgba, image_rgba, true, st, n, p.nextImage[0]);
   for (int i = 0; i + 1 < NUM_PYRS; ++i) pyr_down_uchar_gauss(p.nextImage[i], p.W(i), p.H(i), p.nextImage[i + 1], s);
 }
+namespace {
+// level-0 intensity of two RGBA images in one launch: blockIdx.y 0 = the model image ("last"), 1 = the current side's ("next")
+__global__ void k_rgba_intensity_pair(const uint8_t* __restrict__ last_rgba, const uint8_t* __restrict__ next_rgba, int n, uint8_t* __restrict__ last0,
+                                      uint8_t* __restrict__ next0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uchar4 c = ((const uchar4*)(blockIdx.y == 0 ? last_rgba : next_rgba))[i];
+  (blockIdx.y == 0 ? last0 : next0)[i] = intensity_of((float)c.x, (float)c.y, (float)c.z);
+}
+}  // namespace
+// Model-to-model tracking (the local loop closure's second tracker, ElasticFusion.cpp:463-467): init_icp_model + init_rgb_model on one
+// predicted view and init_icp_maps on the other, as FIVE launches instead of twelve — the two k_model_maps, one launch for both level-0
+// intensity images, one k_pyr_down_multi per pyramid step over {model depth, current depth, model intensity, current intensity}.  The two
+// sides share no buffer (pyr2 / pyr3 keep nextDepth apart from lastDepth), the per-pixel functions are the ones the separate launches
+// call: same results (rocprofv3, closed-loop bench: the separate launches were 4.3 + 4.3 + 2.1 per frame, ~76 us).
+void init_model_pair(const Pyramid& p, const float* model_vertex, const float* model_normal, const uint8_t* model_image_rgba, const float* cur_vertex,
+                     const float* cur_normal, const uint8_t* cur_image_rgba, const TrackState* st, float maxDepthRGB, hipStream_t s) {
+  ModelMapsArgs A;
+  A.pred_vertex = A.fill_vertex = (const float4*)model_vertex;
+  A.pred_normal = A.fill_normal = (const float4*)model_normal;
+  for (int i = 0; i < NUM_PYRS; ++i) { A.vmap[i] = p.vmap_g_prev[i]; A.nmap[i] = p.nmap_g_prev[i]; }
+  A.depth0 = p.lastDepth[0];
+  A.cols = p.W(0); A.rows = p.H(0);
+  A.maxDepthRGB = maxDepthRGB;
+  A.camera_frame = false;
+  hipLaunchKernelGGL(k_model_maps, model_maps_grid(p), dim3(64, 4), 0, s, A, st);
+  A.pred_vertex = A.fill_vertex = (const float4*)cur_vertex;
+  A.pred_normal = A.fill_normal = (const float4*)cur_normal;
+  for (int i = 0; i < NUM_PYRS; ++i) { A.vmap[i] = p.vmap_curr[i]; A.nmap[i] = p.nmap_curr[i]; }
+  A.depth0 = p.nextDepth[0];
+  A.camera_frame = true;
+  hipLaunchKernelGGL(k_model_maps, model_maps_grid(p), dim3(64, 4), 0, s, A, st);
+  const int n = p.W(0) * p.H(0);
+  hipLaunchKernelGGL(k_rgba_intensity_pair, dim3(ceil_div(n, 256), 2), dim3(256), 0, s, model_image_rgba, cur_image_rgba, n, p.lastImage[0], p.nextImage[0]);
+  for (int i = 0; i + 1 < NUM_PYRS; ++i) {
+    PyrJobs J;
+    J.src[0] = p.lastDepth[i]; J.dst[0] = p.lastDepth[i + 1]; J.type[0] = 1;
+    J.src[1] = p.nextDepth[i]; J.dst[1] = p.nextDepth[i + 1]; J.type[1] = 1;
+    J.src[2] = p.lastImage[i]; J.dst[2] = p.lastImage[i + 1]; J.type[2] = 2;
+    J.src[3] = p.nextImage[i]; J.dst[3] = p.nextImage[i + 1]; J.type[3] = 2;
+    J.scols = p.W(i); J.srows = p.H(i);
+    dim3 g = tile_grid(p.W(i + 1), p.H(i + 1));
+    g.z = 4;
+    hipLaunchKernelGGL(k_pyr_down_multi, g, tile_block(), 0, s, J);
+  }
+}
 void init_rgb_frame(const Pyramid& p, const uint8_t* rgb3, hipStream_t s) {
   // populateRGBDData(frame): nextDepth == lastDepth (Q1), only the intensity pyramid is new
   bgr_to_intensity(rgb3, 3, p.W(0), p.H(0), p.nextImage[0], s);
