@@ -72,6 +72,8 @@ def main(so, trials):
             refused += n < 0
             short += n >= 0 and got < FRAMES
             full += got >= FRAMES
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     print("KLG_FUZZ_OK refused %d short %d full %d" % (refused, short, full))
 
 
