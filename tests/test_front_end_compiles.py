@@ -137,11 +137,9 @@ def test_reference_main_controller_compiles_where_it_lies_up_to_the_gl_lines():
         assert re.search(r"%s:[0-9,\- ]*\b%d\b" % (re.escape(f), line), doc), (f, line)
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="the reference checkout is only present in the build container")
-def test_reference_main_controller_compiles_clean_with_the_gl_lines_taken_out(tmp_path):
-    """the other half: with exactly those lines gone, the file compiles — no error hides behind another one.  The statements the lines
-    belong to are blanked in a scratch copy (outside the repository, made and deleted by the test); the copy includes the reference's
-    MainController.h and Tools/ headers from where they lie."""
+def scratch_copy_without_the_gl_statements(tmp_path):
+    """MainController.cpp / .h with exactly the statements of MUST_CHANGE blanked, in a scratch directory outside the repository (made by the
+    test, deleted with pytest's tmp_path); the copy includes the reference's Tools/ headers from where they lie."""
     src = open(REF).read().split("\n")
     hdr = open(os.path.join(REF_DIR, "MainController.h")).read().split("\n")
     # whole statements: (first line, last line), 1-based inclusive, in MainController.cpp — the resizeStream statements, the two feedback-buffer
@@ -156,9 +154,38 @@ def test_reference_main_controller_compiles_clean_with_the_gl_lines_taken_out(tm
     hdr[62] = ""                                        # Resize* resizeStream;
     (tmp_path / "MainController.cpp").write_text("\n".join(src))
     (tmp_path / "MainController.h").write_text("\n".join(hdr))
-    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-fmax-errors=0", "-w", "-DEFUSION_USE_SOPHUS", "-include", "ElasticFusion.h",
-           "-I" + os.path.join(ROOT, "tests", "front_end", "stubs"), "-I" + os.path.join(ROOT, "include"),
-           "-I" + os.path.join(ROOT, "oracle", "host_on_cpu"), "-I" + os.path.join(ROOT, "oracle", "cuda_on_cpu"), "-I" + REF_DIR,
-           str(tmp_path / "MainController.cpp")]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return ["g++", "-std=c++17", "-fmax-errors=0", "-w", "-DEFUSION_USE_SOPHUS", "-include", "ElasticFusion.h",
+            "-I" + os.path.join(ROOT, "tests", "front_end", "stubs"), "-I" + os.path.join(ROOT, "include"),
+            "-I" + os.path.join(ROOT, "oracle", "host_on_cpu"), "-I" + os.path.join(ROOT, "oracle", "cuda_on_cpu"), "-I" + REF_DIR,
+            str(tmp_path / "MainController.cpp")]
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference checkout is only present in the build container")
+def test_reference_main_controller_compiles_clean_with_the_gl_lines_taken_out(tmp_path):
+    """the other half: with exactly those lines gone, the file compiles — no error hides behind another one"""
+    r = subprocess.run(scratch_copy_without_the_gl_statements(tmp_path) + ["-fsyntax-only"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-4000:]
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference checkout is only present in the build container")
+def test_every_library_symbol_the_front_end_needs_is_exported_by_libefusion(tmp_path):
+    """link level: the same translation unit compiled to an object by g++; every undefined symbol of it that belongs to the library (class
+    ElasticFusion and its facades, the pose type, the Resolution / Intrinsics singletons) is a defined dynamic symbol of libefusion.so
+    (built by hipcc: same Itanium ABI, same libstdc++ std::string).  What stays undefined is the front end's own: Pangolin, its readers."""
+    from elasticfusion_amd import build
+    assert os.path.exists(build.SHIM_LIB), "run python -m elasticfusion_amd.build"
+    obj = str(tmp_path / "main_controller.o")
+    r = subprocess.run(scratch_copy_without_the_gl_statements(tmp_path) + ["-c", "-O0", "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-4000:]
+    nm = lambda *a: [ln.split()[-1] for ln in subprocess.run(["nm", *a], stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines() if ln.strip()]
+    undefined = nm("-u", obj)
+    demangled = subprocess.run(["c++filt"], input="\n".join(undefined), stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines()
+    exported = set(nm("-D", "--defined-only", build.SHIM_LIB))
+    ours = re.compile(r"ElasticFusion|efusion::|\bResolution::|\bIntrinsics::|\bVertex::")
+    needed = [(m, d) for m, d in zip(undefined, demangled) if ours.search(d)]
+    names = " ".join(d for _, d in needed)
+    for must in ("ElasticFusion::ElasticFusion(", "ElasticFusion::processFrame(", "ElasticFusion::predict()", "ElasticFusion::savePly()", "ElasticFusion::getFerns()",
+                 "DeformationView::getGraph()", "GlobalModelView::lastCount()", "Resolution::getInstance(", "Intrinsics::getInstance("):
+        assert must in names, (must, names)                       # the check is looking at the right object
+    missing = [d for m, d in needed if m not in exported]
+    assert not missing, missing
