@@ -218,3 +218,17 @@ def test_every_context_entry_point_refuses_a_null_context():
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-500:])
     got = dict(ln.split() for ln in r.stdout.splitlines())
     assert sorted(got) == names and all(int(v) == -1 for v in got.values()), got   # EF_EINVAL
+
+
+def test_documents_name_only_entry_points_the_header_declares():
+    """doc rot: every ef_* identifier INTEGRATION.md / DESIGN.md / README.md / include/ElasticFusion.h mention is declared by include/ef_hip.h
+    (or is the name of a source file / a prefix written with a trailing underscore)"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set(re.findall(r"\b(ef_[a-z0-9_]+)\b", open(os.path.join(root, "include", "ef_hip.h")).read()))
+    files = {"ef_" + os.path.splitext(f)[0][3:] for f in os.listdir(os.path.join(root, "elasticfusion_amd", "csrc")) if f.startswith("ef_")} | {"ef_hip"}
+    local = {"ef_ctx_deleter", "ef_expf", "ef_device", "ef_map"}   # a C++ helper type of the shim header, a device function, two prose prefixes
+    for doc in ("INTEGRATION.md", "DESIGN.md", "README.md", os.path.join("include", "ElasticFusion.h")):
+        names = set(re.findall(r"\b(ef_[a-z0-9_]+)\b", open(os.path.join(root, doc)).read()))
+        unknown = sorted(n for n in names if n not in declared and n not in files and n not in local and not n.endswith("_"))
+        assert not unknown, (doc, unknown)
