@@ -1,5 +1,5 @@
 // Fern database: the keyframe store behind the reference's GLOBAL loop closure and relocalisation (Core/Ferns.h:35-184,
-// Core/Ferns.cpp:22-420).  Everything in here is host-side bookkeeping on 1/8-resolution images the device already produced
+// Core/Ferns.cpp:22-393).  Everything in here is host-side bookkeeping on 1/8-resolution images the device already produced
 // (ef_get_image_resized): `num` random ferns each make four binary tests on one pixel (r, g, b against a byte threshold, depth in
 // mm against a threshold), a frame is the vector of those 4-bit codes, two frames are compared through the inverted lists the
 // ferns keep per code value.  The one piece of per-pixel arithmetic the reference does between a stored frame and a new view — an
@@ -87,7 +87,7 @@ struct ef_ferns {
     const float maxCo = (float)(good < s.goodCodes ? good : s.goodCodes);
     return (maxCo - (float)co) / maxCo;
   }
-  // Ferns.cpp:396-412
+  // Ferns.cpp:378-393
   float blockHDAware(const std::vector<uint8_t>& a, const std::vector<uint8_t>& b) const {
     int count = 0;
     float val = 0;

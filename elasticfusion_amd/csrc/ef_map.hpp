@@ -5,7 +5,7 @@
 // HBM layout: surfels are three float4 streams (SoA) {x,y,z,conf} {colour,0,initTime,lastTime}
 // {nx,ny,nz,radius}: every per-surfel pass issues perfectly coalesced 16-byte loads, and passes that
 // cull on position/time never touch the normal stream.  The 48-byte AoS records of the reference
-// (Core/Shaders/Vertex.cpp:74) exist only at the download / upload boundary.
+// (Core/Shaders/Vertex.cpp:21-41) exist only at the download / upload boundary.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -175,7 +175,7 @@ int ef_get_local_loop(ef_ctx* ctx, ef_local_loop* info, double* constraints_or_n
  * surfel of the current model in map order as {x, y, z, initTime} (times ascend because the map keeps creation order); what the
  * reference hands to DeformationGraph::initialiseGraph.  nodes4_host: max_nodes x 4 floats.  Synchronises. */
 int ef_sample_graph(ef_ctx* ctx, float* nodes4_host, int max_nodes, int* n_out);
-/* ---- fern database (Core/Ferns.h:35-184, Core/Ferns.cpp:22-420): the keyframe store of the GLOBAL loop closure and of
+/* ---- fern database (Core/Ferns.h:35-184, Core/Ferns.cpp:22-393): the keyframe store of the GLOBAL loop closure and of
  * relocalisation.  Host-side object with no GPU state of its own: it encodes the 1/8-resolution predicted views
  * (ef_get_image_resized(EF_IMG_FILL_*, 8, ...)) with `num` random ferns (4 binary tests each: r, g, b
  * against 0..255, depth in mm against 400..max_depth_mm), keeps a frame when it differs enough from all stored ones, and proposes

@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE — CPU oracle. Not part of the product path (see oracle/README.md).
 //
-// CPU restatement of the fern keyframe database, Core/Ferns.cpp:22-420 (Ferns.h:35-184), which the GLOBAL loop closure and relocalisation
+// CPU restatement of the fern keyframe database, Core/Ferns.cpp:22-393 (Ferns.h:35-184), which the GLOBAL loop closure and relocalisation
 // of ElasticFusion::processFrame consult (ElasticFusion.cpp:392-404, 609-618).  Follows the reference function by function; the images
 // are what Resize::image / Resize::vertex read back (80x60 at the default resolution), the fern-to-view registration (Ferns.cpp:243-258)
 // is a callback so that the frame loop can put its own tracker there.  Checked against the compiled Ferns.cpp
@@ -124,7 +124,7 @@ int efo_ferns_add_frame(efo_ferns* f, const uint8_t* rgb, int ch, const float* v
   return 0;
 }
 
-// Ferns::blockHDAware, Ferns.cpp:396-412
+// Ferns::blockHDAware, Ferns.cpp:378-393
 static float blockHDAware(const efo_ferns* f, const std::vector<uint8_t>& a, const std::vector<uint8_t>& b) {
   int count = 0;
   float val = 0;
