@@ -481,7 +481,7 @@ int global_loop_closure(ef_ctx* c, int log_slot, int* accepted_with_graph) {
   G.closest = -1;
   for (int i = 0; i < 16; ++i) G.T_wc_recovery[i] = (i % 5 == 0) ? 1.0 : 0.0;   // Sophus::SE3d T_wc_est; (Ferns.cpp:236)
   ef_ferns* F = ef_closure_ferns(c->closure);
-  // Ferns::findFrame only considers keyframes stored more than 300 ticks ago (Ferns.cpp:225).  While there is none — the host knows: it
+  // Ferns::findFrame only considers keyframes stored more than 300 ticks ago (Ferns.cpp:218).  While there is none — the host knows: it
   // keeps the database — the answer is -1 whatever the view shows, and nothing has to come back from the device: no synchronisation.
   if (!ef_closure_candidate_possible(c->closure, c->tick)) return EF_OK;
   // otherwise: the view's fern codes, computed on the device, + the pose — one small read-back (0.5 KB + the state)

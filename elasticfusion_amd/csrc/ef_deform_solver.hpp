@@ -177,7 +177,7 @@ struct Graph {
 
 // DeformationGraph::optimiseGraphSparse (DeformationGraph.cpp:416-492) on a built graph.  Result.ok is its return value.
 // The three gates of a GLOBAL closure (fernMatch): nothing to do below `entry` metres of mean constraint error (DeformationGraph.cpp:425);
-// accepted only when the optimised mean constraint error is below `meanConsErr` and the energy below `energy` (Deformation.cpp:153).
+// accepted only when the optimised mean constraint error is below `meanConsErr` and the energy below `energy` (Deformation.cpp:154).
 // The defaults are the reference's hard-coded constants.
 struct Gates {
   float entry = 0.06f, meanConsErr = 0.0003f, energy = 0.12f;

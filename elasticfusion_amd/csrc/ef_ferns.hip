@@ -243,7 +243,7 @@ int find_frame_core(ef_ferns* f, const std::vector<uint8_t>& codes, int good, co
   int minId = -1;
   for (size_t i = 0; i < f->frames.size(); ++i) {
     const float d = f->dissimilarity(good, *f->frames[i], co[i]);
-    if (d < minimum && time - f->frames[i]->srcTime > 300) {   // Ferns.cpp:225: only frames seen a while ago can close a loop
+    if (d < minimum && time - f->frames[i]->srcTime > 300) {   // Ferns.cpp:218: only frames seen a while ago can close a loop
       minimum = d;
       minId = (int)i;
     }
@@ -352,7 +352,7 @@ int ef_ferns_find_frame_coded(ef_ferns* f, const uint8_t* codes_in, int good_cod
   f->cooccur(codes, co);
   return find_frame_core(f, codes, good_codes, co, src, T_wc16, time, lost, tracker, user, T_est16_out, cons, max_cons, n_out);
 }
-// can any stored frame close a loop at `time` (Ferns.cpp:225: only frames stored more than 300 ticks ago are candidates)?  0 => findFrame
+// can any stored frame close a loop at `time` (Ferns.cpp:218: only frames stored more than 300 ticks ago are candidates)?  0 => findFrame
 // returns -1 whatever the view looks like, and a caller may skip bringing the view (or its codes) to the host: lastClosest is reset here
 // as findFrame would have reset it
 int ef_ferns_candidate_possible(ef_ferns* f, int time) {

@@ -191,13 +191,13 @@ void ef_ferns_destroy(ef_ferns* f);
 /* the fern table, num rows of {x, y, r, g, b, d}; setting it is only allowed while no frame is stored */
 int ef_ferns_get_table(const ef_ferns* f, int* table6);
 int ef_ferns_set_table(ef_ferns* f, const int* table6);
-/* Ferns::addFrame (Ferns.cpp:79-159): returns 1 when the frame was stored, 0 when it was too similar (or had no valid code),
+/* Ferns::addFrame (Ferns.cpp:78-160): returns 1 when the frame was stored, 0 when it was too similar (or had no valid code),
  * a negative EF_E* on bad arguments */
 int ef_ferns_add_frame(ef_ferns* f, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16,
                        int src_time, float threshold);
 typedef void (*ef_fern_tracker)(void* user, const float* fern_verts4, const float* fern_norms4, const double* T_wc_fern16,
                                 const float* cur_verts4, const float* cur_norms4, double* T_inout16, float* icp_error, float* icp_count);
-/* Ferns::findFrame (Ferns.cpp:161-299).  T_est16_out: the recovered pose (identity when no candidate passed the code gates);
+/* Ferns::findFrame (Ferns.cpp:162-298).  T_est16_out: the recovered pose (identity when no candidate passed the code gates);
  * constraints6_out: up to max_constraints rows {T_wc * p (source), T_est * p (target)} (Ferns.cpp:268-293).  Returns lastClosest
  * (the matched frame's id) or -1. */
 int ef_ferns_find_frame(ef_ferns* f, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16,
@@ -214,7 +214,7 @@ int ef_ferns_add_frame_coded(ef_ferns* f, const uint8_t* codes, int good_codes, 
 int ef_ferns_find_frame_coded(ef_ferns* f, const uint8_t* codes, int good_codes, ef_view_fetch fetch, void* fetch_user, const double* T_wc16, int time,
                               int lost, ef_fern_tracker tracker, void* user, double* T_est16_out, double* constraints6_out, int max_constraints,
                               int* n_constraints_out);
-/* 1 when some stored frame is more than 300 ticks older than `time` (Ferns.cpp:225), i.e. findFrame CAN match; 0: it returns -1 whatever the view */
+/* 1 when some stored frame is more than 300 ticks older than `time` (Ferns.cpp:218), i.e. findFrame CAN match; 0: it returns -1 whatever the view */
 int ef_ferns_candidate_possible(ef_ferns* f, int time);   /* answering 0 it also resets lastClosest to -1, as the findFrame it stands for would */
 int ef_ferns_table_version(const ef_ferns* f);            /* bumped by every ef_ferns_set_table */
 int ef_ferns_count(const ef_ferns* f);          /* frames.size() */
@@ -250,7 +250,7 @@ int ef_closure_local(ef_closure* c, const double* constraints8, int n, int tick,
 int ef_closure_end_frame(ef_closure* c, const uint8_t* rgb, int rgb_channels, const float* verts4, const float* norms4, const double* T_wc16, int tick);
 int ef_closure_counts(const ef_closure* c, int* deforms, int* fern_deforms, int* relative_constraints, int* trajectory_poses);
 /* the gates of the GLOBAL deformation (defaults = the reference's hard-coded 0.06 m entry, 3e-4 m / 0.12 acceptance: DeformationGraph.cpp:425,
- * Deformation.cpp:153; tuned on room-scale trajectories) */
+ * Deformation.cpp:154; tuned on room-scale trajectories) */
 int ef_closure_set_gates(ef_closure* c, float entry_mean_error, float accept_mean_error, float accept_energy);
 int ef_closure_set_fern_thresh(ef_closure* c, float fern_thresh);   /* ElasticFusion::setFernThresh: Ferns::addFrame's threshold from now on */
 /* introspection for tests: the rows the last closure handed to the optimiser (returns their number) and its two error figures */

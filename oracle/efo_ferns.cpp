@@ -94,7 +94,7 @@ int efo_ferns_set_table(efo_ferns* f, const int* t) {
   return 0;
 }
 
-// Ferns::addFrame, Ferns.cpp:79-159
+// Ferns::addFrame, Ferns.cpp:78-160
 int efo_ferns_add_frame(efo_ferns* f, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int src_time, float threshold) {
   KeyFrame frame;
   std::vector<int> coOccurrences;
@@ -169,7 +169,7 @@ static float photometricCheck(const efo_ferns* f, const uint8_t* rgb, int ch, co
   return photoSum / float(photoCount);
 }
 
-// Ferns::findFrame, Ferns.cpp:161-299
+// Ferns::findFrame, Ferns.cpp:162-298
 int efo_ferns_find_frame(efo_ferns* f, const uint8_t* rgb, int ch, const float* verts4, const float* norms4, const double* T_wc16, int time, int lost,
                          efo_fern_tracker tracker, void* user, double* T_est16_out, double* cons, int max_cons, int* n_out) {
   f->lastClosest = -1;

@@ -88,7 +88,7 @@ def test_global_closure_decisions():
     assert np.array_equal(asked["fv"], o.ferns().frame(g.closest)["verts"])
     rows, err, mean = c.lastRows()
     assert rows.shape == seen["rows"].shape and np.abs(rows - seen["rows"]).max() < 1e-12
-    assert err < 0.12 and mean < 3e-4                              # Deformation.cpp:153
+    assert err < 0.12 and mean < 3e-4                              # Deformation.cpp:154
     assert len(graph) == 200 and np.array_equal(graph, seen["got"]["graph"])
     nf = len(o.ferns())
     for i in range(nf):                                            # keyframe poses and the trajectory were deformed along, identically

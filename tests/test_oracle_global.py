@@ -38,7 +38,7 @@ def test_rendered_revisit_is_matched_registered_and_gated():
         rgb, depth, T = seq.frame(k)
         o.process_frame(rgb, depth, k, T_wc=T)
         kept.append(len(o.ferns()))
-        assert o.global_loop().closest == -1                     # nothing is older than 300 ticks yet (Ferns.cpp:225)
+        assert o.global_loop().closest == -1                     # nothing is older than 300 ticks yet (Ferns.cpp:218)
     assert kept[0] == 1 and kept[-1] >= 1 and kept == sorted(kept)   # the first frame is always a keyframe; near-duplicates are not
     assert not calls                                             # no closure attempted: neither a fern match nor open local gates
     o.set_tick(o.tick() + 400)
