@@ -744,6 +744,11 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       timer_end(c, "odomInit");
       timer_begin(c, "odom");
       const bool sample = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0;
+#ifdef EF_FAST_ORDER
+      // BASELINE configs[4] is the hipGraph-captured launch-per-step script; the fast order's persistent launch takes a fresh exchange epoch
+      // per launch as a kernel argument, which a replayed graph cannot give it
+      if (c->use_graph && !sample && !c->timing) tp.persistent = 0;
+#endif
       eft::TrackTail tail{};
       if (c->use_graph && !sample && !c->timing) {
         // key: which of the two intensity pyramids is "next" this frame + the knobs baked into the launch arguments

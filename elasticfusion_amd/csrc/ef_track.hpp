@@ -4,6 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Summation order of the fp32 normal-equation sums.  The shipped build uses THE FAST ORDER (ef_track_fast.inc: per-lane register
+// accumulation, adjacent-pair trees; specified in oracle/efo_track.cpp, which libefo_oracle.so restates bit for bit); the
+// reference-rounding build (-DEF_NO_FMA, libefusion_hip_nofma.so) keeps the REFERENCE's order (reduce.cu:57-140,313-317) and with it
+// the round-3 kernels, pinned against the compiled reduce.cu.  -DEF_REF_ORDER builds the round-3 product (FMAs + reference order) for A/B runs.
+#if !defined(EF_NO_FMA) && !defined(EF_REF_ORDER)
+#define EF_FAST_ORDER 1
+#endif
+
 namespace eft {
 
 constexpr int NUM_PYRS = 3;          // RGBDOdometry.h:114
@@ -27,7 +35,9 @@ constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * SE3_PAIRS > SO3_ACCS * VWARPS ? 2 
 // loop and every Gauss-Newton iteration of the levels with <= PT_MAX_PIXELS pixels in ONE launch; hand-overs between workgroups
 // alternate between two partial regions, and a small synchronisation record (PtSync) sits behind them.
 constexpr int PT_WGS = 128, PT_BLOCK = 512, PT_MAX_ITER = 16, PT_MAX_PIXELS = 8 * VTHREADS, PT_SYNC_FLOATS = 1024;
-constexpr int PARTIAL_ALLOC_FLOATS = 2 * PARTIAL_FLOATS + PT_SYNC_FLOATS;
+// (the fast order's persistent tracker lays its exchange areas over the same allocation: FT_*_OFF in ef_track_fast.inc, 45.8 K floats)
+constexpr int PARTIAL_ALLOC_FLOATS = (2 * PARTIAL_FLOATS + PT_SYNC_FLOATS) > 49152 ? (2 * PARTIAL_FLOATS + PT_SYNC_FLOATS) : 49152;
+constexpr int FT_EPOCHS = 64;        // exchange epochs one launch of the persistent tracker may use (<= 10 SO(3) + 2 x 24 iterations)
 
 struct Intr { float fx, fy, cx, cy; };
 __host__ __device__ inline Intr intr_level(const Intr& k, int level) {  // CameraModel::operator()(level), types.cuh:92-95
@@ -115,6 +125,7 @@ struct Pyramid {               // one RGBDOdometry instance's device buffers (RG
   uint32_t* corres[NUM_PYRS];
   uint8_t* rgbMask[NUM_PYRS];      // iteration-invariant part of residualKernel's gates, built once per frame
   float* partials;                 // PARTIAL_ALLOC_FLOATS: region 0 (what the per-step kernels use), region 1, PtSync (zero-filled at allocation)
+  unsigned epoch = 1;              // fast order: next unused exchange epoch of this instance's persistent launches (host side; 0 = "never written")
   int W(int l) const { return width >> l; }
   int H(int l) const { return height >> l; }
 };
@@ -213,6 +224,7 @@ struct TrackTail {
   float icpWeight;
   Intr k0;
   const float* pairs;
+  int ng = 0;                  // fast order: group partials per accumulator the head's tree looks at (1: the persistent launch left totals)
 };
 TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe = nullptr);
 // 1 when a persistent launch of this tracker instance gave up waiting in a grid barrier (its workgroups were not co-resident), 0

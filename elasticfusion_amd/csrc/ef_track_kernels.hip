@@ -745,11 +745,16 @@ struct StepArgs {
   Intr knext;                 // intrinsics of THIS iteration's level (for the head's K R K^-1)
   bool level_changes;         // this iteration runs at another level than the one whose update the head evaluates
   int it;                     // index of the iteration within the call (tag of the fused launch's record)
+  int ng = 0;                 // fast order: group partials per accumulator the head's tree looks at
 };
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* prev, GNState* next, bool publish, const float* sums,
                                                 const StepArgs& A, efs::SolveScratch& S, const efs::SolvePrefetch& PF, bool stats);
 template <int BLOCK, bool COHERENT = false>
 __device__ __forceinline__ void pair_partials_tree(const float* __restrict__ pairs, bool icp, bool rgb, float* sums_s);
+// reduceSum over what the accumulation launch left -> sums_s[term * SE3_ACCS + acc]: the fast order's 256-leaf tree over `ng` group
+// partials (ef_track_fast.inc), or the reference's 8-warp / 64-block trees over the pair partials (pair_partials_tree)
+template <int BLOCK>
+__device__ __forceinline__ void head_sums(const float* __restrict__ pairs, int ng, bool icp, bool rgb, float* sums_s);
 
 template <int PPT>
 __global__ void __launch_bounds__(REDUCE_BLOCK) k_track_step(const ResidualPackedView V, TrackState* st, const GNState* __restrict__ prev,
@@ -784,7 +789,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_track_step(const ResidualPacke
     if (!A.has_body || blockIdx.x == 0) {
       efs::SolvePrefetch PF{};
       if (t < 64) PF = efs::solve_prefetch(st, prev, slots_prev);
-      pair_partials_tree<REDUCE_BLOCK>(pairs, A.icp, A.rgb, sums_s);
+      head_sums<REDUCE_BLOCK>(pairs, A.ng, A.icp, A.rgb, sums_s);
       __syncthreads();
       if (t < 64) solve_step_wave(st, prev, next, blockIdx.x == 0, sums_s, A, S, PF, blockIdx.x == 0);
       __syncthreads();
@@ -1371,6 +1376,10 @@ k_se3_accum(const IcpView IV, const RgbView RV, const Se3Inputs in, const Se3Out
   EF_ASTAMP(5);
 }
 
+#ifdef EF_FAST_ORDER
+#include "ef_track_fast.inc"
+#endif
+
 // The rest of the reference tree over the 512 virtual-warp partials of `na` accumulators (acc-major):
 //   blockReduceSum's second stage: lanes 0..7 of warp 0 hold the 8 warp sums, the other 24 lanes hold 0.0f
 //     => shfl_down tree of width 8 (offsets 4, 2, 1);
@@ -1617,6 +1626,16 @@ __device__ __forceinline__ void pair_partials_tree(const float* __restrict__ pai
   }
 }
 
+template <int BLOCK>
+__device__ __forceinline__ void head_sums(const float* __restrict__ pairs, int ng, bool icp, bool rgb, float* sums_s) {
+#ifdef EF_FAST_ORDER
+  fast_tree<BLOCK, false>(pairs, ng, (icp ? SE3_ACCS : 0) + (rgb ? SE3_ACCS : 0), sums_s + (icp ? 0 : SE3_ACCS));
+#else
+  (void)ng;
+  pair_partials_tree<BLOCK>(pairs, icp, rgb, sums_s);
+#endif
+}
+
 // tail of getIncrementalTransformation (RGBDOdometry.cpp:555-570) + velocity weighting
 // (ElasticFusion.cpp:369-383) + the float matrices the map kernels consume.
 __device__ inline void publish_pose(TrackState* st) {
@@ -1663,7 +1682,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_track_end(TrackState* st, cons
   if (A.has_head) {
     efs::SolvePrefetch PF{};
     if (t < 64) PF = efs::solve_prefetch(st, prev, slots_prev);
-    pair_partials_tree<REDUCE_BLOCK>(pairs, A.icp, A.rgb, sums_s);
+    head_sums<REDUCE_BLOCK>(pairs, A.ng, A.icp, A.rgb, sums_s);
     __syncthreads();
     if (t < 64) solve_step_wave(st, prev, next, true, sums_s, A, S, PF, true);
     __syncthreads();
@@ -1887,14 +1906,23 @@ __global__ void __launch_bounds__(SO3_BLOCK) k_so3_iteration(const uint8_t* __re
   }
   {
     const m33 IB = m33_load(st->so3_mats), KI = m33_load(st->so3_mats + 9), KR = m33_load(st->so3_mats + 18);
+#ifdef EF_FAST_ORDER
+    so3_accumulate_fast<true>(lastImage, nextImage, cols, rows, IB, KI, KR, lds_rows, partials);   // one group per workgroup; agent-scope stores, drained
+#else
     so3_accumulate(lastImage, nextImage, cols, rows, IB, KI, KR, lds_rows, partials);
+#endif
   }
   // last-workgroup-done: our partials are drained to the coherence point, take a ticket
   __syncthreads();
   if (t == 0) is_last = (take_ticket(&st->so3_ticket) == gridDim.x - 1);
   __syncthreads();
   if (!is_last) return;
+#ifdef EF_FAST_ORDER
+  fast_tree<SO3_BLOCK, true>(partials, fast_plan(cols * rows).NG, SO3_ACCS, red);
+  __syncthreads();
+#else
   final_tree<SO3_BLOCK, SO3_ACCS, true>(partials, lds_rows /* reused: 11*64 floats */, red);
+#endif
   if (t != 0) return;
   st->so3_ticket = 0;
   st->so3_iterations = it + 1;
@@ -1956,11 +1984,21 @@ __global__ void __launch_bounds__(SO3_BLOCK) k_so3_op(const uint8_t* __restrict_
                                                        int cols, int rows, const So3Args a, float* __restrict__ partials) {
   __shared__ float lds_rows[SO3_WPB * SO3_KC * ROW_STRIDE];
   const m33 IB = m33_load(a.imageBasis), KI = m33_load(a.kinv), KR = m33_load(a.krlr);
+#ifdef EF_FAST_ORDER
+  so3_accumulate_fast<false>(lastImage, nextImage, cols, rows, IB, KI, KR, lds_rows, partials);
+#else
   so3_accumulate(lastImage, nextImage, cols, rows, IB, KI, KR, lds_rows, partials);
+#endif
 }
-__global__ void __launch_bounds__(SOLVE_BLOCK) k_final_tree_op(const float* __restrict__ partials, int na, float* __restrict__ out) {
+__global__ void __launch_bounds__(SOLVE_BLOCK) k_final_tree_op(const float* __restrict__ partials, int na, int ng, float* __restrict__ out) {
   __shared__ float bs[SE3_ACCS * 64];
   __shared__ float sums[2 * SE3_ACCS];
+#ifdef EF_FAST_ORDER
+  fast_tree<SOLVE_BLOCK, false>(partials, ng, na, sums);
+  __syncthreads();
+  if ((int)threadIdx.x < na) out[threadIdx.x] = sums[threadIdx.x];
+  return;
+#endif
   if (na == SE3_ACCS) {   // k_se3_accum's pair partials (one term)
     pair_partials_tree<SOLVE_BLOCK>(partials, true, false, sums);
     __syncthreads();
@@ -2483,6 +2521,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
   }
 }
 
+#ifdef EF_FAST_ORDER
+#include "ef_track_fast_persistent.inc"
+#endif
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
@@ -2538,6 +2580,14 @@ namespace {
 template <bool HAS_ICP, bool HAS_RGB, bool PACKED>
 void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int N, const Se3Out& out, hipStream_t s, hipEvent_t start = nullptr,
                   hipEvent_t stop = nullptr) {
+#ifdef EF_FAST_ORDER
+  {   // one workgroup per group of four tasks, four wavefronts per term (ef_track_fast.inc)
+    const FastPlan fp = fast_plan(N);
+    const dim3 fgrid(in.xcd_swizzle ? 8 * fast_groups_per_xcd(fp.NG) : fp.NG), fblock(256 * ((HAS_ICP && HAS_RGB) ? 2 : 1));
+    hipExtLaunchKernelGGL((k_se3_accum_fast<HAS_ICP, HAS_RGB, PACKED>), fgrid, fblock, 0, s, start, stop, 0, IV, RV, in, out.pairs);
+    return;
+  }
+#endif
   constexpr int BLOCK = 64 * 2 * ACC_NW * ((HAS_ICP && HAS_RGB) ? 2 : 1);
   const dim3 grid(VWARPS / ACC_NW), block(BLOCK);
   // CH = steps (of four passes) a wavefront has in flight per round: 640x480 has 19 passes = 5 steps = ONE round of CH = 5; 1280x960 has
@@ -2546,6 +2596,26 @@ void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int
   // other in the CU's one address pipe for longer than the two saved round trips.
   if (N > 8 * VTHREADS) hipExtLaunchKernelGGL((k_se3_accum<5, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
   else hipExtLaunchKernelGGL((k_se3_accum<2, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
+}
+}  // namespace
+
+namespace {
+// fast order: groups of a level / workgroups of a so3Step launch (one per group, XCD-contiguous); the reference order ignores the former
+inline int op_groups(int N) {
+#ifdef EF_FAST_ORDER
+  return fast_plan(N).NG;
+#else
+  (void)N;
+  return 0;
+#endif
+}
+inline int so3_grid(int N) {
+#ifdef EF_FAST_ORDER
+  return 8 * fast_groups_per_xcd(fast_plan(N).NG);
+#else
+  (void)N;
+  return VWARPS / SO3_WPB;
+#endif
 }
 }  // namespace
 
@@ -2561,7 +2631,7 @@ void icp_step_op(const IcpArgs& a, const float* vmap_curr, const float* nmap_cur
   (void)hipStreamSynchronize(s);  // h is a stack buffer
   Se3Inputs in{pose, pose + 9, pose + 12, pose + 21, nullptr, nullptr, 0.f, false};
   launch_accum<true, false, false>(V, RV, in, cols * rows, Se3Out{scratch}, s);
-  hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SE3_ACCS, out29_dev);
+  hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SE3_ACCS, op_groups(cols * rows), out29_dev);
 }
 void rgb_residual_op(const RgbResidualArgs& a, const int16_t* dIdx, const int16_t* dIdy, const float* lastDepth,
                      const float* nextDepth, const uint8_t* lastImage, const uint8_t* nextImage, void* corres, int cols,
@@ -2585,12 +2655,12 @@ void rgb_step_op(const void* corres, float sigma, const float* cloud, float fx, 
   RgbView V{corres, nullptr, cloud, dIdx, dIdy, cols, rows, Intr{fx, fy, 0, 0}, sobelScale};
   Se3Inputs in{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sigma, false};
   launch_accum<false, true, false>(IV, V, in, cols * rows, Se3Out{scratch}, s);
-  hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SE3_ACCS, out29_dev);
+  hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SE3_ACCS, op_groups(cols * rows), out29_dev);
 }
 void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* nextImage, int cols, int rows, float* scratch, float* out11_dev,
                  hipStream_t s) {
-  hipLaunchKernelGGL(k_so3_op, dim3(VWARPS / SO3_WPB), dim3(SO3_BLOCK), 0, s, lastImage, nextImage, cols, rows, a, scratch);
-  hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SO3_ACCS, out11_dev);
+  hipLaunchKernelGGL(k_so3_op, dim3(so3_grid(cols * rows)), dim3(SO3_BLOCK), 0, s, lastImage, nextImage, cols, rows, a, scratch);
+  hipLaunchKernelGGL(k_final_tree_op, dim3(1), dim3(SOLVE_BLOCK), 0, s, (const float*)scratch, SO3_ACCS, op_groups(cols * rows), out11_dev);
 }
 
 // ---- frame tier ----
@@ -2806,11 +2876,12 @@ void launch_step(const Pyramid& p, TrackState* st, int level, int cur, int slots
 // k_se3_accum (normal equations).  `it` = index of the iteration within the call; cur = GNState buffer to read.
 // Returns the buffer the NEXT step reads.
 int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const TrackParams& tp, bool icp, bool rgb, int it, int cur,
-                     bool level_changes, hipStream_t s, KernelProbe* probe) {
+                     int prev_level, hipStream_t s, KernelProbe* probe) {
   const int cols = p.W(level), rows = p.H(level), N = cols * rows;
   const bool sample = probe && level == 0 && probe->used < probe->capacity;
   const int sp = it & 1;
-  StepArgs A{it > 0, rgb, icp, rgb, tp.rgbOnly, tp.icpWeight, kl, level_changes, it};
+  const bool level_changes = level != prev_level;
+  StepArgs A{it > 0, rgb, icp, rgb, tp.rgbOnly, tp.icpWeight, kl, level_changes, it, op_groups(p.W(prev_level) * p.H(prev_level))};
   // The update step as its own ONE-workgroup launch (head only), then the correspondence search alone (body only): three launches
   // per iteration.  Evaluating the update redundantly at the head of every workgroup of the correspondence kernel instead (two
   // launches) was built and measured in round 2: 888 vs 1322 frames/s; dropped from the source in round 3.
@@ -2874,6 +2945,52 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
     }
   }
   int it = 0, cur = 0, prev_level = first_level;
+#ifdef EF_FAST_ORDER
+  // The fast order's persistent launch takes the WHOLE call — k_track_begin, the SO(3) loop, every iteration of every level
+  // (k_track_fast, ef_track_fast_persistent.inc) — or, with `persistent` off / rgbOnly (whose per-level "break" bookkeeping is not in
+  // the kernel), nothing: then every step is its own launch, in the same order of additions.
+  const int n_total = iterations[0] + iterations[1] + iterations[2];
+  if (tp.persistent && !tp.rgbOnly && n_total <= FT_MAX_ITER) {
+    FtArgs FA{};
+    for (int i = 0; i < NUM_PYRS; ++i)
+      FA.L[i] = PtLevel{p.vmap_curr[i], p.nmap_curr[i], p.vmap_g_prev[i], p.nmap_g_prev[i], p.rgbMask[i], p.lastDepth[i], p.nextDepth[i],
+                        p.lastImage[i], p.nextImage[i], p.corres[i], p.dIdx[i], p.dIdy[i], p.W(i), p.H(i), intr_level(k, i)};
+    int n = 0;
+    for (int i = NUM_PYRS - 1; i >= 0; --i)
+      for (int j = 0; j < iterations[i]; ++j) FA.levels |= (unsigned long long)i << (2 * n++);
+    FA.n_iter = n;
+    FA.so3 = tp.so3;
+    FA.so3_last = p.lastNextImage[so3_level];
+    FA.so3_next = p.nextImage[so3_level];
+    FA.so3_cols = p.W(so3_level);
+    FA.so3_rows = p.H(so3_level);
+    FA.kso3 = intr_level(k, so3_level);
+    FA.kfirst = intr_level(k, first_level);
+    FA.icpWeight = tp.icpWeight;
+    FA.distThres = tp.distThres;
+    FA.angleThres = tp.angleThres;
+    FA.partials = p.partials;
+    if (p.epoch > 0xFFFFFFFFu - 2u * FT_EPOCHS) p.epoch = 1;   // (a slot keeps a 2^32-launch-old tag only if nobody wrote it since)
+    FA.epoch = p.epoch;
+    p.epoch += FT_EPOCHS;
+    FA.out_cur = 0;
+    if (icp && rgb) hipLaunchKernelGGL((k_track_fast<true, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, FA, st);
+    else if (icp) hipLaunchKernelGGL((k_track_fast<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, FA, st);
+    else hipLaunchKernelGGL((k_track_fast<false, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, FA, st);
+    track_swap(p, tp);
+    TrackTail tail{0, (n - 1) & 1, n > 0, icp, rgb, tp.rgbOnly, tp.icpWeight, intr_level(k, 0), p.partials + FT_P_OFF};
+    tail.ng = 1;   // the reducers of the last iteration left the TOTALS in column 0
+    return tail;
+  }
+  n_small = 0;
+  hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st, tp.so3, intr_level(k, so3_level), intr_level(k, first_level));
+  if (tp.so3) {
+    for (int i = 0; i < 10; ++i)
+      hipLaunchKernelGGL(k_so3_iteration, dim3(so3_grid(p.W(so3_level) * p.H(so3_level))), dim3(SO3_BLOCK), 0, s,
+                         (const uint8_t*)p.lastNextImage[so3_level], (const uint8_t*)p.nextImage[so3_level], p.W(so3_level), p.H(so3_level),
+                         intr_level(k, so3_level), intr_level(k, first_level), i, st, p.partials);
+  }
+#else
   if (tp.persistent && !tp.rgbOnly && (n_small > 0 || tp.so3)) {
     for (int i = 0; i < NUM_PYRS; ++i)
       PA.L[i] = PtLevel{p.vmap_curr[i], p.nmap_curr[i], p.vmap_g_prev[i], p.nmap_g_prev[i], p.rgbMask[i], p.lastDepth[i], p.nextDepth[i],
@@ -2906,36 +3023,50 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
                            intr_level(k, first_level), i, st, p.partials);
     }
   }
+#endif
   int done = 0;
   for (int i = NUM_PYRS - 1; i >= 0; --i) {
     const Intr kl = intr_level(k, i);
     for (int j = 0; j < iterations[i]; ++j) {
       if (done++ < n_small) continue;   // ran inside the persistent launch
-      cur = launch_iteration(p, st, i, kl, tp, icp, rgb, it, cur, i != prev_level, s, probe);
+      cur = launch_iteration(p, st, i, kl, tp, icp, rgb, it, cur, prev_level, s, probe);
       prev_level = i;
       ++it;
     }
   }
   track_swap(p, tp);
   // the last iteration's update is evaluated at the head of k_track_end (track_end below)
-  return TrackTail{cur, (it - 1) & 1, it > 0, icp, rgb, tp.rgbOnly, tp.icpWeight, intr_level(k, 0), p.partials};
+  TrackTail tail{cur, (it - 1) & 1, it > 0, icp, rgb, tp.rgbOnly, tp.icpWeight, intr_level(k, 0), p.partials};
+  tail.ng = op_groups(p.W(prev_level) * p.H(prev_level));
+  return tail;
 }
 // host-side tail of getIncrementalTransformation: the frame's intensity pyramid becomes the SO(3) reference of the next
 // (RGBDOdometry.cpp:284-288 swaps lastNextImage / nextImage); separate so that a replayed hipGraph can do it without launching
 // developer instrumentation: the -DEF_STAGE_CLOCKS sums of k_track_small (24 x u64, 10 ns ticks; zeros in a normal build), read and reset
 int tracker_small_clocks(const Pyramid& p, unsigned long long* out24, hipStream_t s) {
   if (!p.partials) return -1;
+#ifdef EF_FAST_ORDER
+  unsigned long long* src = (unsigned long long*)((char*)(p.partials + FT_SY_OFF) + offsetof(FtSync, clk));
+#else
   unsigned long long* src = (unsigned long long*)((char*)(p.partials + 2 * PARTIAL_FLOATS) + offsetof(PtSync, clk));
+#endif
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   if (hipMemcpy(out24, src, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return hipMemset(src, 0, 24 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 int tracker_aborted(const Pyramid& p, hipStream_t s) {
   if (!p.partials) return 0;
+#ifdef EF_FAST_ORDER
+  unsigned flag = 0;
+  if (hipMemcpyAsync(&flag, (const char*)(p.partials + FT_SY_OFF) + offsetof(FtSync, abort), sizeof(flag), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  return flag != 0 ? 1 : 0;
+#else
   PtSync h;
   if (hipMemcpyAsync(&h, p.partials + 2 * PARTIAL_FLOATS, offsetof(PtSync, wg_sums), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   return h.abort != 0 ? 1 : 0;
+#endif
 }
 void track_swap(Pyramid& p, const TrackParams& tp) {
   if (tp.so3)
@@ -2944,7 +3075,7 @@ void track_swap(Pyramid& p, const TrackParams& tp) {
 
 // exported for the context: finishing kernels
 void track_end(TrackState* st, const TrackTail& u, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s) {
-  const StepArgs A{u.has_head, false, u.icp, u.rgb, u.rgbOnly, u.icpWeight, u.k0, true, 63};
+  const StepArgs A{u.has_head, false, u.icp, u.rgb, u.rgbOnly, u.icpWeight, u.k0, true, 63, u.ng};
   hipLaunchKernelGGL(k_track_end, dim3(1), dim3(REDUCE_BLOCK), 0, s, st, (const GNState*)&st->gn[u.cur], &st->gn[u.cur ^ 1], u.pairs,
                      (const int*)&st->rgb_slots[u.slots & 1][0][0], A, rgb, weightMultiplier, traj, slot);
 }

@@ -332,6 +332,56 @@ Acc<T, K> two_stage_reduce(int N, F&& products) {
   return block_reduce<T, K>(th2);
 }
 
+#ifdef EFO_FAST_ORDER
+// ---------------------------------------------------------------------------------------------
+// THE FAST ORDER (round 4): the summation order of the SHIPPED build (libefusion_hip.so / libefo_oracle.so).  fp32 addition is not
+// associative, so an order has to be specified; the reference's own (above: 16384 grid-stride threads, warp32 / 8-warp / 64-block
+// trees) is kept by the reference-rounding pair (libefusion_hip_nofma.so / libefo_oracle_nofma.so, pinned against the compiled
+// reduce.cu).  This one is laid out for wave64 hardware and depends on the pixel count N only:
+//   row-group  = 64 consecutive pixels; RG = ceil(N / 64)
+//   task       = U consecutive row-groups, U = max(1, ceil(RG / 1024)); T = ceil(RG / U) <= 1024 tasks
+//   leaf (t,l) = lane l of task t: accumulates pixels 64 (U t + k) + l, k = 0 .. U-1, in that order (one FMA per product, from +0)
+//   total      = the complete binary tree over the leaves in index order t * 64 + l, adjacent pairs first:
+//                s[i] = s[2 i] + s[2 i + 1], level by level (missing leaves are +0: a running sum that starts at +0 is never -0, so
+//                adding the padding is exact)
+// On the GPU: a wavefront per task (per-lane register accumulation, DPP tree with offsets 1, 2, .. 32), four tasks per workgroup
+// ((t0 + t1) + (t2 + t3) through LDS), a 256-leaf tree over the workgroup partials.  Integer sums (Acc<int, 2>) are order-free.
+template <typename T, int K, typename F>
+Acc<T, K> fast_reduce(int N, F&& products) {
+  const int RG = (N + 63) / 64;
+  const int U = std::max(1, (RG + 1023) / 1024);
+  const int T_ = (RG + U - 1) / U;
+  std::vector<Acc<T, K>> s((size_t)T_ * 64);
+  efo::parallel_for(T_, [&](int t0, int t1) {
+    for (int t = t0; t < t1; ++t)
+      for (int l = 0; l < 64; ++l) {
+        Acc<T, K> sum;
+        for (int k = 0; k < K; ++k) sum.v[k] = T(0);
+        for (int u = 0; u < U; ++u) {
+          const long p = 64L * ((long)U * t + u) + l;
+          if (p < N) products((int)p, sum);
+        }
+        s[(size_t)t * 64 + l] = sum;
+      }
+  });
+  size_t n = s.size();
+  while (n > 1) {
+    const size_t h = (n + 1) / 2;
+    for (size_t i = 0; i < h; ++i) {
+      if (2 * i + 1 < n)
+        for (int k = 0; k < K; ++k) s[i].v[k] = s[2 * i].v[k] + s[2 * i + 1].v[k];
+      else
+        s[i] = s[2 * i];
+    }
+    n = h;
+  }
+  return s[0];
+}
+#define EFO_REDUCE fast_reduce
+#else
+#define EFO_REDUCE two_stage_reduce
+#endif
+
 // sum.add(values) of the 29 JtJJtrSE3 members from a 7-vector row (types.cuh:104-143, reduce.cu:291-306).
 // nvcc's default -fmad=true contracts "sum.x += a*b" into an FMA; restated explicitly (efo_common.h).
 inline void add_products7(const float row[7], float found, Acc<float, 29>& sum) {
@@ -396,7 +446,7 @@ void efo_icp_step(const float* Rcurr, const float* tcurr, const float* vmap_curr
     }
     add_products7(row, found ? 1.0f : 0.0f, sum);
   };
-  Acc<float, 29> h = two_stage_reduce<float, 29>(cols * rows, products);
+  Acc<float, 29> h = EFO_REDUCE<float, 29>(cols * rows, products);
   unpack_se3(h, A, b, residual);
 }
 
@@ -481,7 +531,7 @@ void efo_rgb_step(const void* corres_in, float sigma, const float* cloud, float 
     }
     add_products7(row, found ? 1.0f : 0.0f, sum);
   };
-  Acc<float, 29> h = two_stage_reduce<float, 29>(cols * rows, products);
+  Acc<float, 29> h = EFO_REDUCE<float, 29>(cols * rows, products);
   unpack_se3(h, A, b, nullptr);
 }
 
@@ -527,7 +577,7 @@ void efo_so3_step(const uint8_t* lastImage, const uint8_t* nextImage, const floa
     sum.v[9] = EFO_FMA(row[3], row[3], sum.v[9]);
     sum.v[10] += found ? 1.0f : 0.0f;
   };
-  Acc<float, 11> h = two_stage_reduce<float, 11>(cols * rows, products);
+  Acc<float, 11> h = EFO_REDUCE<float, 11>(cols * rows, products);
   int shift = 0;  // reduce.cu:958-969
   for (int i = 0; i < 3; ++i)
     for (int j = i; j < 4; ++j) {

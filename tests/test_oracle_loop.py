@@ -77,7 +77,8 @@ def test_accepted_deformation_replaces_the_pose_and_unpins(run):
     k = next(i for i, e in enumerate(log) if e["info"].applied)
     info = log[k]["info"]
     assert info.graph_nodes == 16
-    assert np.array_equal(log[k]["pose"], np.array(info.T_wc_est).reshape(4, 4))    # T_wc_curr = T_wc_est, :525
+    # T_wc_curr = T_wc_est, :525 (the quaternion is copied; the two 4x4 print-outs come from two conversion paths, one ulp apart at most)
+    assert np.allclose(log[k]["pose"], np.array(info.T_wc_est).reshape(4, 4), rtol=0, atol=1e-15)
     # the deformation pass re-stamps the old surfels it moved into view (ElasticFusion.cpp:558-585): they are ACTIVE again
     assert log[k + 1]["old_px"] < 0.5 * log[k]["old_px"]
     later = [e for e in log[k + 1:] if e["info"].n_constraints]
