@@ -132,6 +132,46 @@ def _kernel_time_struct():
     return KT_FIELDS
 
 
+def roofline_tracker(lib, ef):
+    """the persistent tracker launch (k_track_fast), the kernel that takes the most time of a frame: bytes, us, fraction of HBM peak"""
+    KT = _kernel_time_struct()
+    kt = KT()
+    if not hasattr(lib, "ef_get_tracker_timing") or lib.ef_get_tracker_timing(ef.h, C.byref(kt)) != 0 or kt.launches <= 0:
+        return None
+    ach = kt.bytes_per_launch / (kt.avg_us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "avg_us": round(float(kt.avg_us), 2), "launches_sampled": int(kt.launches), "algorithmic_bytes_per_launch": int(kt.bytes_per_launch),
+            "algorithmic_bytes_per_launch_survey_48B": int(kt.bytes_per_launch_survey),
+            "frac_survey_48B": round(kt.bytes_per_launch_survey / (kt.avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "note": "a chain of 19 dependent Gauss-Newton iterations (two chip-wide exchanges and a 6x6 solve in double each): latency-bound, not bandwidth-bound"}
+
+
+def probe_frames_run(ef, lib, step, first, n, torch):
+    """The replay goes on for n frames behind the timed region: a third of them timed one by one (events between frames, nothing sampled), a
+    third with the persistent tracker launch sampled, a third with the launch-per-step script (bit-identical results, ef_set_persistent_tracker)
+    so that the level-0 normal-equation kernel exists as a launch of its own and is sampled.  Returns per-frame times in ms."""
+    third = max(1, n // 3)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(third + 1)]
+    evs[0].record()
+    for i, k in enumerate(range(first, first + third)):
+        step(k)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    per_frame = [evs[i].elapsed_time(evs[i + 1]) for i in range(third)]
+    lib.ef_kernel_timing(ef.h, C.c_int(1))
+    for k in range(first + third, first + 2 * third):
+        step(k)
+    torch.cuda.synchronize()
+    tracker = roofline_tracker(lib, ef)
+    if tracker is not None:   # the persistent launch ran: sample the per-step script's kernels on the remaining frames
+        ef.setPersistentTracker(False)
+        lib.ef_kernel_timing(ef.h, C.c_int(1))
+    for k in range(first + 2 * third, first + n):
+        step(k)
+    torch.cuda.synchronize()
+    return per_frame, tracker
+
+
 def rooflines(lib, ef, w, h, where):
     """(roofline of the level-0 normal-equation kernel, roofline of the IndexMap splat) from the engine's own dispatch-timestamp samples"""
     KT = _kernel_time_struct()
@@ -223,12 +263,9 @@ def side_leg(torch, api, frames, dev, w, h, device, stream, steps, warmup, prero
     out = {"value": round(steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps}
     if probe_frames:
         lib = api.lib()
-        lib.ef_kernel_timing(ef.h, C.c_int(1))
-        for k in range(first + steps, first + steps + probe_frames):
-            step(k)
-        torch.cuda.synchronize()
-        r, rs = rooflines(lib, ef, w, h, f"{probe_frames} frames that follow the timed region")
-        out["roofline"], out["roofline_index_splat"] = r, rs
+        _, rt = probe_frames_run(ef, lib, step, first + steps, probe_frames, torch)
+        r, rs = rooflines(lib, ef, w, h, f"last third of the {probe_frames} frames that follow the timed region (launch-per-step script)")
+        out["roofline"], out["roofline_index_splat"], out["roofline_tracker"] = r, rs, rt
     T = ef.get_T_wc()
     Tgt = frames[first + steps + probe_frames - 1][2]
     out["pose_err_vs_generating_traj_m"] = round(float(np.linalg.norm(T[:3, 3] - Tgt[:3, 3])), 5)
@@ -367,11 +404,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if not a.probe_inside:   # the same replay goes on; every level-0 accumulation launch and every first index splat is sampled
-        lib.ef_kernel_timing(ef.h, C.c_int(1))
-        for k in range(first_timed + a.steps, first_timed + a.steps + PROBE_FRAMES):
-            step(k)
-        torch.cuda.synchronize()
+    per_frame_ms, rtracker = [], None
+    if not a.probe_inside:   # the same replay goes on: per-frame times, then the sampled kernels (see probe_frames_run)
+        per_frame_ms, rtracker = probe_frames_run(ef, lib, step, first_timed + a.steps, PROBE_FRAMES, torch)
 
     # pose error of the timed run against the generating trajectory (sanity, not the parity bar)
     T = ef.get_T_wc()
@@ -390,8 +425,18 @@ def main():
         return
     agg = multi.aggregate(allstats)
     t_max, value = agg["t_max"], agg["value"]
-    roofline, roofline_splat = rooflines(lib, ef, w, h, (f"{PROBE_FRAMES} frames that follow the timed region (same replay, same map)"
+    roofline, roofline_splat = rooflines(lib, ef, w, h, (f"last third of the {PROBE_FRAMES} frames that follow the timed region (same replay, same map; "
+                                                          "launch-per-step script, bit-identical results)"
                                                          if not a.probe_inside else "sampled frames inside the timed region"))
+    calib = None
+    try:   # box calibration (GPU boxes of the pool differ by 10-20 %): what an empty kernel and a 16 MiB copy cost on THIS box, back to back
+        e_us, s_us = C.c_float(0), C.c_float(0)
+        if lib.ef_dev_calibrate(C.c_void_p(stream), C.byref(e_us), C.byref(s_us)) == 0:
+            calib = {"empty_kernel_us": round(e_us.value, 3), "copy_16MiB_us": round(s_us.value, 3),
+                     "copy_16MiB_GBps": round(2 * 16.777216e6 / (s_us.value * 1e-6) / 1e9, 1) if s_us.value > 0 else None,
+                     "what": "200 back-to-back launches each on the bench's stream, averaged between two events (launch gaps included)"}
+    except Exception as e:
+        calib = {"error": repr(e)}
     mode = ("HOST frames (pinned staging + PCIe upload timed), " if a.host_frames else "") + \
            ("closeLoops (fern database + global closure + local closure every frame, timeDelta 200), " if a.close_loops else "open loop, ") + \
            ("tracker replayed from a hipGraph, " if a.graph else "") + ("ODOMETRY ONLY in the timed region (no fusion), " if a.track_only else "") + \
@@ -421,6 +466,11 @@ def main():
                    "per_rank_fps": [round(x, 2) for x in agg["per_rank_fps"]]},
         "roofline": roofline,
         "roofline_index_splat": roofline_splat,
+        "roofline_tracker": rtracker,
+        "box_calibration": calib,
+        "frame_time_ms": ({"min": round(min(per_frame_ms), 4), "median": round(float(np.median(per_frame_ms)), 4), "max": round(max(per_frame_ms), 4),
+                           "frames": len(per_frame_ms), "what": "GPU time of single frames (events between frames) right behind the timed region"}
+                          if per_frame_ms else None),
     }
     out["config"]["stable_surfels_end"] = int(stable)
     gpu_poses = None
@@ -437,13 +487,14 @@ def main():
         try:
             legs["host_frames_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, host_frames=True, **common)
             legs["host_frames_fps"]["what"] = "the B1 signature: frames handed over as HOST pointers (ef_process_frame: pinned staging + PCIe upload inside the timed region)"
+            out["host_frames_fps"] = legs["host_frames_fps"]["value"]   # (top level too: the drop-in signature's rate, PCIe inclusive; never `value`)
             legs["graph_replay_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, graph=True, **common)
             legs["graph_replay_fps"]["what"] = "BASELINE configs[4]: the tracker's launches replayed from a hipGraph (ef_set_graph_replay), full frame"
             legs["track_only_pairs_per_s"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, track_only=True, **common)
             legs["track_only_pairs_per_s"]["what"] = ("BASELINE configs[4] / configs[0] on the GPU: odometry only (pre-process + SO(3) + 19 ICP+RGB iterations + "
                                                       "prediction at the new pose) on the mature map, no fusion; beside cpu_baseline.tracking_only")
             legs["per_step_tracker_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, per_step=True, **common)
-            legs["per_step_tracker_fps"]["what"] = "the round-2 tracker script (one launch per step) on this box, for the persistent launch's A/B"
+            legs["per_step_tracker_fps"]["what"] = "the launch-per-step tracker script (68 launches instead of one persistent launch) on this box, for the persistent launch's A/B"
             legs["close_loops_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, close_loops=True, **common)
             legs["close_loops_fps"]["what"] = "the reference's DEFAULT mode (closeLoops = true, timeDelta 200): fern database + global closure + local closure every frame"
         except Exception as e:   # never let a side figure cost the line

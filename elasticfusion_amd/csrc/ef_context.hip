@@ -162,6 +162,8 @@ struct ef_ctx {
   // second sampled kernel: the IndexMap point splat (k_index_splat of the first predictIndices of a frame)
   std::vector<hipEvent_t> ks_start, ks_stop;
   eft::KernelProbe probe_splat{nullptr, nullptr, 0, 0};
+  std::vector<hipEvent_t> ka_start, ka_stop;   // the persistent tracker launch (fast order)
+  eft::KernelProbe probe_all{nullptr, nullptr, 0, 0};
 };
 
 namespace {
@@ -778,7 +780,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
         eft::track_swap(c->pyr, tp);
         tail = g->tail;
       } else {
-        tail = eft::track(c->pyr, c->st, c->intr, tp, s, sample ? &c->probe : nullptr);
+        tail = eft::track(c->pyr, c->st, c->intr, tp, s, sample ? &c->probe : nullptr, sample && c->probe_all.start ? &c->probe_all : nullptr);
       }
       eft::track_end(c->st, tail, rgb, weightMultiplier, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
       timer_end(c, "odom");
@@ -1025,6 +1027,8 @@ void ctx_free(ef_ctx* c) {
   for (auto e : c->kt_stop) (void)hipEventDestroy(e);
   for (auto& g : c->tgraph)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  for (auto e : c->ka_start) (void)hipEventDestroy(e);
+  for (auto e : c->ka_stop) (void)hipEventDestroy(e);
   for (auto e : c->ks_start) (void)hipEventDestroy(e);
   for (auto e : c->ks_stop) (void)hipEventDestroy(e);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1726,6 +1730,17 @@ int ef_kernel_timing(ef_ctx* c, int every_n_frames) {
   c->ktime_every = every_n_frames;
   c->probe.used = 0;
   c->probe_splat.used = 0;
+  c->probe_all.used = 0;
+  if (every_n_frames > 0 && c->ka_start.empty()) {
+    const int cap = 1024;
+    c->ka_start.resize(cap);
+    c->ka_stop.resize(cap);
+    for (int i = 0; i < cap; ++i) {
+      EF_HIP(c, hipEventCreate(&c->ka_start[i]));
+      EF_HIP(c, hipEventCreate(&c->ka_stop[i]));
+    }
+    c->probe_all = eft::KernelProbe{c->ka_start.data(), c->ka_stop.data(), cap, 0};
+  }
   if (every_n_frames > 0 && c->ks_start.empty()) {
     const int cap = 1024;
     c->ks_start.resize(cap);
@@ -1761,7 +1776,11 @@ int ef_get_kernel_timing(ef_ctx* c, ef_kernel_time* out) {
     total_ms += ms;
   }
   const bool icp = !c->cfg.rgb_only && c->cfg.icp_weight > 0, rgb = c->cfg.rgb_only || c->cfg.icp_weight < 100;
+#ifdef EF_FAST_ORDER
+  out->name = "k_se3_accum_fast (level 0 of the launch-per-step script: icpStep + rgbStep Jacobian rows + fast-order sums)";
+#else
   out->name = "k_se3_accum (level 0: icpStep + rgbStep Jacobian rows + reference-order sums)";
+#endif
   out->launches = c->probe.used;
   out->avg_us = c->probe.used ? (float)(1e3 * total_ms / c->probe.used) : 0.f;
   // algorithmic bytes of ONE launch of this kernel (DESIGN.md "Roofline accounting"): icpStep 48 B per pixel-visit
@@ -1770,6 +1789,31 @@ int ef_get_kernel_timing(ef_ctx* c, ef_kernel_time* out) {
   // (depth + 2 gradients) are left out (data dependent): a lower bound, which can only understate `achieved`
   out->bytes_per_launch = (double)c->cam.cols * c->cam.rows * ((icp ? 48.0 : 0.0) + (rgb ? 4.0 : 0.0));
   out->bytes_per_launch_survey = (double)c->cam.cols * c->cam.rows * (icp ? 48.0 : 0.0);   // the ICP reduction alone
+  return EF_OK;
+}
+
+// the persistent tracker launch (k_track_fast: SO(3) loop + every Gauss-Newton iteration of every level + their update steps)
+int ef_get_tracker_timing(ef_ctx* c, ef_kernel_time* out) {
+  if (!c || !out) return EF_EINVAL;
+  DeviceGuard dg_(c);
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  double total_ms = 0;
+  for (int i = 0; i < c->probe_all.used; ++i) {
+    float ms = 0;
+    EF_HIP(c, hipEventElapsedTime(&ms, c->ka_start[i], c->ka_stop[i]));
+    total_ms += ms;
+  }
+  const bool icp = !c->cfg.rgb_only && c->cfg.icp_weight > 0, rgb = c->cfg.rgb_only || c->cfg.icp_weight < 100;
+  out->name = "k_track_fast (the whole tracker as one persistent launch: SO(3) loop + every ICP+RGB iteration of every level + the update steps)";
+  out->launches = c->probe_all.used;
+  out->avg_us = c->probe_all.used ? (float)(1e3 * total_ms / c->probe_all.used) : 0.f;
+  // algorithmic bytes of one launch: every iteration visits every pixel of its level once (48 B icpStep + 4 B packed correspondence, as
+  // ef_get_kernel_timing counts one level-0 launch); the SO(3) loop's two u8 images are left out (a lower bound)
+  const int its[3] = {c->cfg.fast_odom ? 3 : 10, c->cfg.pyramid ? 5 : 0, c->cfg.pyramid ? 4 : 0};
+  double visits = 0;
+  for (int l = 0; l < 3; ++l) visits += (double)its[l] * (double)(c->cam.cols >> l) * (double)(c->cam.rows >> l);
+  out->bytes_per_launch = visits * ((icp ? 48.0 : 0.0) + (rgb ? 4.0 : 0.0));
+  out->bytes_per_launch_survey = visits * (icp ? 48.0 : 0.0);
   return EF_OK;
 }
 
@@ -1793,6 +1837,42 @@ int ef_get_splat_timing(ef_ctx* c, ef_kernel_time* out) {
   out->bytes_per_launch = 40.0 * (double)count;
   out->bytes_per_launch_survey = 48.0 * (double)count;   // 48 B per surfel read by the reference's vertex shader
   return EF_OK;
+}
+
+// Box calibration for bench.py (GPU boxes of one pool differ by 10-20 %): an EMPTY kernel and a kernel that streams 16 MB in and 16 MB out
+// with 16-byte accesses, 200 back-to-back launches each on `stream`, averaged over the batch with two events (so launch gaps are in).
+__global__ void k_calib_empty() {}
+__global__ void __launch_bounds__(256) k_calib_stream(const float4* __restrict__ src, float4* __restrict__ dst, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+int ef_dev_calibrate(void* stream, float* empty_us, float* stream16mb_us) {
+  if (!empty_us || !stream16mb_us) return EF_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int n = 1 << 20, reps = 200;   // 1 Mi float4 = 16 MiB
+  float4 *a = nullptr, *b = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = EF_EHIP;
+  float ms = 0;
+  if (hipMalloc((void**)&a, (size_t)n * sizeof(float4)) != hipSuccess || hipMalloc((void**)&b, (size_t)n * sizeof(float4)) != hipSuccess) { rc = EF_ENOMEM; goto done; }
+  if (hipMemsetAsync(a, 0, (size_t)n * sizeof(float4), s) != hipSuccess) goto done;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) goto done;
+  for (int pass = 0; pass < 2; ++pass) {   // pass 0 warms up
+    if (hipEventRecord(e0, s) != hipSuccess) goto done;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_calib_empty, dim3(256), dim3(256), 0, s);
+    if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) goto done;
+    *empty_us = 1e3f * ms / reps;
+    if (hipEventRecord(e0, s) != hipSuccess) goto done;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_calib_stream, dim3(2048), dim3(256), 0, s, (const float4*)a, b, n);
+    if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) goto done;
+    *stream16mb_us = 1e3f * ms / reps;
+  }
+  rc = EF_OK;
+done:
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (a) (void)hipFree(a);
+  if (b) (void)hipFree(b);
+  return rc;
 }
 
 int ef_dev_alloc(void** dev, size_t bytes) { return hipMalloc(dev, bytes ? bytes : 1) == hipSuccess ? EF_OK : EF_ENOMEM; }

@@ -5,7 +5,7 @@
 #include <stdint.h>
 
 // Summation order of the fp32 normal-equation sums.  The shipped build uses THE FAST ORDER (ef_track_fast.inc: per-lane register
-// accumulation, adjacent-pair trees; specified in oracle/efo_track.cpp, which libefo_oracle.so restates bit for bit); the
+// accumulation, adjacent-pair trees; specified in DESIGN.md 5.1 "The fast order", which the test suite's CPU checker restates bit for bit); the
 // reference-rounding build (-DEF_NO_FMA, libefusion_hip_nofma.so) keeps the REFERENCE's order (reduce.cu:57-140,313-317) and with it
 // the round-3 kernels, pinned against the compiled reduce.cu.  -DEF_REF_ORDER builds the round-3 product (FMAs + reference order) for A/B runs.
 #if !defined(EF_NO_FMA) && !defined(EF_REF_ORDER)
@@ -226,7 +226,9 @@ struct TrackTail {
   const float* pairs;
   int ng = 0;                  // fast order: group partials per accumulator the head's tree looks at (1: the persistent launch left totals)
 };
-TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe = nullptr);
+// probe: samples the level-0 normal-equation launches of the launch-per-step script; probe_all: samples the persistent launch (fast order)
+TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe = nullptr,
+                KernelProbe* probe_all = nullptr);
 // 1 when a persistent launch of this tracker instance gave up waiting in a grid barrier (its workgroups were not co-resident), 0
 // otherwise, < 0 on a HIP error; synchronises the stream
 int tracker_aborted(const Pyramid& p, hipStream_t s);

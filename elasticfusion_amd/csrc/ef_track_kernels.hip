@@ -11,6 +11,7 @@
 #include "ef_linalg_dev.hpp"
 #include "ef_solve_dev.hpp"
 #include <stddef.h>
+#include <mutex>
 #include <hip/hip_ext.h>
 #include "ef_track.hpp"
 
@@ -2920,7 +2921,7 @@ int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const
 }
 }  // namespace
 
-TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe) {
+TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe, KernelProbe* probe_all) {
   const bool icp = !tp.rgbOnly && tp.icpWeight > 0;       // RGBDOdometry.cpp:266-267
   const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
   int iterations[NUM_PYRS];
@@ -2974,9 +2975,29 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
     FA.epoch = p.epoch;
     p.epoch += FT_EPOCHS;
     FA.out_cur = 0;
-    if (icp && rgb) hipLaunchKernelGGL((k_track_fast<true, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, FA, st);
-    else if (icp) hipLaunchKernelGGL((k_track_fast<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, FA, st);
-    else hipLaunchKernelGGL((k_track_fast<false, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, FA, st);
+    const bool sample_all = probe_all && probe_all->used < probe_all->capacity;
+    hipEvent_t e0 = sample_all ? probe_all->start[probe_all->used] : nullptr, e1 = sample_all ? probe_all->stop[probe_all->used] : nullptr;
+    if (sample_all) probe_all->used++;
+    {
+      // The launch needs its 256 workgroups resident TOGETHER, one per CU.  Two such launches in flight at once (two contexts of this
+      // process, each on its own stream) could each hold a part of the chip and wait for the rest for ever, so the persistent launches of
+      // a device are chained, in the order the host enqueues them, through one event per device: a launch first waits (on the GPU, not on
+      // the host) for the previous one, whatever stream that ran on.  On one stream this is a no-op.  Ordinary kernels of other streams
+      // only delay it (they end without waiting for anybody); another PROCESS's persistent kernels are outside this chain: bounded spins,
+      // FtSync::abort, tracker_aborted.
+      static std::mutex chain_mu;
+      static hipEvent_t chain_ev[64] = {};
+      std::lock_guard<std::mutex> lk(chain_mu);
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      hipEvent_t& ev = chain_ev[dev & 63];
+      if (ev) (void)hipStreamWaitEvent(s, ev, 0);
+      else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+      if (icp && rgb) hipExtLaunchKernelGGL((k_track_fast<true, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
+      else if (icp) hipExtLaunchKernelGGL((k_track_fast<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
+      else hipExtLaunchKernelGGL((k_track_fast<false, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
+      if (ev) (void)hipEventRecord(ev, s);
+    }
     track_swap(p, tp);
     TrackTail tail{0, (n - 1) & 1, n > 0, icp, rgb, tp.rgbOnly, tp.icpWeight, intr_level(k, 0), p.partials + FT_P_OFF};
     tail.ng = 1;   // the reducers of the last iteration left the TOTALS in column 0

@@ -128,6 +128,105 @@ class Sequence:
         return rgb, depth, self.pose(k)
 
 
+class ClutterSequence(Sequence):
+    """Second scene family (round 4): planar clutter + thin structures + a sensor-like depth channel.
+
+    Same room, trajectory family and albedo as ``Sequence``, without the spheres; instead
+      * PLANAR CLUTTER: a dozen finite rectangular boards standing and lying in the room at 0.8-2.6 m, arbitrary orientation
+        (large coplanar regions, many depth discontinuities, boards partly occluding one another);
+      * THIN STRUCTURES: poles and bars of 1-2.5 cm radius (a few pixels wide: surfels that live on 2-6 px of support);
+      * the depth a structured-light sensor would report: quantised in DISPARITY (1/8 px of a 580 px * 75 mm rig: 3 mm steps at 1 m,
+        3 cm at 3 m), invalid (0) on depth discontinuities and at grazing incidence, rectangular drop-outs that move from frame to
+        frame, and — with ``noise`` — the same z^2 range noise as ``Sequence``.
+    Every frame draws its randomness from (seed, k): frame(k) does not depend on which frames were rendered before."""
+
+    def __init__(self, seed: int = 0xEF0001, **kw):
+        super().__init__(seed, **kw)
+        rng = np.random.RandomState((seed ^ 0xC1A77E5) & 0x7FFFFFFF)
+        self.spheres = []
+        self.boards = []      # (centre, unit normal, unit u, unit v, half u, half v)
+        for _ in range(12):
+            c = np.array([rng.uniform(-0.85, 0.85), rng.uniform(-0.6, 0.6), rng.uniform(0.65, 1.3)])
+            n = rng.normal(size=3) * np.array([0.5, 0.4, 1.0])
+            n /= np.linalg.norm(n)
+            u = np.cross(n, rng.normal(size=3))
+            u /= np.linalg.norm(u)
+            v = np.cross(n, u)
+            self.boards.append((c, n, u, v, rng.uniform(0.10, 0.30), rng.uniform(0.08, 0.25)))
+        self.rods = []        # (point, unit axis, radius, half length)
+        for _ in range(9):
+            c = np.array([rng.uniform(-0.9, 0.9), rng.uniform(-0.6, 0.6), rng.uniform(0.6, 1.35)])
+            a = np.array([0.0, 1.0, 0.0]) if rng.rand() < 0.6 else rng.normal(size=3)
+            a = a / np.linalg.norm(a)
+            self.rods.append((c, a, rng.uniform(0.010, 0.025), rng.uniform(0.4, 1.2)))
+        self._seed = seed
+
+    def frame(self, k: int):
+        T = self._abs_pose(k)
+        R, o = T[:3, :3], T[:3, 3]
+        d = self._dirs @ R.T
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tb = np.where(d > 0, (self.box - o) / d, (-self.box - o) / d)
+        tb = np.where(np.isfinite(tb), tb, np.inf)
+        t = tb.min(-1)
+        axis = tb.argmin(-1)
+        nrm = np.zeros(d.shape)
+        np.put_along_axis(nrm, axis[..., None], -np.sign(np.take_along_axis(d, axis[..., None], -1)), -1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for c, n, u, v, hu, hv in self.boards:
+                den = d @ n
+                tt = ((c - o) @ n) / den
+                p = o + d * tt[..., None] - c
+                hit = (np.abs(den) > 1e-9) & (tt > 1e-6) & (np.abs(p @ u) <= hu) & (np.abs(p @ v) <= hv) & (tt < t)
+                t = np.where(hit, tt, t)
+                nrm = np.where(hit[..., None], n * -np.sign(den)[..., None], nrm)
+            for c, a, r, hl in self.rods:
+                oc = o - c
+                dp = d - (d @ a)[..., None] * a
+                ocp = oc - (oc @ a) * a
+                A = (dp * dp).sum(-1)
+                B = 2 * (dp @ ocp)
+                Cc = ocp @ ocp - r * r
+                disc = B * B - 4 * A * Cc
+                ok = (disc > 0) & (A > 1e-12)
+                tt = (-B - np.sqrt(np.where(ok, disc, 0))) / (2 * A)
+                p = o + d * tt[..., None] - c
+                hit = ok & (tt > 1e-6) & (np.abs(p @ a) <= hl) & (tt < t)
+                t = np.where(hit, tt, t)
+                pn = p - (p @ a)[..., None] * a
+                nrm = np.where(hit[..., None], pn / np.maximum(np.linalg.norm(pn, axis=-1, keepdims=True), 1e-12), nrm)
+        p = o + d * t[..., None]
+        rgb = self._albedo(p)
+        z = t.copy()
+        rng = np.random.RandomState(((self._seed * 2654435761) ^ (k * 40503 + 17)) & 0x7FFFFFFF)
+        if self.noise:
+            z = z + rng.normal(0, 1.0, size=z.shape) * 0.0012 * z * z
+        # disparity quantisation (1/8 px, f * b = 580 px * 0.075 m)
+        fb = 580.0 * 0.075
+        z = fb / (np.rint(fb / z * 8.0) / 8.0)
+        mm = np.rint(1000.0 * z)
+        valid = (mm >= 300) & (mm <= 3000)
+        # no return on depth discontinuities (> 4 cm to a 4-neighbour) and at grazing incidence (> 80 degrees)
+        jump = np.zeros(z.shape, bool)
+        jump[:, 1:] |= np.abs(t[:, 1:] - t[:, :-1]) > 0.04
+        jump[:, :-1] |= np.abs(t[:, 1:] - t[:, :-1]) > 0.04
+        jump[1:, :] |= np.abs(t[1:, :] - t[:-1, :]) > 0.04
+        jump[:-1, :] |= np.abs(t[1:, :] - t[:-1, :]) > 0.04
+        cosi = np.abs((d * nrm).sum(-1)) / np.linalg.norm(d, axis=-1)
+        valid &= ~jump & (cosi > np.cos(np.deg2rad(80.0)))
+        for _ in range(6):   # drop-outs
+            h, w = z.shape
+            y0, x0 = rng.randint(0, h - 8), rng.randint(0, w - 8)
+            valid[y0:y0 + rng.randint(4, max(5, h // 10)), x0:x0 + rng.randint(4, max(5, w // 10))] = False
+        depth = np.where(valid, mm, 0).astype(np.uint16)
+        return rgb, depth, self.pose(k)
+
+
+def make_sequence(seed: int = 0xEF0001, scene: str = "box", **kw) -> "Sequence":
+    """scene 'box' = Sequence (box + spheres, exact depth), 'clutter' = ClutterSequence"""
+    return ClutterSequence(seed, **kw) if scene == "clutter" else Sequence(seed, **kw)
+
+
 def sample_surfels(seq: "Sequence", n: int = 1 << 20, radius: float = 0.004, conf: float = 12.0, init_time: int = 1, last_time: int = 1) -> np.ndarray:
     """~n surfels [m, 12] float32 sampled on the scene's surfaces ("ef_map_upload of surfels sampled on the scene
     surfaces, radius 4 mm, conf 12, times in window"), in ``seq``'s world frame (= its camera frame at k = 0), laid out as the map holds

@@ -405,6 +405,9 @@ int ef_kernel_timing(ef_ctx* ctx, int every_n_frames);
 int ef_get_kernel_timing(ef_ctx* ctx, ef_kernel_time* out);
 /* same sampling (switched on by ef_kernel_timing) of the IndexMap point splat: k_index_splat of the frame's first predictIndices */
 int ef_get_splat_timing(ef_ctx* ctx, ef_kernel_time* out);
+/* same sampling of the persistent tracker launch (k_track_fast: the whole of RGBDOdometry::getIncrementalTransformation, RGBDOdometry.cpp:259-553,
+ * as one launch); launches = 0 while the launch-per-step script runs (ef_set_persistent_tracker(ctx, 0), rgbOnly, graph replay) */
+int ef_get_tracker_timing(ef_ctx* ctx, ef_kernel_time* out);
 
 /* developer instrumentation: the 16 wall_clock64() (100 MHz) stamps the last tracking solve left in the device state;
  * all zero unless the library was built with -DEF_STAGE_CLOCKS (EF_HIPCC_FLAGS=-DEF_STAGE_CLOCKS python -m elasticfusion_amd.build) */
@@ -420,6 +423,9 @@ int ef_dev_upload(void* dev, const void* host, size_t bytes);
 int ef_dev_download(void* host, const void* dev, size_t bytes);
 int ef_dev_memset(void* dev, int value, size_t bytes);
 int ef_dev_sync(void);
+/* box calibration for benchmarks (GPU boxes of one pool differ by 10-20 %): average time per launch of 200 back-to-back launches of an EMPTY
+ * kernel and of a kernel that copies 16 MiB with 16-byte accesses (16 MiB read + 16 MiB written), on `stream` (a hipStream_t, 0 = null stream) */
+int ef_dev_calibrate(void* stream, float* empty_us, float* stream16mb_us);
 int ef_device_count(int* n);
 int ef_set_device(int device);
 
