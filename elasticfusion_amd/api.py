@@ -646,6 +646,16 @@ class ElasticFusion:
     def synchronize(self):
         _chk(lib().ef_synchronize(self.h), self.h)
 
+    def trackerFallbacks(self) -> int:
+        """persistent tracker launches that ran on one workgroup because other work held part of the chip (ef_get_tracker_fallbacks)"""
+        n = c_i(0)
+        _chk(lib().ef_get_tracker_fallbacks(self.h, C.byref(n)), self.h)
+        return n.value
+
+    def debugOccupy(self, workgroups: int, microseconds: int):
+        """test hook: CU-filling workgroups spinning on a stream of their own (ef_debug_occupy)"""
+        _chk(lib().ef_debug_occupy(self.h, c_i(int(workgroups)), c_i(int(microseconds))), self.h)
+
     def stream(self) -> int:
         return int(lib().ef_stream(self.h) or 0)
 

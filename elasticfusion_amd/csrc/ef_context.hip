@@ -164,6 +164,7 @@ struct ef_ctx {
   eft::KernelProbe probe_splat{nullptr, nullptr, 0, 0};
   std::vector<hipEvent_t> ka_start, ka_stop;   // the persistent tracker launch (fast order)
   eft::KernelProbe probe_all{nullptr, nullptr, 0, 0};
+  hipStream_t debug_stream = nullptr;          // ef_debug_occupy
 };
 
 namespace {
@@ -1027,6 +1028,7 @@ void ctx_free(ef_ctx* c) {
   for (auto e : c->kt_stop) (void)hipEventDestroy(e);
   for (auto& g : c->tgraph)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (c->debug_stream) { (void)hipStreamSynchronize(c->debug_stream); (void)hipStreamDestroy(c->debug_stream); }
   for (auto e : c->ka_start) (void)hipEventDestroy(e);
   for (auto e : c->ka_stop) (void)hipEventDestroy(e);
   for (auto e : c->ks_start) (void)hipEventDestroy(e);
@@ -1377,6 +1379,33 @@ int ef_get_covariance(ef_ctx* c, double* cov36) {
   EF_HIP(c, hipMemcpyAsync(&h, c->st, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   EF_HIP(c, hipStreamSynchronize(c->stream));
   efl::lu_inverse<double, 6>(h.lastA, cov36);   // host side, like the reference (Eigen on the CPU)
+  return EF_OK;
+}
+int ef_get_tracker_fallbacks(ef_ctx* c, int* count) {
+  if (!c || !count) return EF_EINVAL;
+  DeviceGuard dg_(c);
+  int total = 0;
+  for (const eft::Pyramid* p : {&c->pyr, &c->pyr2, &c->pyr3}) {
+    const int n = eft::tracker_fallbacks(*p, c->stream);
+    if (n < 0) { c->err = "reading the tracker's fallback counter failed"; return EF_EHIP; }
+    total += n;
+  }
+  *count = total;
+  return EF_OK;
+}
+// developer instrumentation (tests/test_gpu_fallback.py): `workgroups` workgroups of 1024 threads and 128 registers per lane — each fills the
+// register file of a whole CU — spin for `microseconds` on a stream of their own: the chip is partly taken, as by another process
+__global__ void __launch_bounds__(1024) k_debug_occupy(unsigned long long ticks) {
+  asm volatile("v_mov_b32 v127, 0" ::: "v127");
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+int ef_debug_occupy(ef_ctx* c, int workgroups, int microseconds) {
+  if (!c || workgroups < 1 || workgroups > 1024 || microseconds < 1 || microseconds > 2000000) return EF_EINVAL;
+  DeviceGuard dg_(c);
+  if (!c->debug_stream) EF_HIP(c, hipStreamCreateWithFlags(&c->debug_stream, hipStreamNonBlocking));
+  hipLaunchKernelGGL(k_debug_occupy, dim3(workgroups), dim3(1024), 0, c->debug_stream, (unsigned long long)microseconds * 100ull);
+  EF_HIP(c, hipGetLastError());
   return EF_OK;
 }
 // developer instrumentation: per-phase clocks of the persistent small-level launch (-DEF_STAGE_CLOCKS builds; tools/small_clocks.py)

@@ -232,6 +232,9 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
 // 1 when a persistent launch of this tracker instance gave up waiting in a grid barrier (its workgroups were not co-resident), 0
 // otherwise, < 0 on a HIP error; synchronises the stream
 int tracker_aborted(const Pyramid& p, hipStream_t s);
+// fast order: persistent launches of this tracker instance that found the chip partly taken (admission failed) and ran on ONE workgroup
+// instead — same results, ~25x the time; < 0 on a HIP error; synchronises the stream
+int tracker_fallbacks(const Pyramid& p, hipStream_t s);
 int tracker_small_clocks(const Pyramid& p, unsigned long long* out24, hipStream_t s);   // developer instrumentation (-DEF_STAGE_CLOCKS)
 void track_swap(Pyramid& p, const TrackParams& tp);   // the pointer swap track() ends with (for hipGraph replay)
 // tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +

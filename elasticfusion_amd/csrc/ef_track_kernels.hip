@@ -1674,6 +1674,7 @@ __device__ inline void log_pose(const TrackState* st, double* traj, int slot) {
 // Last kernel of getIncrementalTransformation: the update step of the LAST iteration (same head as k_track_step; with no iteration at
 // all the pose is prev's), then the tail on one lane: 0.3 m guard, SVD re-orthonormalisation (RGBDOdometry.cpp:555-570),
 // velocity weighting (ElasticFusion.cpp:369-383), the float matrices of the map passes, the trajectory log.
+__device__ __forceinline__ void track_end_tail(TrackState* st, const float* Rc_in, const float* tc_in, bool rgb, float weightMultiplier, double* traj, int slot);
 __global__ void __launch_bounds__(REDUCE_BLOCK) k_track_end(TrackState* st, const GNState* __restrict__ prev, GNState* next,
                                                              const float* __restrict__ pairs, const int* __restrict__ slots_prev, const StepArgs A,
                                                              bool rgb, float weightMultiplier, double* traj, int slot) {
@@ -1692,9 +1693,13 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_track_end(TrackState* st, cons
     for (int i = 0; i < 3; ++i) S.tcurr[i] = prev->tcurr[i];
   }
   if (t != 0) return;
+  track_end_tail(st, S.Rcurr, S.tcurr, rgb, weightMultiplier, traj, slot);
+}
+// (one lane) 0.3 m guard, SVD re-orthonormalisation, velocity weighting, the float matrices of the map passes, the trajectory log
+__device__ __forceinline__ void track_end_tail(TrackState* st, const float* Rc_in, const float* tc_in, bool rgb, float weightMultiplier, double* traj, int slot) {
   float Rcurr[9], tcurr[3];
-  for (int i = 0; i < 9; ++i) Rcurr[i] = S.Rcurr[i];
-  for (int i = 0; i < 3; ++i) tcurr[i] = S.tcurr[i];
+  for (int i = 0; i < 9; ++i) Rcurr[i] = Rc_in[i];
+  for (int i = 0; i < 3; ++i) tcurr[i] = tc_in[i];
   if (rgb) {
     const float d0 = tcurr[0] - st->tprev[0], d1 = tcurr[1] - st->tprev[1], d2 = tcurr[2] - st->tprev[2];
     if ((double)sqrtf(d0 * d0 + d1 * d1 + d2 * d2) > 0.3) {
@@ -2998,6 +3003,10 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
       else hipExtLaunchKernelGGL((k_track_fast<false, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
       if (ev) (void)hipEventRecord(ev, s);
     }
+    // (returns at once unless the launch above found part of the chip taken: see its admission step)
+    if (icp && rgb) hipLaunchKernelGGL((k_track_serial<true, true>), dim3(1), dim3(REDUCE_BLOCK), 0, s, p.partials, st, FA.epoch);
+    else if (icp) hipLaunchKernelGGL((k_track_serial<true, false>), dim3(1), dim3(REDUCE_BLOCK), 0, s, p.partials, st, FA.epoch);
+    else hipLaunchKernelGGL((k_track_serial<false, true>), dim3(1), dim3(REDUCE_BLOCK), 0, s, p.partials, st, FA.epoch);
     track_swap(p, tp);
     TrackTail tail{0, (n - 1) & 1, n > 0, icp, rgb, tp.rgbOnly, tp.icpWeight, intr_level(k, 0), p.partials + FT_P_OFF};
     tail.ng = 1;   // the reducers of the last iteration left the TOTALS in column 0
@@ -3087,6 +3096,18 @@ int tracker_aborted(const Pyramid& p, hipStream_t s) {
   if (hipMemcpyAsync(&h, p.partials + 2 * PARTIAL_FLOATS, offsetof(PtSync, wg_sums), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   return h.abort != 0 ? 1 : 0;
+#endif
+}
+int tracker_fallbacks(const Pyramid& p, hipStream_t s) {
+#ifdef EF_FAST_ORDER
+  if (!p.partials) return 0;
+  unsigned n = 0;
+  if (hipMemcpyAsync(&n, (const char*)(p.partials + FT_SY_OFF) + offsetof(FtSync, fallbacks), sizeof(n), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  return (int)n;
+#else
+  (void)p; (void)s;
+  return 0;
 #endif
 }
 void track_swap(Pyramid& p, const TrackParams& tp) {

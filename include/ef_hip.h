@@ -409,6 +409,13 @@ int ef_get_splat_timing(ef_ctx* ctx, ef_kernel_time* out);
  * as one launch); launches = 0 while the launch-per-step script runs (ef_set_persistent_tracker(ctx, 0), rgbOnly, graph replay) */
 int ef_get_tracker_timing(ef_ctx* ctx, ef_kernel_time* out);
 
+/* Persistent tracker launches (the default: RGBDOdometry::getIncrementalTransformation, RGBDOdometry.cpp:259-553, as one launch of 256 co-resident
+ * workgroups) that found part of the chip taken by other work and ran on one workgroup instead: same results, ~25x the tracking time, nothing for
+ * the caller to do — a server that sees the count grow is sharing the GPU with something that holds CUs for milliseconds.  Synchronises. */
+int ef_get_tracker_fallbacks(ef_ctx* ctx, int* count);
+/* developer instrumentation for the test of that path: `workgroups` workgroups that each fill one CU spin for `microseconds` on a stream of their own */
+int ef_debug_occupy(ef_ctx* ctx, int workgroups, int microseconds);
+
 /* developer instrumentation: the 16 wall_clock64() (100 MHz) stamps the last tracking solve left in the device state;
  * all zero unless the library was built with -DEF_STAGE_CLOCKS (EF_HIPCC_FLAGS=-DEF_STAGE_CLOCKS python -m elasticfusion_amd.build) */
 int ef_debug_clocks(ef_ctx* ctx, unsigned long long* out16);
