@@ -210,12 +210,76 @@ def rooflines(lib, ef, w, h, where):
     return roofline, roofline_splat
 
 
-def make_engine(api, w, h, device, stream, close_loops=False, graph=False, per_step=False, fused_step=False):
+class _StandInEngine:
+    """--stand-in-engine: what bench.py calls on an engine, doing nothing but counting frames (tests/test_bench_multi_gloo.py: the
+    multi-rank control flow of THIS file — barriers, the one collective, the exit of the ranks that do not print — on CPU with gloo)."""
+    h = None
+
+    def __init__(self, **kw):
+        self.frames = 0
+
+    def processFrameDevice(self, *a, **k):
+        self.frames += 1
+        time.sleep(0.002)
+
+    processFrame = processFrameDevice
+
+    def get_T_wc(self): return np.eye(4)
+    def lastCount(self): return self.frames
+    def downloadMap(self): return np.zeros((1, 12), np.float32)
+    def getConfidenceThreshold(self): return 10.0
+    def trajectory(self): return [np.eye(4)] * self.frames, None
+    def close(self): pass
+    def setPersistentTracker(self, on): pass
+    def setTrackOnly(self, on): pass
+    def setFusedStep(self, on): pass
+    def setGraphReplay(self, on): pass
+    def setInputOverlap(self, on): pass
+    def setInputCuMask(self, n): pass
+
+
+class _StandInLib:
+    def __getattr__(self, name):
+        return lambda *a, **k: -1     # every measurement hook: "nothing sampled"
+
+
+class _StandInApi:
+    LIB_PATH = "stand-in"
+    ElasticFusion = _StandInEngine
+
+    class DevBuf:
+        class _P:
+            value = 0
+        p = _P()
+
+        @staticmethod
+        def from_array(a):
+            return _StandInApi.DevBuf()
+
+    @staticmethod
+    def lib():
+        return _StandInLib()
+
+    @staticmethod
+    def use_library(path):
+        pass
+
+
+class _NoGpu:
+    """torch.cuda's part in this file, for --stand-in-engine"""
+    @staticmethod
+    def synchronize(): pass
+
+
+def make_engine(api, w, h, device, stream, close_loops=False, graph=False, per_step=False, fused_step=False, input_overlap=0):
     sc = w / 640.0
     ef = api.ElasticFusion(width=w, height=h, fx=528.0 * sc, fy=528.0 * sc, cx=320.0 * sc, cy=240.0 * sc, device=device, stream=stream,
                            maxSurfels=max(4 * 1024 * 1024, 6 * w * h), **(dict(closeLoops=True, timeDelta=200) if close_loops else {}))
     if per_step:
         ef.setPersistentTracker(False)
+    if input_overlap:   # frame k + 1's input stage on a second stream (every input_overlap-th CU) beside frame k's fusion and prediction
+        ef.setInputCuMask(input_overlap)
+        ef.setInputOverlap(1)
     if fused_step:
         ef.setFusedStep(True)
     if graph:
@@ -312,6 +376,10 @@ def main():
                     "build, closed loop, odometry only, hipGraph replay, configs[2])")
     ap.add_argument("--preroll", type=int, default=PREROLL, help="development (PMC passes on a pre-seeded map): untimed frames before the warm-up; "
                     "the driver's command never sets it (100: the map's steady state)")
+    ap.add_argument("--input-overlap", type=int, default=0, help="development (A/B): the next frame's input stage on a second stream restricted to every "
+                    "N-th CU (1 = unmasked), beside the previous frame's fusion (ef_set_input_overlap + ef_set_input_cu_mask)")
+    ap.add_argument("--stand-in-engine", action="store_true", help="test hook (tests/test_bench_multi_gloo.py): no GPU, the gloo backend and an engine "
+                    "that only counts frames - exercises this file's multi-rank control flow; the line says \"data\": \"stand-in\"")
     ap.add_argument("--fused-step", action="store_true", help="development (A/B): level-0 update step inside the correspondence-search launch "
                     "(ef_set_fused_step); results are bit-identical")
     ap.add_argument("--per-step-tracker", action="store_true", help="development (A/B): the round-2 tracker script, one launch per step, instead "
@@ -323,7 +391,9 @@ def main():
     rank, local_rank, world = multi.rank_info()
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    plain = not (a.host_frames or a.close_loops or a.graph or a.track_only or a.library or a.preseed or a.per_step_tracker or a.probe_inside or a.fused_step or a.preroll != PREROLL)
+    if world > 1:   # N ranks enqueue ~20 k launches/s each from one host: every rank keeps to its own share of the cores
+        multi.pin_rank_to_cores(local_rank, world)
+    plain = not (a.stand_in_engine or a.host_frames or a.close_loops or a.graph or a.track_only or a.library or a.preseed or a.per_step_tracker or a.probe_inside or a.fused_step or a.input_overlap or a.preroll != PREROLL)
     side = world == 1 and plain and (w, h) == (W, H) and not a.no_side_legs   # the extra keys ride on the default N = 1 line only
 
     # synthetic frames first: the generator forks worker processes, which must happen before HIP / RCCL are initialised
@@ -354,22 +424,29 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        multi.init_process_group("nccl", local_rank)
+    if a.stand_in_engine:
+        if world > 1:
+            multi.init_process_group("gloo", local_rank)
+        api, build, gpu, stream, stats_device = _StandInApi, None, _NoGpu, 0, None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            multi.init_process_group("nccl", local_rank)
 
-    from elasticfusion_amd import api, build
-    if a.library:
-        api.use_library(build.NOFMA_LIB if a.library == "nofma" else a.library)
+        from elasticfusion_amd import api, build
+        if a.library:
+            api.use_library(build.NOFMA_LIB if a.library == "nofma" else a.library)
 
-    # a real (non-null) stream, made torch's current one: the engine enqueues on it, torch.cuda.synchronize() covers it,
-    # and it can be captured into a hipGraph (--graph), which the legacy null stream cannot
-    tstream = torch.cuda.Stream()
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    ef = make_engine(api, w, h, local_rank, stream, close_loops=a.close_loops, graph=a.graph, per_step=a.per_step_tracker, fused_step=a.fused_step)
+        # a real (non-null) stream, made torch's current one: the engine enqueues on it, torch.cuda.synchronize() covers it,
+        # and it can be captured into a hipGraph (--graph), which the legacy null stream cannot
+        tstream = torch.cuda.Stream()
+        torch.cuda.set_stream(tstream)
+        stream = tstream.cuda_stream
+        gpu, stats_device = torch.cuda, "cuda"
+    ef = make_engine(api, w, h, local_rank, stream, close_loops=a.close_loops, graph=a.graph, per_step=a.per_step_tracker, fused_step=a.fused_step,
+                     input_overlap=a.input_overlap)
     dev = [(api.DevBuf.from_array(r), api.DevBuf.from_array(d)) for r, d, _ in frames]
     k0 = 0
     n_pre = 0
@@ -392,20 +469,23 @@ def main():
     lib = api.lib()
     if a.probe_inside:
         lib.ef_kernel_timing(ef.h, C.c_int(8))
-    torch.cuda.synchronize()
+    gpu.synchronize()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    gpu.synchronize()
     t0 = time.perf_counter()
     for k in range(first_timed, first_timed + a.steps):
         step(k)
-    torch.cuda.synchronize()
+    gpu.synchronize()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    gpu.synchronize()
     dt = time.perf_counter() - t0
     per_frame_ms, rtracker = [], None
-    if not a.probe_inside:   # the same replay goes on: per-frame times, then the sampled kernels (see probe_frames_run)
+    if a.stand_in_engine:
+        for k in range(first_timed + a.steps, first_timed + a.steps + PROBE_FRAMES):
+            step(k)
+    elif not a.probe_inside:   # the same replay goes on: per-frame times, then the sampled kernels (see probe_frames_run)
         per_frame_ms, rtracker = probe_frames_run(ef, lib, step, first_timed + a.steps, PROBE_FRAMES, torch)
 
     # pose error of the timed run against the generating trajectory (sanity, not the parity bar)
@@ -416,7 +496,7 @@ def main():
     stable = int((ef.downloadMap()[:, 3] > ef.getConfidenceThreshold()).sum()) if rank == 0 else 0
 
     # the only collective: 32 B per rank over xGMI (RCCL all_gather)
-    allstats = multi.gather_stats([dt, float(a.steps), err_t, float(count)], device="cuda")
+    allstats = multi.gather_stats([dt, float(a.steps), err_t, float(count)], device=stats_device)
     if rank != 0:
         ef.close()
         if world > 1:
@@ -430,6 +510,8 @@ def main():
                                                          if not a.probe_inside else "sampled frames inside the timed region"))
     calib = None
     try:   # box calibration (GPU boxes of the pool differ by 10-20 %): what an empty kernel and a 16 MiB copy cost on THIS box, back to back
+        if a.stand_in_engine:
+            raise RuntimeError("stand-in engine: nothing to calibrate")
         e_us, s_us = C.c_float(0), C.c_float(0)
         if lib.ef_dev_calibrate(C.c_void_p(stream), C.byref(e_us), C.byref(s_us)) == 0:
             calib = {"empty_kernel_us": round(e_us.value, 3), "copy_16MiB_us": round(s_us.value, 3),
@@ -455,7 +537,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "stand-in" if a.stand_in_engine else "synthetic",
         "config": {"workload": f"{w}x{h} synthetic RGB-D replay (box+spheres, Lissajous trajectory), " + mode +
                                "SO(3)+ICP+RGB 3-level tracking (10/5/4 its) + surfel fuse/clean/predict; "
                                + ("stand-in for configs[1] (dyson_lab.klg is not available offline)" if (w, h) == (W, H) else
@@ -536,7 +618,7 @@ def main():
             out["ate_vs_oracle"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     del dev
-    torch.cuda.synchronize()
+    gpu.synchronize()
     if world > 1:
         dist.destroy_process_group()
     _leave()

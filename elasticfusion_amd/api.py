@@ -754,6 +754,7 @@ class ElasticFusion:
     def setConfidenceThreshold(self, v): _chk(lib().ef_set_confidence_threshold(self.h, c_f(v)), self.h)
     def setDepthCutoff(self, v): _chk(lib().ef_set_depth_cutoff(self.h, c_f(v)), self.h)
     def setInputOverlap(self, on): _chk(lib().ef_set_input_overlap(self.h, c_i(int(on))), self.h)
+    def setInputCuMask(self, one_in_n): _chk(lib().ef_set_input_cu_mask(self.h, c_i(int(one_in_n))), self.h)
     def setDeformation(self, graph, isFern=False):
         g = np.ascontiguousarray(graph, np.float32).reshape(-1, 16)
         _chk(lib().ef_set_deformation(self.h, _ptr(g), c_i(len(g)), c_i(int(isFern))), self.h)

@@ -1149,6 +1149,25 @@ int ef_process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* dept
   DeviceGuard dg_(c);
   return process_frame(c, rgb_dev, depth_dev, hipMemcpyDeviceToDevice, timestamp, wm, T);
 }
+// The input stream restricted to every n-th CU (hipExtStreamCreateWithCUMask; n <= 1: the whole chip): the next frame's bilateral filter —
+// the one ALU-bound kernel of a frame — then runs beside the previous frame's fusion and prediction on a quarter of the chip instead of
+// flooding every CU the latency-bound map kernels are trying to run on.
+int ef_set_input_cu_mask(ef_ctx* c, int one_in_n) {
+  if (!c || one_in_n < 0 || one_in_n > 32) return EF_EINVAL;
+  DeviceGuard dg_(c);
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->in_stream) { EF_HIP(c, hipStreamSynchronize(c->in_stream)); EF_HIP(c, hipStreamDestroy(c->in_stream)); c->in_stream = nullptr; }
+  if (one_in_n <= 1) {
+    EF_HIP(c, hipStreamCreateWithFlags(&c->in_stream, hipStreamNonBlocking));
+    return EF_OK;
+  }
+  int cus = 0;
+  EF_HIP(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->cfg.device));
+  std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+  for (int i = 0; i < cus; i += one_in_n) mask[(size_t)i / 32] |= 1u << (i % 32);
+  EF_HIP(c, hipExtStreamCreateWithCUMask(&c->in_stream, (uint32_t)mask.size(), mask.data()));
+  return EF_OK;
+}
 int ef_set_input_overlap(ef_ctx* c, int on) {
   if (!c || on < 0 || on > 2) return EF_EINVAL;
   c->overlap = on != 0;
@@ -1224,6 +1243,7 @@ int ef_solve_deformation_gated(const float* nodes4, int n_nodes, const ef_graph_
 }
 int ef_enable_global_closure(ef_ctx* c, int num_ferns, float photo_thresh, float fern_thresh, unsigned seed) {
   if (!c || num_ferns < 50) return EF_EINVAL;
+  if (num_ferns > FERN_CODES_PAD) { c->err = "ef_enable_global_closure: at most 512 ferns"; return EF_EINVAL; }   // (every refusal before the first allocation)
   DeviceGuard dg_(c);
   if (!c->cfg.close_loops) { c->err = "ef_enable_global_closure: the context was created with close_loops = 0"; return EF_ESTATE; }
   if (c->closure) { c->err = "ef_enable_global_closure: already enabled"; return EF_ESTATE; }
@@ -1240,7 +1260,6 @@ int ef_enable_global_closure(ef_ctx* c, int num_ferns, float photo_thresh, float
   EF_HIP(c, hipHostMalloc((void**)&c->h_view_end, n * 36));
   EF_HIP(c, hipHostMalloc((void**)&c->h_codes, FERN_CODES_BYTES));
   EF_HIP(c, hipHostMalloc((void**)&c->h_codes_end, FERN_CODES_BYTES));
-  if (num_ferns > FERN_CODES_PAD) { c->err = "ef_enable_global_closure: at most 512 ferns"; return EF_EINVAL; }
   c->fern_num = num_ferns;
   EF_ALLOC(c, c->fern_table_dev, (size_t)num_ferns * 6);
   EF_ALLOC(c, c->fern_codes_dev, (size_t)FERN_CODES_BYTES);
@@ -1536,6 +1555,12 @@ int ef_restore_state(ef_ctx* c, int tick, const double* q4_t3, const uint8_t* rg
   DeviceGuard dg_(c);
   hipStream_t s = c->stream;
   const int W = c->cam.cols, H = c->cam.rows;
+  if (c->closure) {
+    // the fern database and the pose graph are not part of a checkpoint: a record still pending from before the restore belongs to the OLD
+    // replay and goes where it was headed before tick and pose change under it
+    const int fr = flush_end_record(c);
+    if (fr != EF_OK) return fr;
+  }
   EF_HIP(c, hipMemcpyAsync(c->rgb, rgb_prev, (size_t)W * H * 3, hipMemcpyHostToDevice, s));
   EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_prev, (size_t)W * H * 2, hipMemcpyHostToDevice, s));
   EF_HIP(c, hipStreamSynchronize(s));   // the caller's buffers are pageable and only borrowed

@@ -2091,6 +2091,7 @@ __device__ __forceinline__ unsigned pt_load(const unsigned* p) { return __hip_at
 __device__ __forceinline__ int pt_loadi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // one thread per workgroup, after the workgroup's agent-scope stores were drained and a __syncthreads()
 __device__ __forceinline__ void pt_arrive(PtSync* Y) {
+  __atomic_signal_fence(__ATOMIC_RELEASE);   // (compiler only: the payload stores were drained with s_waitcnt vmcnt(0) before this call)
   const unsigned old = __hip_atomic_fetch_add(&Y->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (old == PT_WGS - 1) {   // last arriver: re-arm the counter, then open the generation
     __hip_atomic_store(&Y->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2102,7 +2103,10 @@ __device__ __forceinline__ void pt_arrive(PtSync* Y) {
 __device__ __forceinline__ bool pt_wait(PtSync* Y, unsigned target, bool dead) {
   if (dead) return true;
   for (int i = 0; i < PT_SPIN; ++i) {
-    if ((int)(pt_load(&Y->gen) - target) >= 0) return false;
+    // (relaxed poll + agent-scope payload loads behind it, which no L1 serves: an ACQUIRE load here costs a cache invalidate per poll,
+    // MI355X_MICROARCH.md "polling with acquire loads: 2-3x slower per hop"; the signal fence keeps the COMPILER from moving a payload
+    // load above the poll, the hardware returns a wavefront's loads in order)
+    if ((int)(pt_load(&Y->gen) - target) >= 0) { __atomic_signal_fence(__ATOMIC_ACQUIRE); return false; }
     if ((i & 255) == 255 && pt_load(&Y->abort)) return true;
     __builtin_amdgcn_s_sleep(1);
   }
@@ -2284,6 +2288,18 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
       st->lastSO3Error = Z.err;
       st->lastSO3Count = Z.cnt;
       st->so3_iterations = Z.iterations;
+    }
+    if (!HAS_RGB) {
+      // ICP only (icpWeight >= 100) after an SO(3) loop: no barrier A separates the last SO(3) iteration's gather from the first SE(3)
+      // iteration's publish, and the two use overlapping floats of the same region when the parities match: a fast workgroup could
+      // overwrite sums a slow one is still reading.  One more barrier closes the window.
+      if (t == 0) {
+        pt_arrive(Y);
+        flag_s = pt_wait(Y, gen_next, dead) ? 1 : 0;
+      }
+      __syncthreads();
+      dead = dead || flag_s != 0;
+      ++gen_next;
     }
   }
   // ---- the Gauss-Newton iterations of the small levels, RGBDOdometry.cpp:371-553 ----

@@ -22,6 +22,27 @@ def sequence_seed(rank: int) -> int:
     return BASE_SEED + rank
 
 
+def cores_of_rank(local_rank: int, ranks_on_host: int, cores=None):
+    """Contiguous share of the host's cores for one rank: N ranks of one node each enqueue some twenty thousand kernel launches a second
+    (a frame is ~18 launches at ~1400 frames/s) from their own host thread; left to the scheduler they migrate and share caches with the
+    other ranks' frame generators.  cores: the CPUs this process may use (default: os.sched_getaffinity)."""
+    cores = sorted(cores if cores is not None else os.sched_getaffinity(0))
+    n = max(1, ranks_on_host)
+    per = max(1, len(cores) // n)
+    lo = min(local_rank * per, max(0, len(cores) - per))
+    return cores[lo:lo + per]
+
+
+def pin_rank_to_cores(local_rank: int, ranks_on_host: int):
+    try:
+        mine = cores_of_rank(local_rank, ranks_on_host)
+        if mine:
+            os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError):   # not Linux, or a cpuset that forbids it: keep the scheduler's placement
+        return None
+
+
 def init_process_group(backend: str, local_rank: int):
     import torch
     import torch.distributed as dist

@@ -78,6 +78,10 @@ int ef_process_frame_dev(ef_ctx* ctx, const uint8_t* rgb_dev, const uint16_t* de
  * needs only the new images (copy-in, bilateral filter + metric depth, frame-side pyramids) is enqueued on a second
  * internal stream and runs while the previous frame is still being fused.  Results are identical either way. */
 int ef_set_input_overlap(ef_ctx* ctx, int on);
+/* ... and that second stream restricted to every n-th CU of the chip (n <= 1: no restriction, the default): the bilateral filter of frame k + 1,
+ * the one ALU-bound kernel of a frame, then shares the chip with the latency-bound fusion / prediction kernels of frame k instead of displacing
+ * them.  (With the persistent tracker, which needs the whole chip to itself, use overlap mode 1: the input stage waits for the tracker.) */
+int ef_set_input_cu_mask(ef_ctx* ctx, int one_in_n);
 /* hipGraph replay of the tracker (default off): the ~70 kernel launches of one getIncrementalTransformation
  * (RGBDOdometry.cpp:259-571) are captured once per pyramid parity and replayed with one hipGraphLaunch per frame.
  * Identical results; it only trims host-side launch work (BASELINE.json configs[4]). */

@@ -503,6 +503,15 @@ void efo_rgb_residual(float minScale, const int16_t* dIdx, const int16_t* dIdy, 
   *sigmaSum = h.v[1];
 }
 
+#ifdef EFO_FAST_ORDER
+// test hook (tests/test_oracle_fast_order.py): THE FAST ORDER applied to plain numbers — leaf (t, l) adds v[64 (U t + k) + l] for
+// k = 0 .. U - 1 in order, then the adjacent-pair tree — so that the order itself is pinned by an independent restatement
+void efo_fast_order_sum(const float* v, int N, float* out) {
+  auto products = [&](int i, Acc<float, 1>& sum) { sum.v[0] = sum.v[0] + v[i]; };
+  *out = fast_reduce<float, 1>(N, products).v[0];
+}
+#endif
+
 // rgbStep = rgbKernel + reduceSum, reduce.cu:403-550
 void efo_rgb_step(const void* corres_in, float sigma, const float* cloud, float fx, float fy, const int16_t* dIdx,
                   const int16_t* dIdy, float sobelScale, int cols, int rows, float* A, float* b) {
