@@ -139,10 +139,18 @@ def roofline_tracker(lib, ef):
     if not hasattr(lib, "ef_get_tracker_timing") or lib.ef_get_tracker_timing(ef.h, C.byref(kt)) != 0 or kt.launches <= 0:
         return None
     ach = kt.bytes_per_launch / (kt.avg_us * 1e-6) / 1e9
+    traffic = tsrc = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pj = json.load(f)
+        traffic = int(pj["also"]["k_track_fast"]["traffic_bytes_per_launch"])
+        tsrc = "committed PMC measurement (profiles/pmc_traffic.json: " + str(pj["also"]["k_track_fast"].get("source", "")) + "), 640x480, not measured in this run"
+    except Exception:
+        pass
     return {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "avg_us": round(float(kt.avg_us), 2), "launches_sampled": int(kt.launches), "algorithmic_bytes_per_launch": int(kt.bytes_per_launch),
             "algorithmic_bytes_per_launch_survey_48B": int(kt.bytes_per_launch_survey),
-            "frac_survey_48B": round(kt.bytes_per_launch_survey / (kt.avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac_survey_48B": round(kt.bytes_per_launch_survey / (kt.avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
             "note": "a chain of 19 dependent Gauss-Newton iterations (two chip-wide exchanges and a 6x6 solve in double each): latency-bound, not bandwidth-bound"}
 
 
@@ -191,7 +199,10 @@ def rooflines(lib, ef, w, h, where):
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json" if (w, h) == (W, H) else "pmc_traffic_1280x960.json")) as f:
                 pj = json.load(f)
             src = "committed PMC measurement (profiles/" + ("pmc_traffic.json" if (w, h) == (W, H) else "pmc_traffic_1280x960.json") + ": " + str(pj.get("source", "tools/pmc_traffic.sh")) + "), not measured in this run"
-            traffic, traffic_source = int(pj["traffic_bytes_per_launch"]), src
+            if "k_se3_accum_fast" in str(pj.get("kernel", "")):
+                traffic, traffic_source = int(pj["traffic_bytes_per_launch"]), src
+            else:   # a measurement of the round-3 kernel (reference order): not this kernel's traffic
+                traffic_source = "not re-measured for k_se3_accum_fast at this size (the committed file holds round 3's k_se3_accum)"
             straffic, ssource = int(pj["also"]["k_index_splat"]["traffic_bytes_per_launch"]), src
         except Exception:
             pass

@@ -1082,10 +1082,16 @@ int ef_create(const ef_config* cfg, ef_ctx** out) {
   c->cam = efm::Cam{cfg->width, cfg->height, cfg->fx, cfg->fy, cfg->cx, cfg->cy};
   c->intr = eft::Intr{cfg->fx, cfg->fy, cfg->cx, cfg->cy};
   {
-    // the persistent small-level launch needs its 128 workgroups resident together, one per CU: on a device (or a partition of one:
-    // CPX mode exposes 32 CUs) that cannot hold them the per-step script is the default; ef_set_persistent_tracker can still ask for it
+    // the persistent tracker launch needs its workgroups resident together, one per CU (fast order: 256, the reference-order launch of
+    // the small levels: 128): on a device (or a partition of one: CPX mode exposes 32 CUs) that cannot hold them the per-step script is
+    // the default; ef_set_persistent_tracker can still ask for it (the fast order's launch then falls back to one workgroup every frame)
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus < eft::PT_WGS) c->persistent = false;
+#ifdef EF_FAST_ORDER
+    const int need = 256;
+#else
+    const int need = eft::PT_WGS;
+#endif
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus < need) c->persistent = false;
   }
   if (cfg->stream) {
     c->stream = (hipStream_t)cfg->stream;
@@ -1125,8 +1131,10 @@ int ef_synchronize(ef_ctx* c) {
   for (const eft::Pyramid* p : {&c->pyr, &c->pyr2, &c->pyr3}) {
     const int a = eft::tracker_aborted(*p, c->stream);
     if (a != 0) {
-      c->err = a > 0 ? "the persistent tracker launch timed out in a grid barrier (its 128 workgroups were not resident together): results "
-                       "since then are invalid; recreate the context, or run it with ef_set_persistent_tracker(ctx, 0)"
+      c->err = a > 0 ? "a persistent tracker launch timed out waiting for another workgroup AFTER its whole grid had reported in (with the fast "
+                       "order this is a protocol failure, not a busy chip: a chip partly taken is handled by the one-workgroup fallback, "
+                       "ef_get_tracker_fallbacks): results since then are invalid; recreate the context, or run it with "
+                       "ef_set_persistent_tracker(ctx, 0)"
                      : "hipMemcpy (tracker status)";
       return EF_EHIP;
     }

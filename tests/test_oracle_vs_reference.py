@@ -22,7 +22,9 @@ pytestmark = pytest.mark.skipif(not efo.have_reference(), reason="oracle/_ref/li
 
 # max |a-b| / max|b| over one output array, FMA-specified oracle vs FMA-free reference
 TOL_ELEMENTWISE = 1e-5   # maps touched by dot/cross (the cross product of two nearly parallel differences amplifies one rounding)
-TOL_SUMS = 1e-5          # 27-product normal equations over up to 307200 pixels
+TOL_SUMS = 3e-5          # 27-product normal equations over up to 307200 pixels: the specified (shipped) oracle differs from the compiled reference by its
+                         # fused multiply-adds AND, since round 4, by its summation order (THE FAST ORDER); measured worst case 1.02e-5 of the
+                         # vector's largest entry (J^T r at level 0, a sum with cancellation); the reference's own order stays bit-exact (nofma above)
 
 
 @pytest.fixture(scope="module")

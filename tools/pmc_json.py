@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from the per-kernel PMC summaries tools/pmc_traffic.sh leaves in gpurun_out/.
 
-    python tools/pmc_json.py <tag>          # reads gpurun_out/<tag>_{FETCH,WRITE}_SIZE_per_kernel.csv and *_calibration.txt
+    python tools/pmc_json.py <tag> [<tag2>]   # reads gpurun_out/<tag>_{FETCH,WRITE}_SIZE_per_kernel.csv and *_calibration.txt
+                                              # tag: a run of the launch-per-step script (k_se3_accum_fast is a launch of its own there),
+                                              # tag2: a default run (the persistent tracker launch k_track_fast), same calibration
 
 HBM-side bytes per launch = FETCH_SIZE x (bytes per counted KB, from the calibration kernel) + WRITE_SIZE x (same).
 """
@@ -16,7 +18,7 @@ tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out")
 
 
-def per_kernel(ctr):
+def per_kernel(ctr, tag=tag):
     out = {}
     with open(os.path.join(src, f"{tag}_{ctr}_per_kernel.csv")) as f:
         for r in csv.DictReader(f):
@@ -43,7 +45,7 @@ def pick(prefix, level0_only=False):
 
 
 k, f, w = pick("k_se3_accum")
-doc = {"kernel": re.sub(r"^.*?(k_se3_accum<[^>]*>).*$", r"\1", k), "FETCH_SIZE_KB_per_dispatch": round(f, 3),
+doc = {"kernel": re.sub(r"^.*?(k_se3_accum\w*<[^>]*>).*$", r"\1", k), "FETCH_SIZE_KB_per_dispatch": round(f, 3),
        "WRITE_SIZE_KB_per_dispatch": round(w, 3), "fetch_bytes_per_counted_KB": cf, "write_bytes_per_counted_KB": cw,
        "traffic_bytes_per_launch": int(round(f * cf + w * cw)), "source": f"tools/pmc_traffic.sh {tag}", "also": {}}
 for name in ("k_index_splat", "k_index_resolve"):
@@ -52,6 +54,14 @@ for name in ("k_index_splat", "k_index_resolve"):
         _, f2, w2 = p
         doc["also"][name] = {"FETCH_SIZE_KB_per_dispatch": round(f2, 3), "WRITE_SIZE_KB_per_dispatch": round(w2, 3),
                              "traffic_bytes_per_launch": int(round(f2 * cf + w2 * cw))}
+if len(sys.argv) > 2:   # the persistent tracker launch, from a default run
+    tag2 = sys.argv[2]
+    f2, w2 = per_kernel("FETCH_SIZE", tag2), per_kernel("WRITE_SIZE", tag2)
+    ks = [k for k in f2 if "k_track_fast" in k]
+    if ks:
+        k = max(ks, key=lambda k: f2[k][1])
+        doc["also"]["k_track_fast"] = {"FETCH_SIZE_KB_per_dispatch": round(f2[k][1], 3), "WRITE_SIZE_KB_per_dispatch": round(w2.get(k, (0, 0.0))[1], 3),
+                                       "traffic_bytes_per_launch": int(round(f2[k][1] * cf + w2.get(k, (0, 0.0))[1] * cw)), "source": f"tools/pmc_traffic.sh {tag2}"}
 doc["how"] = (f"tools/pmc_traffic.sh {tag}: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
               "`bench.py --steps 12 --warmup 3`; calibrated on k_transform_maps (75497472 B read + written, 4 B/lane planar): "
               "FETCH_SIZE counts half the bytes (gfx950), WRITE_SIZE is exact")
