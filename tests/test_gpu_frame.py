@@ -100,9 +100,11 @@ def test_pipelined_frames_match_oracle(hip, seq):
         rgb, depth, _ = seq.frame(k)
         o.process_frame(rgb, depth, k * 33333)
     runs = []
-    for overlap in (True, False):
+    for overlap in (True, False, 4):   # 4: the input stream restricted to every 4th CU (ef_set_input_cu_mask)
         ef = hip.ElasticFusion()
-        ef.setInputOverlap(overlap)
+        if overlap == 4:
+            ef.setInputCuMask(4)
+        ef.setInputOverlap(bool(overlap))
         for k in range(n):
             rgb, depth, _ = seq.frame(k)
             ef.processFrame(rgb, depth, k * 33333)
@@ -113,8 +115,9 @@ def test_pipelined_frames_match_oracle(hip, seq):
         assert np.array_equal(runs[-1][1].view(np.uint32), o.map().view(np.uint32))
         assert np.array_equal(runs[-1][2], o.buffer("depthFiltered"))
         ef.close()
-    for a, b in zip(runs[0], runs[1]):
-        assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+    for other in (1, 2):
+        for a, b in zip(runs[0], runs[other]):
+            assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
 
 
 @pytest.mark.parametrize("cfg", [dict(), dict(icpThresh=100.0), dict(so3=False), dict(fastOdom=True)], ids=["default", "icp_only", "no_so3", "fastOdom"])
