@@ -86,13 +86,16 @@ int ef_set_input_cu_mask(ef_ctx* ctx, int one_in_n);
  * (RGBDOdometry.cpp:259-571) are captured once per pyramid parity and replayed with one hipGraphLaunch per frame.
  * Identical results; it only trims host-side launch work (BASELINE.json configs[4]). */
 int ef_set_graph_replay(ef_ctx* ctx, int on);
-/* The tracker's small pyramid levels (every level of at most 131072 pixels: levels 2 and 1 at 640x480), its SO(3) pre-alignment and
- * its first kernel as ONE persistent launch of 128 co-resident workgroups (default, on) instead of one launch per step (off: the
- * round-2 script, 38 launches more per frame).  Same arithmetic in the same order: results are bit-identical either way
- * (RGBDOdometry.cpp:259-553; tests/test_gpu_frame.py runs both).  The persistent launch needs its 128 workgroups resident at the same
- * time (512 threads, 36 KB of LDS each: half the CUs of one MI355X); every wait in it is bounded, and a launch whose grid could not
- * become resident (other work holding the chip's wave slots for ever) makes ef_synchronize return EF_EHIP instead of hanging.  On a
- * device that reports fewer than 128 CUs (a partition of the chip) the default is off. */
+/* The whole of RGBDOdometry::getIncrementalTransformation (RGBDOdometry.cpp:259-553: the SO(3) pre-alignment loop and every Gauss-Newton
+ * iteration of every pyramid level, with their update steps) as ONE persistent launch of 256 co-resident workgroups, one per CU (default, on)
+ * instead of one launch per step (off: 68 launches per call).  The same sums in the same order: results are bit-identical either way
+ * (tests/test_gpu_frame.py runs both).  The launch needs the whole chip at once; it checks that at its start, and when other work holds
+ * part of the chip for milliseconds (another process, a long kernel on another stream) the call runs on one workgroup instead — slower, the
+ * same results, nothing for the caller to do (ef_get_tracker_fallbacks counts these).  Persistent launches of one process on one device are
+ * chained in enqueue order, so several contexts never starve one another.  On a device that reports fewer than 256 CUs (a partition of
+ * the chip), with rgbOnly and under ef_set_graph_replay the launch-per-step script runs.  (The reference-rounding build,
+ * libefusion_hip_nofma.so, keeps round 3's form: the levels of at most 131072 pixels + the SO(3) loop as one launch of 128 workgroups, whose
+ * time-out makes ef_synchronize return EF_EHIP.) */
 int ef_set_persistent_tracker(ef_ctx* ctx, int on);
 /* Level-0 Gauss-Newton iterations as TWO launches instead of three: the update step (one workgroup's worth of work) is evaluated by
  * workgroup 0 of the correspondence-search launch and handed to that launch's other workgroups as tagged granules (they poll with their
