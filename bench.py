@@ -200,7 +200,10 @@ def rooflines(lib, ef, w, h, where):
                 pj = json.load(f)
             src = "committed PMC measurement (profiles/" + ("pmc_traffic.json" if (w, h) == (W, H) else "pmc_traffic_1280x960.json") + ": " + str(pj.get("source", "tools/pmc_traffic.sh")) + "), not measured in this run"
             if "k_se3_accum_fast" in str(pj.get("kernel", "")):
-                traffic, traffic_source = int(pj["traffic_bytes_per_launch"]), src
+                # one kernel name for all three levels: the PMC mean is over the 19 launches of a call; the level-0 figure is that mean's ratio
+                # to the algorithmic bytes (1.14) applied to a level-0 launch
+                traffic = int(pj.get("traffic_bytes_per_level0_launch_estimate", pj["traffic_bytes_per_launch"]))
+                traffic_source = src + "; level-0 launch = the measured traffic / algorithmic ratio of the call's 19 launches (" + str(pj.get("traffic_over_algorithmic")) + ") x this launch's algorithmic bytes"
             else:   # a measurement of the round-3 kernel (reference order): not this kernel's traffic
                 traffic_source = "not re-measured for k_se3_accum_fast at this size (the committed file holds round 3's k_se3_accum)"
             straffic, ssource = int(pj["also"]["k_index_splat"]["traffic_bytes_per_launch"]), src

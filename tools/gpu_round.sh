@@ -17,6 +17,8 @@ if [ "$what" = "tests" ]; then
   tail -3 $out/${tag}_smoke.log
   exit 0
 fi
+timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_driver_cmd.json 2> $out/${tag}_bench_driver_cmd.err; echo "bench (driver's command) rc=$?"
+cut -c1-400 $out/${tag}_bench_driver_cmd.json
 timeout 420 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?"
 cut -c1-1500 $out/${tag}_bench.json; tail -3 $out/${tag}_bench.err
 cd /tmp
