@@ -549,8 +549,12 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
     efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], count, c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick, c->cfg.time_delta,
                           c->zbuf, c->pm, none, nullptr, nullptr, false, nullptr, s);
   // :451-459, IndexMap::INACTIVE: surfels last seen at or before tick - timeDelta
+  // (the prediction stamps st2->model_view_stamp with this frame's value when it shows at least one surfel: the model-to-model tracker's
+  // persistent launch leaves at once otherwise — nothing can be registered against an empty view, and the reference's tracker, which runs
+  // all the same, ends on zero sums: the stamp only says which frames those are)
+  const unsigned view_stamp = (unsigned)c->tick * 2u + 1u;
   efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], count, c->maxDepthProcessed, c->cfg.confidence, 0, c->tick - c->cfg.time_delta,
-                        c->cfg.time_delta, c->zbuf, c->old, none, nullptr, nullptr, false, nullptr, s);
+                        c->cfg.time_delta, c->zbuf, c->old, none, nullptr, nullptr, false, nullptr, s, &c->st2->model_view_stamp, view_stamp);
   eft::copy_pose(c->st2, c->st, s);                                                              // :469
   const float maxDepthRGB = 6.0f;                                                                // RGBDOdometry.cpp:42
   // :463 initICPModel(inactive view) + :464 initRGBModel(its image) + :466-467 initICP / initRGB(active view), fused (eft::init_model_pair)
@@ -563,6 +567,8 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
   tp.fused_step = c->fused_step ? 1 : 0;
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
+  tp.empty_model_flag = &c->st2->model_view_stamp;
+  tp.empty_model_value = view_stamp;
   const eft::TrackTail tail2 = eft::track(c->pyr2, c->st2, c->intr, tp, s, nullptr);
   eft::track_end(c->st2, tail2, true, 1.0f, nullptr, -1, s);
   eft::sample_constraints((const float*)c->pm.vertex, c->old.time, W, H, step, c->cons_dev, s);  // :485-486

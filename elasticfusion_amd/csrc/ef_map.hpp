@@ -96,7 +96,9 @@ void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, co
                       float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, PredictMaps out,
                       // optional fused fill-in + denseEnough sampling (null fill.image => skipped)
                       FillMaps fill, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthroughImage,
-                      unsigned* dense_counter, hipStream_t s);
+                      unsigned* dense_counter, hipStream_t s,
+                      // optional: *nonempty_flag = nonempty_value when the view shows at least one surfel (the caller stamps a fresh value per use)
+                      unsigned* nonempty_flag = nullptr, unsigned nonempty_value = 0);
 // IndexMap::synthesizeDepth (splat.vert + depth_splat.frag): float depth of the nearest splat per pixel, 0 = none
 void synthesize_depth(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
                       float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s);

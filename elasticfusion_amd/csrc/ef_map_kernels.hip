@@ -621,7 +621,8 @@ __global__ void __launch_bounds__(BLK) k_surface_resolve(const Cam cam, const fl
                                                           float confThreshold, int time, int maxTime, int timeDelta,
                                                           unsigned long long* zbuf, PredictMaps out, FillMaps fill,
                                                           const uint16_t* __restrict__ depth_filtered, const uint8_t* __restrict__ rgb3,
-                                                          bool passthroughImage, unsigned* dense_counter) {
+                                                          bool passthroughImage, unsigned* dense_counter, unsigned* nonempty_flag,
+                                                          unsigned nonempty_value) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= cam.cols * cam.rows) return;
   const int py = pi / cam.cols, px = pi - py * cam.cols;
@@ -630,6 +631,7 @@ __global__ void __launch_bounds__(BLK) k_surface_resolve(const Cam cam, const fl
   float4 vt = make_float4(0, 0, 0, 0), nm = make_float4(0, 0, 0, 0);
   uint16_t tm = 0;
   if (key != ZBUF_EMPTY) {
+    if (nonempty_flag) *nonempty_flag = nonempty_value;   // "this view shows at least one surfel", stamped with the caller's value (no reset pass)
     zbuf[pi] = ZBUF_EMPTY;
     const uint32_t id = (uint32_t)key;
     const rt34 T = rt34_load16(T16);
@@ -1194,16 +1196,17 @@ void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSo
 
 void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
                       float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, PredictMaps out, FillMaps fill,
-                      const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthroughImage, unsigned* dense_counter, hipStream_t s) {
+                      const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthroughImage, unsigned* dense_counter, hipStream_t s,
+                      unsigned* nonempty_flag, unsigned nonempty_value) {
   hipLaunchKernelGGL(k_surface_splat, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
                      time, maxTime, timeDelta, zbuf);
   const dim3 g(ceil_div(cam.cols * cam.rows, BLK));
   if (fill.image)
     hipLaunchKernelGGL(k_surface_resolve<true>, g, dim3(BLK), 0, s, cam, T_cw16_dev, map, maxDepth, confThreshold, time, maxTime, timeDelta,
-                       zbuf, out, fill, depth_filtered, rgb3, passthroughImage, dense_counter);
+                       zbuf, out, fill, depth_filtered, rgb3, passthroughImage, dense_counter, nonempty_flag, nonempty_value);
   else
     hipLaunchKernelGGL(k_surface_resolve<false>, g, dim3(BLK), 0, s, cam, T_cw16_dev, map, maxDepth, confThreshold, time, maxTime, timeDelta,
-                       zbuf, out, fill, depth_filtered, rgb3, passthroughImage, dense_counter);
+                       zbuf, out, fill, depth_filtered, rgb3, passthroughImage, dense_counter, nonempty_flag, nonempty_value);
 }
 void synthesize_depth(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth, float confThreshold,
                       int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s) {

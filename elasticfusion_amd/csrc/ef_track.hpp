@@ -100,6 +100,7 @@ struct TrackState {
   unsigned step_timeout;      // sticky: a workgroup gave up waiting for the record (bounded spin)
   unsigned long long dbg_clock[16];   // developer instrumentation (EF_STAGE_CLOCKS builds only)
   unsigned map_counts[2];     // live surfels of the two ping-pong map buffers (clean reads one, writes the other)
+  unsigned model_view_stamp;  // model-to-model tracker (local loop closure): the INACTIVE prediction stamps this with the frame's value when it shows a surfel
   // float matrices consumed by the map kernels
   float T_cw[16];             // T_wc.inverse().matrix().cast<float>()  (IndexMap.cpp:208)
   float pose_f[16];           // T_wc.cast<float>().matrix()            (GlobalModel.cpp:403)
@@ -144,6 +145,11 @@ struct TrackParams {           // host-side knobs of getIncrementalTransformatio
   float icpWeight;
   float distThres, angleThres; // RGBDOdometry.h:41-42
   int fused_step = 0;          // level-0 iterations: update step inside the correspondence-search launch (two launches per iteration)
+  // fast order, persistent launch only: when *empty_model_flag != empty_model_value the MODEL side of this call is known to be empty (the
+  // inactive prediction of the local loop closure showed no surfel: ElasticFusion.cpp:451-471 still runs the tracker on it) — no pixel can
+  // find a correspondence in any iteration, every sum is zero, and the launch leaves what nineteen zero updates leave, at once
+  const unsigned* empty_model_flag = nullptr;
+  unsigned empty_model_value = 0;
   int persistent = 1;          // (int: the struct is compared with memcmp, no tail padding) small levels + SO(3) in one persistent launch (k_track_small); false = one launch per step (round 2)
 };
 

@@ -2996,6 +2996,8 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
     FA.epoch = p.epoch;
     p.epoch += FT_EPOCHS;
     FA.out_cur = 0;
+    FA.empty_model_flag = tp.so3 ? nullptr : tp.empty_model_flag;   // (the SO(3) loop looks at the frame-side images only: not covered by the shortcut)
+    FA.empty_model_value = tp.empty_model_value;
     const bool sample_all = probe_all && probe_all->used < probe_all->capacity;
     hipEvent_t e0 = sample_all ? probe_all->start[probe_all->used] : nullptr, e1 = sample_all ? probe_all->stop[probe_all->used] : nullptr;
     if (sample_all) probe_all->used++;
