@@ -304,6 +304,54 @@ def make_engine(api, w, h, device, stream, close_loops=False, graph=False, per_s
     return ef
 
 
+def sequences_on_one_gpu(api, frames, dev, w, h, device, m, steps, warmup, preroll):
+    """m independent replays of the same frames sharing ONE GPU — m contexts, each with its own stream and its own host thread, running the
+    launch-per-step tracker script (the persistent launch takes the whole chip: co-located sequences overlap better without it) — aggregate
+    frames/s and whether all m ended on the same bits.  A side figure (BASELINE configs[3] puts one sequence on each GPU)."""
+    import threading
+    ctxs = []
+    for _ in range(m):
+        ef = make_engine(api, w, h, device, 0, per_step=True)   # stream 0 = the context creates its own non-blocking stream
+        ctxs.append(ef)
+    first = 1 + preroll + warmup
+    go, done = threading.Barrier(m + 1), threading.Barrier(m + 1)
+    errs = []
+
+    def worker(ef):
+        try:
+            for k in range(first):
+                ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
+            ef.synchronize()
+            go.wait()
+            for k in range(first, first + steps):
+                ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
+            ef.synchronize()
+        except Exception as e:   # a broken barrier would hang the others: report instead
+            errs.append(repr(e))
+            go.abort()
+            done.abort()
+            return
+        done.wait()
+
+    th = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+    for t in th:
+        t.start()
+    go.wait()
+    t0 = time.perf_counter()
+    done.wait()
+    dt = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    poses = [c.get_T_wc() for c in ctxs]
+    counts = [c.lastCount() for c in ctxs]
+    for c in ctxs:
+        c.close()
+    if errs:
+        return {"error": errs[0]}
+    return {"value": round(m * steps / dt, 2), "per_sequence": round(steps / dt, 2), "sequences": m, "steps": steps,
+            "identical_results": bool(all(np.array_equal(poses[0], q) for q in poses) and len(set(counts)) == 1)}
+
+
 def preseed(ef, seed, w, h, n, frame0):
     """a map of ~n surfels sampled on the scene's surfaces instead of the first frame's seeding"""
     from elasticfusion_amd import synth
@@ -595,6 +643,12 @@ def main():
             legs["close_loops_fps"]["what"] = "the reference's DEFAULT mode (closeLoops = true, timeDelta 200): fern database + global closure + local closure every frame"
         except Exception as e:   # never let a side figure cost the line
             legs["error"] = repr(e)
+        try:
+            legs["four_sequences_on_one_gpu_fps"] = sequences_on_one_gpu(api, frames, dev, w, h, local_rank, 4, a.steps, a.warmup, a.preroll)
+            legs["four_sequences_on_one_gpu_fps"]["what"] = ("AGGREGATE frames/s of four independent replays sharing this GPU (four contexts, four host threads, launch-per-step "
+                                                             "tracker scripts; results identical across the four): what a server with more streams than GPUs gets per device")
+        except Exception as e:
+            legs["four_sequences_on_one_gpu_fps"] = {"error": repr(e)}
         try:
             bdev = [(api.DevBuf.from_array(r), api.DevBuf.from_array(d)) for r, d, _ in big]
             leg = side_leg(torch, api, big, bdev, BIG["w"], BIG["h"], local_rank, stream, BIG["steps"], BIG["warmup"], BIG["preroll"],
