@@ -444,8 +444,8 @@ def main():
                     "that only counts frames - exercises this file's multi-rank control flow; the line says \"data\": \"stand-in\"")
     ap.add_argument("--fused-step", action="store_true", help="development (A/B): level-0 update step inside the correspondence-search launch "
                     "(ef_set_fused_step); results are bit-identical")
-    ap.add_argument("--per-step-tracker", action="store_true", help="development (A/B): the round-2 tracker script, one launch per step, instead "
-                    "of the persistent small-level launch (ef_set_persistent_tracker(ctx, 0)); results are bit-identical")
+    ap.add_argument("--per-step-tracker", action="store_true", help="development (A/B): the tracker as one launch per step (68 launches) instead "
+                    "of the persistent launch (ef_set_persistent_tracker(ctx, 0)); results are bit-identical")
     a = ap.parse_args()
     w, h = a.width, a.height
 

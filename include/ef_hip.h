@@ -426,8 +426,8 @@ int ef_debug_occupy(ef_ctx* ctx, int workgroups, int microseconds);
 /* developer instrumentation: the 16 wall_clock64() (100 MHz) stamps the last tracking solve left in the device state;
  * all zero unless the library was built with -DEF_STAGE_CLOCKS (EF_HIPCC_FLAGS=-DEF_STAGE_CLOCKS python -m elasticfusion_amd.build) */
 int ef_debug_clocks(ef_ctx* ctx, unsigned long long* out16);
-/* developer instrumentation of the persistent small-level launch (zeros unless the library was built with -DEF_STAGE_CLOCKS): 24 sums
- * of 10 ns ticks per phase since the last call, tools/small_clocks.py names them */
+/* developer instrumentation of the persistent tracker launch (zeros unless the library was built with -DEF_STAGE_CLOCKS): 24 sums
+ * of 10 ns ticks per phase since the last call; tools/fast_clocks.py (reference-order builds: tools/small_clocks.py) names them */
 int ef_debug_small_clocks(ef_ctx* ctx, unsigned long long* out24);
 
 /* ---- device memory helpers (so that a non-HIP host can drive the operator tier) ---- */
