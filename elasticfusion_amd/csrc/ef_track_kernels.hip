@@ -2607,9 +2607,8 @@ void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int
     const FastPlan fp = fast_plan(N);
     const dim3 fgrid(in.xcd_swizzle ? 8 * fast_groups_per_xcd(fp.NG) : fp.NG), fblock(256 * ((HAS_ICP && HAS_RGB) ? 2 : 1));
     hipExtLaunchKernelGGL((k_se3_accum_fast<HAS_ICP, HAS_RGB, PACKED>), fgrid, fblock, 0, s, start, stop, 0, IV, RV, in, out.pairs);
-    return;
   }
-#endif
+#else
   constexpr int BLOCK = 64 * 2 * ACC_NW * ((HAS_ICP && HAS_RGB) ? 2 : 1);
   const dim3 grid(VWARPS / ACC_NW), block(BLOCK);
   // CH = steps (of four passes) a wavefront has in flight per round: 640x480 has 19 passes = 5 steps = ONE round of CH = 5; 1280x960 has
@@ -2618,6 +2617,7 @@ void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int
   // other in the CU's one address pipe for longer than the two saved round trips.
   if (N > 8 * VTHREADS) hipExtLaunchKernelGGL((k_se3_accum<5, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
   else hipExtLaunchKernelGGL((k_se3_accum<2, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
+#endif
 }
 }  // namespace
 
