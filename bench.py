@@ -646,7 +646,8 @@ def main():
         try:
             legs["four_sequences_on_one_gpu_fps"] = sequences_on_one_gpu(api, frames, dev, w, h, local_rank, 4, a.steps, a.warmup, a.preroll)
             legs["four_sequences_on_one_gpu_fps"]["what"] = ("AGGREGATE frames/s of four independent replays sharing this GPU (four contexts, four host threads, launch-per-step "
-                                                             "tracker scripts; results identical across the four): what a server with more streams than GPUs gets per device")
+                                                             "tracker scripts; results identical across the four): what a server with more streams than GPUs gets per device.  With --steps 20 the "
+                                                             "timed region is ~25 ms and thread start-up skew understates it: 150-step runs read 3780 (profiles/r04o_shared_gpu.jsonl)")
         except Exception as e:
             legs["four_sequences_on_one_gpu_fps"] = {"error": repr(e)}
         try:
