@@ -7,8 +7,9 @@
 // Summation order of the fp32 normal-equation sums.  The shipped build uses THE FAST ORDER (ef_track_fast.inc: per-lane register
 // accumulation, adjacent-pair trees; specified in DESIGN.md 5.1 "The fast order", which the test suite's CPU checker restates bit for bit); the
 // reference-rounding build (-DEF_NO_FMA, libefusion_hip_nofma.so) keeps the REFERENCE's order (reduce.cu:57-140,313-317) and with it
-// the round-3 kernels, pinned against the compiled reduce.cu.  -DEF_REF_ORDER builds the round-3 product (FMAs + reference order) for A/B runs.
-#if !defined(EF_NO_FMA) && !defined(EF_REF_ORDER)
+// the round-3 kernels, pinned against the compiled reduce.cu.  -DEF_REF_ORDER builds the round-3 product (FMAs + reference order) for A/B runs;
+// -DEF_NO_FMA -DEF_FORCE_FAST_ORDER the fourth corner (no FMAs + fast order) of the round-5 parity factorial (tools/parity_factorial.py).
+#if defined(EF_FORCE_FAST_ORDER) || (!defined(EF_NO_FMA) && !defined(EF_REF_ORDER))
 #define EF_FAST_ORDER 1
 #endif
 
