@@ -285,12 +285,14 @@ class _NoGpu:
     def synchronize(): pass
 
 
-def make_engine(api, w, h, device, stream, close_loops=False, graph=False, per_step=False, fused_step=False, input_overlap=0):
+def make_engine(api, w, h, device, stream, close_loops=False, graph=False, per_step=False, fused_step=False, input_overlap=0, round3=False):
     sc = w / 640.0
     ef = api.ElasticFusion(width=w, height=h, fx=528.0 * sc, fy=528.0 * sc, cx=320.0 * sc, cy=240.0 * sc, device=device, stream=stream,
                            maxSurfels=max(4 * 1024 * 1024, 6 * w * h), **(dict(closeLoops=True, timeDelta=200) if close_loops else {}))
     if per_step:
         ef.setPersistentTracker(False)
+    if round3:
+        ef.setPersistentTracker(2)
     if input_overlap:   # frame k + 1's input stage on a second stream (every input_overlap-th CU) beside frame k's fusion and prediction
         ef.setInputCuMask(input_overlap)
         ef.setInputOverlap(1)
@@ -429,8 +431,9 @@ def main():
                     "replayed (ef_set_graph_replay); bit-identical results, NOT the headline (measured: no faster, the host is not the limit)")
     ap.add_argument("--track-only", action="store_true", help="BASELINE.json configs[4]: odometry only on the map the pre-roll built "
                     "(ef_set_track_only during the timed region: pre-process, track, predict; no fusion) -> pairs/s")
-    ap.add_argument("--library", default=None, help="'nofma' = libefusion_hip_nofma.so, the reference-rounding build (bit for bit the "
-                    "reference's own sources compiled without contraction), or a path; default: the shipped libefusion_hip.so")
+    ap.add_argument("--library", default=None, help="'fast' = libefusion_hip_fast.so, the opt-in build (fused multiply-adds + fast summation order), or a "
+                    "path; default: the shipped libefusion_hip.so = the reference rounding (bit for bit the reference's own sources compiled "
+                    "without contraction)")
     ap.add_argument("--preseed", type=int, default=0, help="SURVEY 8(d) config 3: start from a map of about this many surfels sampled on the "
                     "scene's surfaces (radius 4 mm, confidence 12) brought in with ef_map_upload + ef_restore_state instead of seeding from "
                     "the first frame; with --width 1280 --height 960 --preseed 1048576 = BASELINE.json configs[2], the HBM-bound map")
@@ -446,6 +449,8 @@ def main():
                     "(ef_set_fused_step); results are bit-identical")
     ap.add_argument("--per-step-tracker", action="store_true", help="development (A/B): the tracker as one launch per step (68 launches) instead "
                     "of the persistent launch (ef_set_persistent_tracker(ctx, 0)); results are bit-identical")
+    ap.add_argument("--round3-tracker", action="store_true", help="development (A/B, reference-order builds): round 3's tracker script — the small levels + SO(3) "
+                    "as one launch of 128 workgroups (k_track_small), three launches per level-0 iteration (ef_set_persistent_tracker(ctx, 2)); bit-identical")
     a = ap.parse_args()
     w, h = a.width, a.height
 
@@ -455,7 +460,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if world > 1:   # N ranks enqueue ~20 k launches/s each from one host: every rank keeps to its own share of the cores
         multi.pin_rank_to_cores(local_rank, world)
-    plain = not (a.stand_in_engine or a.host_frames or a.close_loops or a.graph or a.track_only or a.library or a.preseed or a.per_step_tracker or a.probe_inside or a.fused_step or a.input_overlap or a.preroll != PREROLL)
+    plain = not (a.stand_in_engine or a.host_frames or a.close_loops or a.graph or a.track_only or a.library or a.preseed or a.per_step_tracker or a.round3_tracker or a.probe_inside or a.fused_step or a.input_overlap or a.preroll != PREROLL)
     side = world == 1 and plain and (w, h) == (W, H) and not a.no_side_legs   # the extra keys ride on the default N = 1 line only
 
     # synthetic frames first: the generator forks worker processes, which must happen before HIP / RCCL are initialised
@@ -499,7 +504,7 @@ def main():
 
         from elasticfusion_amd import api, build
         if a.library:
-            api.use_library(build.NOFMA_LIB if a.library == "nofma" else a.library)
+            api.use_library(build.FAST_LIB if a.library == "fast" else a.library)
 
         # a real (non-null) stream, made torch's current one: the engine enqueues on it, torch.cuda.synchronize() covers it,
         # and it can be captured into a hipGraph (--graph), which the legacy null stream cannot
@@ -508,7 +513,7 @@ def main():
         stream = tstream.cuda_stream
         gpu, stats_device = torch.cuda, "cuda"
     ef = make_engine(api, w, h, local_rank, stream, close_loops=a.close_loops, graph=a.graph, per_step=a.per_step_tracker, fused_step=a.fused_step,
-                     input_overlap=a.input_overlap)
+                     input_overlap=a.input_overlap, round3=a.round3_tracker)
     dev = [(api.DevBuf.from_array(r), api.DevBuf.from_array(d)) for r, d, _ in frames]
     k0 = 0
     n_pre = 0
@@ -584,8 +589,8 @@ def main():
     mode = ("HOST frames (pinned staging + PCIe upload timed), " if a.host_frames else "") + \
            ("closeLoops (fern database + global closure + local closure every frame, timeDelta 200), " if a.close_loops else "open loop, ") + \
            ("tracker replayed from a hipGraph, " if a.graph else "") + ("ODOMETRY ONLY in the timed region (no fusion), " if a.track_only else "") + \
-           ("one launch per tracker step (round-2 script), " if a.per_step_tracker else "") + ("level-0 update step fused into the search launch, " if a.fused_step else "") + \
-           (f"reference-rounding build ({os.path.basename(api.LIB_PATH)}), " if a.library else "") + \
+           ("one launch per tracker step (round-2 script), " if a.per_step_tracker else "") + ("round 3's tracker script (k_track_small + launch-per-step level 0), " if a.round3_tracker else "") + ("level-0 update step fused into the search launch, " if a.fused_step else "") + \
+           (f"library {os.path.basename(api.LIB_PATH)}, " if a.library else "reference-rounding build (libefusion_hip.so: no fused multiply-add, the reference's summation order), ") + \
            (f"map pre-seeded with {n_pre} surfels sampled on the scene (radius 4 mm, confidence 12), " if a.preseed else "")
     out = {
         "metric": f"frames/s per GPU, {w}x{h} 3-level ICP+fuse",
@@ -600,6 +605,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "stand-in" if a.stand_in_engine else "synthetic",
+        "parity": ("bit-exact: the timed library is the reference rounding (every result equal to the reference's own sources compiled without contraction; "
+                   "tests/test_gpu_vs_reference.py, profiles/r05_parity_factorial.json)" if not a.library else "see --library"),
         "config": {"workload": f"{w}x{h} synthetic RGB-D replay (box+spheres, Lissajous trajectory), " + mode +
                                "SO(3)+ICP+RGB 3-level tracking (10/5/4 its) + surfel fuse/clean/predict; "
                                + ("stand-in for configs[1] (dyson_lab.klg is not available offline)" if (w, h) == (W, H) else
@@ -660,13 +667,15 @@ def main():
             del bdev
         except Exception as e:
             legs["config2_1280x960_1M"] = {"error": repr(e)}
-        try:   # the build whose every result is bit-identical to the reference's own sources (compiled without contraction)
-            api.use_library(build.NOFMA_LIB)
-            legs["reference_rounding_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, **common)
-            legs["reference_rounding_fps"]["what"] = ("libefusion_hip_nofma.so (INTEGRATION.md 'reference rounding'): no fused multiply-add anywhere, bit for bit the "
-                                                     "reference's .cu / .cpp / GLSL arithmetic (tests/test_gpu_vs_reference.py, test_gpu_steady.py)")
+        try:   # the opt-in fast build: fused multiply-adds + the fast summation order + the whole tracker as one persistent launch
+            api.use_library(build.FAST_LIB)
+            legs["fast_build_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, **common)
+            legs["fast_build_fps"]["what"] = ("libefusion_hip_fast.so (INTEGRATION.md 'the fast build', opt-in): bit for bit its own specification (tests/test_gpu_fast_build.py), "
+                                             "NOT inside 1e-4 m / 1e-4 rad of the reference rounding on every frame (19 of 113 one-frame checkpoints over the bar: "
+                                             "profiles/r05_parity_factorial.json) — which is why `value` is the reference-rounding build's rate")
+            out["value_fast_build"] = legs["fast_build_fps"]["value"]   # (top level too; never `value`)
         except Exception as e:
-            legs["reference_rounding_fps"] = {"error": repr(e)}
+            legs["fast_build_fps"] = {"error": repr(e)}
         finally:
             api.use_library(None)
         out["side_legs"] = legs

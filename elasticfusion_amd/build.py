@@ -1,6 +1,13 @@
 """Builds libefusion_hip.so (hand-written HIP, gfx950 only) in-tree with hipcc.
 
     python -m elasticfusion_amd.build [--force]
+    python -m elasticfusion_amd.build --variant <name> [-D...]      (development / A-B builds: VARIANTS below)
+
+Two libraries with the same C ABI are built (csrc/ef_build.hpp):
+    libefusion_hip.so        the shipped default: REFERENCE ROUNDING (no fused multiply-add, the reference's summation order) — every result bit
+                             for bit the reference's own sources compiled without contraction; what libefusion.so links and bench.py times
+    libefusion_hip_fast.so   opt-in (-DEF_FAST_BUILD): fused multiply-adds + the fast summation order; faster, and outside the 1e-4 m / 1e-4 rad
+                             bar on 17 % of frames (profiles/r05_parity_factorial.json)
 
 -ffp-contract=off: fused multiply-adds appear only where the kernels spell them out (fmaf), which is what
 makes the integer-valued stages (u16/u8/i16 pyramids, correspondences, index maps) bit-exact against the
@@ -14,9 +21,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libefusion_hip.so")
-NOFMA_LIB = os.path.join(HERE, "libefusion_hip_nofma.so")   # TEST-ONLY variant (-DEF_NO_FMA, see csrc/ef_device.hpp): compared bit
-                                                              # for bit with the compiled reference in tests/test_gpu_vs_reference.py
+LIB = os.path.join(HERE, "libefusion_hip.so")            # reference rounding (the default)
+FAST_LIB = os.path.join(HERE, "libefusion_hip_fast.so")   # -DEF_FAST_BUILD (opt-in)
+NOFMA_LIB = LIB                                           # (rounds 1-4 kept the reference rounding in a test-only libefusion_hip_nofma.so: now the default)
+VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_hip_<name>.so
+    "reforder": ["-DEF_FAST_BUILD", "-DEF_REF_ORDER"],         # fused multiply-adds + the reference's order (round 3's product; parity factorial)
+    "nofma_fast": ["-DEF_FORCE_FAST_ORDER"],                   # no fused multiply-adds + the fast order (parity factorial)
+    "clocks": ["-DEF_STAGE_CLOCKS"],                           # phase clocks of the default build's tracker (tools/small_clocks.py)
+    "fast_clocks": ["-DEF_FAST_BUILD", "-DEF_STAGE_CLOCKS"],   # phase clocks of the fast build's persistent tracker (tools/fast_clocks.py)
+}
 SHIM_LIB = os.path.join(HERE, "libefusion.so")          # class ElasticFusion (include/ElasticFusion.h) over the C ABI
 SOURCES = ["ef_track_kernels.hip", "ef_map_kernels.hip", "ef_context.hip", "ef_ferns.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -31,7 +44,7 @@ def _hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB) or not os.path.exists(SHIM_LIB) or not os.path.exists(NOFMA_LIB):
+    if not os.path.exists(LIB) or not os.path.exists(SHIM_LIB) or not os.path.exists(FAST_LIB):
         return True
     t = os.path.getmtime(LIB)
     root = os.path.dirname(HERE)
@@ -45,9 +58,9 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    objs = {"": [], "_nofma": []}
+    objs = {"": [], "_fast": []}
     procs = []
-    for variant, extra in (("", []), ("_nofma", ["-DEF_NO_FMA"])):
+    for variant, extra in (("", []), ("_fast", ["-DEF_FAST_BUILD"])):
         for src in SOURCES:
             obj = os.path.join(CSRC, src.replace(".hip", variant + ".o"))
             cmd = [_hipcc(), *FLAGS, *extra, *os.environ.get("EF_HIPCC_FLAGS", "").split(), "-c", os.path.join(CSRC, src), "-o", obj]
@@ -61,7 +74,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    for variant, target in (("", LIB), ("_nofma", NOFMA_LIB)):
+    for variant, target in (("", LIB), ("_fast", FAST_LIB)):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target, *objs[variant], "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
@@ -84,8 +97,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 def build_variant(name: str, extra_flags: list[str]) -> str:
     """TEST / DEVELOPMENT builds of libefusion_hip under another name (libefusion_hip_<name>.so, selected with EF_HIP_LIB in the Python
-    harness; never loaded by the product): e.g. build_variant("valu", ["-DEF_ACCUM_VALU"]) = the normal-equation kernel with
-    its outer products on the VALU instead of the matrix pipe, for A/B runs on one GPU box."""
+    harness; never loaded by the product).  A name of VARIANTS brings its flags; extra_flags are added."""
+    extra_flags = VARIANTS.get(name, []) + list(extra_flags)
     target = os.path.join(HERE, f"libefusion_hip_{name}.so")
     objs = []
     procs = []

@@ -152,7 +152,8 @@ struct ef_ctx {
   bool use_graph = false;
   bool track_only = false;       // ef_set_track_only: odometry on a frozen map (BASELINE.json configs[4])
   bool fused_step = false;       // ef_set_fused_step: level-0 update step inside the correspondence-search launch
-  bool persistent = true;        // ef_set_persistent_tracker: small pyramid levels + SO(3) in one persistent launch (k_track_small)
+  int persistent = 1;            // ef_set_persistent_tracker: 1 = the whole tracker as one persistent launch of 256 workgroups, 0 = one launch per step,
+                                 // 2 = (reference-order builds) round 3's launch of the small levels on 128 workgroups
   struct TrackGraph { hipGraphExec_t exec = nullptr; const void* key = nullptr; eft::TrackParams tp{}; eft::TrackTail tail{}; };
   TrackGraph tgraph[2];
   // HIP-event sampling of the dominant kernel (ef_kernel_timing)
@@ -446,7 +447,7 @@ void fern_tracker_device(void* user, const float* fv, const float* fn, const dou
   eft::init_icp_maps(c->pyr3, (const float*)d_cv, (const float*)d_cn, zero_image, c->st3, 6.0f, s);
   eft::TrackParams tp;
   tp.rgbOnly = false; tp.pyramid = false; tp.fastOdom = false; tp.so3 = false; tp.icpWeight = 100.f;
-  tp.persistent = c->persistent ? 1 : 0;
+  tp.persistent = c->persistent;
   tp.fused_step = c->fused_step ? 1 : 0;
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
@@ -563,7 +564,7 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
   eft::init_rgb_sobel(c->pyr2, s);
   eft::TrackParams tp;
   tp.rgbOnly = false; tp.pyramid = c->cfg.pyramid != 0; tp.fastOdom = c->cfg.fast_odom != 0; tp.so3 = false; tp.icpWeight = 10.f;   // :471
-  tp.persistent = c->persistent ? 1 : 0;
+  tp.persistent = c->persistent;
   tp.fused_step = c->fused_step ? 1 : 0;
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
@@ -734,7 +735,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       tp.fastOdom = c->cfg.fast_odom != 0;
       tp.so3 = c->cfg.so3 != 0;
       tp.icpWeight = c->cfg.icp_weight;
-      tp.persistent = c->persistent ? 1 : 0;
+      tp.persistent = c->persistent;
       tp.fused_step = c->fused_step ? 1 : 0;
       tp.distThres = 0.10f;                                   // RGBDOdometry.h:41
       tp.angleThres = sinf(20.f * 3.14159254f / 180.f);       // RGBDOdometry.h:42
@@ -753,11 +754,9 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       timer_end(c, "odomInit");
       timer_begin(c, "odom");
       const bool sample = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0;
-#ifdef EF_FAST_ORDER
-      // BASELINE configs[4] is the hipGraph-captured launch-per-step script; the fast order's persistent launch takes a fresh exchange epoch
+      // BASELINE configs[4] is the hipGraph-captured launch-per-step script; the persistent launch takes a fresh exchange epoch
       // per launch as a kernel argument, which a replayed graph cannot give it
       if (c->use_graph && !sample && !c->timing) tp.persistent = 0;
-#endif
       eft::TrackTail tail{};
       if (c->use_graph && !sample && !c->timing) {
         // key: which of the two intensity pyramids is "next" this frame + the knobs baked into the launch arguments
@@ -1092,12 +1091,14 @@ int ef_create(const ef_config* cfg, ef_ctx** out) {
     // the small levels: 128): on a device (or a partition of one: CPX mode exposes 32 CUs) that cannot hold them the per-step script is
     // the default; ef_set_persistent_tracker can still ask for it (the fast order's launch then falls back to one workgroup every frame)
     int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess) cus = 0;
+    if (cus < 256) {
 #ifdef EF_FAST_ORDER
-    const int need = 256;
+      c->persistent = 0;
 #else
-    const int need = eft::PT_WGS;
+      c->persistent = cus >= eft::PT_WGS ? 2 : 0;   // round 3's launch of the small levels needs 128 co-resident workgroups
 #endif
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus < need) c->persistent = false;
+    }
   }
   if (cfg->stream) {
     c->stream = (hipStream_t)cfg->stream;
@@ -1105,6 +1106,12 @@ int ef_create(const ef_config* cfg, ef_ctx** out) {
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return EF_EHIP; }
     c->own_stream = true;
+  }
+  if (!efm::bilateral_table()) {   // the depth filter's weight table of this device (built once per process and device, here at the latest)
+    g_create_error = "bilateral weight table: allocation or launch failed";
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return EF_EHIP;
   }
   const int r = ctx_init(c);
   if (r != EF_OK) {
@@ -1368,7 +1375,7 @@ int ef_set_fused_step(ef_ctx* c, int on) {
 int ef_set_track_only(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->track_only = on != 0; return EF_OK; }
 int ef_set_persistent_tracker(ef_ctx* c, int on) {
   if (!c) return EF_EINVAL;
-  c->persistent = on != 0;
+  c->persistent = on < 0 ? 0 : (on > 2 ? 1 : on);
   for (auto& g : c->tgraph)   // captured tracker graphs hold the other script
     if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
   return EF_OK;
@@ -1872,7 +1879,11 @@ int ef_get_tracker_timing(ef_ctx* c, ef_kernel_time* out) {
     total_ms += ms;
   }
   const bool icp = !c->cfg.rgb_only && c->cfg.icp_weight > 0, rgb = c->cfg.rgb_only || c->cfg.icp_weight < 100;
+#ifdef EF_FAST_ORDER
   out->name = "k_track_fast (the whole tracker as one persistent launch: SO(3) loop + every ICP+RGB iteration of every level + the update steps)";
+#else
+  out->name = "k_track_ref (the whole tracker as one persistent launch, reference summation order: SO(3) loop + every ICP+RGB iteration of every level + the update steps)";
+#endif
   out->launches = c->probe_all.used;
   out->avg_us = c->probe_all.used ? (float)(1e3 * total_ms / c->probe_all.used) : 0.f;
   // algorithmic bytes of one launch: every iteration visits every pixel of its level once (48 B icpStep + 4 B packed correspondence, as

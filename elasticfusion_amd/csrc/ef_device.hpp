@@ -8,12 +8,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "ef_build.hpp"
 
-// Fused multiply-adds of the tracking kernels appear only through EF_FMA.  The product build fuses them (the
-// numerics specification shared with the oracle); building with -DEF_NO_FMA (libefusion_hip_nofma.so, test-only) splits each
+// Multiply-adds of the tracking kernels appear only through EF_FMA.  The shipped default (ef_build.hpp: reference rounding) splits each
 // into an IEEE multiply and an IEEE add, which is what the reference's own CUDA sources compute when compiled without
-// contraction — that variant is compared bit for bit with the compiled reference / its golden vectors on the GPU
-// (tests/test_gpu_vs_reference.py).
+// contraction — compared bit for bit with the compiled reference / its golden vectors on the GPU (tests/test_gpu_vs_reference.py);
+// the opt-in fast build (-DEF_FAST_BUILD) fuses them.
 #ifdef EF_NO_FMA
 #define EF_FMA(a, b, c) ((a) * (b) + (c))
 #else

@@ -70,6 +70,9 @@ struct CompactScratch {
 };
 
 // ---- pre-processing (ComputePack FILTER / METRIC / METRIC_FILTERED, ElasticFusion.cpp:655-673) ----
+// the bilateral filter's weight table of the current device (built on first use, synchronously; null on a HIP error).  ef_create asks
+// for it so that no later call — possibly inside a stream capture — is the first
+const float* bilateral_table();
 void filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s);
 void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, hipStream_t s);
 // fused: bilateral + both metric conversions in one pass over the raw depth

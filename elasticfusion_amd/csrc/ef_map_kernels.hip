@@ -6,6 +6,7 @@
 // GL-defined behaviour is specified as N1-N5 in SURVEY.md §8a (restated in DESIGN.md).
 #include "ef_device.hpp"
 #include <stdlib.h>
+#include <mutex>
 #include <hip/hip_ext.h>
 #include "ef_map.hpp"
 
@@ -126,71 +127,88 @@ __device__ __forceinline__ uint16_t bilateral_px(const uint16_t* __restrict__ ra
 __device__ __forceinline__ float metric_px(unsigned value, unsigned maxv) {
   return (value > maxv || value < 300U) ? 0.0f : (float)value / 1000.0f;
 }
-// Bilateral filter, the fast path.  The arithmetic of bilateral_px is kept operation for operation (the filtered depth must
-// be the oracle's, bit for bit); what changes is how it is fed and issued:
+// Bilateral filter, the fast path (round 5: the weights come from a table).  The arithmetic of bilateral_px is kept operation for
+// operation (the filtered depth must be the oracle's, bit for bit); what changes is how it is fed and issued:
+//   * the weight of a tap, ef_expf(-(S + d * d * c)), depends on two small integers only: its squared distance dx^2 + dy^2 (27 distinct
+//     values in the 13 x 13 window) and |d| = |value - tmp| (depths are integers; beyond |d| = 395 the argument is below -87 and the weight is
+//     exactly +0 for every S).  A 27 x 400 table of these weights, each entry evaluated ONCE with the very expression of bilateral_px
+//     (k_bilateral_table: bit-identical by construction; rounds 1-4 evaluated 169 polynomial exps per pixel, 43 us of ALU), lives in HBM per
+//     device (43 KB) and is copied into LDS by every workgroup; a tap is then a subtraction, a clamp, a conversion and an LDS look-up;
 //   * the 76 x 20 neighbourhood of a 64 x 8 pixel tile is staged once in LDS as float (169 global loads per pixel -> 1);
-//   * every lane filters TWO pixels (rows y and y + 4) with float2 arithmetic, which the compiler issues as packed
-//     v_pk_{mul,add,fma}_f32 — one instruction per pair; the chain per tap is ~18 packed + 12 scalar ops for two pixels;
-//   * taps outside the image are given the weight +0 instead of being skipped: x + 0 == x exactly, so the two sums see the
-//     same sequence of non-trivial additions in the same order as the clipped loops of depth_bilateral.frag:49-72.
+//   * every lane filters TWO pixels (rows y and y + 4); both loops fully unrolled, so the table row of a tap is an immediate offset;
+//   * taps outside the image read a sentinel far away from every depth: their |d| clamps to a zero column of the table, and
+//     x + sentinel * 0 == x exactly, so the two sums see the same sequence of non-trivial additions in the same order as the clipped
+//     loops of depth_bilateral.frag:49-72.
 typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr int PRE_TW = 64, PRE_TH = 8, PRE_R = 6, PRE_LW = PRE_TW + 2 * PRE_R, PRE_LH = PRE_TH + 2 * PRE_R;
-__device__ __forceinline__ float2v ef_expf2(float2v x) {   // ef_expf on both lanes of the pair
-  const float2v n = {rintf(x.x * 1.44269504088896341f), rintf(x.y * 1.44269504088896341f)};
-  float2v r = __builtin_elementwise_fma(n, (float2v)(-0.693359375f), x);
-  r = __builtin_elementwise_fma(n, (float2v)(2.12194440e-4f), r);
-  float2v p = (float2v)(1.9875691500e-4f);
-  p = __builtin_elementwise_fma(p, r, (float2v)(1.3981999507e-3f));
-  p = __builtin_elementwise_fma(p, r, (float2v)(8.3334519073e-3f));
-  p = __builtin_elementwise_fma(p, r, (float2v)(4.1665795894e-2f));
-  p = __builtin_elementwise_fma(p, r, (float2v)(1.6666665459e-1f));
-  p = __builtin_elementwise_fma(p, r, (float2v)(5.0000001201e-1f));
-  const float2v e = __builtin_elementwise_fma(p, r * r, r) + (float2v)(1.0f);
-  float2v o = {ldexpf(e.x, (int)n.x), ldexpf(e.y, (int)n.y)};
-  if (x.x < -87.0f) o.x = 0.0f;
-  if (x.y < -87.0f) o.y = 0.0f;
-  return o;
+constexpr int BIL_ROWS = 27, BIL_COLS = 400, BIL_ZERO = 396;   // columns >= BIL_ZERO hold +0 (|d| >= 396: 396^2 * 0.000555556 > 87)
+constexpr float BIL_OUTSIDE = 1.0e6f;                            // sentinel of a tap outside the image
+struct BilRows {   // (|dy|, |dx|) -> first float of the table row of dx^2 + dy^2
+  int distinct[BIL_ROWS];
+  int base[PRE_R + 1][PRE_R + 1];
+  constexpr BilRows() : distinct{}, base{} {
+    int n = 0;
+    for (int s2 = 0; s2 <= 2 * PRE_R * PRE_R; ++s2) {
+      bool hit = false;
+      for (int a = 0; a <= PRE_R; ++a)
+        for (int b = 0; b <= PRE_R; ++b)
+          if (a * a + b * b == s2) { hit = true; base[a][b] = n * BIL_COLS; }
+      if (hit) distinct[n++] = s2;
+    }
+  }
+};
+constexpr BilRows BIL{};
+static_assert(BIL.distinct[BIL_ROWS - 1] == 2 * PRE_R * PRE_R && BIL.base[PRE_R][PRE_R] == (BIL_ROWS - 1) * BIL_COLS, "27 distinct squared distances");
+__global__ void k_bilateral_table(float* __restrict__ table) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BIL_ROWS * BIL_COLS) return;
+  const int r = i / BIL_COLS, k = i - r * BIL_COLS;
+  const float sigma_space2_inv_half = 0.024691358f, sigma_color2_inv_half = 0.000555556f;
+  const float space2 = (float)BIL.distinct[r];
+  const float d = (float)k;
+  const float color2 = d * d;
+  table[i] = k < BIL_ZERO ? ef_expf(-(space2 * sigma_space2_inv_half + color2 * sigma_color2_inv_half)) : 0.0f;
 }
 template <bool WITH_METRIC>
-__global__ void __launch_bounds__(256) k_preprocess(const uint16_t* __restrict__ raw, int cols, int rows, unsigned maxv,
+__global__ void __launch_bounds__(256) k_preprocess(const uint16_t* __restrict__ raw, int cols, int rows, unsigned maxv, const float* __restrict__ table,
                                                      uint16_t* __restrict__ filtered, float* __restrict__ metric,
                                                      float* __restrict__ metric_filtered) {
+  __shared__ __attribute__((aligned(16))) float tab[BIL_ROWS * BIL_COLS];
   __shared__ float tile[PRE_LH][PRE_LW];
   const int x0 = blockIdx.x * PRE_TW, y0 = blockIdx.y * PRE_TH;
   const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
+  {
+    const float4* src = (const float4*)table;
+    float4* dst = (float4*)tab;
+#pragma unroll
+    for (int i = 0; i < (BIL_ROWS * BIL_COLS / 4 + 255) / 256; ++i) {
+      const int q = t + i * 256;
+      if (q < BIL_ROWS * BIL_COLS / 4) dst[q] = src[q];
+    }
+  }
   for (int i = t; i < PRE_LH * PRE_LW; i += 256) {
     const int ly = i / PRE_LW, lx = i - ly * PRE_LW;
     const int gx = x0 + lx - PRE_R, gy = y0 + ly - PRE_R;
-    tile[ly][lx] = (gx >= 0 && gx < cols && gy >= 0 && gy < rows) ? (float)raw[gy * cols + gx] : 0.0f;
+    tile[ly][lx] = (gx >= 0 && gx < cols && gy >= 0 && gy < rows) ? (float)raw[gy * cols + gx] : BIL_OUTSIDE;
   }
   __syncthreads();
   const int x = x0 + tx, ya = y0 + ty, yb = ya + 4;
   if (x >= cols) return;
   const bool in_a = ya < rows, in_b = yb < rows;
   const float2v value = {tile[ty + PRE_R][tx + PRE_R], tile[ty + 4 + PRE_R][tx + PRE_R]};
-  const unsigned va = (unsigned)value.x, vb = (unsigned)value.y;
+  const unsigned va = in_a ? (unsigned)value.x : 0u, vb = in_b ? (unsigned)value.y : 0u;
   const bool gate_a = in_a && !(va > maxv || va < 300U), gate_b = in_b && !(vb > maxv || vb < 300U);
-  const float sigma_space2_inv_half = 0.024691358f, sigma_color2_inv_half = 0.000555556f;
-  const bool interior = x0 >= PRE_R && y0 >= PRE_R && x0 + PRE_TW + PRE_R <= cols && y0 + PRE_TH + PRE_R <= rows;   // block-uniform
   float2v sum1 = (float2v)(0.0f), sum2 = (float2v)(0.0f);
   if (gate_a || gate_b) {
+#pragma unroll
     for (int dy = -PRE_R; dy <= PRE_R; ++dy) {
-      const float fdy2 = (float)(dy * dy);
-      const bool row_a = interior || (ya + dy >= 0 && ya + dy < rows), row_b = interior || (yb + dy >= 0 && yb + dy < rows);
 #pragma unroll
       for (int dx = -PRE_R; dx <= PRE_R; ++dx) {
+        const float* row = tab + BIL.base[dy < 0 ? -dy : dy][dx < 0 ? -dx : dx];   // (an immediate once both loops are unrolled)
         const float2v tmp = {tile[ty + PRE_R + dy][tx + PRE_R + dx], tile[ty + 4 + PRE_R + dy][tx + PRE_R + dx]};
-        const float space2 = (float)(dx * dx) + fdy2;            // (x-cx)^2 + (y-cy)^2: exact small integers, any order
-        const float S = space2 * sigma_space2_inv_half;
         const float2v d = value - tmp;
-        const float2v color2 = d * d;
-        const float2v arg = (float2v)(S) + color2 * (float2v)(sigma_color2_inv_half);
-        float2v w = ef_expf2(-arg);
-        if (!interior) {
-          const bool col_ok = x + dx >= 0 && x + dx < cols;
-          if (!(col_ok && row_a)) w.x = 0.0f;
-          if (!(col_ok && row_b)) w.y = 0.0f;
-        }
+        const int ia = (int)fminf(fabsf(d.x), (float)BIL_ZERO), ib = (int)fminf(fabsf(d.y), (float)BIL_ZERO);
+        const float2v w = {row[ia], row[ib]};
         sum1 = sum1 + tmp * w;
         sum2 = sum2 + w;
       }
@@ -1132,17 +1150,34 @@ __global__ void __launch_bounds__(BLK) k_cand_scatter(Candidates cand, const uin
 // ------------------------------------------------------------------------------------------
 static inline dim3 tgrid(int cols, int rows) { return dim3(ceil_div(cols, 64), ceil_div(rows, 4)); }
 
+// The bilateral filter's weight table (k_bilateral_table): one 43 KB buffer per device for the life of the process, built on first use
+// (ef_create asks for it, so the first use is never inside a stream capture) and complete before the call returns.
+const float* bilateral_table() {
+  static std::mutex mu;
+  static float* tables[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tables[dev]) {
+    float* p = nullptr;
+    if (hipMalloc(&p, sizeof(float) * BIL_ROWS * BIL_COLS) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(k_bilateral_table, dim3(ceil_div(BIL_ROWS * BIL_COLS, 256)), dim3(256), 0, (hipStream_t)0, p);
+    if (hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+    tables[dev] = p;
+  }
+  return tables[dev];
+}
 void filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s) {
-  hipLaunchKernelGGL(k_preprocess<false>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered,
-                     (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(k_preprocess<false>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), bilateral_table(),
+                     filtered, (float*)nullptr, (float*)nullptr);
 }
 void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_metricise, dim3(ceil_div(cols * rows, 256)), dim3(256), 0, s, in, cols * rows, (unsigned)(maxD * 1000.0f), out);
 }
 void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric, float* metric_filtered,
                       hipStream_t s, unsigned extra_lds) {
-  hipLaunchKernelGGL(k_preprocess<true>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), extra_lds, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), filtered, metric,
-                     metric_filtered);
+  hipLaunchKernelGGL(k_preprocess<true>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), extra_lds, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), bilateral_table(),
+                     filtered, metric, metric_filtered);
 }
 namespace {
 __global__ void k_copy_map(SurfelSoA src, const unsigned* __restrict__ count_dev, SurfelSoA dst) {

@@ -4,14 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// Summation order of the fp32 normal-equation sums.  The shipped build uses THE FAST ORDER (ef_track_fast.inc: per-lane register
-// accumulation, adjacent-pair trees; specified in DESIGN.md 5.1 "The fast order", which the test suite's CPU checker restates bit for bit); the
-// reference-rounding build (-DEF_NO_FMA, libefusion_hip_nofma.so) keeps the REFERENCE's order (reduce.cu:57-140,313-317) and with it
-// the round-3 kernels, pinned against the compiled reduce.cu.  -DEF_REF_ORDER builds the round-3 product (FMAs + reference order) for A/B runs;
-// -DEF_NO_FMA -DEF_FORCE_FAST_ORDER the fourth corner (no FMAs + fast order) of the round-5 parity factorial (tools/parity_factorial.py).
-#if defined(EF_FORCE_FAST_ORDER) || (!defined(EF_NO_FMA) && !defined(EF_REF_ORDER))
-#define EF_FAST_ORDER 1
-#endif
+#include "ef_build.hpp"
+// Summation order of the fp32 normal-equation sums (ef_build.hpp decides).  The shipped default keeps the REFERENCE's order
+// (reduce.cu:57-140,313-317; kernels of DESIGN_reference_order.md, pinned against the compiled reduce.cu); -DEF_FAST_BUILD
+// (libefusion_hip_fast.so, opt-in) uses THE FAST ORDER (ef_track_fast.inc: per-lane register accumulation, adjacent-pair trees; specified in
+// DESIGN.md 5.1, which the test suite's CPU checker restates bit for bit).
 
 namespace eft {
 
@@ -127,7 +124,8 @@ struct Pyramid {               // one RGBDOdometry instance's device buffers (RG
   uint32_t* corres[NUM_PYRS];
   uint8_t* rgbMask[NUM_PYRS];      // iteration-invariant part of residualKernel's gates, built once per frame
   float* partials;                 // PARTIAL_ALLOC_FLOATS: region 0 (what the per-step kernels use), region 1, PtSync (zero-filled at allocation)
-  unsigned epoch = 1;              // fast order: next unused exchange epoch of this instance's persistent launches (host side; 0 = "never written")
+  unsigned epoch = 1;              // next unused exchange epoch of this instance's persistent launches (host side; 0 = "never written")
+  int last_mode = 0;               // host side: 1 = the exchange areas hold a 256-workgroup persistent launch's granules (k_track_fast / k_track_ref)
   int W(int l) const { return width >> l; }
   int H(int l) const { return height >> l; }
 };
@@ -141,18 +139,22 @@ struct KernelProbe {
   int used;
 };
 
-struct TrackParams {           // host-side knobs of getIncrementalTransformation
+struct TrackParams {           // host-side knobs of getIncrementalTransformation.  Compared and copied with memcmp / memcpy (the hipGraph cache key,
+                               // ef_context.hip): NO padding anywhere — every byte is a member (static_assert below)
   bool rgbOnly, pyramid, fastOdom, so3;
   float icpWeight;
   float distThres, angleThres; // RGBDOdometry.h:41-42
   int fused_step = 0;          // level-0 iterations: update step inside the correspondence-search launch (two launches per iteration)
-  // fast order, persistent launch only: when *empty_model_flag != empty_model_value the MODEL side of this call is known to be empty (the
+  int persistent = 1;          // 1: the whole call as ONE persistent launch of 256 workgroups (k_track_fast / k_track_ref); 0: one launch per step (round 2);
+                               // 2 (reference-order builds): round 3's launch of the small levels (k_track_small, 128 workgroups) + one launch per level-0 step
+  // persistent launch only: when *empty_model_flag != empty_model_value the MODEL side of this call is known to be empty (the
   // inactive prediction of the local loop closure showed no surfel: ElasticFusion.cpp:451-471 still runs the tracker on it) — no pixel can
   // find a correspondence in any iteration, every sum is zero, and the launch leaves what nineteen zero updates leave, at once
   const unsigned* empty_model_flag = nullptr;
   unsigned empty_model_value = 0;
-  int persistent = 1;          // (int: the struct is compared with memcmp, no tail padding) small levels + SO(3) in one persistent launch (k_track_small); false = one launch per step (round 2)
+  int reserved_ = 0;           // (explicit: no tail padding)
 };
+static_assert(sizeof(TrackParams) == 4 + 4 + 8 + 4 + 4 + 8 + 4 + 4, "TrackParams has no padding bytes (it is compared with memcmp)");
 
 // ---- operator-tier launchers (raw device pointers) ----
 void pyr_down_u16(const uint16_t* src, int scols, int srows, uint16_t* dst, hipStream_t s);

@@ -30,19 +30,29 @@ inline dim3 tile_block() { return dim3(TILE_X, TILE_Y); }
 // image operators
 // ------------------------------------------------------------------------------------------
 
-// pyrDownGaussKernel, cudafuncs.cu:75-109
+// pyrDownGaussKernel, cudafuncs.cu:75-109.  Round 5: all 25 taps are LOADED first (clamped addresses, one round trip) and the clipped
+// loops of the reference become predicated additions in the same order — the loops with their run-time bounds kept the compiler from
+// unrolling, and 25 dependent load -> use round trips (~12 us for a 320 x 240 image) were the whole cost of the pyramid kernels.
 __device__ __forceinline__ void pyr_down_u16_px(const uint16_t* __restrict__ src, int scols, int srows, uint16_t* __restrict__ dst, int x, int y) {
   const int dcols = scols / 2;
   const int D = 5;
   const float sigma_color = 30.f;
-  const int center = src[(2 * y) * scols + 2 * x];
-  const int x_mi = max(0, 2 * x - D / 2) - 2 * x, y_mi = max(0, 2 * y - D / 2) - 2 * y;
-  const int x_ma = min(scols, 2 * x - D / 2 + D) - 2 * x, y_ma = min(srows, 2 * y - D / 2 + D) - 2 * y;
+  int vals[D * D];
+#pragma unroll
+  for (int yi = -D / 2; yi <= D / 2; ++yi)
+#pragma unroll
+    for (int xi = -D / 2; xi <= D / 2; ++xi)
+      vals[(yi + D / 2) * D + xi + D / 2] = src[min(max(2 * y + yi, 0), srows - 1) * scols + min(max(2 * x + xi, 0), scols - 1)];
+  const int center = vals[(D / 2) * D + D / 2];
   float sum = 0, wall = 0;
-  for (int yi = y_mi; yi < y_ma; ++yi)
-    for (int xi = x_mi; xi < x_ma; ++xi) {
-      const int val = src[(2 * y + yi) * scols + 2 * x + xi];
-      if (abs(val - center) < 3 * sigma_color) {
+#pragma unroll
+  for (int yi = -D / 2; yi <= D / 2; ++yi)
+#pragma unroll
+    for (int xi = -D / 2; xi <= D / 2; ++xi) {
+      // the reference's bounds: max(0, 2 x - 2) - 2 x <= xi < min(scols, 2 x + 3) - 2 x (and the same in y)
+      const bool in = 2 * x + xi >= 0 && 2 * x + xi < scols && 2 * y + yi >= 0 && 2 * y + yi < srows;
+      const int val = vals[(yi + D / 2) * D + xi + D / 2];
+      if (in && abs(val - center) < 3 * sigma_color) {
         const int ax = abs(xi), ay = abs(yi);
         const float wx = ax == 0 ? 0.375f : (ax == 1 ? 0.25f : 0.0625f);
         const float wy = ay == 0 ? 0.375f : (ay == 1 ? 0.25f : 0.0625f);
@@ -219,17 +229,29 @@ __device__ __forceinline__ float gauss25(int idx) {  // {1 4 6 4 1} (x) {1 4 6 4
   return wr * wc;
 }
 
-// pyrDownKernelGaussF, cudafuncs.cu:383-411 (quirk Q7 kept)
+// {1 4 6 4 1}[r] as gauss25 indexes it (r counted from the END of the clipped window: quirk Q7), r in 0..4
+__device__ __forceinline__ float gauss5(int r) { return r == 2 ? 6.f : ((r == 1 || r == 3) ? 4.f : 1.f); }
+// pyrDownKernelGaussF, cudafuncs.cu:383-411 (quirk Q7 kept).  Round 5: taps loaded first, predicated additions in the reference's order (see
+// pyr_down_u16_px); the weight of window position (oy, ox) is gauss25((ty - cy - 1) * 5 + (tx - cx - 1)) as before.
 __device__ __forceinline__ void pyr_down_gauss_f_px(const float* __restrict__ src, int scols, int srows, float* __restrict__ dst, int x, int y) {
   const int dcols = scols / 2, D = 5;
   const int tx = min(2 * x - D / 2 + D, scols - 1), ty = min(2 * y - D / 2 + D, srows - 1);
+  float vals[D * D];
+#pragma unroll
+  for (int oy = 0; oy < D; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < D; ++ox)
+      vals[oy * D + ox] = src[min(max(2 * y - D / 2 + oy, 0), srows - 1) * scols + min(max(2 * x - D / 2 + ox, 0), scols - 1)];
   float sum = 0;
   int count = 0;
-  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-      const float s = src[cy * scols + cx];
-      if (!isnan(s)) {
-        const float g = gauss25((ty - cy - 1) * 5 + (tx - cx - 1));
+#pragma unroll
+  for (int oy = 0; oy < D; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < D; ++ox) {
+      const int cy = 2 * y - D / 2 + oy, cx = 2 * x - D / 2 + ox;
+      const float s = vals[oy * D + ox];
+      if (cy >= 0 && cy < ty && cx >= 0 && cx < tx && !isnan(s)) {
+        const float g = gauss5(ty - cy - 1) * gauss5(tx - cx - 1);
         sum += s * g;
         count = (int)((float)count + g);
       }
@@ -242,18 +264,27 @@ __global__ void k_pyr_down_gauss_f(const float* __restrict__ src, int scols, int
   pyr_down_gauss_f_px(src, scols, srows, dst, x, y);
 }
 
-// pyrDownKernelIntensityGauss, cudafuncs.cu:512-542
+// pyrDownKernelIntensityGauss, cudafuncs.cu:512-542 (taps loaded first, as above)
 __device__ __forceinline__ void pyr_down_uchar_gauss_px(const uint8_t* __restrict__ src, int scols, int srows, uint8_t* __restrict__ dst, int x, int y) {
   const int dcols = scols / 2, D = 5;
   const int tx = min(2 * x - D / 2 + D, scols - 1), ty = min(2 * y - D / 2 + D, srows - 1);
+  int vals[D * D];
+#pragma unroll
+  for (int oy = 0; oy < D; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < D; ++ox)
+      vals[oy * D + ox] = src[min(max(2 * y - D / 2 + oy, 0), srows - 1) * scols + min(max(2 * x - D / 2 + ox, 0), scols - 1)];
   float sum = 0;
   int count = 0;
-  for (int cy = max(0, 2 * y - D / 2); cy < ty; ++cy)
-    for (int cx = max(0, 2 * x - D / 2); cx < tx; ++cx) {
-      const int s = src[cy * scols + cx];
-      if (s > 0) {
-        const float g = gauss25((ty - cy - 1) * 5 + (tx - cx - 1));
-        sum += (float)s * g;
+#pragma unroll
+  for (int oy = 0; oy < D; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < D; ++ox) {
+      const int cy = 2 * y - D / 2 + oy, cx = 2 * x - D / 2 + ox;
+      const int sv = vals[oy * D + ox];
+      if (cy >= 0 && cy < ty && cx >= 0 && cx < tx && sv > 0) {
+        const float g = gauss5(ty - cy - 1) * gauss5(tx - cx - 1);
+        sum += (float)sv * g;
         count = (int)((float)count + g);
       }
     }
@@ -304,21 +335,58 @@ __global__ void k_bgr_to_intensity(const uint8_t* __restrict__ src, int n, uint8
   dst[i] = intensity_of((float)s[0], (float)s[1], (float)s[2]);
 }
 
-// applyKernel, cudafuncs.cu:612-637 (quirk Q6 kept)
-__device__ __forceinline__ void sobel_px(const uint8_t* __restrict__ src, int cols, int rows, int x, int y, int16_t* dx, int16_t* dy) {
+// applyKernel, cudafuncs.cu:612-637 (quirk Q6 kept: the kernel index k counts down over the taps the clipped loops VISIT, so it shifts
+// at the image border).  Round 5: the nine taps come preloaded (v[dj + 1][di + 1], anything where the tap is outside the image) and the
+// loops become predicated additions in the reference's order; interior pixels see compile-time weights.
+__device__ __forceinline__ float sobel_gsx(int k) {   // gsx[k] of cudafuncs.cu:612-637
+  const float a = 0.52201f, b = 0.79451f;
+  return k == 8 ? -a : k == 7 ? 0.00000f : k == 6 ? a : k == 5 ? -b : k == 4 ? -0.00000f : k == 3 ? b : k == 2 ? -a : k == 1 ? 0.00000f : a;
+}
+__device__ __forceinline__ float sobel_gsy(int k) {
+  const float a = 0.52201f, b = 0.79451f;
+  return k == 8 ? -a : k == 7 ? -b : k == 6 ? -a : (k >= 3) ? 0.00000f : k == 2 ? a : k == 1 ? b : a;
+}
+__device__ __forceinline__ void sobel_taps(const float (&v)[3][3], int cols, int rows, int x, int y, int16_t& dx, int16_t& dy) {
   const float gsx[9] = {0.52201f, 0.00000f, -0.52201f, 0.79451f, -0.00000f, -0.79451f, 0.52201f, 0.00000f, -0.52201f};
   const float gsy[9] = {0.52201f, 0.79451f, 0.52201f, 0.00000f, 0.00000f, 0.00000f, -0.52201f, -0.79451f, -0.52201f};
   float dxVal = 0, dyVal = 0;
-  int k = 8;
-  for (int j = max(y - 1, 0); j <= min(y + 1, rows - 1); ++j)
-    for (int i = max(x - 1, 0); i <= min(x + 1, cols - 1); ++i) {
-      const float s = (float)src[j * cols + i];
-      dxVal += s * gsx[k];
-      dyVal += s * gsy[k];
-      --k;
-    }
-  dx[y * cols + x] = (int16_t)(int)dxVal;
-  dy[y * cols + x] = (int16_t)(int)dyVal;
+  if (x >= 1 && y >= 1 && x <= cols - 2 && y <= rows - 2) {
+    int k = 8;
+#pragma unroll
+    for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+      for (int di = 0; di < 3; ++di) {
+        dxVal += v[dj][di] * gsx[k];
+        dyVal += v[dj][di] * gsy[k];
+        --k;
+      }
+  } else {
+    const int jlo = max(y - 1, 0), ilo = max(x - 1, 0), ni = min(x + 1, cols - 1) - ilo + 1;
+#pragma unroll
+    for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+      for (int di = 0; di < 3; ++di) {
+        const int j = y - 1 + dj, i = x - 1 + di;
+        if (j >= 0 && j <= rows - 1 && i >= 0 && i <= cols - 1) {
+          const int k = 8 - ((j - jlo) * ni + (i - ilo));
+          dxVal += v[dj][di] * sobel_gsx(k);
+          dyVal += v[dj][di] * sobel_gsy(k);
+        }
+      }
+  }
+  dx = (int16_t)(int)dxVal;
+  dy = (int16_t)(int)dyVal;
+}
+__device__ __forceinline__ void sobel_px(const uint8_t* __restrict__ src, int cols, int rows, int x, int y, int16_t* dx, int16_t* dy) {
+  float v[3][3];
+#pragma unroll
+  for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+    for (int di = 0; di < 3; ++di) v[dj][di] = (float)src[min(max(y - 1 + dj, 0), rows - 1) * cols + min(max(x - 1 + di, 0), cols - 1)];
+  int16_t ox, oy;
+  sobel_taps(v, cols, rows, x, y, ox, oy);
+  dx[y * cols + x] = ox;
+  dy[y * cols + x] = oy;
 }
 __global__ void k_sobel(const uint8_t* __restrict__ src, int cols, int rows, int16_t* __restrict__ dx, int16_t* __restrict__ dy) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -351,17 +419,35 @@ __global__ void k_sobel_levels(const SobelLevels L) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= cols || y >= rows) return;
   const uint8_t* __restrict__ img = L.src[l];
-  sobel_px(img, cols, rows, x, y, L.dx[l], L.dy[l]);
   const int k = y * cols + x;
+  // the 4 x 4 window (y - 2 .. y + 1) x (x - 2 .. x + 1) covers the Sobel taps and the "no zero pixel" window: 16 loads, one round trip
+  int w[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) w[a][b] = img[min(max(y - 2 + a, 0), rows - 1) * cols + min(max(x - 2 + b, 0), cols - 1)];
+  const float nd = L.nextDepth[l][k];
+  float v[3][3];
+#pragma unroll
+  for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+    for (int di = 0; di < 3; ++di) v[dj][di] = (float)w[dj + 1][di + 1];
+  int16_t sx, sy;
+  sobel_taps(v, cols, rows, x, y, sx, sy);
+  L.dx[l][k] = sx;
+  L.dy[l][k] = sy;
   bool ok = (x < cols - 5 && y < rows - 1);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {   // u in [max(y - 2, 0), min(y + 2, rows)), v in [max(x - 2, 0), min(x + 2, cols))
+      const int u = y - 2 + a, vv = x - 2 + b;
+      if (u >= 0 && u < rows && vv >= 0 && vv < cols) ok = ok && (w[a][b] > 0);
+    }
   if (ok) {
-    for (int u = max(y - 2, 0); u < min(y + 2, rows); ++u)
-      for (int v = max(x - 2, 0); v < min(x + 2, cols); ++v) ok = ok && (img[u * cols + v] > 0);
-  }
-  if (ok) {
-    const int valx = L.dx[l][k], valy = L.dy[l][k];
+    const int valx = sx, valy = sy;
     const float mTwo = (float)((valx * valx) + (valy * valy));
-    ok = mTwo >= L.minScale[l] && !isnan(L.nextDepth[l][k]);
+    ok = mTwo >= L.minScale[l] && !isnan(nd);
   }
   L.mask[l][k] = ok ? 1 : 0;
   L.corres[l][k] = 0u;
@@ -1632,8 +1718,12 @@ __device__ __forceinline__ void head_sums(const float* __restrict__ pairs, int n
 #ifdef EF_FAST_ORDER
   fast_tree<BLOCK, false>(pairs, ng, (icp ? SE3_ACCS : 0) + (rgb ? SE3_ACCS : 0), sums_s + (icp ? 0 : SE3_ACCS));
 #else
-  (void)ng;
-  pair_partials_tree<BLOCK>(pairs, icp, rgb, sums_s);
+  if (ng == 1) {   // the persistent launch's reducers left the TOTALS in column 0 of every accumulator (k_track_ref)
+    const int na = (icp ? SE3_ACCS : 0) + (rgb ? SE3_ACCS : 0);
+    if ((int)threadIdx.x < na) sums_s[(icp ? 0 : SE3_ACCS) + threadIdx.x] = pairs[(size_t)threadIdx.x * 256];
+  } else {
+    pair_partials_tree<BLOCK>(pairs, icp, rgb, sums_s);
+  }
 #endif
 }
 
@@ -2543,8 +2633,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
   }
 }
 
+#include "ef_track_exchange.inc"
 #ifdef EF_FAST_ORDER
 #include "ef_track_fast_persistent.inc"
+#else
+#include "ef_track_ref_persistent.inc"
 #endif
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -2958,7 +3051,7 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
   // "break" bookkeeping is not in the persistent kernel).
   int n_small = 0;
   PtArgs PA{};
-  if (tp.persistent && !tp.rgbOnly) {
+  if (tp.persistent == 2 && !tp.rgbOnly) {   // (reference-order builds only: the fast order has no launch of the small levels)
     bool fits = true;
     for (int i = NUM_PYRS - 1; i >= 0 && fits; --i) {
       if (iterations[i] == 0) continue;
@@ -2967,12 +3060,21 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
     }
   }
   int it = 0, cur = 0, prev_level = first_level;
-#ifdef EF_FAST_ORDER
-  // The fast order's persistent launch takes the WHOLE call — k_track_begin, the SO(3) loop, every iteration of every level
-  // (k_track_fast, ef_track_fast_persistent.inc) — or, with `persistent` off / rgbOnly (whose per-level "break" bookkeeping is not in
-  // the kernel), nothing: then every step is its own launch, in the same order of additions.
+  // The persistent launch of 256 co-resident workgroups takes the WHOLE call — k_track_begin, the SO(3) loop, every iteration of every level
+  // (fast order: k_track_fast, ef_track_fast_persistent.inc; reference order: k_track_ref, ef_track_ref_persistent.inc) — or, with `persistent`
+  // off / rgbOnly (whose per-level "break" bookkeeping is not in the kernels), nothing: then every step is its own launch, in the same order
+  // of additions.  (Reference-order builds: persistent == 2 asks for round 3's launch of the small levels, k_track_small, below.)
   const int n_total = iterations[0] + iterations[1] + iterations[2];
-  if (tp.persistent && !tp.rgbOnly && n_total <= FT_MAX_ITER) {
+#ifdef EF_FAST_ORDER
+  const int pmode = tp.persistent ? 1 : 0;
+#else
+  const int pmode = tp.persistent;
+#endif
+  if (pmode == 1 && !tp.rgbOnly && n_total <= FT_MAX_ITER) {
+    if (p.last_mode != 1) {   // another script of this instance may have left anything in the exchange areas: tags must never match by accident
+      (void)hipMemsetAsync(p.partials, 0, sizeof(float) * PARTIAL_ALLOC_FLOATS, s);
+      p.last_mode = 1;
+    }
     FtArgs FA{};
     for (int i = 0; i < NUM_PYRS; ++i)
       FA.L[i] = PtLevel{p.vmap_curr[i], p.nmap_curr[i], p.vmap_g_prev[i], p.nmap_g_prev[i], p.rgbMask[i], p.lastDepth[i], p.nextDepth[i],
@@ -3016,20 +3118,37 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
       hipEvent_t& ev = chain_ev[dev & 63];
       if (ev) (void)hipStreamWaitEvent(s, ev, 0);
       else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+#ifdef EF_FAST_ORDER
       if (icp && rgb) hipExtLaunchKernelGGL((k_track_fast<true, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
       else if (icp) hipExtLaunchKernelGGL((k_track_fast<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
       else hipExtLaunchKernelGGL((k_track_fast<false, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
+#else
+      if (icp && rgb) hipExtLaunchKernelGGL((k_track_ref<true, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
+      else if (icp) hipExtLaunchKernelGGL((k_track_ref<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
+      else hipExtLaunchKernelGGL((k_track_ref<false, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
+#endif
       if (ev) (void)hipEventRecord(ev, s);
     }
     // (returns at once unless the launch above found part of the chip taken: see its admission step)
+#ifdef EF_FAST_ORDER
     if (icp && rgb) hipLaunchKernelGGL((k_track_serial<true, true>), dim3(1), dim3(REDUCE_BLOCK), 0, s, p.partials, st, FA.epoch);
     else if (icp) hipLaunchKernelGGL((k_track_serial<true, false>), dim3(1), dim3(REDUCE_BLOCK), 0, s, p.partials, st, FA.epoch);
     else hipLaunchKernelGGL((k_track_serial<false, true>), dim3(1), dim3(REDUCE_BLOCK), 0, s, p.partials, st, FA.epoch);
+#else
+    if (icp && rgb) hipLaunchKernelGGL((k_track_ref_serial<true, true>), dim3(1), dim3(FT_BLOCK), 0, s, p.partials, st, FA.epoch);
+    else if (icp) hipLaunchKernelGGL((k_track_ref_serial<true, false>), dim3(1), dim3(FT_BLOCK), 0, s, p.partials, st, FA.epoch);
+    else hipLaunchKernelGGL((k_track_ref_serial<false, true>), dim3(1), dim3(FT_BLOCK), 0, s, p.partials, st, FA.epoch);
+#endif
     track_swap(p, tp);
     TrackTail tail{0, (n - 1) & 1, n > 0, icp, rgb, tp.rgbOnly, tp.icpWeight, intr_level(k, 0), p.partials + FT_P_OFF};
     tail.ng = 1;   // the reducers of the last iteration left the TOTALS in column 0
     return tail;
   }
+  if (p.last_mode == 1) {   // (the per-step kernels' plain partials and k_track_small's barrier words start from zeros)
+    (void)hipMemsetAsync(p.partials, 0, sizeof(float) * PARTIAL_ALLOC_FLOATS, s);
+    p.last_mode = 0;
+  }
+#ifdef EF_FAST_ORDER
   n_small = 0;
   hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st, tp.so3, intr_level(k, so3_level), intr_level(k, first_level));
   if (tp.so3) {
@@ -3039,7 +3158,7 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
                          intr_level(k, so3_level), intr_level(k, first_level), i, st, p.partials);
   }
 #else
-  if (tp.persistent && !tp.rgbOnly && (n_small > 0 || tp.so3)) {
+  if (tp.persistent == 2 && !tp.rgbOnly && (n_small > 0 || tp.so3)) {
     for (int i = 0; i < NUM_PYRS; ++i)
       PA.L[i] = PtLevel{p.vmap_curr[i], p.nmap_curr[i], p.vmap_g_prev[i], p.nmap_g_prev[i], p.rgbMask[i], p.lastDepth[i], p.nextDepth[i],
                         p.lastImage[i], p.nextImage[i], p.corres[i], p.dIdx[i], p.dIdy[i], p.W(i), p.H(i), intr_level(k, i)};
@@ -3093,10 +3212,9 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
 // developer instrumentation: the -DEF_STAGE_CLOCKS sums of k_track_small (24 x u64, 10 ns ticks; zeros in a normal build), read and reset
 int tracker_small_clocks(const Pyramid& p, unsigned long long* out24, hipStream_t s) {
   if (!p.partials) return -1;
-#ifdef EF_FAST_ORDER
   unsigned long long* src = (unsigned long long*)((char*)(p.partials + FT_SY_OFF) + offsetof(FtSync, clk));
-#else
-  unsigned long long* src = (unsigned long long*)((char*)(p.partials + 2 * PARTIAL_FLOATS) + offsetof(PtSync, clk));
+#ifndef EF_FAST_ORDER
+  if (p.last_mode != 1) src = (unsigned long long*)((char*)(p.partials + 2 * PARTIAL_FLOATS) + offsetof(PtSync, clk));   // k_track_small
 #endif
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   if (hipMemcpy(out24, src, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
@@ -3104,29 +3222,25 @@ int tracker_small_clocks(const Pyramid& p, unsigned long long* out24, hipStream_
 }
 int tracker_aborted(const Pyramid& p, hipStream_t s) {
   if (!p.partials) return 0;
-#ifdef EF_FAST_ORDER
+#ifndef EF_FAST_ORDER
+  if (p.last_mode != 1) {   // round 3's launch of the small levels (k_track_small) keeps its flag in PtSync
+    PtSync h;
+    if (hipMemcpyAsync(&h, p.partials + 2 * PARTIAL_FLOATS, offsetof(PtSync, wg_sums), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    return h.abort != 0 ? 1 : 0;
+  }
+#endif
   unsigned flag = 0;
   if (hipMemcpyAsync(&flag, (const char*)(p.partials + FT_SY_OFF) + offsetof(FtSync, abort), sizeof(flag), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   return flag != 0 ? 1 : 0;
-#else
-  PtSync h;
-  if (hipMemcpyAsync(&h, p.partials + 2 * PARTIAL_FLOATS, offsetof(PtSync, wg_sums), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
-  if (hipStreamSynchronize(s) != hipSuccess) return -1;
-  return h.abort != 0 ? 1 : 0;
-#endif
 }
 int tracker_fallbacks(const Pyramid& p, hipStream_t s) {
-#ifdef EF_FAST_ORDER
-  if (!p.partials) return 0;
+  if (!p.partials || p.last_mode != 1) return 0;
   unsigned n = 0;
   if (hipMemcpyAsync(&n, (const char*)(p.partials + FT_SY_OFF) + offsetof(FtSync, fallbacks), sizeof(n), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   return (int)n;
-#else
-  (void)p; (void)s;
-  return 0;
-#endif
 }
 void track_swap(Pyramid& p, const TrackParams& tp) {
   if (tp.so3)

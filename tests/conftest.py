@@ -64,6 +64,21 @@ def oracle_state(frames):
     return f
 
 
+@pytest.fixture()
+def fast_pair():
+    """The OPT-IN fast build and ITS specification: api bound to libefusion_hip_fast.so, efo to libefo_oracle_fast.so (fused multiply-adds +
+    the fast summation order).  Everything else in the suite runs the default pair = the reference rounding.  Yields the api module;
+    oracle objects must be created inside the test."""
+    import efo
+    from elasticfusion_amd import api, build
+    api.use_library(build.FAST_LIB)
+    try:
+        with efo.whole_library("fast"):
+            yield api
+    finally:
+        api.use_library(None)
+
+
 def rgba_of(rgb):
     h, w, _ = rgb.shape
     out = np.full((h, w, 4), 255, np.uint8)

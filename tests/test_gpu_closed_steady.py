@@ -56,7 +56,9 @@ def test_closed_loop_steady_state_matches_oracle_at_default_thresholds():
         assert same_floats(np.array(a.stats, np.float32), np.array(b.stats, np.float32)), (k, list(a.stats), list(b.stats))
         assert same_floats(np.array(a.cov_diag), np.array(b.cov_diag)), (k, list(a.cov_diag), list(b.cov_diag))
         assert same_floats(np.array(a.T_wc_est), np.array(b.T_wc_est)), k
-        assert np.array_equal(bits(ca), bits(cb)), k
+        # the constraints are T * (x, y, z, 1) in DOUBLE with T = the double pose matrices, which may differ in their last bit between the
+        # GPU's and the host's libm (sin / cos of the update step: DESIGN.md 2, the 1e-15 of the pose assertion above); times and pins exact
+        assert ca.shape == cb.shape and np.array_equal(bits(ca[:, 6:]), bits(cb[:, 6:])) and (len(ca) == 0 or np.abs(ca - cb).max() <= 4e-15), k
         second_tracker_frames += int(a.attempted and a.stats[1] > 0)
         if a.gates_ok and not opened:
             inactive_before = prev_inactive

@@ -1,6 +1,6 @@
-"""GPU: the persistent tracker launch when part of the chip is taken.
+"""GPU: the persistent tracker launch (the default build's k_track_ref and the opt-in fast build's k_track_fast) when part of the chip is taken.
 
-k_track_fast needs its 256 workgroups resident together.  Other work that holds CUs for milliseconds (another process, a long kernel on
+The launch needs its 256 workgroups resident together.  Other work that holds CUs for milliseconds (another process, a long kernel on
 another stream) makes that impossible; the launch then notices at its admission step and runs the whole call on workgroup 0 alone
 (ef_track_fast_persistent.inc: ft_serial) — slower, but the same tasks, partials and trees: the results must stay bit-identical to the
 oracle, with no error, no flag to clear and no host in the loop (VERDICT r3 item 8 / ADVICE r3: "degrade, not invalidate")."""
@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 
 def test_starved_persistent_launch_falls_back_and_stays_oracle_identical(seq):
     from elasticfusion_amd import api
+    run_starved(api, seq)
+
+
+def test_starved_persistent_launch_of_the_fast_build_falls_back(fast_pair, seq):
+    run_starved(fast_pair, seq)
+
+
+def run_starved(api, seq):
     n = 10
     frames = [seq.frame(k) for k in range(n)]
     o = efo.Fusion()

@@ -122,12 +122,13 @@ def test_pipelined_frames_match_oracle(hip, seq):
 
 @pytest.mark.parametrize("cfg", [dict(), dict(icpThresh=100.0), dict(so3=False), dict(fastOdom=True)], ids=["default", "icp_only", "no_so3", "fastOdom"])
 def test_persistent_and_per_step_tracker_scripts_agree(hip, seq, cfg):
-    """The small pyramid levels + SO(3) as ONE persistent launch (k_track_small, the default since round 3) and as one launch per step
-    (ef_set_persistent_tracker(ctx, 0), the round-2 script) are the same arithmetic in the same order: statistics, pose, trajectory
-    and map must be bit-identical, frame after frame — whichever of the two the oracle comparisons of this file ran."""
+    """The whole tracker as ONE persistent launch of 256 workgroups (the default: k_track_ref in the reference order since round 5, k_track_fast in
+    the opt-in fast build), as one launch per step (ef_set_persistent_tracker(ctx, 0), the round-2 script) and — reference-order builds —
+    as round 3's launch of the small levels on 128 workgroups (mode 2: k_track_small) are the same arithmetic in the same order: statistics,
+    pose, trajectory and map must be bit-identical, frame after frame — whichever of them the oracle comparisons of this file ran."""
     n = 14
     runs = []
-    for persistent, fused in ((True, False), (False, False), (True, True)):   # fused: level-0 update step inside the search launch (ef_set_fused_step)
+    for persistent, fused in ((1, False), (0, False), (1, True), (2, False)):   # fused: level-0 update step inside the search launch (ef_set_fused_step)
         ef = hip.ElasticFusion(**cfg)
         ef.setPersistentTracker(persistent)
         ef.setFusedStep(fused)
@@ -140,7 +141,7 @@ def test_persistent_and_per_step_tracker_scripts_agree(hip, seq, cfg):
         ef.synchronize()                      # also: no barrier of the persistent launches timed out
         runs.append((rec, ef.downloadMap()))
         ef.close()
-    for other in (1, 2):
+    for other in (1, 2, 3):
         for k in range(1, n):
             for x, y in zip(runs[0][0][k], runs[other][0][k]):
                 assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), (other, k, x, y)

@@ -5,10 +5,10 @@ become stable, so only a long run reaches the regime the headline metric is meas
 by the MODEL prediction (denseEnough, ElasticFusion.cpp:256-268,304-305), combinedPredict with real overdraw, clean()
 removing stale unstable surfels (copy_unstable.vert:114-120).  Three comparisons:
 
-  1. product build (fused multiply-adds as specified) vs the oracle, bit for bit, frame after frame, with and without
-     sensor noise;
-  2. the no-FMA build vs the no-FMA oracle (== the reference's own sources compiled without contraction), bit for bit;
-  3. product build vs no-FMA build, both free-running: the divergence two legitimate roundings of the same arithmetic
+  1. the shipped default (reference rounding: no fused multiply-add, the reference's summation order) vs the oracle (== the
+     reference's own sources compiled without contraction), bit for bit, frame after frame, with and without sensor noise;
+  2. the opt-in fast build vs its oracle, bit for bit: tests/test_gpu_fast_build.py::test_steady_state_equals_the_fast_oracle;
+  3. default vs fast build, both free-running: the divergence two legitimate roundings of the same arithmetic
      accumulate over 130 frames, held against the north_star bars (pose 1e-4 m / 1e-4 rad, surfels 1e-5 relative).
 """
 import json
@@ -38,19 +38,25 @@ def _frame_job(args):
 _frame_job.cache = {}
 
 
-@pytest.fixture(scope="module")
-def sequences():
-    """{name: [(rgb, depth, T_wc)] * N}; generated once per module (spawned workers: the parent may already hold a HIP runtime)"""
+def make_sequences(names=("clean", "noisy")):
+    """{name: [(rgb, depth, T_wc)] * N} (spawned workers: the parent may already hold a HIP runtime)"""
     import multiprocessing as mp
     from elasticfusion_amd import synth
     out = {}
     ctx = mp.get_context("spawn")
     with ctx.Pool(max(1, min(16, (os.cpu_count() or 2) - 1))) as pool:
         pending = pool.map_async(_frame_job, [(SEQS["clean"]["seed"], k) for k in range(N)], chunksize=4)
-        s = synth.Sequence(SEQS["noisy"]["seed"], noise=True)   # the noise generator is one stream: these frames are made in order
-        out["noisy"] = [s.frame(k) for k in range(N)]
+        if "noisy" in names:
+            s = synth.Sequence(SEQS["noisy"]["seed"], noise=True)   # the noise generator is one stream: these frames are made in order
+            out["noisy"] = [s.frame(k) for k in range(N)]
         out["clean"] = pending.get()
     return out
+
+
+@pytest.fixture(scope="module")
+def sequences():
+    """generated once per module"""
+    return make_sequences()
 
 
 def dense_enough(image_rgba):
@@ -140,21 +146,6 @@ def test_default_config_reaches_steady_state_and_matches_oracle(sequences, name)
                        frames_with_stale_candidates=int(sum(c > 0 for c in h["stale_candidates"]))), f)
 
 
-def test_nofma_build_matches_reference_arithmetic_in_steady_state(sequences):
-    """libefusion_hip_nofma.so (every specified FMA split into multiply + add) against the oracle built the same way, which is
-    bit for bit what the reference's own .cu / .cpp / GLSL sources compute when compiled without contraction (oracle/README.md)."""
-    from elasticfusion_amd import api, build
-    frames = sequences["clean"]
-    api.use_library(build.NOFMA_LIB)
-    try:
-        h = run_hip(api, frames)
-    finally:
-        api.use_library(None)
-    with efo.whole_library("nofma"):
-        o = run_oracle(frames)
-    assert_same_run(h, o, "nofma")
-
-
 def pose_err(T, Tr):
     dt = float(np.linalg.norm(T[:3, 3] - Tr[:3, 3]))
     dR = T[:3, :3].T @ Tr[:3, :3]
@@ -162,9 +153,9 @@ def pose_err(T, Tr):
 
 
 def test_fma_placement_divergence_free_running(sequences):
-    """Product build vs no-FMA build, both free-running on the same frames.  nvcc's actual FMA choices cannot be observed here;
-    the two builds bracket them (everything the specification fuses vs nothing fused), so their divergence says how far a real
-    nvcc build of the reference can sit from the product.
+    """The shipped default (reference rounding) vs the opt-in fast build (fused multiply-adds + fast order), both free-running on the
+    same frames.  nvcc's actual FMA choices cannot be observed here; the two builds bracket them (nothing fused vs everything the
+    specification fuses), so their divergence says how far a real nvcc build of the reference can sit from either.
 
     MEASURED (MI355X, round 2, gpurun_out/fma_divergence.json): the two roundings part at the second frame and sit
     1-3 mm / 1-2 mrad apart after 130 frames — the tracker is a feedback loop (pose -> association -> map -> pose) that amplifies a
@@ -175,10 +166,10 @@ def test_fma_placement_divergence_free_running(sequences):
     from scipy.spatial import cKDTree
     from elasticfusion_amd import api, build
     frames = sequences["clean"]
-    a = run_hip(api, frames)
-    api.use_library(build.NOFMA_LIB)
+    b = run_hip(api, frames)                    # b: the shipped default = reference rounding
+    api.use_library(build.FAST_LIB)
     try:
-        b = run_hip(api, frames)
+        a = run_hip(api, frames)                # a: the opt-in fast build
     finally:
         api.use_library(None)
     errs = [pose_err(a["pose"][k], b["pose"][k]) for k in range(N)]
@@ -191,10 +182,10 @@ def test_fma_placement_divergence_free_running(sequences):
     d, idx = cKDTree(mb[:, :3].astype(np.float64)).query(ma[:, :3].astype(np.float64))
     scale = np.linalg.norm(ma[:, :3], axis=1)
     rec = dict(frames=N, max_pose_divergence_m=max_dt, max_pose_divergence_rad=max_da, final_pose_divergence_m=errs[-1][0],
-               surfels_product=int(len(ma)), surfels_nofma=int(len(mb)),
+               surfels_fast_build=int(len(ma)), surfels_reference_rounding=int(len(mb)),
                fraction_position_within_1e5_relative=float((d <= 1e-5 * scale).mean()),
                fraction_position_within_5mm=float((d <= 5e-3).mean()), median_surfel_distance_m=float(np.median(d)),
-               max_err_vs_generating_traj_product_m=max(err_a), max_err_vs_generating_traj_nofma_m=max(err_b),
+               max_err_vs_generating_traj_fast_build_m=max(err_a), max_err_vs_generating_traj_reference_rounding_m=max(err_b),
                north_star_pose_bar_met=bool(max_dt <= 1e-4 and max_da <= 1e-4),
                identical_trajectory_frames=int(sum(np.array_equal(a["pose"][k], b["pose"][k]) for k in range(N))))
     os.makedirs(OUT, exist_ok=True)

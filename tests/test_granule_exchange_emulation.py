@@ -30,10 +30,11 @@ def lib(tmp_path_factory):
     a = open(os.path.join(CSRC, "ef_track_fast.inc")).read()
     b = open(os.path.join(CSRC, "ef_track_fast_persistent.inc")).read()
     i, j = a.index("struct FastPlan {"), a.index("// lane 0 receives the adjacent-pair tree")
-    k, l = b.index("__device__ __forceinline__ int ft_column("), b.index("__device__ __forceinline__ int ft_level_of(")
+    k, l = b.index("__device__ __forceinline__ int ft_column("), b.index("// the reducer's part of exchange B")
     text = a[i:j] + b[k:l]
     assert "fast_group_of" in text and "ft_column" in text and "fast_plan" in text
-    wgs = int(re.search(r"constexpr int FT_WGS = (\d+)", b).group(1))
+    x = open(os.path.join(CSRC, "ef_track_exchange.inc")).read()   # the exchanges themselves (shared by both summation orders since round 5)
+    wgs = int(re.search(r"constexpr int FT_WGS = (\d+)", x).group(1))
     cut = os.path.join(tmp, "exchange_cut.inc")
     open(cut, "w").write(text)
     so = os.path.join(tmp, "exchange.so")

@@ -1,4 +1,4 @@
-"""CPU: THE FAST ORDER (the summation order of the shipped build, oracle/efo_track.cpp) against an independent numpy restatement of its
+"""CPU: THE FAST ORDER (the summation order of the opt-in fast build libefusion_hip_fast.so, oracle/efo_track.cpp built -DEFO_FAST_ORDER = libefo_oracle_fast.so) against an independent numpy restatement of its
 specification, bit for bit: row-groups of 64 pixels; U = max(1, ceil(RG / 1024)) row-groups per task; leaf (task, lane) adds its pixels in
 order; the total is the complete adjacent-pair binary tree over the leaves in index order task * 64 + lane (missing leaves = +0).
 The HIP kernels are held to the oracle's sums bit for bit (tests/test_gpu_ops_tracking.py, test_gpu_frame.py, ...); this file holds the
@@ -33,7 +33,9 @@ def spec_sum(v):
 
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 4800, 7600, 19200, 76800, 100 * 76, 307200, 332 * 252, 1228800])
 def test_fast_order_sum_equals_the_specification(n):
-    lib = efo.lib()
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", efo.ORACLE_DIR, "libefo_oracle_fast.so"])
+    lib = C.CDLL(efo.FAST_SO)
     lib.efo_fast_order_sum.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.efo_fast_order_sum.restype = None
     rng = np.random.RandomState(n)

@@ -1,0 +1,42 @@
+#!/bin/bash
+# One GPU-box visit (round 5): usage (repo root on the GPU box): bash tools/gpu_visit.sh <tag> <what...>
+#   tests        the whole -m gpu suite (no -x: every failure is seen) + smoke()
+#   ab           200-step bench of the default library and of the listed variants on THIS box (same frames): AB_LIBS="- fast nofma_fast"
+#   pytest:<expr>   python -m pytest tests -m gpu -k <expr>
+tag=${1:-run}; shift
+out=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $out
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+for what in "$@"; do
+  case $what in
+    tests)
+      timeout 900 python -m pytest tests -m gpu -q --timeout=300 --durations=10 > $out/${tag}_gpu_tests.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_gpu_tests.log
+      grep -E "passed|failed|error|FAILED|ERROR" $out/${tag}_gpu_tests.log | tail -30 | cut -c1-300
+      timeout 120 python __graft_entry__.py --smoke > $out/${tag}_smoke.log 2>&1; echo "smoke rc=$?" >> $out/${tag}_smoke.log
+      tail -3 $out/${tag}_smoke.log ;;
+    pytest:*)
+      timeout 600 python -m pytest tests -m gpu -q --timeout=300 -k "${what#pytest:}" > $out/${tag}_gpu_tests_k.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_gpu_tests_k.log
+      tail -25 $out/${tag}_gpu_tests_k.log | cut -c1-300 ;;
+    ab2)   # in-process A/B (tools/ab_bench.py): AB_SPECS="d d@2 fast"
+      timeout 400 python tools/ab_bench.py ${AB_ARGS:-} ${AB_SPECS:-d fast} 2>&1 | grep -v "^$" | tee -a $out/${tag}_ab.log | tail -12 ;;
+    clocks)
+      timeout 120 python tools/fast_clocks.py elasticfusion_amd/libefusion_hip_clocks.so 140 > $out/${tag}_clocks.jsonl 2>$out/${tag}_clocks.err; cat $out/${tag}_clocks.jsonl; tail -2 $out/${tag}_clocks.err ;;
+    ab)
+      for rep in 1 2; do
+        for v in ${AB_LIBS:-- fast}; do
+          # "-" = the default library; "name" = libefusion_hip_<name>.so; "+flag" = the default library with bench.py --flag (e.g. +round3-tracker)
+          lib=""
+          case $v in
+            -) ;;
+            +*) lib="--${v#+}" ;;
+            *) lib="--library $GRAFT_REPO_ROOT/elasticfusion_amd/libefusion_hip_$v.so" ;;
+          esac
+          timeout 300 python bench.py --no-cpu-baseline --no-side-legs --steps 200 --warmup 20 --frames-cache /tmp/efframes $lib 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('[$v]', d['value'], 'fps', d['ms_per_step'], 'ms', d.get('frame_time_ms'))" | tee -a $out/${tag}_ab.log
+        done
+      done ;;
+  esac
+done
