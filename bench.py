@@ -42,6 +42,8 @@ _gen_frame.cache = {}
 
 
 PROBE_FRAMES = 24   # frames AFTER the timed region on which the two roofline kernels are sampled (see main)
+SELF_CHECK = 200    # frames behind the probe frames, timed as ONE more region on the default N = 1 line (`value_200_steps`): the driver's command times 20 steps
+                    # (~12 ms), where +-3 % of run-to-run noise decides every comparison; the longer region of the same run shows it in the record itself
 PREROLL = 100   # untimed frames before --warmup: the map reaches its steady state (stable surfels, model-fed tracker, clean() removing
                # stale unstable surfels) whatever --steps / --warmup the caller chose, so the timed region is the representative workload
 
@@ -132,29 +134,43 @@ def _kernel_time_struct():
     return KT_FIELDS
 
 
-def roofline_tracker(lib, ef):
-    """the persistent tracker launch (k_track_fast), the kernel that takes the most time of a frame: bytes, us, fraction of HBM peak"""
+def pmc_traffic_of(kernel_prefix, w, h):
+    """HBM-side bytes per launch of a kernel from the COMMITTED PMC measurement (rocprofv3 PMC passes cannot run inside this process):
+    profiles/pmc_traffic.json (640x480) / pmc_traffic_1280x960.json, written by tools/pmc_json.py from tools/pmc_traffic.sh's passes"""
+    try:
+        name = "pmc_traffic.json" if (w, h) == (W, H) else ("pmc_traffic_1280x960.json" if (w, h) == (1280, 960) else None)
+        if name is None:
+            return None, None
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            pj = json.load(f)
+        for k, rec in pj.get("kernels", {}).items():
+            if k.startswith(kernel_prefix):
+                return int(rec["traffic_bytes_per_launch"]), (f"committed PMC measurement (profiles/{name}: {rec.get('source', pj.get('source', ''))}; FETCH_SIZE and WRITE_SIZE in separate "
+                                                              "rocprofv3 passes, calibrated on a known-byte kernel), not measured in this run")
+    except Exception:
+        pass
+    return None, None
+
+
+def roofline_tracker(lib, ef, w=W, h=H):
+    """the persistent tracker launch (k_track_ref / k_track_fast), the kernel that takes the most time of a frame: bytes, us, fraction of HBM peak"""
     KT = _kernel_time_struct()
     kt = KT()
     if not hasattr(lib, "ef_get_tracker_timing") or lib.ef_get_tracker_timing(ef.h, C.byref(kt)) != 0 or kt.launches <= 0:
         return None
     ach = kt.bytes_per_launch / (kt.avg_us * 1e-6) / 1e9
-    traffic = tsrc = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pj = json.load(f)
-        traffic = int(pj["also"]["k_track_fast"]["traffic_bytes_per_launch"])
-        tsrc = "committed PMC measurement (profiles/pmc_traffic.json: " + str(pj["also"]["k_track_fast"].get("source", "")) + "), 640x480, not measured in this run"
-    except Exception:
-        pass
-    return {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+    name = kt.name.decode()
+    traffic, tsrc = pmc_traffic_of(name.split(" ")[0], w, h)
+    return {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "avg_us": round(float(kt.avg_us), 2), "launches_sampled": int(kt.launches), "algorithmic_bytes_per_launch": int(kt.bytes_per_launch),
             "algorithmic_bytes_per_launch_survey_48B": int(kt.bytes_per_launch_survey),
             "frac_survey_48B": round(kt.bytes_per_launch_survey / (kt.avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-            "note": "a chain of 19 dependent Gauss-Newton iterations (two chip-wide exchanges and a 6x6 solve in double each): latency-bound, not bandwidth-bound"}
+            "timer": "dispatch begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of the launch on the frames right behind the timed region (same replay, same map)",
+            "note": "the dominant kernel of the timed region: a chain of 19 dependent Gauss-Newton iterations (two chip-wide exchanges and a 6x6 solve in double each) — "
+                    "latency-bound, not bandwidth-bound; most of its algorithmic bytes are served by the L2s / MALL across iterations (traffic << algorithmic)"}
 
 
-def probe_frames_run(ef, lib, step, first, n, torch):
+def probe_frames_run(ef, lib, step, first, n, torch, w=W, h=H):
     """The replay goes on for n frames behind the timed region: a third of them timed one by one (events between frames, nothing sampled), a
     third with the persistent tracker launch sampled, a third with the launch-per-step script (bit-identical results, ef_set_persistent_tracker)
     so that the level-0 normal-equation kernel exists as a launch of its own and is sampled.  Returns per-frame times in ms."""
@@ -170,13 +186,15 @@ def probe_frames_run(ef, lib, step, first, n, torch):
     for k in range(first + third, first + 2 * third):
         step(k)
     torch.cuda.synchronize()
-    tracker = roofline_tracker(lib, ef)
+    tracker = roofline_tracker(lib, ef, w, h)
     if tracker is not None:   # the persistent launch ran: sample the per-step script's kernels on the remaining frames
         ef.setPersistentTracker(False)
         lib.ef_kernel_timing(ef.h, C.c_int(1))
     for k in range(first + 2 * third, first + n):
         step(k)
     torch.cuda.synchronize()
+    if tracker is not None:
+        ef.setPersistentTracker(True)
     return per_frame, tracker
 
 
@@ -192,23 +210,8 @@ def rooflines(lib, ef, w, h, where):
         achieved_survey = kt.bytes_per_launch_survey / (kt.avg_us * 1e-6) / 1e9
         # HBM-side bytes per launch: rocprofv3 PMC passes cannot run inside this process, so this is the measurement
         # COMMITTED under profiles/ by tools/pmc_traffic.sh for this kernel and workload (see traffic_source), not a live value
-        traffic, traffic_source, straffic, ssource = None, None, None, None
-        try:
-            if (w, h) not in ((W, H), (1280, 960)):
-                raise KeyError("committed PMC measurements exist for the default workload and for configs[2]")
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json" if (w, h) == (W, H) else "pmc_traffic_1280x960.json")) as f:
-                pj = json.load(f)
-            src = "committed PMC measurement (profiles/" + ("pmc_traffic.json" if (w, h) == (W, H) else "pmc_traffic_1280x960.json") + ": " + str(pj.get("source", "tools/pmc_traffic.sh")) + "), not measured in this run"
-            if "k_se3_accum_fast" in str(pj.get("kernel", "")):
-                # one kernel name for all three levels: the PMC mean is over the 19 launches of a call; the level-0 figure is that mean's ratio
-                # to the algorithmic bytes (1.14) applied to a level-0 launch
-                traffic = int(pj.get("traffic_bytes_per_level0_launch_estimate", pj["traffic_bytes_per_launch"]))
-                traffic_source = src + "; level-0 launch = the measured traffic / algorithmic ratio of the call's 19 launches (" + str(pj.get("traffic_over_algorithmic")) + ") x this launch's algorithmic bytes"
-            else:   # a measurement of the round-3 kernel (reference order): not this kernel's traffic
-                traffic_source = "not re-measured for k_se3_accum_fast at this size (the committed file holds round 3's k_se3_accum)"
-            straffic, ssource = int(pj["also"]["k_index_splat"]["traffic_bytes_per_launch"]), src
-        except Exception:
-            pass
+        traffic, traffic_source = pmc_traffic_of(kt.name.decode().split(" ")[0], w, h)
+        straffic, ssource = pmc_traffic_of("k_index_splat", w, h)
         roofline = {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_us": round(float(kt.avg_us), 3), "timer": "dispatch begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of every level-0 launch of the " + where,
@@ -391,9 +394,9 @@ def side_leg(torch, api, frames, dev, w, h, device, stream, steps, warmup, prero
     out = {"value": round(steps / dt, 2), "ms_per_step": round(1e3 * dt / steps, 4), "steps": steps}
     if probe_frames:
         lib = api.lib()
-        _, rt = probe_frames_run(ef, lib, step, first + steps, probe_frames, torch)
+        _, rt = probe_frames_run(ef, lib, step, first + steps, probe_frames, torch, w, h)
         r, rs = rooflines(lib, ef, w, h, f"last third of the {probe_frames} frames that follow the timed region (launch-per-step script)")
-        out["roofline"], out["roofline_index_splat"], out["roofline_tracker"] = r, rs, rt
+        out["roofline"], out["roofline_index_splat"], out["roofline_level0_per_step"] = rt, rs, r
     T = ef.get_T_wc()
     Tgt = frames[first + steps + probe_frames - 1][2]
     out["pose_err_vs_generating_traj_m"] = round(float(np.linalg.norm(T[:3, 3] - Tgt[:3, 3])), 5)
@@ -466,7 +469,8 @@ def main():
     # synthetic frames first: the generator forks worker processes, which must happen before HIP / RCCL are initialised
     # frame 0 seeds the map (tick 1); pre-roll and warm-up are never timed; the last PROBE_FRAMES frames continue the same replay with
     # the per-kernel sampling switched on (a sampled launch carries profiling timestamps, which the timed region is kept free of)
-    n_frames = 1 + a.preroll + a.warmup + a.steps + PROBE_FRAMES
+    self_check = SELF_CHECK if (side or (world == 1 and plain and (w, h) == (W, H))) and a.steps < SELF_CHECK else 0
+    n_frames = 1 + a.preroll + a.warmup + a.steps + PROBE_FRAMES + self_check
     seed = multi.sequence_seed(rank)
     cache = f"{a.frames_cache}.{rank}.{w}x{h}.{n_frames}.npz" if a.frames_cache else None
     if cache and os.path.exists(cache):
@@ -553,7 +557,7 @@ def main():
         for k in range(first_timed + a.steps, first_timed + a.steps + PROBE_FRAMES):
             step(k)
     elif not a.probe_inside:   # the same replay goes on: per-frame times, then the sampled kernels (see probe_frames_run)
-        per_frame_ms, rtracker = probe_frames_run(ef, lib, step, first_timed + a.steps, PROBE_FRAMES, torch)
+        per_frame_ms, rtracker = probe_frames_run(ef, lib, step, first_timed + a.steps, PROBE_FRAMES, torch, w, h)
 
     # pose error of the timed run against the generating trajectory (sanity, not the parity bar)
     T = ef.get_T_wc()
@@ -561,6 +565,19 @@ def main():
     err_t = float(np.linalg.norm(T[:3, 3] - Tgt[:3, 3]))
     count = ef.lastCount()
     stable = int((ef.downloadMap()[:, 3] > ef.getConfidenceThreshold()).sum()) if rank == 0 else 0
+    roofline, roofline_splat = rooflines(lib, ef, w, h, (f"last third of the {PROBE_FRAMES} frames that follow the timed region (same replay, same map; "
+                                                          "launch-per-step script, bit-identical results)"
+                                                         if not a.probe_inside else "sampled frames inside the timed region"))
+    value_200 = None
+    if self_check and not a.stand_in_engine and not a.probe_inside:   # the same replay goes on: one more, longer timed region (never `value`)
+        lib.ef_kernel_timing(ef.h, C.c_int(0))
+        k1 = first_timed + a.steps + PROBE_FRAMES
+        gpu.synchronize()
+        t1 = time.perf_counter()
+        for k in range(k1, k1 + self_check):
+            step(k)
+        gpu.synchronize()
+        value_200 = self_check / (time.perf_counter() - t1)
 
     # the only collective: 32 B per rank over xGMI (RCCL all_gather)
     allstats = multi.gather_stats([dt, float(a.steps), err_t, float(count)], device=stats_device)
@@ -572,9 +589,6 @@ def main():
         return
     agg = multi.aggregate(allstats)
     t_max, value = agg["t_max"], agg["value"]
-    roofline, roofline_splat = rooflines(lib, ef, w, h, (f"last third of the {PROBE_FRAMES} frames that follow the timed region (same replay, same map; "
-                                                          "launch-per-step script, bit-identical results)"
-                                                         if not a.probe_inside else "sampled frames inside the timed region"))
     calib = None
     try:   # box calibration (GPU boxes of the pool differ by 10-20 %): what an empty kernel and a 16 MiB copy cost on THIS box, back to back
         if a.stand_in_engine:
@@ -615,9 +629,12 @@ def main():
                    "preroll_frames": a.preroll, "surfels_end": int(count),
                    "pose_err_vs_generating_traj_m": round(err_t, 5),
                    "per_rank_fps": [round(x, 2) for x in agg["per_rank_fps"]]},
-        "roofline": roofline,
+        # the dominant kernel of the timed region (the persistent tracker launch); when the launch-per-step script was timed (--per-step-tracker,
+        # --graph, rgbOnly) there is no such launch and the level-0 normal-equation kernel stands here
+        "roofline": rtracker if rtracker is not None else roofline,
         "roofline_index_splat": roofline_splat,
-        "roofline_tracker": rtracker,
+        "roofline_level0_per_step": roofline if rtracker is not None else None,
+        "value_200_steps": (round(value_200, 2) if value_200 else None),
         "box_calibration": calib,
         "frame_time_ms": ({"min": round(min(per_frame_ms), 4), "median": round(float(np.median(per_frame_ms)), 4), "max": round(max(per_frame_ms), 4),
                            "frames": len(per_frame_ms), "what": "GPU time of single frames (events between frames) right behind the timed region"}

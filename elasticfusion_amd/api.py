@@ -643,6 +643,10 @@ class ElasticFusion:
         """small pyramid levels + SO(3) in one persistent launch (default) or one launch per step (ef_set_persistent_tracker)"""
         _chk(lib().ef_set_persistent_tracker(self.h, c_i(int(on))), self.h)
 
+    def debugInjectTrackerAbort(self):
+        """test hook (ef_debug_inject_tracker_abort): what a persistent tracker launch leaves when a wait timed out after admission"""
+        _chk(lib().ef_debug_inject_tracker_abort(self.h), self.h)
+
     def synchronize(self):
         _chk(lib().ef_synchronize(self.h), self.h)
 

@@ -58,6 +58,8 @@ struct ef_ctx {
   int overlap_mode = 1;          // ef_set_input_overlap: 1 = whole input stage after the previous tracker; 2 = copy + bilateral filter already during it
   bool overlap = false;
   bool staged_pending = false;
+  unsigned* h_abort = nullptr;   // 4 words of host-mapped pinned memory: k_track_end copies a tracker instance's sticky abort flag here (d_abort: the device alias)
+  unsigned* d_abort = nullptr;
   uint8_t* h_rgb = nullptr;      // pinned staging
   uint16_t* h_depth = nullptr;
   // tracker
@@ -452,7 +454,7 @@ void fern_tracker_device(void* user, const float* fv, const float* fn, const dou
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
   const eft::TrackTail tail = eft::track(c->pyr3, c->st3, c->intr3, tp, s, nullptr);
-  eft::track_end(c->st3, tail, false, 1.0f, nullptr, -1, s);
+  eft::track_end(c->st3, tail, false, 1.0f, nullptr, -1, s, eft::tracker_abort_word(c->pyr3), c->d_abort + 2);
   if (e == hipSuccess) e = hipMemcpyAsync(&c->h_states[1], c->st3, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e == hipSuccess) e = hipGetLastError();
@@ -571,7 +573,7 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
   tp.empty_model_flag = &c->st2->model_view_stamp;
   tp.empty_model_value = view_stamp;
   const eft::TrackTail tail2 = eft::track(c->pyr2, c->st2, c->intr, tp, s, nullptr);
-  eft::track_end(c->st2, tail2, true, 1.0f, nullptr, -1, s);
+  eft::track_end(c->st2, tail2, true, 1.0f, nullptr, -1, s, eft::tracker_abort_word(c->pyr2), c->d_abort + 1);
   eft::sample_constraints((const float*)c->pm.vertex, c->old.time, W, H, step, c->cons_dev, s);  // :485-486
   EF_HIP(c, hipMemcpyAsync(&c->h_states[0], c->st, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
   EF_HIP(c, hipMemcpyAsync(&c->h_states[1], c->st2, sizeof(eft::TrackState), hipMemcpyDeviceToHost, s));
@@ -674,6 +676,15 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
                   float weightMultiplier, const double* in_T_wc) {
   hipStream_t s = c->stream;
   const int W = c->cam.cols, H = c->cam.rows;
+  // a persistent tracker launch of an EARLIER frame gave up waiting after admission (a protocol failure, sticky: every later launch of that
+  // instance returns at once): k_track_end has copied the flag into host-mapped memory; reported here, where the front end calls
+  // (class ElasticFusion::processFrame throws), without synchronising — ef_synchronize reports the same condition for the frames in flight
+  if (c->h_abort && (c->h_abort[0] | c->h_abort[1] | c->h_abort[2])) {
+    c->err = "a persistent tracker launch of an earlier frame timed out waiting for another workgroup after its whole grid had reported in (a protocol "
+             "failure, not a busy chip: that case runs on one workgroup, ef_get_tracker_fallbacks): the poses and the map since then are invalid; "
+             "recreate the context (ef_set_persistent_tracker(ctx, 0) selects the launch-per-step script)";
+    return EF_EHIP;
+  }
   // Input stage: everything that needs nothing but the new frame.  With overlap on it is enqueued on in_stream and
   // waits only for the previous frame's TRACKER (the last reader of the frame-side pyramids); it then runs concurrently
   // with the previous frame's fusion + prediction on `stream`, which read the other set of frame images.
@@ -788,7 +799,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       } else {
         tail = eft::track(c->pyr, c->st, c->intr, tp, s, sample ? &c->probe : nullptr, sample && c->probe_all.start ? &c->probe_all : nullptr);
       }
-      eft::track_end(c->st, tail, rgb, weightMultiplier, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
+      eft::track_end(c->st, tail, rgb, weightMultiplier, log_slot >= 0 ? c->traj : nullptr, log_slot, s, eft::tracker_abort_word(c->pyr), c->d_abort);
       timer_end(c, "odom");
       c->tracking_ok = true;
       if (c->reloc) {   // :326-366: the tracker's verdict on itself, read back where the reference reads lastICPError / getCovariance()
@@ -908,6 +919,9 @@ int ctx_init(ef_ctx* c) {
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_input_done, hipEventDisableTiming));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_track_done, hipEventDisableTiming));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+  EF_HIP(c, hipHostMalloc((void**)&c->h_abort, 4 * sizeof(unsigned), hipHostMallocMapped));
+  memset(c->h_abort, 0, 4 * sizeof(unsigned));
+  EF_HIP(c, hipHostGetDevicePointer((void**)&c->d_abort, c->h_abort, 0));
   EF_HIP(c, hipHostMalloc((void**)&c->h_rgb, P * 3));
   EF_HIP(c, hipHostMalloc((void**)&c->h_depth, P * 2));
   // tracker pyramids (zero-filled: the stale y/z planes of quirk Q3 are then deterministic)
@@ -1017,6 +1031,7 @@ void ctx_free(ef_ctx* c) {
   for (hipEvent_t e : {c->ev_input_done, c->ev_track_done, c->ev_staged, c->ev_frame_done[0], c->ev_frame_done[1]})
     if (e) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
+  if (c->h_abort) (void)hipHostFree(c->h_abort);
   if (c->h_rgb) (void)hipHostFree(c->h_rgb);
   if (c->h_depth) (void)hipHostFree(c->h_depth);
   if (c->h_cons) (void)hipHostFree(c->h_cons);
@@ -1446,6 +1461,17 @@ int ef_debug_occupy(ef_ctx* c, int workgroups, int microseconds) {
   if (!c->debug_stream) EF_HIP(c, hipStreamCreateWithFlags(&c->debug_stream, hipStreamNonBlocking));
   hipLaunchKernelGGL(k_debug_occupy, dim3(workgroups), dim3(1024), 0, c->debug_stream, (unsigned long long)microseconds * 100ull);
   EF_HIP(c, hipGetLastError());
+  return EF_OK;
+}
+// test hook: raises the sticky abort flag of the frame tracker's persistent launches, as a wait that timed out would
+int ef_debug_inject_tracker_abort(ef_ctx* c) {
+  if (!c) return EF_EINVAL;
+  DeviceGuard dg_(c);
+  unsigned* w = eft::tracker_abort_word(c->pyr);
+  if (!w) return EF_EINVAL;
+  const unsigned one = 1u;
+  EF_HIP(c, hipMemcpyAsync(w, &one, sizeof(one), hipMemcpyHostToDevice, c->stream));
+  EF_HIP(c, hipStreamSynchronize(c->stream));
   return EF_OK;
 }
 // developer instrumentation: per-phase clocks of the persistent small-level launch (-DEF_STAGE_CLOCKS builds; tools/small_clocks.py)

@@ -398,8 +398,12 @@ __global__ void __launch_bounds__(BLK) k_index_splat(const Cam cam, const float*
     if (p.z > maxDepth || p.z < 0 || ftime - ct.w > ftd) continue;
     const float u = ((cam.fx * p.x) / p.z) + cam.cx;
     const float v = ((cam.fy * p.y) / p.z) + cam.cy;
-    if (!(u >= 0 && u < (float)cam.cols && v >= 0 && v < (float)cam.rows)) continue;  // N1
-    const int px = (int)floorf(u), py = (int)floorf(v);
+    // index_map.vert:52-53 hands the point over in NDC (float) and the viewport transform brings it back, evaluated exactly on the float
+    // NDC value (N1; the oracle's efo_predict_indices has the same lines): bit for bit the compiled shader's pixel, also on a pixel edge
+    const float xn = (u - (float)cam.cols * 0.5f) / ((float)cam.cols * 0.5f), yn = (v - (float)cam.rows * 0.5f) / ((float)cam.rows * 0.5f);
+    const double xw = ((double)xn + 1.0) * 0.5 * (double)cam.cols, yw = ((double)yn + 1.0) * 0.5 * (double)cam.rows;
+    if (!(xw >= 0 && xw < cam.cols && yw >= 0 && yw < cam.rows)) continue;  // N1
+    const int px = (int)floor(xw), py = (int)floor(yw);
     atomicMin(&zbuf[colmajor ? px * cam.rows + py : py * cam.cols + px], zkey(p.z, id));   // N2
   }
 }

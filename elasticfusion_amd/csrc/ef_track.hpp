@@ -249,7 +249,11 @@ void track_swap(Pyramid& p, const TrackParams& tp);   // the pointer swap track(
 // tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +
 // velocity weighting (ElasticFusion.cpp:369-383) + the float matrices of the map passes
 // traj / slot: device trajectory log (16 doubles per frame; t_T_wc of ElasticFusion.cpp:588) or null
-void track_end(TrackState* st, const TrackTail& tail, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s);
+// abort_word / abort_report: the instance's sticky abort flag (tracker_abort_word) and a word of host-mapped pinned memory it is copied to
+// when set (both null: not reported)
+void track_end(TrackState* st, const TrackTail& tail, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s,
+               const unsigned* abort_word = nullptr, unsigned* abort_report = nullptr);
+unsigned* tracker_abort_word(const Pyramid& p);
 // caller-supplied pose (in_T_wc, ElasticFusion.cpp:367-369): sets q/t from the row-major 4x4, optionally keeping the old
 // pose as "previous" for the velocity weighting, publishes the float matrices, re-arms the denseEnough() tally
 void pose_injected(TrackState* st, const double* T_wc16, bool save_prev, float weightMultiplier, bool with_weighting, double* traj,

@@ -1767,7 +1767,8 @@ __device__ inline void log_pose(const TrackState* st, double* traj, int slot) {
 __device__ __forceinline__ void track_end_tail(TrackState* st, const float* Rc_in, const float* tc_in, bool rgb, float weightMultiplier, double* traj, int slot);
 __global__ void __launch_bounds__(REDUCE_BLOCK) k_track_end(TrackState* st, const GNState* __restrict__ prev, GNState* next,
                                                              const float* __restrict__ pairs, const int* __restrict__ slots_prev, const StepArgs A,
-                                                             bool rgb, float weightMultiplier, double* traj, int slot) {
+                                                             bool rgb, float weightMultiplier, double* traj, int slot, const unsigned* abort_word,
+                                                             unsigned* abort_report) {
   __shared__ efs::SolveScratch S;
   __shared__ float sums_s[2 * SE3_ACCS];
   const int t = threadIdx.x;
@@ -1784,6 +1785,12 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) k_track_end(TrackState* st, cons
   }
   if (t != 0) return;
   track_end_tail(st, S.Rcurr, S.tcurr, rgb, weightMultiplier, traj, slot);
+  // the sticky "a persistent launch gave up waiting" flag of this tracker instance, handed to the HOST (a word of mapped pinned memory the
+  // next ef_process_frame looks at without synchronising): a protocol failure is reported where the front end calls, not only by ef_synchronize
+  if (abort_report) {
+    const unsigned v = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v) __hip_atomic_store(abort_report, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 // (one lane) 0.3 m guard, SVD re-orthonormalisation, velocity weighting, the float matrices of the map passes, the trajectory log
 __device__ __forceinline__ void track_end_tail(TrackState* st, const float* Rc_in, const float* tc_in, bool rgb, float weightMultiplier, double* traj, int slot) {
@@ -3248,10 +3255,19 @@ void track_swap(Pyramid& p, const TrackParams& tp) {
 }
 
 // exported for the context: finishing kernels
-void track_end(TrackState* st, const TrackTail& u, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s) {
+void track_end(TrackState* st, const TrackTail& u, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s, const unsigned* abort_word,
+               unsigned* abort_report) {
   const StepArgs A{u.has_head, false, u.icp, u.rgb, u.rgbOnly, u.icpWeight, u.k0, true, 63, u.ng};
   hipLaunchKernelGGL(k_track_end, dim3(1), dim3(REDUCE_BLOCK), 0, s, st, (const GNState*)&st->gn[u.cur], &st->gn[u.cur ^ 1], u.pairs,
-                     (const int*)&st->rgb_slots[u.slots & 1][0][0], A, rgb, weightMultiplier, traj, slot);
+                     (const int*)&st->rgb_slots[u.slots & 1][0][0], A, rgb, weightMultiplier, traj, slot, abort_word, abort_word ? abort_report : nullptr);
+}
+// device address of the sticky abort word of this tracker instance's persistent launches (FtSync::abort; round 3's k_track_small: PtSync::abort)
+unsigned* tracker_abort_word(const Pyramid& p) {
+  if (!p.partials) return nullptr;
+#ifndef EF_FAST_ORDER
+  if (p.last_mode != 1) return (unsigned*)((char*)(p.partials + 2 * PARTIAL_FLOATS) + offsetof(PtSync, abort));
+#endif
+  return (unsigned*)((char*)(p.partials + FT_SY_OFF) + offsetof(FtSync, abort));
 }
 void pose_injected(TrackState* st, const double* T_wc16, bool save_prev, float weightMultiplier, bool with_weighting, double* traj, int slot,
                    hipStream_t s) {

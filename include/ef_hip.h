@@ -422,6 +422,11 @@ int ef_get_tracker_timing(ef_ctx* ctx, ef_kernel_time* out);
 int ef_get_tracker_fallbacks(ef_ctx* ctx, int* count);
 /* developer instrumentation for the test of that path: `workgroups` workgroups that each fill one CU spin for `microseconds` on a stream of their own */
 int ef_debug_occupy(ef_ctx* ctx, int workgroups, int microseconds);
+/* test hook: raises the sticky "a persistent tracker launch gave up waiting" flag of the frame tracker, as a wait that timed out after admission
+ * would.  From then on every persistent launch of the context returns at once; the frame whose tracker saw the flag hands it to the host, the
+ * NEXT ef_process_frame[_dev] (class ElasticFusion::processFrame: throws) returns EF_EHIP without having enqueued anything, and so does
+ * ef_synchronize.  Results since the flag was raised are invalid. */
+int ef_debug_inject_tracker_abort(ef_ctx* ctx);
 
 /* developer instrumentation: the 16 wall_clock64() (100 MHz) stamps the last tracking solve left in the device state;
  * all zero unless the library was built with -DEF_STAGE_CLOCKS (EF_HIPCC_FLAGS=-DEF_STAGE_CLOCKS python -m elasticfusion_amd.build) */

@@ -190,8 +190,13 @@ void efo_predict_indices(const efo_cam* cam, const double* T_wc16, int time, con
     if (p.z > maxDepth || p.z < 0 || (float)time - s[7] > (float)timeDelta) continue;
     float u = ((cam->fx * p.x) / p.z) + cam->cx;
     float v = ((cam->fy * p.y) / p.z) + cam->cy;
-    if (!(u >= 0 && u < (float)cols && v >= 0 && v < (float)rows)) continue;  // N1
-    int px = (int)floorf(u), py = (int)floorf(v);
+    // index_map.vert:52-53 hands the point over in NDC — x = (u - cols * 0.5) / (cols * 0.5), in float — and the viewport transform brings it
+    // back to a window position, (x + 1) * cols / 2, evaluated exactly on the float NDC value (N1): a point within ~1e-5 px of a pixel edge
+    // lands in the neighbouring pixel, which floor(u) would not see (rounds 1-4 tolerated 2e-4 of the pixels for it)
+    const float xn = (u - (float)cols * 0.5f) / ((float)cols * 0.5f), yn = (v - (float)rows * 0.5f) / ((float)rows * 0.5f);
+    const double xw = ((double)xn + 1.0) * 0.5 * (double)cols, yw = ((double)yn + 1.0) * 0.5 * (double)rows;
+    if (!(xw >= 0 && xw < cols && yw >= 0 && yw < rows)) continue;  // N1: culled by its centre
+    int px = (int)std::floor(xw), py = (int)std::floor(yw);
     int pi = py * cols + px;
     if (!(p.z < zbuf[pi])) continue;  // N2 (strict: earlier id keeps ties)
     zbuf[pi] = p.z;

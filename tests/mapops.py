@@ -116,10 +116,10 @@ def run_passes(be, inp, cam=None):
 
 
 INDEX_OUTPUTS = ("index", "index_vertConf", "index_colorTime", "index_normRad")
-# fraction of index-map PIXELS that may differ between the shader run and the specification: a point's window position is
-# floor(u) in the specification and floor(((ndc + 1) / 2) * size) after index_map.vert's round trip through NDC in
-# the shader run, which moves a point sitting within ~1e-5 px of a pixel edge into the neighbouring pixel (N1)
-INDEX_PIXEL_TOLERANCE = 2e-4
+# fraction of index-map PIXELS that may differ between the shader run and the specification: NONE since round 5 — the specification now
+# restates index_map.vert's round trip through NDC (window position floor(((ndc + 1) / 2) * size) on the float NDC value, which moves a
+# point sitting within ~1e-5 px of a pixel edge into the neighbouring pixel, N1); rounds 1-4 took floor(u) and tolerated 2e-4 of the pixels
+INDEX_PIXEL_TOLERANCE = 0.0
 
 
 def index_pixels_differing(a, b):

@@ -45,3 +45,30 @@ def run_starved(api, seq):
     assert ef.trackerFallbacks() >= 3      # each occupied frame ran on one workgroup
     assert np.array_equal(ef.downloadMap().view(np.uint32), o.map().view(np.uint32))
     ef.close()
+
+
+@pytest.mark.parametrize("which", ["default", "fast"])
+def test_a_protocol_failure_is_reported_where_the_front_end_calls(seq, which):
+    """the sticky abort of a persistent launch (a wait that timed out AFTER admission) used to be seen by ef_synchronize only, which
+    class ElasticFusion::processFrame never calls.  Now the frame whose tracker saw the flag hands it to the host (k_track_end -> a word of mapped
+    pinned memory) and the NEXT ef_process_frame returns EF_EHIP — no synchronisation on the way — as does ef_synchronize."""
+    from elasticfusion_amd import api, build
+    api.use_library(build.FAST_LIB if which == "fast" else None)
+    try:
+        ef = api.ElasticFusion()
+        for k in range(4):
+            rgb, depth, _ = seq.frame(k)
+            ef.processFrame(rgb, depth, k * 33333)
+        ef.synchronize()
+        ef.debugInjectTrackerAbort()                       # what a timed-out wait leaves
+        rgb, depth, _ = seq.frame(4)
+        ef.processFrame(rgb, depth, 4 * 33333)             # this frame's tracker sees the flag (its launch returns at once) and reports it
+        ef.get_T_wc()                                      # (any getter: the frame has run)
+        rgb, depth, _ = seq.frame(5)
+        with pytest.raises(api.EFError, match="persistent tracker launch"):
+            ef.processFrame(rgb, depth, 5 * 33333)
+        with pytest.raises(api.EFError):
+            ef.synchronize()
+        ef.close()
+    finally:
+        api.use_library(None)
