@@ -191,7 +191,10 @@ typedef struct efo_global_loop {
   float icp_error, icp_count;          /* of the fern tracker, when it ran */
   double T_wc_recovery[16];
 } efo_global_loop;
+void efo_fusion_get_pose_qt(const efo_fusion*, double* q4_t3);
 void efo_fusion_set_tick(efo_fusion*, int tick);
+/* test hook: the oracle's side of ef_map_upload + ef_restore_state (map, tick, pose as held: quaternion xyzw + translation, the frame processed last) */
+void efo_fusion_restore(efo_fusion*, const float* surfels12, int count, int tick, const double* q4_t3, const uint8_t* rgb_prev, const uint16_t* depth_prev);
 /* relocalisation (the reference constructor's `reloc`, ElasticFusion.cpp:326-366,411-413,536,601-604,624-649) */
 void efo_fusion_set_reloc(efo_fusion*, int on);
 void efo_fusion_reloc_state(const efo_fusion*, int* out4 /* lost, trackingOk, trackingCount, lastFrameRecovery */);

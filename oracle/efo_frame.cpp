@@ -522,6 +522,10 @@ void efo_fusion_process_frame(efo_fusion* f, const uint8_t* rgb, const uint16_t*
   f->processFrame(rgb, depth, ts, wm, T);
 }
 void efo_fusion_get_pose(const efo_fusion* f, double* T) { f->pose16(T); }
+void efo_fusion_get_pose_qt(const efo_fusion* f, double* q4_t3) {   // the pose as held: quaternion xyzw + translation
+  for (int i = 0; i < 4; ++i) q4_t3[i] = f->T_wc.q[i];
+  for (int i = 0; i < 3; ++i) q4_t3[4 + i] = f->T_wc.t[i];
+}
 int efo_fusion_map_count(const efo_fusion* f) { return f->count; }
 void efo_fusion_map_download(const efo_fusion* f, float* s) { std::memcpy(s, f->surfels.data(), (size_t)f->count * 48); }
 // GlobalModel::downloadMap as the reference has it (GlobalModel.cpp:673-706): vbos[renderSource] truncated to the post-clean count
@@ -547,6 +551,30 @@ void efo_fusion_set_close_loops(efo_fusion* f, int on, int icpCountThresh, float
 }
 void efo_fusion_set_loop_solver(efo_fusion* f, efo_loop_solver fn, void* user) { f->solver = fn; f->solverUser = user; }
 void efo_fusion_set_tick(efo_fusion* f, int tick) { f->tick = tick; }
+// TEST HOOK — the oracle's side of the engine's checkpoint / resume pair (ef_map_upload + ef_restore_state, csrc/ef_context.hip): a map brought
+// in from outside (12 floats per surfel), the tick, the pose as held (quaternion xyzw + translation) and the frame processed last — its
+// pre-processing and SO(3) reference image are re-done (what processFrame left of it: filtered depth for the fill-in, initFirstRGB's target),
+// then predict() as at the end of a frame.  What bench.py --preseed (BASELINE configs[2]) and the one-frame harness start from.
+void efo_fusion_restore(efo_fusion* f, const float* surfels12, int count, int tick, const double* q4_t3, const uint8_t* rgb_prev, const uint16_t* depth_prev) {
+  const efo_fusion_params& p = f->p;
+  const size_t P = (size_t)p.width * p.height;
+  std::memcpy(f->surfels.data(), surfels12, (size_t)count * 48);
+  f->count = count;
+  std::memcpy(f->depthRaw.data(), depth_prev, P * 2);
+  std::memcpy(f->rgb.data(), rgb_prev, P * 3);
+  for (size_t i = 0; i < P; ++i) { f->rgba[i * 4] = f->rgb[i * 3]; f->rgba[i * 4 + 1] = f->rgb[i * 3 + 1]; f->rgba[i * 4 + 2] = f->rgb[i * 3 + 2]; f->rgba[i * 4 + 3] = 255; }
+  efo_filter_depth(f->depthRaw.data(), p.width, p.height, p.depthCut, f->depthFiltered.data());
+  efo_metricise_depth(f->depthRaw.data(), p.width, p.height, p.depthCut, f->depthMetric.data());
+  efo_metricise_depth(f->depthFiltered.data(), p.width, p.height, p.depthCut, f->depthMetricFiltered.data());
+  efo_odom_init_first_rgb(f->frameToModel, f->rgba.data());
+  for (int i = 0; i < 4; ++i) f->T_wc.q[i] = q4_t3[i];
+  for (int i = 0; i < 3; ++i) f->T_wc.t[i] = q4_t3[4 + i];
+  f->tick = tick;
+  f->lost = f->lastFrameRecovery = false;
+  f->trackingOk = true;
+  f->trackingCount = 0;
+  f->predict();
+}
 void efo_fusion_set_reloc(efo_fusion* f, int on) { f->reloc = on != 0; }
 // {lost, trackingOk of the last frame, trackingCount, lastFrameRecovery}
 void efo_fusion_reloc_state(const efo_fusion* f, int* out4) {

@@ -595,6 +595,24 @@ class Fusion:
     def set_tick(self, tick):
         lib().efo_fusion_set_tick(self.h_, c_i(int(tick)))
 
+    def pose_qt(self):
+        qt = np.zeros(7, np.float64)
+        lib().efo_fusion_get_pose_qt(self.h_, ptr(qt))
+        return qt
+
+    def checkpoint(self, last_rgb, last_depth):
+        """what a replay carries from one process_frame to the next (api.ElasticFusion.checkpoint's fields)"""
+        return dict(map=self.map().copy(), tick=self.tick(), qt=self.pose_qt(), rgb=np.ascontiguousarray(last_rgb, np.uint8).copy(),
+                    depth=np.ascontiguousarray(last_depth, np.uint16).copy())
+
+    def restore(self, ck):
+        """the oracle's side of api.ElasticFusion.restore(checkpoint): dict(map [n, 12] float32, tick, qt [7] float64, rgb, depth)"""
+        m = f32(ck["map"]).reshape(-1, 12)
+        assert len(m) <= self.p.maxSurfels, (len(m), self.p.maxSurfels)
+        qt = np.ascontiguousarray(ck["qt"], np.float64).reshape(7)
+        rgb, depth = np.ascontiguousarray(ck["rgb"], np.uint8), np.ascontiguousarray(ck["depth"], np.uint16)
+        lib().efo_fusion_restore(self.h_, ptr(m), c_i(len(m)), c_i(int(ck["tick"])), ptr(qt), ptr(rgb), ptr(depth))
+
     # ---- relocalisation (ElasticFusion.cpp:326-366,411-413,536,601-604,624-649) ----
     def set_reloc(self, on=True):
         lib().efo_fusion_set_reloc(self.h_, c_i(int(on)))

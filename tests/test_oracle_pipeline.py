@@ -212,3 +212,26 @@ def test_bootstrap_drift_is_frame_to_frame_odometry():
     efo.set_threads(1)
     assert 0.003 < runs["default"] < 0.008, runs
     assert runs["stable_at_once"] < 0.0025 < runs["default"], runs
+
+
+def test_oracle_resumed_from_a_checkpoint_continues_bit_for_bit():
+    """efo_fusion_restore (the oracle's side of ef_map_upload + ef_restore_state; what the GPU parity test of BASELINE configs[2]'s pre-seeded
+    map and the one-frame harness start from): a fresh oracle restored from {map, tick, pose as held, last frame} runs the next frames exactly
+    like the oracle the checkpoint was taken from."""
+    from elasticfusion_amd import synth
+    sq = synth.Sequence(seed=0xEF0005, width=320, height=240)
+    kw = dict(width=320, height=240, fx=sq.fx, fy=sq.fy, cx=sq.cx, cy=sq.cy, maxSurfels=1 << 19, confidence=2.0)
+    frames = [sq.frame(k) for k in range(9)]
+    a = efo.Fusion(**kw)
+    for k in range(6):
+        a.process_frame(frames[k][0], frames[k][1], k * 33333)
+    ck = a.checkpoint(frames[5][0], frames[5][1])
+    b = efo.Fusion(**kw)
+    b.restore(ck)
+    assert b.tick() == a.tick() and b.map_count() == a.map_count() and np.array_equal(b.pose(), a.pose())
+    for k in range(6, 9):
+        for o in (a, b):
+            o.process_frame(frames[k][0], frames[k][1], k * 33333)
+        assert np.array_equal(np.asarray(a.stats(), np.float32).view(np.uint32), np.asarray(b.stats(), np.float32).view(np.uint32)), k
+        assert np.array_equal(a.pose(), b.pose()) and a.map_count() == b.map_count(), k
+    assert np.array_equal(a.map().view(np.uint32), b.map().view(np.uint32))
