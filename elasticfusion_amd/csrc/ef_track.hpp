@@ -234,6 +234,10 @@ struct TrackTail {
   Intr k0;
   const float* pairs;
   int ng = 0;                  // fast order: group partials per accumulator the head's tree looks at (1: the persistent launch left totals)
+  // reference-order builds, after the persistent launch: track_end is ONE launch that also stands where k_track_serial stood (k_track_ref_end)
+  bool merged_end = false;
+  unsigned epoch = 0;          // the persistent launch's first epoch (its admission verdict is tagged with it)
+  float* partials = nullptr;
 };
 // probe: samples the level-0 normal-equation launches of the launch-per-step script; probe_all: samples the persistent launch (fast order)
 TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe = nullptr,

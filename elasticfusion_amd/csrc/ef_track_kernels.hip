@@ -3141,14 +3141,15 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
     if (icp && rgb) hipLaunchKernelGGL((k_track_serial<true, true>), dim3(1), dim3(REDUCE_BLOCK), 0, s, p.partials, st, FA.epoch);
     else if (icp) hipLaunchKernelGGL((k_track_serial<true, false>), dim3(1), dim3(REDUCE_BLOCK), 0, s, p.partials, st, FA.epoch);
     else hipLaunchKernelGGL((k_track_serial<false, true>), dim3(1), dim3(REDUCE_BLOCK), 0, s, p.partials, st, FA.epoch);
-#else
-    if (icp && rgb) hipLaunchKernelGGL((k_track_ref_serial<true, true>), dim3(1), dim3(FT_BLOCK), 0, s, p.partials, st, FA.epoch);
-    else if (icp) hipLaunchKernelGGL((k_track_ref_serial<true, false>), dim3(1), dim3(FT_BLOCK), 0, s, p.partials, st, FA.epoch);
-    else hipLaunchKernelGGL((k_track_ref_serial<false, true>), dim3(1), dim3(FT_BLOCK), 0, s, p.partials, st, FA.epoch);
 #endif
     track_swap(p, tp);
     TrackTail tail{0, (n - 1) & 1, n > 0, icp, rgb, tp.rgbOnly, tp.icpWeight, intr_level(k, 0), p.partials + FT_P_OFF};
     tail.ng = 1;   // the reducers of the last iteration left the TOTALS in column 0
+#ifndef EF_FAST_ORDER
+    tail.merged_end = true;   // (the one-workgroup fallback rides at the head of track_end's launch: k_track_ref_end)
+    tail.epoch = FA.epoch;
+    tail.partials = p.partials;
+#endif
     return tail;
   }
   if (p.last_mode == 1) {   // (the per-step kernels' plain partials and k_track_small's barrier words start from zeros)
@@ -3258,6 +3259,15 @@ void track_swap(Pyramid& p, const TrackParams& tp) {
 void track_end(TrackState* st, const TrackTail& u, bool rgb, float weightMultiplier, double* traj, int slot, hipStream_t s, const unsigned* abort_word,
                unsigned* abort_report) {
   const StepArgs A{u.has_head, false, u.icp, u.rgb, u.rgbOnly, u.icpWeight, u.k0, true, 63, u.ng};
+#ifndef EF_FAST_ORDER
+  if (u.merged_end) {
+    unsigned* report = abort_word ? abort_report : nullptr;
+    if (u.icp && u.rgb) hipLaunchKernelGGL((k_track_ref_end<true, true>), dim3(1), dim3(FT_BLOCK), 0, s, u.partials, st, u.epoch, A, u.slots, rgb, weightMultiplier, traj, slot, report);
+    else if (u.icp) hipLaunchKernelGGL((k_track_ref_end<true, false>), dim3(1), dim3(FT_BLOCK), 0, s, u.partials, st, u.epoch, A, u.slots, rgb, weightMultiplier, traj, slot, report);
+    else hipLaunchKernelGGL((k_track_ref_end<false, true>), dim3(1), dim3(FT_BLOCK), 0, s, u.partials, st, u.epoch, A, u.slots, rgb, weightMultiplier, traj, slot, report);
+    return;
+  }
+#endif
   hipLaunchKernelGGL(k_track_end, dim3(1), dim3(REDUCE_BLOCK), 0, s, st, (const GNState*)&st->gn[u.cur], &st->gn[u.cur ^ 1], u.pairs,
                      (const int*)&st->rgb_slots[u.slots & 1][0][0], A, rgb, weightMultiplier, traj, slot, abort_word, abort_word ? abort_report : nullptr);
 }

@@ -92,10 +92,11 @@ int ef_set_graph_replay(ef_ctx* ctx, int on);
  * (tests/test_gpu_frame.py runs both).  The launch needs the whole chip at once; it checks that at its start, and when other work holds
  * part of the chip for milliseconds (another process, a long kernel on another stream) the call runs on one workgroup instead — slower, the
  * same results, nothing for the caller to do (ef_get_tracker_fallbacks counts these).  Persistent launches of one process on one device are
- * chained in enqueue order, so several contexts never starve one another.  On a device that reports fewer than 256 CUs (a partition of
- * the chip), with rgbOnly and under ef_set_graph_replay the launch-per-step script runs.  (The reference-rounding build,
- * libefusion_hip_nofma.so, keeps round 3's form: the levels of at most 131072 pixels + the SO(3) loop as one launch of 128 workgroups, whose
- * time-out makes ef_synchronize return EF_EHIP.) */
+ * chained in enqueue order, so several contexts never starve one another.  With rgbOnly and under ef_set_graph_replay the launch-per-step
+ * script runs.  on = 2 (reference-order builds: the default library; what a device that reports 128 .. 255 CUs gets by default, fewer: 0):
+ * round 3's form — the levels of at most 131072 pixels + the SO(3) loop as one launch of 128 workgroups, three launches per level-0 iteration —
+ * whose time-out makes ef_synchronize return EF_EHIP.  A protocol failure of either persistent form (a wait that timed out after the whole
+ * grid had reported in) is sticky and is reported by the NEXT ef_process_frame[_dev] and by ef_synchronize (EF_EHIP). */
 int ef_set_persistent_tracker(ef_ctx* ctx, int on);
 /* Level-0 Gauss-Newton iterations as TWO launches instead of three: the update step (one workgroup's worth of work) is evaluated by
  * workgroup 0 of the correspondence-search launch and handed to that launch's other workgroups as tagged granules (they poll with their

@@ -20,6 +20,12 @@ for what in "$@"; do
       tail -25 $out/${tag}_gpu_tests_k.log | cut -c1-300 ;;
     ab2)   # in-process A/B (tools/ab_bench.py): AB_SPECS="d d@2 fast"
       timeout 400 python tools/ab_bench.py ${AB_ARGS:-} ${AB_SPECS:-d fast} 2>&1 | grep -v "^$" | tee -a $out/${tag}_ab.log | tail -12 ;;
+    prof)   # rocprofv3 kernel stats of the driver's command (no CPU baseline, no side legs)
+      cd /tmp
+      timeout 240 rocprofv3 --kernel-trace --stats -d /tmp/prof -o ${tag} --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-side-legs --steps 20 --warmup 5 > $out/${tag}_prof_stdout.log 2>&1
+      find /tmp/prof -name "${tag}_kernel_stats.csv" -exec cp {} $out/${tag}_bench_kernel_stats.csv \;
+      head -30 $out/${tag}_bench_kernel_stats.csv | cut -c1-160; tail -2 $out/${tag}_prof_stdout.log | cut -c1-600
+      cd $GRAFT_REPO_ROOT ;;
     clocks)
       timeout 120 python tools/fast_clocks.py elasticfusion_amd/libefusion_hip_clocks.so 140 > $out/${tag}_clocks.jsonl 2>$out/${tag}_clocks.err; cat $out/${tag}_clocks.jsonl; tail -2 $out/${tag}_clocks.err ;;
     ab)
