@@ -421,7 +421,7 @@ def main():
     ap.add_argument("--probe-inside", action="store_true", help="development: sample the roofline kernels inside the timed region (1 frame in 8) "
                     "instead of on the frames that follow it")
     ap.add_argument("--frames-cache", default=None, help="development: keep the generated synthetic frames in this .npz between runs "
-                    "(A/B runs of library variants on one GPU box, tools/gpu_ab.sh); never used by the driver")
+                    "(A/B runs of library variants on one GPU box, tools/ab_bench.py); never used by the driver")
     ap.add_argument("--width", type=int, default=W, help="1280 (with --height 960) = BASELINE.json configs[2]; NOT the headline metric")
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--host-frames", action="store_true", help="hand the frames over as HOST buffers (ef_process_frame: copy into pinned "

@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# EF_HIP_LIB: developer override (A/B of two builds on one GPU box, tools/gpu_ab.sh); never a CPU fallback
+# EF_HIP_LIB: developer override (A/B of two builds on one GPU box, tools/ab_bench.py); never a CPU fallback
 LIB_PATH = os.environ.get("EF_HIP_LIB") or os.path.join(_HERE, "libefusion_hip.so")
 _lib = None
 

@@ -524,13 +524,13 @@ __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const floa
     if (!S.ok) continue;
     const int px0 = max(0, (int)ceilf(S.u - S.hs - 0.5f)), px1 = min(cam.cols - 1, (int)ceilf(S.u + S.hs - 0.5f) - 1);
     const int py0 = max(0, (int)ceilf(S.v - S.hs - 0.5f)), py1 = min(cam.rows - 1, (int)ceilf(S.v + S.hs - 0.5f) - 1);
-    const int w = px1 - px0 + 1, nfrag = w * (py1 - py0 + 1);
-    for (int f = (int)sub; f < nfrag; f += SPLAT_LANES) {
-      const int fy = f / w, px = px0 + (f - fy * w), py = py0 + fy;
+    const int hgt = py1 - py0 + 1, nfrag = (px1 - px0 + 1) * hgt;
+    for (int f = (int)sub; f < nfrag; f += SPLAT_LANES) {   // (the sprite's fragments column by column: the lanes of a surfel stay in one cache line)
+      const int fx = f / hgt, py = py0 + (f - fx * hgt), px = px0 + fx;
       float z;
       if (!sprite_fragment(cam, S, px, py, z)) continue;
       if (z != z) continue;
-      atomicMin(&zbuf[py * cam.cols + px], zkey(z, id));
+      atomicMin(&zbuf[px * cam.rows + py], zkey(z, id));   // column-major z-buffer: see k_surface_resolve
     }
   }
 #else
@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const floa
         if (z != z) continue;
         const int ly = py - by0;
         if (ly < th) atomicMin(&tile[ly * bw + (px - bx0)], zkey(z, id));
-        else atomicMin(&zbuf[py * cam.cols + px], zkey(z, id));
+        else atomicMin(&zbuf[px * cam.rows + py], zkey(z, id));
       }
     }
     __syncthreads();
@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const floa
       const unsigned long long k = tile[i];
       if (k != ~0ull) {
         const int ly = i / bw, lx = i - ly * bw;
-        atomicMin(&zbuf[(by0 + ly) * cam.cols + (bx0 + lx)], k);
+        atomicMin(&zbuf[(bx0 + lx) * cam.rows + (by0 + ly)], k);
       }
     }
     __syncthreads();   // the tile and the box are re-used by the next chunk
@@ -645,16 +645,22 @@ __global__ void __launch_bounds__(BLK) k_surface_resolve(const Cam cam, const fl
                                                           const uint16_t* __restrict__ depth_filtered, const uint8_t* __restrict__ rgb3,
                                                           bool passthroughImage, unsigned* dense_counter, unsigned* nonempty_flag,
                                                           unsigned nonempty_value) {
-  const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= cam.cols * cam.rows) return;
-  const int py = pi / cam.cols, px = pi - py * cam.cols;
-  const unsigned long long key = zbuf[pi];
+  // Round 5: the surface z-buffer is COLUMN-major (texel (x, y) at x * rows + y), like the index maps of the frame tier: surfels are
+  // created in column-major pixel order and move little, so consecutive ids splat onto vertically adjacent pixels and the 64-bit atomics of a
+  // wavefront fall into a few cache lines instead of one line per sprite row (k_surface_splat: 33 us on the mature map, sigma 15).  The resolve
+  // walks 16 x 16 pixel tiles with every wavefront on an 8 x 8 block, consecutive lanes going DOWN a column: its z-buffer reads are eight full
+  // 64-byte lines, its surfel gathers follow consecutive ids, and its row-major outputs still leave in 8-pixel runs.
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int px = blockIdx.x * 16 + (wave & 1) * 8 + (lane >> 3), py = blockIdx.y * 16 + (wave >> 1) * 8 + (lane & 7);
+  if (px >= cam.cols || py >= cam.rows) return;
+  const int pi = py * cam.cols + px, zi = px * cam.rows + py;
+  const unsigned long long key = zbuf[zi];
   uchar4 im = make_uchar4(0, 0, 0, 0);
   float4 vt = make_float4(0, 0, 0, 0), nm = make_float4(0, 0, 0, 0);
   uint16_t tm = 0;
   if (key != ZBUF_EMPTY) {
     if (nonempty_flag) *nonempty_flag = nonempty_value;   // "this view shows at least one surfel", stamped with the caller's value (no reset pass)
-    zbuf[pi] = ZBUF_EMPTY;
+    zbuf[zi] = ZBUF_EMPTY;
     const uint32_t id = (uint32_t)key;
     const rt34 T = rt34_load16(T16);
     const float4 pc = map.pos_conf[id], ct = map.col_time[id], nr = map.nrm_rad[id];
@@ -679,13 +685,14 @@ __global__ void __launch_bounds__(BLK) k_surface_resolve(const Cam cam, const fl
 }
 // IndexMap::synthesizeDepth (G6): depth_splat.frag's only output is the intersection depth the z-buffer key already holds
 __device__ __forceinline__ float depth_of_key(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
-__global__ void __launch_bounds__(BLK) k_depth_resolve(int n, unsigned long long* zbuf, float* __restrict__ depth) {
+__global__ void __launch_bounds__(BLK) k_depth_resolve(int cols, int rows, unsigned long long* zbuf, float* __restrict__ depth) {
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pi >= n) return;
-  const unsigned long long key = zbuf[pi];
+  if (pi >= cols * rows) return;
+  const int py = pi / cols, px = pi - py * cols, zi = px * rows + py;   // (column-major z-buffer: k_surface_resolve)
+  const unsigned long long key = zbuf[zi];
   float z = 0.f;   // glClearColor(0, 0, 0, 0)
   if (key != ZBUF_EMPTY) {
-    zbuf[pi] = ZBUF_EMPTY;
+    zbuf[zi] = ZBUF_EMPTY;
     z = depth_of_key((uint32_t)(key >> 32));
   }
   depth[pi] = z;
@@ -759,20 +766,37 @@ __global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates 
       const f3 ray{xl, yl, 1};
       const float lenRay = sqrtf(dot(ray, ray));
       const float lenN = sqrtf(dot(vNormLocal, vNormLocal));
+      // N4: the 16 taps {-1, 0, 0, +1}^2 touch 9 distinct texels.  Round 5: all 27 loads (index, vertex + confidence, normal + radius of the 9
+      // texels) are issued up front, unconditionally — inside the conditionals of the tap loop they formed chains of up to 48 DEPENDENT
+      // round trips (index -> vertex -> normal, tap after tap: the compiler cannot speculate a load across a branch); the 16 taps are then
+      // evaluated on registers in the reference's order (a duplicate tap never changes `best`: dist < bestDist is strict)
+      uint32_t idx9[3][3];
+      float4 vc9[3][3], nr9[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int tx = clampi(i + a - 1, 0, cam.cols - 1);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const int ty = clampi(j + b - 1, 0, cam.rows - 1);
+          const int ti = im_texel(A.im, cam, tx, ty);
+          idx9[a][b] = A.im.index[ti];
+          vc9[a][b] = A.im.vert_conf[ti];
+          nr9[a][b] = A.im.norm_rad[ti];
+        }
+      }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const int tx = clampi(i + (a == 0 ? -1 : (a == 3 ? 1 : 0)), 0, cam.cols - 1);  // N4 taps {-1,0,0,+1}
+        const int a3 = a == 0 ? 0 : (a == 3 ? 2 : 1);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const int ty = clampi(j + (b == 0 ? -1 : (b == 3 ? 1 : 0)), 0, cam.rows - 1);
-          const int ti = im_texel(A.im, cam, tx, ty);
-          const uint32_t current = A.im.index[ti];
+          const int b3 = b == 0 ? 0 : (b == 3 ? 2 : 1);
+          const uint32_t current = idx9[a3][b3];
           if (current > 0U) {
-            const float4 vc = A.im.vert_conf[ti];
+            const float4 vc = vc9[a3][b3];
             if (fabsf((vc.z * lambda) - (vPosLocal.z * lambda)) < 0.05f) {
               const f3 cr = cross(ray, f3{vc.x, vc.y, vc.z});
               const float dist = sqrtf(dot(cr, cr)) / lenRay;
-              const float4 nr = A.im.norm_rad[ti];
+              const float4 nr = nr9[a3][b3];
               const f3 nn{nr.x, nr.y, nr.z};
               const float cang = dot(nn, vNormLocal) / (sqrtf(dot(nn, nn)) * lenN);
               const bool angOk = (cang > 0.87758255f && cang <= 1.0f);  // abs(acos(c)) < 0.5, NaN-false
@@ -1239,7 +1263,7 @@ void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, co
                       unsigned* nonempty_flag, unsigned nonempty_value) {
   hipLaunchKernelGGL(k_surface_splat, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
                      time, maxTime, timeDelta, zbuf);
-  const dim3 g(ceil_div(cam.cols * cam.rows, BLK));
+  const dim3 g(ceil_div(cam.cols, 16), ceil_div(cam.rows, 16));   // 16 x 16 pixel tiles, 8 x 8 per wavefront
   if (fill.image)
     hipLaunchKernelGGL(k_surface_resolve<true>, g, dim3(BLK), 0, s, cam, T_cw16_dev, map, maxDepth, confThreshold, time, maxTime, timeDelta,
                        zbuf, out, fill, depth_filtered, rgb3, passthroughImage, dense_counter, nonempty_flag, nonempty_value);
@@ -1252,7 +1276,7 @@ void synthesize_depth(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, co
   hipLaunchKernelGGL(k_surface_splat, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
                      time, maxTime, timeDelta, zbuf);
   const int n = cam.cols * cam.rows;
-  hipLaunchKernelGGL(k_depth_resolve, dim3(ceil_div(n, BLK)), dim3(BLK), 0, s, n, zbuf, depth);
+  hipLaunchKernelGGL(k_depth_resolve, dim3(ceil_div(n, BLK)), dim3(BLK), 0, s, cam.cols, cam.rows, zbuf, depth);
 }
 void fill_in(const Cam& cam, PredictMaps pred, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthrough, bool passthroughImage,
              FillMaps out, hipStream_t s) {

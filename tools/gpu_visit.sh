@@ -3,6 +3,11 @@
 #   tests        the whole -m gpu suite (no -x: every failure is seen) + smoke()
 #   ab           200-step bench of the default library and of the listed variants on THIS box (same frames): AB_LIBS="- fast nofma_fast"
 #   pytest:<expr>   python -m pytest tests -m gpu -k <expr>
+#   ab2          in-process A/B (tools/ab_bench.py): AB_SPECS="d d@2 fast"
+#   prof         rocprofv3 --kernel-trace --stats of the driver's command (no CPU baseline, no side legs)
+#   bench        the driver's command as the driver runs it (side legs + CPU baseline) -> <tag>_bench_driver_cmd.json
+#   pmc          HBM-side traffic: FETCH_SIZE / WRITE_SIZE passes + calibration (tools/pmc_traffic.sh), then tools/pmc_json.py -> profiles/pmc_traffic.json
+#   clocks       phase clocks of the persistent tracker (libefusion_hip_clocks.so: python -m elasticfusion_amd.build --variant clocks)
 tag=${1:-run}; shift
 out=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $out
@@ -26,6 +31,12 @@ for what in "$@"; do
       find /tmp/prof -name "${tag}_kernel_stats.csv" -exec cp {} $out/${tag}_bench_kernel_stats.csv \;
       head -30 $out/${tag}_bench_kernel_stats.csv | cut -c1-160; tail -2 $out/${tag}_prof_stdout.log | cut -c1-600
       cd $GRAFT_REPO_ROOT ;;
+    bench)
+      timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_driver_cmd.json 2> $out/${tag}_bench_driver_cmd.err; echo "bench (driver's command) rc=$?"
+      cut -c1-700 $out/${tag}_bench_driver_cmd.json; tail -2 $out/${tag}_bench_driver_cmd.err ;;
+    pmc)
+      bash tools/pmc_traffic.sh ${tag}_pmc 2>&1 | tail -12
+      python tools/pmc_json.py ${tag}_pmc --out $out/${tag}_pmc_traffic.json 2>&1 | tail -30 ;;
     clocks)
       timeout 120 python tools/fast_clocks.py elasticfusion_amd/libefusion_hip_clocks.so 140 > $out/${tag}_clocks.jsonl 2>$out/${tag}_clocks.err; cat $out/${tag}_clocks.jsonl; tail -2 $out/${tag}_clocks.err ;;
     ab)
