@@ -759,9 +759,9 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
         EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
       } else {
         eft::build_pyramids(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image,
-                            c->cfg.frame_to_frame_rgb != 0, fold_copies ? rgb_src : c->rgb, c->st, s, fold_copies ? c->rgb : nullptr);
+                            c->cfg.frame_to_frame_rgb != 0, fold_copies ? rgb_src : c->rgb, c->st, s, fold_copies ? c->rgb : nullptr, rgb);
       }
-      if (rgb) eft::init_rgb_sobel(c->pyr, s);
+      if (rgb && overlap) eft::init_rgb_sobel(c->pyr, s);
       timer_end(c, "odomInit");
       timer_begin(c, "odom");
       const bool sample = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0;

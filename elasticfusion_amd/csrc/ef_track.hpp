@@ -221,7 +221,8 @@ void init_model_pair(const Pyramid& p, const float* model_vertex4, const float* 
 // init_icp + init_rgb_model + init_rgb_frame in three launches (single-stream frame script; needs init_icp_model first)
 void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, const uint8_t* pred_image_rgba,
                     const uint8_t* fill_image_rgba, bool frameToFrameRGB, const uint8_t* rgb3, const TrackState* st, hipStream_t s,
-                    uint8_t* rgb_keep = nullptr);   // rgb_keep: also store the frame's RGB there (the caller's buffer is only borrowed)
+                    uint8_t* rgb_keep = nullptr,    // rgb_keep: also store the frame's RGB there (the caller's buffer is only borrowed)
+                    bool with_sobel = false);       // with_sobel: init_rgb_sobel's work in the same launch as the vertex / normal maps
 // initFirstRGB, RGBDOdometry.cpp:246-257
 void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
 // getIncrementalTransformation, RGBDOdometry.cpp:259-571, entirely enqueued.  The update step of an iteration is evaluated at the head of the

@@ -120,10 +120,8 @@ struct VNLevels {
   Intr k[NUM_PYRS];
   float cutoff;
 };
-__global__ void k_vmap_nmap_levels(const VNLevels L) {
-  const int l = blockIdx.z;
+__device__ __forceinline__ void vmap_nmap_px(const VNLevels& L, int l, int u, int v) {
   const int cols = L.cols[l], rows = L.rows[l];
-  const int u = blockIdx.x * blockDim.x + threadIdx.x, v = blockIdx.y * blockDim.y + threadIdx.y;
   if (u >= cols || v >= rows) return;
   const uint16_t* __restrict__ depth = L.depth[l];
   float* __restrict__ vmap = L.vmap[l];
@@ -149,6 +147,9 @@ __global__ void k_vmap_nmap_levels(const VNLevels L) {
   } else {
     nmap[v * cols + u] = qnan();
   }
+}
+__global__ void k_vmap_nmap_levels(const VNLevels L) {
+  vmap_nmap_px(L, blockIdx.z, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y * blockDim.y + threadIdx.y);
 }
 
 // tranformMapsKernel, cudafuncs.cu:221-270 (R, t read from device memory)
@@ -413,10 +414,8 @@ struct SobelLevels {
   float minScale[NUM_PYRS];
   int cols[NUM_PYRS], rows[NUM_PYRS];
 };
-__global__ void k_sobel_levels(const SobelLevels L) {
-  const int l = blockIdx.z;
+__device__ __forceinline__ void sobel_mask_px(const SobelLevels& L, int l, int x, int y) {
   const int cols = L.cols[l], rows = L.rows[l];
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= cols || y >= rows) return;
   const uint8_t* __restrict__ img = L.src[l];
   const int k = y * cols + x;
@@ -451,6 +450,16 @@ __global__ void k_sobel_levels(const SobelLevels L) {
   }
   L.mask[l][k] = ok ? 1 : 0;
   L.corres[l][k] = 0u;
+}
+__global__ void k_sobel_levels(const SobelLevels L) {
+  sobel_mask_px(L, blockIdx.z, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y * blockDim.y + threadIdx.y);
+}
+// k_vmap_nmap_levels and k_sobel_levels as ONE launch (round 5: they only share their inputs' producers, and every launch boundary of the frame
+// script is 2-6 us depending on the box): blockIdx.z = 0..2 vertex / normal maps of level z, 3..5 Sobel + photometric gates of level z - 3
+__global__ void k_vn_sobel_levels(const VNLevels V, const SobelLevels S) {
+  const int z = blockIdx.z, x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (z < NUM_PYRS) vmap_nmap_px(V, z, x, y);
+  else sobel_mask_px(S, z - NUM_PYRS, x, y);
 }
 
 // projectPointsKernel, cudafuncs.cu:670-688
@@ -2933,9 +2942,10 @@ __global__ void k_intensity_both(const uint8_t* __restrict__ rgb3, const uint8_t
 // initICP's depth pyramid + both halves of populateRGBDData in THREE launches instead of twelve (single-stream frame
 // script): level-0 intensities, then one k_pyr_down_multi per pyramid step over {frame depth u16, model depth f32,
 // model intensity, frame intensity}; then the per-level vertex/normal maps.  Same per-pixel functions, same results.
+static SobelLevels sobel_levels_of(const Pyramid& p);
 void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, const uint8_t* pred_image_rgba,
                     const uint8_t* fill_image_rgba, bool frameToFrameRGB, const uint8_t* rgb3, const TrackState* st, hipStream_t s,
-                    uint8_t* rgb_keep) {
+                    uint8_t* rgb_keep, bool with_sobel) {
   const int n = p.W(0) * p.H(0);
   hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 2), dim3(256), 0, s, rgb3, pred_image_rgba, fill_image_rgba, frameToFrameRGB, st,
                      n, p.nextImage[0], p.lastImage[0], rgb_keep);
@@ -2961,10 +2971,20 @@ void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, fl
   }
   L.cutoff = cutoff;
   dim3 g = tile_grid(p.W(0), p.H(0));
+  if (with_sobel) {   // init_rgb_sobel's launch rides along
+    g.z = 2 * NUM_PYRS;
+    hipLaunchKernelGGL(k_vn_sobel_levels, g, tile_block(), 0, s, L, sobel_levels_of(p));
+    return;
+  }
   g.z = NUM_PYRS;
   hipLaunchKernelGGL(k_vmap_nmap_levels, g, tile_block(), 0, s, L);
 }
 void init_rgb_sobel(const Pyramid& p, hipStream_t s) {
+  dim3 g = tile_grid(p.W(0), p.H(0));
+  g.z = NUM_PYRS;
+  hipLaunchKernelGGL(k_sobel_levels, g, tile_block(), 0, s, sobel_levels_of(p));
+}
+static SobelLevels sobel_levels_of(const Pyramid& p) {
   SobelLevels L;
   const float minGrad[NUM_PYRS] = {5, 3, 1};  // RGBDOdometry.cpp:112-114
   const float sobelScale = 1.0f / 8.0f;       // RGBDOdometry.cpp:39-40
@@ -2974,9 +2994,7 @@ void init_rgb_sobel(const Pyramid& p, hipStream_t s) {
     L.minScale[i] = (float)(pow((double)minGrad[i], 2.0) / pow((double)sobelScale, 2.0));  // RGBDOdometry.cpp:425
     L.cols[i] = p.W(i); L.rows[i] = p.H(i);
   }
-  dim3 g = tile_grid(p.W(0), p.H(0));
-  g.z = NUM_PYRS;
-  hipLaunchKernelGGL(k_sobel_levels, g, tile_block(), 0, s, L);
+  return L;
 }
 
 void init_first_rgb(const Pyramid& p, const uint8_t* rgb3, hipStream_t s) {
