@@ -7,6 +7,8 @@
 #   prof         rocprofv3 --kernel-trace --stats of the driver's command (no CPU baseline, no side legs)
 #   bench        the driver's command as the driver runs it (side legs + CPU baseline) -> <tag>_bench_driver_cmd.json
 #   pmc          HBM-side traffic: FETCH_SIZE / WRITE_SIZE passes + calibration (tools/pmc_traffic.sh), then tools/pmc_json.py -> profiles/pmc_traffic.json
+#   pmcbig       the same passes on BASELINE configs[2] (tools/pmc_traffic_big.sh) -> <tag>_pmc_traffic_1280x960.json
+#   factorial    tools/parity_factorial.py -> <tag>_parity_factorial.json
 #   clocks       phase clocks of the persistent tracker (libefusion_hip_clocks.so: python -m elasticfusion_amd.build --variant clocks)
 tag=${1:-run}; shift
 out=$GRAFT_REPO_ROOT/gpurun_out
@@ -37,6 +39,16 @@ for what in "$@"; do
     pmc)
       bash tools/pmc_traffic.sh ${tag}_pmc 2>&1 | tail -12
       python tools/pmc_json.py ${tag}_pmc --out $out/${tag}_pmc_traffic.json 2>&1 | tail -30 ;;
+    pmcbig)   # BASELINE configs[2] (1280x960, ~1 M pre-seeded surfels); after `pmc` of the same tag (its calibration is reused)
+      bash tools/pmc_traffic_big.sh ${tag}_pmcbig 2>&1 | tail -6
+      for c in FETCH_SIZE WRITE_SIZE; do cp $out/${tag}_pmc_${c}_calibration.txt $out/${tag}_pmcbig_${c}_calibration.txt; done
+      python tools/pmc_json.py ${tag}_pmcbig --out $out/${tag}_pmc_traffic_1280x960.json 2>&1 | tail -20 ;;
+    factorial)
+      timeout 300 python tools/parity_factorial.py $out/${tag}_parity_factorial.json > $out/${tag}_parity_factorial.log 2>&1; echo "factorial rc=$?"
+      python -c "
+import json; s = json.load(open('$out/${tag}_parity_factorial.json'))['summary']
+for k in ('fma_reference_order', 'nofma_fast_order', 'fma_fast_order'): print(k, s[k]['over_the_bar'], s[k]['pose_difference_m'])
+print(s['motion_error_against_the_generating_trajectory_m'])" ;;
     clocks)
       timeout 120 python tools/fast_clocks.py elasticfusion_amd/libefusion_hip_clocks.so 140 > $out/${tag}_clocks.jsonl 2>$out/${tag}_clocks.err; cat $out/${tag}_clocks.jsonl; tail -2 $out/${tag}_clocks.err ;;
     ab)
