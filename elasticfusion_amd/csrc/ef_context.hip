@@ -697,7 +697,10 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   std::swap(c->depth_metric_filtered, c->depth_metric_filtered_alt);
   const bool track_this = c->tick > 1 && !in_T_wc;
   c->frame_parity ^= 1;
-  if (overlap) EF_HIP(c, hipStreamWaitEvent(sb, c->overlap_mode == 2 ? c->ev_frame_done[c->frame_parity] : c->ev_track_done, 0));
+  // (mode 2 would put the bilateral filter on the chip WHILE the persistent tracker launch wants all of its CUs: its admission would fail and the
+  // frame would run on the one-workgroup fallback — mode 1 is what such a context gets)
+  const int overlap_mode = (c->overlap_mode == 2 && c->persistent == 1 && !c->use_graph) ? 1 : c->overlap_mode;
+  if (overlap) EF_HIP(c, hipStreamWaitEvent(sb, overlap_mode == 2 ? c->ev_frame_done[c->frame_parity] : c->ev_track_done, 0));
   // the frame images are referenced by later stages of this frame and by the next frame's tracker
   // (fill-in / predict read depth_filtered + rgb), so they are copied into context-owned buffers
   // Frames that are already in HBM are not copied by separate launches in the single-stream script: the bilateral filter
@@ -714,7 +717,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   timer_begin(c, "Preprocess");
   efm::preprocess_depth(depth_in, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb, 0u);
   timer_end(c, "Preprocess");
-  if (overlap && c->overlap_mode == 2) EF_HIP(c, hipStreamWaitEvent(sb, c->ev_track_done, 0));
+  if (overlap && overlap_mode == 2) EF_HIP(c, hipStreamWaitEvent(sb, c->ev_track_done, 0));
   if (track_this && overlap) {   // the single-stream script builds all pyramids together below (eft::build_pyramids)
     eft::init_icp(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, sb);
     eft::init_rgb_frame(c->pyr, c->rgb, sb);

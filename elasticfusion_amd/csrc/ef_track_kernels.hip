@@ -3090,10 +3090,14 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
   // off / rgbOnly (whose per-level "break" bookkeeping is not in the kernels), nothing: then every step is its own launch, in the same order
   // of additions.  (Reference-order builds: persistent == 2 asks for round 3's launch of the small levels, k_track_small, below.)
   const int n_total = iterations[0] + iterations[1] + iterations[2];
+  // (a caller capturing `s` into a graph of its own gets the launch-per-step script: the persistent launches take a fresh epoch per launch
+  // and wait for the device's chain event, neither of which a replayed graph can carry)
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(s, &capture) == hipSuccess && capture != hipStreamCaptureStatusNone;
 #ifdef EF_FAST_ORDER
-  const int pmode = tp.persistent ? 1 : 0;
+  const int pmode = (tp.persistent && !capturing) ? 1 : 0;
 #else
-  const int pmode = tp.persistent;
+  const int pmode = capturing ? 0 : tp.persistent;
 #endif
   if (pmode == 1 && !tp.rgbOnly && n_total <= FT_MAX_ITER) {
     if (p.last_mode != 1) {   // another script of this instance may have left anything in the exchange areas: tags must never match by accident
@@ -3140,9 +3144,10 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
       std::lock_guard<std::mutex> lk(chain_mu);
       int dev = 0;
       (void)hipGetDevice(&dev);
-      hipEvent_t& ev = chain_ev[dev & 63];
+      hipEvent_t unchained = nullptr;   // (a device index beyond the table: no chain, the bounded spins remain)
+      hipEvent_t& ev = (dev >= 0 && dev < 64) ? chain_ev[dev] : unchained;
       if (ev) (void)hipStreamWaitEvent(s, ev, 0);
-      else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+      else if (&ev == &unchained || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
 #ifdef EF_FAST_ORDER
       if (icp && rgb) hipExtLaunchKernelGGL((k_track_fast<true, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
       else if (icp) hipExtLaunchKernelGGL((k_track_fast<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);

@@ -76,7 +76,8 @@ int ef_process_frame_dev(ef_ctx* ctx, const uint8_t* rgb_dev, const uint16_t* de
                          float weight_multiplier, const double* in_T_wc16);
 /* Input-stage overlap (default off; on = 1, or 2 to start the copy-in and the bilateral filter already during the previous tracker): the part of a frame that
  * needs only the new images (copy-in, bilateral filter + metric depth, frame-side pyramids) is enqueued on a second
- * internal stream and runs while the previous frame is still being fused.  Results are identical either way. */
+ * internal stream and runs while the previous frame is still being fused.  Results are identical either way.  A context whose tracker is the
+ * persistent launch (ef_set_persistent_tracker 1, the default on a 256-CU chip) treats 2 as 1: that launch needs every CU to itself. */
 int ef_set_input_overlap(ef_ctx* ctx, int on);
 /* ... and that second stream restricted to every n-th CU of the chip (n <= 1: no restriction, the default): the bilateral filter of frame k + 1,
  * the one ALU-bound kernel of a frame, then shares the chip with the latency-bound fusion / prediction kernels of frame k instead of displacing

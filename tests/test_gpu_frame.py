@@ -100,11 +100,13 @@ def test_pipelined_frames_match_oracle(hip, seq):
         rgb, depth, _ = seq.frame(k)
         o.process_frame(rgb, depth, k * 33333)
     runs = []
-    for overlap in (True, False, 4):   # 4: the input stream restricted to every 4th CU (ef_set_input_cu_mask)
+    # 4: the input stream restricted to every 4th CU (ef_set_input_cu_mask); 2: the bilateral filter already DURING the previous tracker — which a
+    # context whose tracker is the persistent launch (all 256 CUs to itself) runs as mode 1: no frame may end up on the one-workgroup fallback
+    for overlap in (True, False, 4, 2):
         ef = hip.ElasticFusion()
         if overlap == 4:
             ef.setInputCuMask(4)
-        ef.setInputOverlap(bool(overlap))
+        ef.setInputOverlap(2 if overlap == 2 else int(bool(overlap)))
         for k in range(n):
             rgb, depth, _ = seq.frame(k)
             ef.processFrame(rgb, depth, k * 33333)
@@ -114,8 +116,9 @@ def test_pipelined_frames_match_oracle(hip, seq):
         assert ef.lastCount() == o.map_count()
         assert np.array_equal(runs[-1][1].view(np.uint32), o.map().view(np.uint32))
         assert np.array_equal(runs[-1][2], o.buffer("depthFiltered"))
+        assert ef.trackerFallbacks() == 0, overlap
         ef.close()
-    for other in (1, 2):
+    for other in (1, 2, 3):
         for a, b in zip(runs[0], runs[other]):
             assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
 
