@@ -143,10 +143,13 @@ def pmc_traffic_of(kernel_prefix, w, h):
             return None, None
         with open(os.path.join(ROOT, "profiles", name)) as f:
             pj = json.load(f)
-        for k, rec in pj.get("kernels", {}).items():
-            if k.startswith(kernel_prefix):
-                return int(rec["traffic_bytes_per_launch"]), (f"committed PMC measurement (profiles/{name}: {rec.get('source', pj.get('source', ''))}; FETCH_SIZE and WRITE_SIZE in separate "
-                                                              "rocprofv3 passes, calibrated on a known-byte kernel), not measured in this run")
+        # (k_track_ref is not k_track_ref_end; of a templated kernel's instances, the one that moves the most bytes: level 0's)
+        hits = [rec for k, rec in pj.get("kernels", {}).items() if k == kernel_prefix or k.startswith(kernel_prefix + "<")]
+        if hits:
+            rec = max(hits, key=lambda r: r["traffic_bytes_per_launch"])
+            what = f"; its launches: {rec['launches_are']}" if "launches_are" in rec else ""
+            return int(rec["traffic_bytes_per_launch"]), (f"committed PMC measurement (profiles/{name}: {rec.get('source', pj.get('source', ''))}; FETCH_SIZE and WRITE_SIZE in separate "
+                                                          f"rocprofv3 passes, calibrated on a known-byte kernel{what}), not measured in this run")
     except Exception:
         pass
     return None, None

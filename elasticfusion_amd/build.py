@@ -29,6 +29,8 @@ VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_
     "nofma_fast": ["-DEF_FORCE_FAST_ORDER"],                   # no fused multiply-adds + the fast order (parity factorial)
     "clocks": ["-DEF_STAGE_CLOCKS"],                           # phase clocks of the default build's tracker (tools/small_clocks.py)
     "fast_clocks": ["-DEF_FAST_BUILD", "-DEF_STAGE_CLOCKS"],   # phase clocks of the fast build's persistent tracker (tools/fast_clocks.py)
+    "ldlt": ["-DEF_LDLT_EVERY_LANE"],                          # A/B: the 6x6 factorisation with the whole matrix in every lane (ef_solve_dev.hpp)
+    "ldlt_clocks": ["-DEF_LDLT_EVERY_LANE", "-DEF_STAGE_CLOCKS"],
 }
 SHIM_LIB = os.path.join(HERE, "libefusion.so")          # class ElasticFusion (include/ElasticFusion.h) over the C ABI
 SOURCES = ["ef_track_kernels.hip", "ef_map_kernels.hip", "ef_context.hip", "ef_ferns.hip"]

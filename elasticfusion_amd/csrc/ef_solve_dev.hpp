@@ -169,6 +169,97 @@ __device__ __forceinline__ double m3_inverse_entry(const double* m, int e) {
   return r;
 }
 
+// A/B (-DEF_LDLT_EVERY_LANE): the same factorisation with the WHOLE matrix in every lane's registers — no shuffles, no
+// read-lanes; the pivot index is the same in every lane, so the symmetric swap is a uniform branch over static register indices instead of
+// 13 conditional swaps per candidate.  The matrix is bitwise symmetric and stays so (ldlt6_wave keeps both triangles equal), so only the lower
+// triangle is held: 21 doubles.  The same IEEE operations on every element, in efl::ldlt_solve's order.
+__device__ __forceinline__ constexpr int ldlt6_at(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+template <int K, int M_>
+__device__ __forceinline__ void ldlt6_swap(double (&A)[21], unsigned& perm /* entry q in bits 3 q .. 3 q + 2 */) {
+  // new(i, j) = old(pi(i), pi(j)), pi = the transposition (K M_), on the lower triangle
+  double B[21];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      const int pi = (i == K) ? M_ : ((i == M_) ? K : i), pj = (j == K) ? M_ : ((j == M_) ? K : j);
+      B[ldlt6_at(i, j)] = A[ldlt6_at(pi, pj)];
+    }
+#pragma unroll
+  for (int q = 0; q < 21; ++q) A[q] = B[q];
+  const unsigned pk = (perm >> (3 * K)) & 7u, pm = (perm >> (3 * M_)) & 7u;
+  perm = (perm & ~((7u << (3 * K)) | (7u << (3 * M_)))) | (pm << (3 * K)) | (pk << (3 * M_));
+}
+template <int K>
+__device__ __forceinline__ void ldlt6_step(double (&A)[21], unsigned& perm) {
+  int p = K;
+  double best = fabs(A[ldlt6_at(K, K)]);
+#pragma unroll
+  for (int m = K + 1; m < 6; ++m) {
+    const double v = fabs(A[ldlt6_at(m, m)]);
+    const bool gt = v > best;
+    best = gt ? v : best;
+    p = gt ? m : p;
+  }
+  p = __builtin_amdgcn_readfirstlane(p);   // (every lane holds the same matrix)
+  if (K + 1 < 6 && p == K + 1) ldlt6_swap<K, (K + 1 < 6 ? K + 1 : K)>(A, perm);
+  else if (K + 2 < 6 && p == K + 2) ldlt6_swap<K, (K + 2 < 6 ? K + 2 : K)>(A, perm);
+  else if (K + 3 < 6 && p == K + 3) ldlt6_swap<K, (K + 3 < 6 ? K + 3 : K)>(A, perm);
+  else if (K + 4 < 6 && p == K + 4) ldlt6_swap<K, (K + 4 < 6 ? K + 4 : K)>(A, perm);
+  else if (K + 5 < 6 && p == K + 5) ldlt6_swap<K, (K + 5 < 6 ? K + 5 : K)>(A, perm);
+  const double d = A[ldlt6_at(K, K)];
+  if (!(d == 0.0)) {
+    double colk[6];
+#pragma unroll
+    for (int i = K + 1; i < 6; ++i) colk[i] = A[ldlt6_at(i, K)];
+#pragma unroll
+    for (int i = K + 1; i < 6; ++i) {
+      const double l = colk[i] / d;
+#pragma unroll
+      for (int j = K + 1; j <= i; ++j) A[ldlt6_at(i, j)] = A[ldlt6_at(i, j)] - l * colk[j];
+      A[ldlt6_at(i, K)] = l;
+    }
+  }
+}
+__device__ __forceinline__ void ldlt6_every_lane(double a, SolveScratch& S) {
+  const int lane = threadIdx.x & 63;
+  if (lane < 36) S.A[lane] = a;
+  wave_sync();
+  double A[21];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) A[ldlt6_at(i, j)] = S.A[i * 6 + j];
+  unsigned perm = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12) | (5u << 15);
+  ldlt6_step<0>(A, perm);
+  ldlt6_step<1>(A, perm);
+  ldlt6_step<2>(A, perm);
+  ldlt6_step<3>(A, perm);
+  ldlt6_step<4>(A, perm);
+  ldlt6_step<5>(A, perm);
+  double y[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) y[q] = S.b[(perm >> (3 * q)) & 7u];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < r; ++c) y[r] -= A[ldlt6_at(r, c)] * y[c];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const double d = A[ldlt6_at(r, r)];
+    y[r] = (fabs(d) > DBL_MIN) ? y[r] / d : 0.0;
+  }
+#pragma unroll
+  for (int r = 5; r >= 0; --r)
+#pragma unroll
+    for (int c = r + 1; c < 6; ++c) y[r] -= A[ldlt6_at(c, r)] * y[c];
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) S.x[(perm >> (3 * q)) & 7u] = y[q];
+  }
+  wave_sync();
+}
+
 struct SolveInputs {
   bool icp, rgb, rgbOnly;
   float icpWeight;
@@ -208,7 +299,11 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, ef
   }
   wave_sync();
   EF_STAMP(st, 4);
+#ifdef EF_LDLT_EVERY_LANE
+  ldlt6_every_lane(a, S);
+#else
   ldlt6_wave(a, S);
+#endif
   EF_STAMP(st, 5);
   // ---- computeUpdateSE3 (OdometryProvider.h:73-96): rodrigues(result[3..5]) and the 4x4 increment ----
   {

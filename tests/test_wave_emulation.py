@@ -121,3 +121,6 @@ def test_wave_parallel_ldlt_equals_the_scalar_statement(tmp_path):
         shipped.run_ldlt6_scalar(P(A), P(b), P(want))
         shipped.run_ldlt6_wave(P(A), P(b), P(got))
         assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (k, got, want)
+        got2 = np.zeros(6)
+        shipped.run_ldlt6_every_lane(P(A), P(b), P(got2))     # the whole-matrix-per-lane variant (-DEF_LDLT_EVERY_LANE)
+        assert np.array_equal(got2.view(np.uint64), want.view(np.uint64)), (k, got2, want)

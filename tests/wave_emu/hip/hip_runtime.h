@@ -77,6 +77,7 @@ inline double __shfl(double v, int src, int width) { if (width != 64) std::abort
 inline int __shfl(int v, int src, int width) { if (width != 64) std::abort(); return (int)(unsigned)emu::exchange((unsigned)v, src); }
 inline float __shfl(float v, int src, int width) { return __int_as_float(__shfl(__float_as_int(v), src, width)); }
 inline int __builtin_amdgcn_readlane(int v, int src) { return (int)(unsigned)emu::exchange((unsigned)v, src); }   // src is wave-uniform
+inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(unsigned)emu::exchange((unsigned)v, 0); }
 inline void __builtin_amdgcn_wave_barrier() { emu::wave.barrier->arrive_and_wait(); }
 #define __builtin_amdgcn_fence(...) ((void)0)   /* the barrier of the emulation orders the lanes' memory accesses */
 inline int __double2hiint(double d) { unsigned long long b; std::memcpy(&b, &d, 8); return (int)(b >> 32); }

@@ -9,6 +9,8 @@
 #   pmc          HBM-side traffic: FETCH_SIZE / WRITE_SIZE passes + calibration (tools/pmc_traffic.sh), then tools/pmc_json.py -> profiles/pmc_traffic.json
 #   pmcbig       the same passes on BASELINE configs[2] (tools/pmc_traffic_big.sh) -> <tag>_pmc_traffic_1280x960.json
 #   factorial    tools/parity_factorial.py -> <tag>_parity_factorial.json
+#   shared       aggregate frames/s of 1, 2, 4 replays sharing the GPU -> <tag>_shared_gpu.jsonl
+#   variant:<v>  libefusion_hip_<v>.so beside the default: phase clocks (<v>_clocks), the frame / reference / steady-state parity tests through it
 #   clocks       phase clocks of the persistent tracker (libefusion_hip_clocks.so: python -m elasticfusion_amd.build --variant clocks)
 tag=${1:-run}; shift
 out=$GRAFT_REPO_ROOT/gpurun_out
@@ -49,6 +51,14 @@ for what in "$@"; do
 import json; s = json.load(open('$out/${tag}_parity_factorial.json'))['summary']
 for k in ('fma_reference_order', 'nofma_fast_order', 'fma_fast_order'): print(k, s[k]['over_the_bar'], s[k]['pose_difference_m'])
 print(s['motion_error_against_the_generating_trajectory_m'])" ;;
+    shared)   # several replays sharing this GPU (tools/shared_gpu_bench.py)
+      timeout 300 python tools/shared_gpu_bench.py --steps 150 --sequences ${SHARED_SEQUENCES:-1,2,4} 2>/dev/null | tee $out/${tag}_shared_gpu.jsonl ;;
+    variant:*)   # a development build (python -m elasticfusion_amd.build --variant <name> [and <name>_clocks]) beside the default: clocks, parity, A/B
+      v=${what#variant:}
+      [ -f elasticfusion_amd/libefusion_hip_${v}_clocks.so ] && timeout 200 python tools/fast_clocks.py elasticfusion_amd/libefusion_hip_clocks.so elasticfusion_amd/libefusion_hip_${v}_clocks.so 140 > $out/${tag}_clocks_${v}.jsonl 2>$out/${tag}_clocks_${v}.err
+      cat $out/${tag}_clocks_${v}.jsonl | cut -c1-900
+      EF_HIP_LIB=$GRAFT_REPO_ROOT/elasticfusion_amd/libefusion_hip_${v}.so timeout 500 python -m pytest tests -m gpu -q --timeout=300 -k "${VARIANT_TESTS:-test_gpu_frame or vs_reference or test_gpu_steady}" > $out/${tag}_gpu_tests_${v}.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_gpu_tests_${v}.log
+      tail -6 $out/${tag}_gpu_tests_${v}.log | cut -c1-300 ;;
     clocks)
       timeout 120 python tools/fast_clocks.py elasticfusion_amd/libefusion_hip_clocks.so 140 > $out/${tag}_clocks.jsonl 2>$out/${tag}_clocks.err; cat $out/${tag}_clocks.jsonl; tail -2 $out/${tag}_clocks.err ;;
     ab)

@@ -4,8 +4,9 @@
     python tools/pmc_json.py <tag> [<tag_per_step>] [--out profiles/pmc_traffic.json]
 
 <tag>: a run of the default script (gpurun_out/<tag>_{FETCH,WRITE}_SIZE_per_kernel.csv + *_calibration.txt): the persistent tracker launch
-(k_track_ref; k_track_fast in the fast build), the IndexMap splat and every other kernel of a frame; <tag_per_step>: a run with
---per-step-tracker, in which the level-0 normal equations are a launch of their own (k_se3_accum), same calibration.
+(k_track_ref; k_track_fast in the fast build), the IndexMap splat and every other kernel of a frame — and, from the frames bench.py replays
+with the launch-per-step script behind its timed region, the level-0 normal equations as a launch of their own (k_se3_accum<5, ...>);
+<tag_per_step> (optional): take k_se3_accum from a run with --per-step-tracker instead, same calibration.
 
 HBM-side bytes per launch = FETCH_SIZE x (bytes per counted KB, from the calibration kernel) + WRITE_SIZE x (same); bench.py reads
 kernels[<name>].traffic_bytes_per_launch by kernel-name prefix (pmc_traffic_of).
@@ -52,11 +53,15 @@ for t, wanted in ((tag, None), (args[1] if len(args) > 1 else None, ("k_se3_accu
     fetch, write = per_kernel("FETCH_SIZE", t), per_kernel("WRITE_SIZE", t)
     for k, (n, f) in fetch.items():
         name = short(k)
-        if not name.startswith("k_") or name.startswith("k_calib") or (wanted and not name.startswith(wanted)) or (not wanted and name.startswith("k_se3_accum")):
+        if not name.startswith("k_") or name.startswith("k_calib") or (wanted and not name.startswith(wanted)) or (not wanted and len(args) > 1 and name.startswith("k_se3_accum")):
             continue
         w = write.get(k, (0, 0.0))[1]
         rec = {"dispatches": n, "FETCH_SIZE_KB_per_dispatch": round(f, 3), "WRITE_SIZE_KB_per_dispatch": round(w, 3),
                "traffic_bytes_per_launch": int(round(f * cf + w * cw)), "source": f"tools/pmc_traffic.sh {t}"}
+        if name.startswith("k_se3_accum<5"):
+            # bench.py runs the launch-per-step script on the frames behind its timed region: the <5, ...> instance is every launch over more than
+            # 8 x 16384 pixels — at 640x480 exactly the level-0 launches, at 1280x960 levels 0 AND 1 (10 : 5 launches a frame)
+            rec["launches_are"] = "level 0" if "1280" not in out_path else "levels 0 and 1 (10 : 5 per frame; level 1 carries a quarter of level 0's pixels)"
         if name in doc["kernels"] and doc["kernels"][name]["traffic_bytes_per_launch"] >= rec["traffic_bytes_per_launch"]:
             continue   # (templated kernels: keep the instance with the most bytes per dispatch)
         doc["kernels"][name] = rec
