@@ -674,7 +674,7 @@ def main():
             legs["four_sequences_on_one_gpu_fps"] = sequences_on_one_gpu(api, frames, dev, w, h, local_rank, 4, a.steps, a.warmup, a.preroll)
             legs["four_sequences_on_one_gpu_fps"]["what"] = ("AGGREGATE frames/s of four independent replays sharing this GPU (four contexts, four host threads, launch-per-step "
                                                              "tracker scripts; results identical across the four): what a server with more streams than GPUs gets per device.  With --steps 20 the "
-                                                             "timed region is ~25 ms and thread start-up skew understates it: 150-step runs read 3780 (profiles/r04o_shared_gpu.jsonl)")
+                                                             "timed region is ~25 ms and thread start-up skew understates it: 150-step runs read 1732 / 2525 / 3715 for 1 / 2 / 4 replays (profiles/r05l_shared_gpu.jsonl)")
         except Exception as e:
             legs["four_sequences_on_one_gpu_fps"] = {"error": repr(e)}
         try:
@@ -691,7 +691,7 @@ def main():
             api.use_library(build.FAST_LIB)
             legs["fast_build_fps"] = side_leg(torch, api, frames, dev, w, h, local_rank, stream, **common)
             legs["fast_build_fps"]["what"] = ("libefusion_hip_fast.so (INTEGRATION.md 'the fast build', opt-in): bit for bit its own specification (tests/test_gpu_fast_build.py), "
-                                             "NOT inside 1e-4 m / 1e-4 rad of the reference rounding on every frame (19 of 113 one-frame checkpoints over the bar: "
+                                             "NOT inside 1e-4 m / 1e-4 rad of the reference rounding on every frame (15 of 113 one-frame checkpoints over the bar: "
                                              "profiles/r05_parity_factorial.json) — which is why `value` is the reference-rounding build's rate")
             out["value_fast_build"] = legs["fast_build_fps"]["value"]   # (top level too; never `value`)
         except Exception as e:

@@ -7,7 +7,7 @@ Two libraries with the same C ABI are built (csrc/ef_build.hpp):
     libefusion_hip.so        the shipped default: REFERENCE ROUNDING (no fused multiply-add, the reference's summation order) — every result bit
                              for bit the reference's own sources compiled without contraction; what libefusion.so links and bench.py times
     libefusion_hip_fast.so   opt-in (-DEF_FAST_BUILD): fused multiply-adds + the fast summation order; faster, and outside the 1e-4 m / 1e-4 rad
-                             bar on 17 % of frames (profiles/r05_parity_factorial.json)
+                             bar on 13 % of one-frame checkpoints (profiles/r05_parity_factorial.json)
 
 -ffp-contract=off: fused multiply-adds appear only where the kernels spell them out (fmaf), which is what
 makes the integer-valued stages (u16/u8/i16 pyramids, correspondences, index maps) bit-exact against the
@@ -29,8 +29,8 @@ VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_
     "nofma_fast": ["-DEF_FORCE_FAST_ORDER"],                   # no fused multiply-adds + the fast order (parity factorial)
     "clocks": ["-DEF_STAGE_CLOCKS"],                           # phase clocks of the default build's tracker (tools/small_clocks.py)
     "fast_clocks": ["-DEF_FAST_BUILD", "-DEF_STAGE_CLOCKS"],   # phase clocks of the fast build's persistent tracker (tools/fast_clocks.py)
-    "ldlt": ["-DEF_LDLT_EVERY_LANE"],                          # A/B: the 6x6 factorisation with the whole matrix in every lane (ef_solve_dev.hpp)
-    "ldlt_clocks": ["-DEF_LDLT_EVERY_LANE", "-DEF_STAGE_CLOCKS"],
+    "ldlt_wave": ["-DEF_LDLT_WAVE"],                           # A/B: rounds 2-4's 6x6 factorisation, one matrix element per lane (ef_solve_dev.hpp)
+    "ldlt_wave_clocks": ["-DEF_LDLT_WAVE", "-DEF_STAGE_CLOCKS"],
 }
 SHIM_LIB = os.path.join(HERE, "libefusion.so")          # class ElasticFusion (include/ElasticFusion.h) over the C ABI
 SOURCES = ["ef_track_kernels.hip", "ef_map_kernels.hip", "ef_context.hip", "ef_ferns.hip"]

@@ -91,6 +91,8 @@ __device__ __forceinline__ int se3_member_of(int i, int j) {
 
 // Eigen::LDLT-style solve of the 6x6 system held one element per lane (lane e < 36 holds A[e/6][e%6], bitwise
 // symmetric); b in S.b.  Mirrors efl::ldlt_solve<double,6> operation for operation.  Result in S.x (all 6 entries).
+// (Rounds 2-4's version, kept for the A/B and the host emulation — tests/test_wave_emulation.py runs both against the scalar statement;
+// the update step runs ldlt6_every_lane below.)
 __device__ __forceinline__ void ldlt6_wave(double a, SolveScratch& S) {
   const int lane = threadIdx.x & 63;
   const int e = lane < 36 ? lane : 0;
@@ -169,9 +171,9 @@ __device__ __forceinline__ double m3_inverse_entry(const double* m, int e) {
   return r;
 }
 
-// A/B (-DEF_LDLT_EVERY_LANE): the same factorisation with the WHOLE matrix in every lane's registers — no shuffles, no
-// read-lanes; the pivot index is the same in every lane, so the symmetric swap is a uniform branch over static register indices instead of
-// 13 conditional swaps per candidate.  The matrix is bitwise symmetric and stays so (ldlt6_wave keeps both triangles equal), so only the lower
+// The same factorisation with the WHOLE matrix in every lane's registers (round 5; what the update step runs) — no shuffles, no read-lanes
+// on the six pivots' critical path; the pivot index is the same in every lane, so the symmetric swap is a uniform branch over static register
+// indices instead of 13 conditional swaps per candidate.  The matrix is bitwise symmetric and stays so (ldlt6_wave keeps both triangles equal), so only the lower
 // triangle is held: 21 doubles.  The same IEEE operations on every element, in efl::ldlt_solve's order.
 __device__ __forceinline__ constexpr int ldlt6_at(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 template <int K, int M_>
@@ -299,10 +301,10 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, ef
   }
   wave_sync();
   EF_STAMP(st, 4);
-#ifdef EF_LDLT_EVERY_LANE
-  ldlt6_every_lane(a, S);
+#ifdef EF_LDLT_WAVE
+  ldlt6_wave(a, S);         // rounds 2-4 (A/B: python -m elasticfusion_amd.build --variant ldlt_wave)
 #else
-  ldlt6_wave(a, S);
+  ldlt6_every_lane(a, S);   // round 5: 2.14 -> 1.88 us per update step (profiles/r05l_clocks_ldlt.jsonl), 16 registers fewer in k_track_ref
 #endif
   EF_STAMP(st, 5);
   // ---- computeUpdateSE3 (OdometryProvider.h:73-96): rodrigues(result[3..5]) and the 4x4 increment ----

@@ -208,12 +208,12 @@ def test_fast_build_one_frame_from_identical_state(pool):
         assert q["fraction_within_1e5_among_same_decision"] >= 0.998 and q["fraction_association_decision_differs"] <= 2e-3, r
         assert q["fraction_within_1e5_relative"] >= 0.997, r
         assert abs(r["surfels_a"] - r["surfels_b"]) <= 2e-3 * r["surfels_b"], r
-    # Pose of the FAST build.  MEASURED (round 4 / 5, profiles/r04h_one_frame_parity.json, r05_parity_factorial.json, 113 checkpoints): median
-    # 7.2e-6 m / 5.9e-6 rad, p95 1.7e-4 m / 2.2e-4 rad, max 1.9e-3 m / 5.2e-4 rad (clutter scene with sensor noise, frame 40); 19 of 113
-    # checkpoints exceed the north_star bar.  The factorial says why: fused multiply-adds + the REFERENCE's order 19 / 113, NO fused
-    # multiply-adds + the fast order 2 / 113 (median 9e-7 m) — the contraction inside the per-pixel geometry moves the pose, the order of
-    # the sums hardly does.  What is asserted here is what holds on every run: the typical checkpoint is an order of magnitude inside the
-    # bar and no checkpoint is off by more than a few millimetres.  The bar itself, on EVERY checkpoint: the test below.
+    # Pose of the FAST build.  MEASURED (round 5 on the final kernels, profiles/r05k_one_frame_parity.json, r05_parity_factorial.json, 113 checkpoints):
+    # median 8.3e-6 m / 7.1e-6 rad, p95 2.5e-4 m / 1.6e-4 rad, max 8.6e-4 m / 3.5e-4 rad (box scene, seed 0xEF0003, frame 100); 15 of 113
+    # checkpoints exceed the north_star bar (round 4's donor trajectories: 19, max 1.9e-3 m).  The factorial says why: fused multiply-adds + the
+    # REFERENCE's order 15 / 113, NO fused multiply-adds + the fast order 2 / 113 (median 7e-7 m) — the contraction inside the per-pixel geometry
+    # moves the pose, the order of the sums hardly does.  What is asserted here is what holds on every run: the typical checkpoint is an order of
+    # magnitude inside the bar and no checkpoint is off by more than a few millimetres.  The bar itself, on EVERY checkpoint: the test below.
     assert summary["pose_difference_m"]["median"] <= 2e-5 and summary["pose_difference_rad"]["median"] <= 2e-5, summary
     assert float(np.percentile(dm, 75)) <= 1e-4 and float(np.percentile(da, 75)) <= 1e-4, summary
     assert summary["pose_difference_m"]["max"] <= 5e-3 and summary["pose_difference_rad"]["max"] <= 2e-3, summary
@@ -222,7 +222,7 @@ def test_fast_build_one_frame_from_identical_state(pool):
 
 @pytest.mark.xfail(strict=False, reason="the OPT-IN fast build (libefusion_hip_fast.so), not the shipped default: 1e-4 m / 1e-4 rad against the reference rounding "
                                         "does not hold on every frame once multiply-adds are fused — parity factorial, profiles/r05_parity_factorial.json: FMA + "
-                                        "reference order 19 / 113 over the bar, FMA + fast order 19 / 113, no FMA + fast order 2 / 113; which is why the shipped "
+                                        "reference order 15 / 113 over the bar, FMA + fast order 15 / 113, no FMA + fast order 2 / 113; which is why the shipped "
                                         "default is the reference rounding itself (0 / 113 by construction, bit for bit the compiled reference)")
 def test_north_star_pose_bar_on_every_checkpoint_fast_build():
     """north_star: 1e-4 m / 1e-4 rad between the opt-in FAST build and the reference rounding (= the shipped default), one frame from identical
