@@ -170,7 +170,9 @@ def roofline_tracker(lib, ef, w=W, h=H):
             "frac_survey_48B": round(kt.bytes_per_launch_survey / (kt.avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
             "timer": "dispatch begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of the launch on the frames right behind the timed region (same replay, same map)",
             "note": "the dominant kernel of the timed region: a chain of 19 dependent Gauss-Newton iterations (two chip-wide exchanges and a 6x6 solve in double each) — "
-                    "latency-bound, not bandwidth-bound; most of its algorithmic bytes are served by the L2s / MALL across iterations (traffic << algorithmic)"}
+                    "latency-bound, not bandwidth-bound; " + ("most of its algorithmic bytes are served by the L2s / MALL across iterations (traffic << algorithmic)"
+                                                              if traffic is None or traffic < kt.bytes_per_launch else
+                                                              "at this size the maps no longer stay in the L2s between iterations: the HBM-side traffic is the algorithmic bytes and a little more")}
 
 
 def probe_frames_run(ef, lib, step, first, n, torch, w=W, h=H):
