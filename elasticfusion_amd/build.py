@@ -3,11 +3,12 @@
     python -m elasticfusion_amd.build [--force]
     python -m elasticfusion_amd.build --variant <name> [-D...]      (development / A-B builds: VARIANTS below)
 
-Two libraries with the same C ABI are built (csrc/ef_build.hpp):
-    libefusion_hip.so        the shipped default: REFERENCE ROUNDING (no fused multiply-add, the reference's summation order) — every result bit
-                             for bit the reference's own sources compiled without contraction; what libefusion.so links and bench.py times
-    libefusion_hip_fast.so   opt-in (-DEF_FAST_BUILD): fused multiply-adds + the fast summation order; faster, and outside the 1e-4 m / 1e-4 rad
-                             bar on 13 % of one-frame checkpoints (profiles/r05_parity_factorial.json)
+ONE library is shipped (csrc/ef_build.hpp):
+    libefusion_hip.so        REFERENCE ROUNDING (no fused multiply-add, the reference's summation order) — every result bit for bit the
+                             reference's own sources compiled without contraction; what libefusion.so links and bench.py times
+Round 4's build (-DEF_FAST_BUILD: fused multiply-adds + the fast summation order; no faster since round 5 and outside the 1e-4 m / 1e-4 rad
+bar on 15 of 113 one-frame checkpoints, profiles/r05_parity_factorial.json) is no longer built by build(): it is the development variant
+"fast" (`--variant fast` -> libefusion_hip_fast.so), kept for the parity factorial and the `-m "gpu and fastbuild"` tests.
 
 -ffp-contract=off: fused multiply-adds appear only where the kernels spell them out (fmaf), which is what
 makes the integer-valued stages (u16/u8/i16 pyramids, correspondences, index maps) bit-exact against the
@@ -22,9 +23,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libefusion_hip.so")            # reference rounding (the default)
-FAST_LIB = os.path.join(HERE, "libefusion_hip_fast.so")   # -DEF_FAST_BUILD (opt-in)
+FAST_LIB = os.path.join(HERE, "libefusion_hip_fast.so")   # build_variant("fast"): NOT part of build() since round 6
 NOFMA_LIB = LIB                                           # (rounds 1-4 kept the reference rounding in a test-only libefusion_hip_nofma.so: now the default)
 VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_hip_<name>.so
+    "fast": ["-DEF_FAST_BUILD"],                               # round 4's shipped build: fused multiply-adds + the fast order (DESIGN_fast_build.md)
     "reforder": ["-DEF_FAST_BUILD", "-DEF_REF_ORDER"],         # fused multiply-adds + the reference's order (round 3's product; parity factorial)
     "nofma_fast": ["-DEF_FORCE_FAST_ORDER"],                   # no fused multiply-adds + the fast order (parity factorial)
     "clocks": ["-DEF_STAGE_CLOCKS"],                           # phase clocks of the default build's tracker (tools/small_clocks.py)
@@ -46,11 +48,11 @@ def _hipcc() -> str:
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB) or not os.path.exists(SHIM_LIB) or not os.path.exists(FAST_LIB):
+    if not os.path.exists(LIB) or not os.path.exists(SHIM_LIB):
         return True
     t = os.path.getmtime(LIB)
     root = os.path.dirname(HERE)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".o")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".inc", ".hpp", ".h"))]
     deps += [os.path.join(root, "include", "ef_hip.h"), os.path.join(root, "include", "ElasticFusion.h"), os.path.join(root, "include", "efusion_klg.hpp"), os.path.join(root, "include", "efusion_jpeg.hpp"),
              os.path.join(root, "tools", "efusion_replay.cpp"), __file__]
     replay = os.path.join(HERE, "efusion_replay")
@@ -60,27 +62,25 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    objs = {"": [], "_fast": []}
+    objs = []
     procs = []
-    for variant, extra in (("", []), ("_fast", ["-DEF_FAST_BUILD"])):
-        for src in SOURCES:
-            obj = os.path.join(CSRC, src.replace(".hip", variant + ".o"))
-            cmd = [_hipcc(), *FLAGS, *extra, *os.environ.get("EF_HIPCC_FLAGS", "").split(), "-c", os.path.join(CSRC, src), "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-            objs[variant].append(obj)
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [_hipcc(), *FLAGS, *os.environ.get("EF_HIPCC_FLAGS", "").split(), "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    for variant, target in (("", LIB), ("_fast", FAST_LIB)):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target, *objs[variant], "-Wl,-rpath,/opt/rocm/lib"]
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}")
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
     # libefusion.so: host-only C++ (compiled by hipcc for the shared __host__ __device__ linear-algebra header)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", SHIM_LIB,
            os.path.join(CSRC, "efusion_shim.hip"), "-L" + HERE, "-lefusion_hip", "-lz", "-ldl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]

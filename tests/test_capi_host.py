@@ -66,12 +66,12 @@ def test_product_sources_never_reference_the_oracle():
 
 
 def test_shipped_libraries_read_no_environment_variables():
-    """No developer knob reaches the product through the environment: libefusion_hip.so, libefusion_hip_fast.so and libefusion.so do not import getenv
+    """No developer knob reaches the product through the environment: libefusion_hip.so and libefusion.so do not import getenv
     (or secure_getenv), so EF_* variables cannot change which kernel a drop-in library runs."""
     import subprocess
     from elasticfusion_amd import api, build
     build.build()
-    for so in (api.LIB_PATH, build.FAST_LIB, os.path.join(os.path.dirname(api.LIB_PATH), "libefusion.so")):
+    for so in (api.LIB_PATH, os.path.join(os.path.dirname(api.LIB_PATH), "libefusion.so")):
         syms = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
         assert not re.search(r"\bU (secure_)?getenv\b", syms), so
     for base in ("elasticfusion_amd/csrc", "include"):

@@ -17,6 +17,7 @@ def test_starved_persistent_launch_falls_back_and_stays_oracle_identical(seq):
     run_starved(api, seq)
 
 
+@pytest.mark.fastbuild
 def test_starved_persistent_launch_of_the_fast_build_falls_back(fast_pair, seq):
     run_starved(fast_pair, seq)
 
@@ -47,7 +48,7 @@ def run_starved(api, seq):
     ef.close()
 
 
-@pytest.mark.parametrize("which", ["default", "fast"])
+@pytest.mark.parametrize("which", ["default", pytest.param("fast", marks=pytest.mark.fastbuild)])
 def test_a_protocol_failure_is_reported_where_the_front_end_calls(seq, which):
     """the sticky abort of a persistent launch (a wait that timed out AFTER admission) used to be seen by ef_synchronize only, which
     class ElasticFusion::processFrame never calls.  Now the frame whose tracker saw the flag hands it to the host (k_track_end -> a word of mapped

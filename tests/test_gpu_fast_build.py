@@ -13,7 +13,7 @@ import pytest
 
 import efo
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.fastbuild]
 
 
 def test_operator_tier_sums_equal_the_fast_oracle(fast_pair, frames):

@@ -152,6 +152,7 @@ def pose_err(T, Tr):
     return dt, float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)))
 
 
+@pytest.mark.fastbuild
 def test_fma_placement_divergence_free_running(sequences):
     """The shipped default (reference rounding) vs the opt-in fast build (fused multiply-adds + fast order), both free-running on the
     same frames.  nvcc's actual FMA choices cannot be observed here; the two builds bracket them (nothing fused vs everything the
