@@ -631,6 +631,10 @@ class ElasticFusion:
     def predict(self):
         _chk(lib().ef_predict(self.h), self.h)
 
+    def setResidentLevels(self, on=True):
+        """level-resident pixel data in the persistent tracker launch (ef_set_resident_levels; default on)"""
+        _chk(lib().ef_set_resident_levels(self.h, c_i(int(on))), self.h)
+
     def setFusedStep(self, on=True):
         """level-0 update step inside the correspondence-search launch (ef_set_fused_step)"""
         _chk(lib().ef_set_fused_step(self.h, c_i(int(on))), self.h)

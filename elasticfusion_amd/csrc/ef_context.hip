@@ -153,6 +153,7 @@ struct ef_ctx {
   // captured once per pyramid parity (the SO(3) reference / frame intensity buffers swap every frame) and replayed
   bool use_graph = false;
   bool track_only = false;       // ef_set_track_only: odometry on a frozen map (BASELINE.json configs[4])
+  bool no_resident = false;      // ef_set_resident_levels(ctx, 0): the persistent tracker launch streams every level's pixel data (round 5's kernel; A/B)
   bool fused_step = false;       // ef_set_fused_step: level-0 update step inside the correspondence-search launch
   int persistent = 1;            // ef_set_persistent_tracker: 1 = the whole tracker as one persistent launch of 256 workgroups, 0 = one launch per step,
                                  // 2 = (reference-order builds) round 3's launch of the small levels on 128 workgroups
@@ -451,6 +452,7 @@ void fern_tracker_device(void* user, const float* fv, const float* fn, const dou
   tp.rgbOnly = false; tp.pyramid = false; tp.fastOdom = false; tp.so3 = false; tp.icpWeight = 100.f;
   tp.persistent = c->persistent;
   tp.fused_step = c->fused_step ? 1 : 0;
+  tp.no_resident = c->no_resident ? 1 : 0;
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
   const eft::TrackTail tail = eft::track(c->pyr3, c->st3, c->intr3, tp, s, nullptr);
@@ -568,6 +570,7 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
   tp.rgbOnly = false; tp.pyramid = c->cfg.pyramid != 0; tp.fastOdom = c->cfg.fast_odom != 0; tp.so3 = false; tp.icpWeight = 10.f;   // :471
   tp.persistent = c->persistent;
   tp.fused_step = c->fused_step ? 1 : 0;
+  tp.no_resident = c->no_resident ? 1 : 0;
   tp.distThres = 0.10f;
   tp.angleThres = sinf(20.f * 3.14159254f / 180.f);
   tp.empty_model_flag = &c->st2->model_view_stamp;
@@ -751,6 +754,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       tp.icpWeight = c->cfg.icp_weight;
       tp.persistent = c->persistent;
       tp.fused_step = c->fused_step ? 1 : 0;
+  tp.no_resident = c->no_resident ? 1 : 0;
       tp.distThres = 0.10f;                                   // RGBDOdometry.h:41
       tp.angleThres = sinf(20.f * 3.14159254f / 180.f);       // RGBDOdometry.h:42
       const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
@@ -1391,6 +1395,7 @@ int ef_set_fused_step(ef_ctx* c, int on) {
   return EF_OK;
 }
 int ef_set_track_only(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->track_only = on != 0; return EF_OK; }
+int ef_set_resident_levels(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->no_resident = on == 0; return EF_OK; }
 int ef_set_persistent_tracker(ef_ctx* c, int on) {
   if (!c) return EF_EINVAL;
   c->persistent = on < 0 ? 0 : (on > 2 ? 1 : on);
@@ -1478,10 +1483,10 @@ int ef_debug_inject_tracker_abort(ef_ctx* c) {
   return EF_OK;
 }
 // developer instrumentation: per-phase clocks of the persistent small-level launch (-DEF_STAGE_CLOCKS builds; tools/small_clocks.py)
-int ef_debug_small_clocks(ef_ctx* c, unsigned long long* out24) {
-  if (!c || !out24) return EF_EINVAL;
+int ef_debug_small_clocks(ef_ctx* c, unsigned long long* out32) {
+  if (!c || !out32) return EF_EINVAL;
   DeviceGuard dg_(c);
-  return eft::tracker_small_clocks(c->pyr, out24, c->stream) == 0 ? EF_OK : EF_EHIP;
+  return eft::tracker_small_clocks(c->pyr, out32, c->stream) == 0 ? EF_OK : EF_EHIP;
 }
 int ef_debug_clocks(ef_ctx* c, unsigned long long* out16) {
   if (!c || !out16) return EF_EINVAL;

@@ -152,7 +152,8 @@ struct TrackParams {           // host-side knobs of getIncrementalTransformatio
   // find a correspondence in any iteration, every sum is zero, and the launch leaves what nineteen zero updates leave, at once
   const unsigned* empty_model_flag = nullptr;
   unsigned empty_model_value = 0;
-  int reserved_ = 0;           // (explicit: no tail padding)
+  int no_resident = 0;         // development (A/B): 1 = the persistent launch streams every level's pixel data as in round 5 (ef_set_resident_levels(ctx, 0));
+                               // (this member also makes the tail explicit: no padding)
 };
 static_assert(sizeof(TrackParams) == 4 + 4 + 8 + 4 + 4 + 8 + 4 + 4, "TrackParams has no padding bytes (it is compared with memcmp)");
 
@@ -249,7 +250,7 @@ int tracker_aborted(const Pyramid& p, hipStream_t s);
 // fast order: persistent launches of this tracker instance that found the chip partly taken (admission failed) and ran on ONE workgroup
 // instead — same results, ~25x the time; < 0 on a HIP error; synchronises the stream
 int tracker_fallbacks(const Pyramid& p, hipStream_t s);
-int tracker_small_clocks(const Pyramid& p, unsigned long long* out24, hipStream_t s);   // developer instrumentation (-DEF_STAGE_CLOCKS)
+int tracker_small_clocks(const Pyramid& p, unsigned long long* out32, hipStream_t s);   // developer instrumentation (-DEF_STAGE_CLOCKS)
 void track_swap(Pyramid& p, const TrackParams& tp);   // the pointer swap track() ends with (for hipGraph replay)
 // tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +
 // velocity weighting (ElasticFusion.cpp:369-383) + the float matrices of the map passes

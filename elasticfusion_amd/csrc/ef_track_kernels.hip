@@ -1060,6 +1060,68 @@ __device__ __forceinline__ f32x4 quad_outer(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
 #endif
 }
+// Phase B of one step for the reference-rounding build (round 6).  The DPP formulation above — 8 ds_bpermute, two quad transposes (32 moves /
+// selects), then 48 broadcast multiplies + 48 adds per lane — is 136 VALU instructions per step, a third of an ICP step and more than half of a
+// photometric one, and the normal-equation kernels are VALU-ISSUE bound (round 6: with every pixel-addressed load of an iteration removed the
+// persistent launch was no faster, profiles/r06b_*).  Here the rows cross lanes through LDS instead: the lane that computed the row of pass
+// 4 s + jl of virtual thread vl (load layout, lane = 16 jl + vl) writes its 8 values once (two 16-byte stores); lane 4 v + j then reads, for each of
+// the step's passes q, the WHOLE row of (v, q) (two 16-byte broadcast reads: the four lanes of a quad read the same address) plus its own two
+// components, and the rank-1 updates are plain register arithmetic — c0[i] += R[i] * R[j], c1[i] += R[i] * R[4 + j], c2[i] += R[4 + i] * R[4 + j] —
+// which the compiler emits as PACKED f32 multiplies and adds (v_pk_mul_f32 / v_pk_add_f32: two products per instruction, each product rounded, then
+// added: the same two roundings as v_mul + v_add).  48 VALU instructions per step instead of 136, 18 LDS instructions (their own issue port).
+// Element (i, j) of every block receives the same products in the same (pass) order as quad_outer gives it: bit-identical sums.
+// One 2 KB buffer per wavefront (LDS operations of a wavefront execute in order: no barrier, a compiler fence only).
+__device__ __forceinline__ float* quad_rowbuf() {
+  __shared__ float4 rb[8][128];   // [wavefront of the workgroup (<= 512 threads)][lo4 of lane 0..63 | hi4 of lane 0..63]
+  return (float*)rb[(threadIdx.x >> 6) & 7];
+}
+__device__ __forceinline__ void quad_rows_accumulate(const float (&rows)[8], int s, int K, f32x4 (&c)[3]) {
+#ifdef EF_NO_FMA
+  const int lane = threadIdx.x & 63, j = lane & 3, v = lane >> 2;
+  float* wb = quad_rowbuf();
+  f32x4* w4 = (f32x4*)wb;
+  w4[lane] = f32x4{rows[0], rows[1], rows[2], rows[3]};
+  w4[64 + lane] = f32x4{rows[4], rows[5], rows[6], rows[7]};
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // Passes in order: the chain of every accumulator is the reference thread's.  No test for 4 s + q < K (the DPP formulation skips the passes
+  // beyond the level's last): the row of a visit that does not exist is eight exact +0, its products are +0, and a running sum that started
+  // at +0 is never -0, so x + (+0) == x bit for bit — while a uniform branch per pass makes the compiler copy all twelve accumulators at every
+  // join (measured in the ISA: 12 v_mov per pass, more than the arithmetic they guard).
+  (void)K;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int W = 16 * q + v;   // the lane that computed pass 4 s + q of virtual thread v
+    const f32x4 lo4 = w4[W], hi4 = w4[64 + W];
+    const float lo = wb[4 * W + j], hi = wb[256 + 4 * W + j];
+    c[0] = c[0] + lo4 * lo;
+    c[1] = c[1] + lo4 * hi;
+    c[2] = c[2] + hi4 * hi;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the next step's stores stay behind these reads)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+  const int lane = threadIdx.x & 63, j = lane & 3;
+  const int gather_from = (16 * j + (lane >> 2)) * 4;
+  float r[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) r[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(gather_from, __float_as_int(rows[q])));
+  float lo[4] = {r[0], r[1], r[2], r[3]};
+  float hi[4] = {r[4], r[5], r[6], r[7]};
+  quad_transpose(lo, j);
+  quad_transpose(hi, j);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (4 * s + q < K) {
+      c[0] = quad_outer(lo[q], lo[q], c[0]);
+      c[1] = quad_outer(lo[q], hi[q], c[1]);
+      c[2] = quad_outer(hi[q], hi[q], c[2]);
+    }
+  }
+#endif
+}
 // (which outer product, register i, lane-in-quad j) -> JtJJtrSE3 member index, or -1 for duplicates / unused outputs.
 // kind 0: lo x lo, 1: lo x hi, 2: hi x hi with lo = row[0..3], hi = (row[4], row[5], row[6], found)
 __device__ __forceinline__ int quad_member(int kind, int i, int j) {
@@ -1301,22 +1363,7 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
     }
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
-      if (s0 + u < S) {   // uniform
-#pragma unroll
-        for (int q = 0; q < 8; ++q) rows[u][q] = __int_as_float(__builtin_amdgcn_ds_bpermute(gather_from, __float_as_int(rows[u][q])));
-        float lo[4] = {rows[u][0], rows[u][1], rows[u][2], rows[u][3]};
-        float hi[4] = {rows[u][4], rows[u][5], rows[u][6], rows[u][7]};
-        quad_transpose(lo, j);
-        quad_transpose(hi, j);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (4 * (s0 + u) + q < K) {   // uniform; passes in order: the chain of every accumulator is the reference thread's
-            c[0] = quad_outer(lo[q], lo[q], c[0]);
-            c[1] = quad_outer(lo[q], hi[q], c[1]);
-            c[2] = quad_outer(hi[q], hi[q], c[2]);
-          }
-        }
-      }
+      if (s0 + u < S) quad_rows_accumulate(rows[u], s0 + u, K, c);   // uniform; phase B
     }
   }
 }
@@ -3129,6 +3176,21 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
     FA.out_cur = 0;
     FA.empty_model_flag = tp.so3 ? nullptr : tp.empty_model_flag;   // (the SO(3) loop looks at the frame-side images only: not covered by the shortcut)
     FA.empty_model_value = tp.empty_model_value;
+#ifndef EF_FAST_ORDER
+    // level-resident pixel data (ef_track_ref_persistent.inc, rt_res_mode): the largest need of a level whose slots fit — both sides, or the
+    // ICP side alone (1280 x 960 level 0) — under what the chip gives one workgroup beside the kernel's static LDS
+    unsigned res_bytes = 0;
+    if (!tp.no_resident && rt_res_budget() > 0) {
+      for (int i = 0; i < NUM_PYRS; ++i) {
+        if (iterations[i] == 0) continue;
+        const unsigned S = (unsigned)(((p.W(i) * p.H(i) + VTHREADS - 1) / VTHREADS + 3) >> 2);
+        const unsigned n2 = S * ((icp ? RT_ICP_STEP_BYTES : 0) + (rgb ? RT_RGB_STEP_BYTES : 0)), n1 = icp ? S * RT_ICP_STEP_BYTES : 0u;
+        const unsigned need = n2 <= rt_res_budget() ? n2 : (n1 <= rt_res_budget() ? n1 : 0u);
+        res_bytes = need > res_bytes ? need : res_bytes;
+      }
+    }
+    FA.res_bytes = res_bytes;
+#endif
     const bool sample_all = probe_all && probe_all->used < probe_all->capacity;
     hipEvent_t e0 = sample_all ? probe_all->start[probe_all->used] : nullptr, e1 = sample_all ? probe_all->stop[probe_all->used] : nullptr;
     if (sample_all) probe_all->used++;
@@ -3153,9 +3215,9 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
       else if (icp) hipExtLaunchKernelGGL((k_track_fast<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
       else hipExtLaunchKernelGGL((k_track_fast<false, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
 #else
-      if (icp && rgb) hipExtLaunchKernelGGL((k_track_ref<true, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
-      else if (icp) hipExtLaunchKernelGGL((k_track_ref<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
-      else hipExtLaunchKernelGGL((k_track_ref<false, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
+      if (icp && rgb) hipExtLaunchKernelGGL((k_track_ref<true, true>), dim3(FT_WGS), dim3(FT_BLOCK), res_bytes, s, e0, e1, 0, FA, st);
+      else if (icp) hipExtLaunchKernelGGL((k_track_ref<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), res_bytes, s, e0, e1, 0, FA, st);
+      else hipExtLaunchKernelGGL((k_track_ref<false, true>), dim3(FT_WGS), dim3(FT_BLOCK), res_bytes, s, e0, e1, 0, FA, st);
 #endif
       if (ev) (void)hipEventRecord(ev, s);
     }
@@ -3241,15 +3303,17 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
 // host-side tail of getIncrementalTransformation: the frame's intensity pyramid becomes the SO(3) reference of the next
 // (RGBDOdometry.cpp:284-288 swaps lastNextImage / nextImage); separate so that a replayed hipGraph can do it without launching
 // developer instrumentation: the -DEF_STAGE_CLOCKS sums of k_track_small (24 x u64, 10 ns ticks; zeros in a normal build), read and reset
-int tracker_small_clocks(const Pyramid& p, unsigned long long* out24, hipStream_t s) {
+int tracker_small_clocks(const Pyramid& p, unsigned long long* out32, hipStream_t s) {
   if (!p.partials) return -1;
   unsigned long long* src = (unsigned long long*)((char*)(p.partials + FT_SY_OFF) + offsetof(FtSync, clk));
+  int n = 32;
 #ifndef EF_FAST_ORDER
-  if (p.last_mode != 1) src = (unsigned long long*)((char*)(p.partials + 2 * PARTIAL_FLOATS) + offsetof(PtSync, clk));   // k_track_small
+  if (p.last_mode != 1) { src = (unsigned long long*)((char*)(p.partials + 2 * PARTIAL_FLOATS) + offsetof(PtSync, clk)); n = 24; }   // k_track_small
 #endif
+  for (int i = 0; i < 32; ++i) out32[i] = 0ull;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
-  if (hipMemcpy(out24, src, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return hipMemset(src, 0, 24 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+  if (hipMemcpy(out32, src, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return hipMemset(src, 0, n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 int tracker_aborted(const Pyramid& p, hipStream_t s) {
   if (!p.partials) return 0;

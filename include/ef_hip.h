@@ -104,6 +104,11 @@ int ef_set_persistent_tracker(ef_ctx* ctx, int on);
  * pixel loads in flight) instead of being a launch of its own.  Same arithmetic, bit-identical results.  Off by default (measured:
  * DESIGN.md 6). */
 int ef_set_fused_step(ef_ctx* ctx, int on);
+/* The persistent tracker launch keeps the pose-INDEPENDENT inputs of a pyramid level's pixel visits (current vertex / normal maps: the operands
+ * of icpStep's search that the pixel itself addresses, Core/Cuda/reduce.cu:228-262; the frame's depth, intensity, gradients and the photometric
+ * gate: residualKernel's, reduce.cu:631-667) in LDS for all iterations of the level (round 6; default on).  0 = stream them from memory in every
+ * iteration as round 5's launch did (A/B).  Same arithmetic on the same values: bit-identical results. */
+int ef_set_resident_levels(ef_ctx* ctx, int on);
 /* Odometry only (BASELINE.json configs[4], "open-loop odometry-only ... throughput ceiling"): frames are pre-processed, tracked against
  * the model prediction and the prediction is renewed at the new pose, but nothing is fused (the map stays as it is: indexMap, fuse and
  * clean of ElasticFusion.cpp:536-585 are skipped, like a frame whose tracking failed under relocalisation).  Off by default. */
@@ -433,9 +438,9 @@ int ef_debug_inject_tracker_abort(ef_ctx* ctx);
 /* developer instrumentation: the 16 wall_clock64() (100 MHz) stamps the last tracking solve left in the device state;
  * all zero unless the library was built with -DEF_STAGE_CLOCKS (EF_HIPCC_FLAGS=-DEF_STAGE_CLOCKS python -m elasticfusion_amd.build) */
 int ef_debug_clocks(ef_ctx* ctx, unsigned long long* out16);
-/* developer instrumentation of the persistent tracker launch (zeros unless the library was built with -DEF_STAGE_CLOCKS): 24 sums
+/* developer instrumentation of the persistent tracker launch (zeros unless the library was built with -DEF_STAGE_CLOCKS): 32 sums
  * of 10 ns ticks per phase since the last call; tools/fast_clocks.py (reference-order builds: tools/small_clocks.py) names them */
-int ef_debug_small_clocks(ef_ctx* ctx, unsigned long long* out24);
+int ef_debug_small_clocks(ef_ctx* ctx, unsigned long long* out32);
 
 /* ---- device memory helpers (so that a non-HIP host can drive the operator tier) ---- */
 int ef_dev_alloc(void** dev, size_t bytes);

@@ -131,10 +131,13 @@ def test_persistent_and_per_step_tracker_scripts_agree(hip, seq, cfg):
     pose, trajectory and map must be bit-identical, frame after frame — whichever of them the oracle comparisons of this file ran."""
     n = 14
     runs = []
-    for persistent, fused in ((1, False), (0, False), (1, True), (2, False)):   # fused: level-0 update step inside the search launch (ef_set_fused_step)
+    # fused: level-0 update step inside the search launch (ef_set_fused_step); resident: the persistent launch's level-resident pixel data (round 6,
+    # ef_set_resident_levels; off = round 5's streaming launch)
+    for persistent, fused, resident in ((1, False, True), (0, False, True), (1, True, True), (2, False, True), (1, False, False)):
         ef = hip.ElasticFusion(**cfg)
         ef.setPersistentTracker(persistent)
         ef.setFusedStep(fused)
+        ef.setResidentLevels(resident)
         rec = []
         for k in range(n):
             rgb, depth, _ = seq.frame(k)
@@ -144,7 +147,7 @@ def test_persistent_and_per_step_tracker_scripts_agree(hip, seq, cfg):
         ef.synchronize()                      # also: no barrier of the persistent launches timed out
         runs.append((rec, ef.downloadMap()))
         ef.close()
-    for other in (1, 2, 3):
+    for other in (1, 2, 3, 4):
         for k in range(1, n):
             for x, y in zip(runs[0][0][k], runs[other][0][k]):
                 assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y), (other, k, x, y)

@@ -24,28 +24,40 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--preroll", type=int, default=100)
     ap.add_argument("--close-loops", action="store_true")
+    ap.add_argument("--big", action="store_true", help="BASELINE configs[2]: 1280x960 on a map pre-seeded with ~1 M surfels (bench.py's side leg: preroll 16, warm-up 24)")
     a = ap.parse_args()
     import bench
     from elasticfusion_amd import api, build
+    w, h = (1280, 960) if a.big else (640, 480)
+    if a.big:
+        a.preroll = 16
     n = 1 + a.preroll + 20 + a.steps
-    frames = bench.generate_frames(0xEF0001, n)
+    frames = bench.generate_frames(0xEF0001, n, w, h)
     out = {}
     dev = None
     for rep in range(a.reps):
         for spec in a.specs:
-            base, _, ov = spec.partition("+ov")
+            nores = spec.endswith("+nores")   # round 5's streaming persistent launch (ef_set_resident_levels(ctx, 0))
+            spec_ = spec[:-6] if nores else spec
+            base, _, ov = spec_.partition("+ov")
             name, _, mode = base.partition("@")
             api.use_library(None if name in ("d", "-") else os.path.join(os.path.dirname(build.LIB), f"libefusion_hip_{name}.so"))
             dev = [(api.DevBuf.from_array(r), api.DevBuf.from_array(d)) for r, d, _ in frames]   # (per library: the allocator is the library's)
-            ef = bench.make_engine(api, 640, 480, 0, 0, close_loops=a.close_loops)
+            ef = bench.make_engine(api, w, h, 0, 0, close_loops=a.close_loops)
+            k0 = 0
+            if a.big:
+                bench.preseed(ef, 0xEF0001, w, h, 1 << 20, frames[0])
+                k0 = 1
             if mode != "":
                 ef.setPersistentTracker(int(mode))
+            if nores:
+                ef.setResidentLevels(False)
             if ov != "":
                 if int(ov) > 1:
                     ef.setInputCuMask(int(ov))
                 ef.setInputOverlap(1)
             first = 1 + a.preroll + 20
-            for k in range(first):
+            for k in range(k0, first):
                 ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
             ef.synchronize()
             t0 = time.perf_counter()

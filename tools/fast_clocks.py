@@ -17,6 +17,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from elasticfusion_amd import api, synth
 
 n = 140
+NORES = "--nores" in sys.argv   # round 5's streaming persistent launch (ef_set_resident_levels(ctx, 0))
+sys.argv = [a for a in sys.argv if a != "--nores"]
 libs = [a for a in sys.argv[1:] if not a.isdigit()] or [None]
 for a in sys.argv[1:]:
     if a.isdigit():
@@ -28,8 +30,10 @@ for path in libs:
     if path:
         api.use_library(os.path.abspath(path))
     ef = api.ElasticFusion()
+    if NORES:
+        ef.setResidentLevels(False)
     L = api.lib()
-    out = (C.c_ulonglong * 24)()
+    out = (C.c_ulonglong * 32)()
     for k, (rgb, depth) in enumerate(frames):
         ef.processFrame(rgb, depth, k * 33333)
         if k == n - 41:
@@ -42,10 +46,12 @@ for path in libs:
     rec = {"library": os.path.basename(api.LIB_PATH), "launches": int(launches), "so3_iterations_per_launch": round(so3_its / launches, 2),
            "se3_iterations_per_launch": round(se3_its / launches, 2), "whole_launch_us": us(v[11] / launches), "begin_us": us(v[0] / launches),
            "so3_per_iteration_us": {"rows_trees_publish": us(v[1] / so3_its), "exchange": us(v[2] / so3_its), "update": us(v[4] / so3_its)},
-           "se3_per_iteration_us": {"head_solve": us(v[6] / se3_its), "search_publish_A": us(v[7] / se3_its), "icp_task_wave0": us(v[8] / se3_its),
+           "se3_per_iteration_us": {"head_solve": us(v[6] / se3_its), "search_publish_A": us(v[7] / se3_its), "icp_rows_wave0_resident": us(v[8] / se3_its),
                                     "rest_of_tasks_trees_publish_B": us(v[9] / se3_its), "exchange_B": us(v[10] / se3_its)},
            "solve_phases_us": {"A_b": us(v[3] / max(se3_its - launches, 1)), "ldlt": us(v[5] / max(se3_its - launches, 1)), "rodrigues": us(v[18] / max(se3_its - launches, 1)),
                                "compose_Rcurr": us(v[19] / max(se3_its - launches, 1)), "krk": us(v[23] / max(se3_its - launches, 1))},
+           "resident_levels": (not NORES),
+           "resident_photometric_wavefront_us": {"search": us(v[24] / se3_its), "publish_A_sweep_sigma": us(v[25] / se3_its), "rows": us(v[26] / se3_its)},
            "iteration_us_by_level": {f"L{l}": us(v[12 + l] / max(v[15 + l], 1)) for l in range(3)},
            "iterations_by_level": {f"L{l}": round(v[15 + l] / launches, 2) for l in range(3)}}
     print(json.dumps(rec), flush=True)

@@ -29,7 +29,7 @@ for path in libs:
         api.use_library(os.path.abspath(path))
     ef = api.ElasticFusion()
     L = api.lib()
-    out = (C.c_ulonglong * 24)()
+    out = (C.c_ulonglong * 32)()
     for k, (rgb, depth) in enumerate(frames):
         ef.processFrame(rgb, depth, k * 33333)
         if k == n - 41:
