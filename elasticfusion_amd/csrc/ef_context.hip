@@ -57,6 +57,7 @@ struct ef_ctx {
   int frame_parity = 0;
   int overlap_mode = 1;          // ef_set_input_overlap: 1 = whole input stage after the previous tracker; 2 = copy + bilateral filter already during it
   bool overlap = false;
+  bool events_live = false;      // the previous frame recorded ev_track_done (and, in mode 2, ev_frame_done): see process_frame
   bool staged_pending = false;
   unsigned* h_abort = nullptr;   // 4 words of host-mapped pinned memory: k_track_end copies a tracker instance's sticky abort flag here (d_abort: the device alias)
   unsigned* d_abort = nullptr;
@@ -693,6 +694,11 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   // with the previous frame's fusion + prediction on `stream`, which read the other set of frame images.
   const bool overlap = c->overlap && !c->timing && c->in_stream != nullptr;
   hipStream_t sb = overlap ? c->in_stream : s;
+  // Round 6: the events the second stream waits for are recorded only while the overlap is on — an event record between two kernels of a stream is
+  // a barrier packet, measured as a 6 us bubble each (three per frame: profiles/r06f_timeline_single_stream.txt).  The first overlapped frame
+  // after a frame that recorded none joins the streams on the host instead.
+  const bool want_events = c->overlap && c->in_stream != nullptr;
+  if (overlap && !c->events_live) EF_HIP(c, hipStreamSynchronize(s));
   std::swap(c->rgb, c->rgb_alt);
   std::swap(c->depth_raw, c->depth_raw_alt);
   std::swap(c->depth_filtered, c->depth_filtered_alt);
@@ -708,7 +714,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   // (fill-in / predict read depth_filtered + rgb), so they are copied into context-owned buffers
   // Frames that are already in HBM are not copied by separate launches in the single-stream script: the bilateral filter
   // reads the caller's depth directly (nothing later needs the raw image) and the RGB copy rides on the intensity kernel.
-  const bool fold_copies = kind == hipMemcpyDeviceToDevice && !overlap && track_this;
+  const bool fold_copies = kind == hipMemcpyDeviceToDevice && track_this;
   const uint16_t* depth_in = c->depth_raw;
   if (fold_copies) {
     depth_in = depth_src;
@@ -721,10 +727,9 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   efm::preprocess_depth(depth_in, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb, 0u);
   timer_end(c, "Preprocess");
   if (overlap && overlap_mode == 2) EF_HIP(c, hipStreamWaitEvent(sb, c->ev_track_done, 0));
-  if (track_this && overlap) {   // the single-stream script builds all pyramids together below (eft::build_pyramids)
-    eft::init_icp(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, sb);
-    eft::init_rgb_frame(c->pyr, c->rgb, sb);
-  }
+  if (track_this && overlap)   // the single-stream script builds all pyramids together below (eft::build_pyramids)
+    eft::build_pyramids_frame_side(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, fold_copies ? rgb_src : c->rgb, sb,
+                                   fold_copies ? c->rgb : nullptr);
   if (overlap) EF_HIP(c, hipEventRecord(c->ev_input_done, sb));
 
   const bool rgbOnly = c->cfg.rgb_only != 0;
@@ -742,7 +747,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
                   &c->st->map_counts[c->cur], c->cs, s);
     eft::init_first_rgb(c->pyr, c->rgb, s);
     if (log_slot >= 0) eft::log_pose(c->st, c->traj, log_slot, s);
-    EF_HIP(c, hipEventRecord(c->ev_track_done, s));
+    if (want_events) EF_HIP(c, hipEventRecord(c->ev_track_done, s));
     timer_end(c, "feedbackBuffers");
   } else {
     if (!in_T_wc) {
@@ -762,7 +767,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       eft::init_icp_model(c->pyr, (const float*)c->pm.vertex, (const float*)c->pm.normal, (const float*)c->fm.vertex,
                           (const float*)c->fm.normal, c->st, 6.0f /* maxDepthRGB, RGBDOdometry.cpp:42 */, s);
       if (overlap) {
-        eft::init_rgb_model(c->pyr, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, c->st, s);
+        eft::build_pyramids_model_side(c->pyr, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, c->st, s);
         EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
       } else {
         eft::build_pyramids(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image,
@@ -835,7 +840,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       eft::pose_injected(c->st, in_T_wc, true, weightMultiplier, true, log_slot >= 0 ? c->traj : nullptr, log_slot, s);
     }
     // from here on nothing of this frame reads the frame-side pyramids: the next frame's input stage may start
-    EF_HIP(c, hipEventRecord(c->ev_track_done, s));
+    if (want_events) EF_HIP(c, hipEventRecord(c->ev_track_done, s));
     // mid-frame predict() of ElasticFusion.cpp:387 is dead work without loop closure: skipped
     if (c->cfg.close_loops) {
       int fern_graph = 0;
@@ -900,7 +905,8 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
     timer_end(c, "ferns");
     if (r != EF_OK) return r;
   }
-  EF_HIP(c, hipEventRecord(c->ev_frame_done[c->frame_parity], s));
+  if (want_events && c->overlap_mode == 2) EF_HIP(c, hipEventRecord(c->ev_frame_done[c->frame_parity], s));
+  c->events_live = want_events;
   if (!c->lost) c->tick++;   // :601-604
   EF_HIP(c, hipGetLastError());
   return EF_OK;
@@ -1034,6 +1040,7 @@ int ctx_init(ef_ctx* c) {
 void ctx_free(ef_ctx* c) {
   if (c->in_stream) (void)hipStreamSynchronize(c->in_stream);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream) eft::persistent_chain_forget(c->stream);   // (a borrowed stream may be destroyed by its owner right after this call)
   if (c->in_stream) (void)hipStreamDestroy(c->in_stream);
   for (hipEvent_t e : {c->ev_input_done, c->ev_track_done, c->ev_staged, c->ev_frame_done[0], c->ev_frame_done[1]})
     if (e) (void)hipEventDestroy(e);
@@ -1215,6 +1222,7 @@ int ef_set_input_overlap(ef_ctx* c, int on) {
   if (!c || on < 0 || on > 2) return EF_EINVAL;
   c->overlap = on != 0;
   c->overlap_mode = on == 2 ? 2 : 1;
+  c->events_live = false;   // (the next overlapped frame joins the streams on the host: the events of the other mode were not recorded)
   return EF_OK;
 }
 int ef_set_deformation(ef_ctx* c, const float* graph, int nodes, int is_fern) {

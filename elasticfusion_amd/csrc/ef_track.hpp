@@ -215,6 +215,11 @@ void init_rgb_frame(const Pyramid& p, const uint8_t* rgb3, hipStream_t s);
 void init_icp_maps(const Pyramid& p, const float* vertex4, const float* normal4, const uint8_t* image_rgba, const TrackState* st,
                    float maxDepthRGB, hipStream_t s);
 void init_rgb_sobel(const Pyramid& p, hipStream_t s);
+// build_pyramids for the two-stream frame script: the half that reads nothing but the new frame / the half that reads the model prediction
+void build_pyramids_frame_side(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, const uint8_t* rgb3, hipStream_t s,
+                               uint8_t* rgb_keep);
+void build_pyramids_model_side(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* fill_image_rgba, bool frameToFrameRGB,
+                               const TrackState* st, hipStream_t s);
 // init_icp_model + init_rgb_model (model view, its own image, no fill-in) + init_icp_maps (current view) of a model-to-model tracker in five launches
 void init_model_pair(const Pyramid& p, const float* model_vertex4, const float* model_normal4, const uint8_t* model_image_rgba,
                      const float* cur_vertex4, const float* cur_normal4, const uint8_t* cur_image_rgba, const TrackState* st, float maxDepthRGB,
@@ -250,6 +255,8 @@ int tracker_aborted(const Pyramid& p, hipStream_t s);
 // fast order: persistent launches of this tracker instance that found the chip partly taken (admission failed) and ran on ONE workgroup
 // instead — same results, ~25x the time; < 0 on a HIP error; synchronises the stream
 int tracker_fallbacks(const Pyramid& p, hipStream_t s);
+// a stream that launched persistent trackers is about to be destroyed (or synchronised for good): the per-device chain must not record on it
+void persistent_chain_forget(hipStream_t s);
 int tracker_small_clocks(const Pyramid& p, unsigned long long* out32, hipStream_t s);   // developer instrumentation (-DEF_STAGE_CLOCKS)
 void track_swap(Pyramid& p, const TrackParams& tp);   // the pointer swap track() ends with (for hipGraph replay)
 // tail of getIncrementalTransformation (0.3 m guard, SVD re-orthonormalisation, RGBDOdometry.cpp:555-570) +

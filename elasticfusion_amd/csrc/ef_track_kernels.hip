@@ -1294,13 +1294,11 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
                                             int slot_a, int slot_b, bool with_slots, f32x4 (&c)[3]) {
   const int S = (K + 3) >> 2;
   const int lane = threadIdx.x & 63;
-  const int j = lane & 3;                    // quad layout (phase B): lane = 4 v + j
   // Phase A runs in the LOAD layout, lane = 16 jl + vl: a quarter-wave (16 lanes) covers 16 consecutive pixels of ONE pass, so
   // every planar load touches one 64-byte segment per quarter-wave (four 16-byte pieces of four different rows in the quad
-  // layout: 4x the tag look-ups of the CU's one address pipe).  The rows then move to the quad layout through the LDS crossbar
-  // (ds_bpermute: lane 4 v + j takes lane 16 j + v's), 8 moves per step.
+  // layout: 4x the tag look-ups of the CU's one address pipe).  The rows then move to the quad layout (phase B: lane = 4 v + j) through
+  // LDS (quad_rows_accumulate; the fast build: ds_bpermute, lane 4 v + j takes lane 16 j + v's, 8 moves per step).
   const int jl = lane >> 4, g = gbase + (lane & 15);
-  const int gather_from = (16 * j + (lane >> 2)) * 4;
   IcpPose P;
   if (ICP) {
     P.Rcurr = m33_load(in.Rcurr);
@@ -2971,10 +2969,10 @@ namespace {
 // both level-0 intensity images in one launch: blockIdx.y 0 = the camera frame ("next"), 1 = the model image ("last")
 __global__ void k_intensity_both(const uint8_t* __restrict__ rgb3, const uint8_t* __restrict__ pred, const uint8_t* __restrict__ fill,
                                  bool force_fill, const TrackState* __restrict__ st, int n, uint8_t* __restrict__ next0,
-                                 uint8_t* __restrict__ last0, uint8_t* __restrict__ rgb_keep) {
+                                 uint8_t* __restrict__ last0, uint8_t* __restrict__ rgb_keep, int first_half) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  if (blockIdx.y == 0) {
+  if (blockIdx.y + first_half == 0) {   // (first_half + gridDim.y halves: both in the single-stream script, one each in the two-stream script)
     const uint8_t* sp = rgb3 + (size_t)i * 3;
     const uint8_t r = sp[0], g = sp[1], b = sp[2];
     next0[i] = intensity_of((float)r, (float)g, (float)b);
@@ -2990,12 +2988,13 @@ __global__ void k_intensity_both(const uint8_t* __restrict__ rgb3, const uint8_t
 // script): level-0 intensities, then one k_pyr_down_multi per pyramid step over {frame depth u16, model depth f32,
 // model intensity, frame intensity}; then the per-level vertex/normal maps.  Same per-pixel functions, same results.
 static SobelLevels sobel_levels_of(const Pyramid& p);
+static void build_vn_levels(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, bool with_sobel, hipStream_t s);
 void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, const uint8_t* pred_image_rgba,
                     const uint8_t* fill_image_rgba, bool frameToFrameRGB, const uint8_t* rgb3, const TrackState* st, hipStream_t s,
                     uint8_t* rgb_keep, bool with_sobel) {
   const int n = p.W(0) * p.H(0);
   hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 2), dim3(256), 0, s, rgb3, pred_image_rgba, fill_image_rgba, frameToFrameRGB, st,
-                     n, p.nextImage[0], p.lastImage[0], rgb_keep);
+                     n, p.nextImage[0], p.lastImage[0], rgb_keep, 0);
   for (int i = 0; i + 1 < NUM_PYRS; ++i) {
     PyrJobs J;
     J.src[0] = i == 0 ? (const void*)depth_filtered : (const void*)p.depth_tmp[i]; J.dst[0] = p.depth_tmp[i + 1]; J.type[0] = 0;
@@ -3007,6 +3006,48 @@ void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, fl
     g.z = 4;
     hipLaunchKernelGGL(k_pyr_down_multi, g, tile_block(), 0, s, J);
   }
+  build_vn_levels(p, depth_filtered, k, cutoff, with_sobel, s);
+}
+// The two-stream frame script (ef_set_input_overlap; round 6): build_pyramids split by what each kernel READS, so that the half that needs
+// nothing but the new frame runs on the input stream beside the previous frame's fusion and prediction.  Same per-pixel functions, same
+// results; four launches each instead of round 5's six and seven.
+//   frame side:  level-0 intensity of the frame (+ the context's copy of the RGB image), two pyramid steps over {frame depth u16, frame
+//                intensity}, the vertex / normal maps of all levels
+//   model side:  (behind init_icp_model) level-0 intensity of the model image, two pyramid steps over {model depth f32, model intensity};
+//                the Sobel / photometric-gate launch (init_rgb_sobel) reads both sides (the gate tests the MODEL's depth: quirk Q1) and
+//                follows the join
+void build_pyramids_frame_side(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, const uint8_t* rgb3, hipStream_t s,
+                               uint8_t* rgb_keep) {
+  const int n = p.W(0) * p.H(0);
+  hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 1), dim3(256), 0, s, rgb3, (const uint8_t*)nullptr, (const uint8_t*)nullptr, false,
+                     (const TrackState*)nullptr, n, p.nextImage[0], p.lastImage[0], rgb_keep, 0);
+  for (int i = 0; i + 1 < NUM_PYRS; ++i) {
+    PyrJobs J{};
+    J.src[0] = i == 0 ? (const void*)depth_filtered : (const void*)p.depth_tmp[i]; J.dst[0] = p.depth_tmp[i + 1]; J.type[0] = 0;
+    J.src[1] = p.nextImage[i]; J.dst[1] = p.nextImage[i + 1]; J.type[1] = 2;
+    J.scols = p.W(i); J.srows = p.H(i);
+    dim3 g = tile_grid(p.W(i + 1), p.H(i + 1));
+    g.z = 2;
+    hipLaunchKernelGGL(k_pyr_down_multi, g, tile_block(), 0, s, J);
+  }
+  build_vn_levels(p, depth_filtered, k, cutoff, false, s);
+}
+void build_pyramids_model_side(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* fill_image_rgba, bool frameToFrameRGB,
+                               const TrackState* st, hipStream_t s) {
+  const int n = p.W(0) * p.H(0);
+  hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 1), dim3(256), 0, s, (const uint8_t*)nullptr, pred_image_rgba, fill_image_rgba,
+                     frameToFrameRGB, st, n, p.nextImage[0], p.lastImage[0], (uint8_t*)nullptr, 1);
+  for (int i = 0; i + 1 < NUM_PYRS; ++i) {
+    PyrJobs J{};
+    J.src[0] = p.lastDepth[i]; J.dst[0] = p.lastDepth[i + 1]; J.type[0] = 1;
+    J.src[1] = p.lastImage[i]; J.dst[1] = p.lastImage[i + 1]; J.type[1] = 2;
+    J.scols = p.W(i); J.srows = p.H(i);
+    dim3 g = tile_grid(p.W(i + 1), p.H(i + 1));
+    g.z = 2;
+    hipLaunchKernelGGL(k_pyr_down_multi, g, tile_block(), 0, s, J);
+  }
+}
+static void build_vn_levels(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, bool with_sobel, hipStream_t s) {
   VNLevels L;
   for (int i = 0; i < NUM_PYRS; ++i) {
     L.depth[i] = i == 0 ? depth_filtered : p.depth_tmp[i];
@@ -3107,6 +3148,19 @@ int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const
 }
 }  // namespace
 
+namespace {
+std::mutex g_chain_mu;                 // the per-device chain of persistent launches (see track())
+hipStream_t g_chain_last[64] = {};
+bool g_chain_has[64] = {};
+hipEvent_t g_chain_ev[64] = {};
+inline bool last_valid_other(int dev, hipStream_t s) { return g_chain_has[dev] && g_chain_last[dev] != s; }
+}  // namespace
+void persistent_chain_forget(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_chain_mu);
+  for (int d = 0; d < 64; ++d)
+    if (g_chain_has[d] && g_chain_last[d] == s) { g_chain_has[d] = false; g_chain_last[d] = nullptr; }
+}
+
 TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe, KernelProbe* probe_all) {
   const bool icp = !tp.rgbOnly && tp.icpWeight > 0;       // RGBDOdometry.cpp:266-267
   const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
@@ -3201,15 +3255,24 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
       // the host) for the previous one, whatever stream that ran on.  On one stream this is a no-op.  Ordinary kernels of other streams
       // only delay it (they end without waiting for anybody); another PROCESS's persistent kernels are outside this chain: bounded spins,
       // FtSync::abort, tracker_aborted.
-      static std::mutex chain_mu;
-      static hipEvent_t chain_ev[64] = {};
-      std::lock_guard<std::mutex> lk(chain_mu);
+      // Round 6: the chain costs nothing while ONE stream launches them (the common case: an event record between two kernels of a stream is a
+      // barrier packet, measured as a 6 us bubble behind every tracker launch in profiles/r06f_timeline_single_stream.txt) — the dependency is
+      // created by the launch that finds ANOTHER stream's launch before it: it records the event on that stream now (everything enqueued there
+      // so far, the persistent launch included) and makes its own stream wait for it.  persistent_chain_forget() drops a stream that is destroyed.
+      std::lock_guard<std::mutex> lk(g_chain_mu);
       int dev = 0;
       (void)hipGetDevice(&dev);
-      hipEvent_t unchained = nullptr;   // (a device index beyond the table: no chain, the bounded spins remain)
-      hipEvent_t& ev = (dev >= 0 && dev < 64) ? chain_ev[dev] : unchained;
-      if (ev) (void)hipStreamWaitEvent(s, ev, 0);
-      else if (&ev == &unchained || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+      if (dev >= 0 && dev < 64) {   // (a device index beyond the table: no chain, the bounded spins remain)
+        hipStream_t& last = g_chain_last[dev];
+        hipEvent_t& ev = g_chain_ev[dev];
+        if (last_valid_other(dev, s)) {
+          if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+          if (ev && hipEventRecord(ev, last) == hipSuccess) (void)hipStreamWaitEvent(s, ev, 0);
+          (void)hipGetLastError();
+        }
+        last = s;
+        g_chain_has[dev] = true;
+      }
 #ifdef EF_FAST_ORDER
       if (icp && rgb) hipExtLaunchKernelGGL((k_track_fast<true, true>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
       else if (icp) hipExtLaunchKernelGGL((k_track_fast<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), 0, s, e0, e1, 0, FA, st);
@@ -3219,7 +3282,6 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
       else if (icp) hipExtLaunchKernelGGL((k_track_ref<true, false>), dim3(FT_WGS), dim3(FT_BLOCK), res_bytes, s, e0, e1, 0, FA, st);
       else hipExtLaunchKernelGGL((k_track_ref<false, true>), dim3(FT_WGS), dim3(FT_BLOCK), res_bytes, s, e0, e1, 0, FA, st);
 #endif
-      if (ev) (void)hipEventRecord(ev, s);
     }
     // (returns at once unless the launch above found part of the chip taken: see its admission step)
 #ifdef EF_FAST_ORDER
