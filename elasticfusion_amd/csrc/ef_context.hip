@@ -9,6 +9,7 @@
 #include <string.h>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ef_hip.h"
@@ -58,11 +59,21 @@ struct ef_ctx {
   int overlap_mode = 1;          // ef_set_input_overlap: 1 = whole input stage after the previous tracker; 2 = copy + bilateral filter already during it
   bool overlap = false;
   bool events_live = false;      // the previous frame recorded ev_track_done (and, in mode 2, ev_frame_done): see process_frame
-  bool staged_pending = false;
+  // host-pointer frames (ef_process_frame, the reference's processFrame signature): a ring of pinned staging pairs and device landing pairs; the
+  // upload runs on copy_stream, the frame script reads the landing pair in place (round 6)
+  static constexpr int RING = 3;
+  uint8_t* h_rgb_ring[RING] = {};
+  uint16_t* h_depth_ring[RING] = {};
+  uint8_t* d_rgb_ring[RING] = {};
+  uint16_t* d_depth_ring[RING] = {};
+  hipEvent_t ev_h2d[RING] = {};
+  hipStream_t copy_stream = nullptr;
+  unsigned host_seq = 0;           // host-pointer frames submitted so far
+  unsigned mark_value = 0;         // what this frame's prediction writes into *h_consumed (host_seq + 1; 0: nothing)
+  unsigned* h_consumed = nullptr;  // host-mapped: 1 + the index of the last host-pointer frame whose input images the GPU has finished reading
+  unsigned* d_consumed = nullptr;
   unsigned* h_abort = nullptr;   // 4 words of host-mapped pinned memory: k_track_end copies a tracker instance's sticky abort flag here (d_abort: the device alias)
   unsigned* d_abort = nullptr;
-  uint8_t* h_rgb = nullptr;      // pinned staging
-  uint16_t* h_depth = nullptr;
   // tracker
   eft::Pyramid pyr{};
   eft::TrackState* st = nullptr;
@@ -317,9 +328,12 @@ int do_predict(ef_ctx* c, bool count_dense = true) {
   // ElasticFusion::predict(), ElasticFusion.cpp:621-653: combinedPredict(ACTIVE) + FillIn (fused into the resolve).  Right after a
   // relocalisation the whole model is rendered (time = 0: no surfel is too old); while the camera is lost the fill-in passes the raw
   // frame through (a second, plain fill-in pass over the fused one: the rare path)
+  // (a host-pointer frame: this launch, behind every reader of the frame's landing buffers, tells the host that their ring slot is free again)
   efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence,
                         c->last_frame_recovery ? 0 : c->tick, c->tick, c->cfg.time_delta, c->zbuf, c->pm, c->fm, c->depth_filtered, c->rgb,
-                        c->cfg.frame_to_frame_rgb != 0, count_dense ? &c->st->dense_count : nullptr, c->stream);
+                        c->cfg.frame_to_frame_rgb != 0, count_dense ? &c->st->dense_count : nullptr, c->stream, nullptr, 0u,
+                        (count_dense && c->mark_value) ? c->d_consumed : nullptr, c->mark_value);
+  if (count_dense) c->mark_value = 0;
   if (c->lost) efm::fill_in(c->cam, c->pm, c->depth_filtered, c->rgb, true, true, c->fm, c->stream);
   return EF_OK;
 }
@@ -677,7 +691,7 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
 
 // rgb_src / depth_src: host (pinned staging) or device pointers, `kind` says which
 int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, hipMemcpyKind kind, int64_t timestamp,
-                  float weightMultiplier, const double* in_T_wc) {
+                  float weightMultiplier, const double* in_T_wc, hipEvent_t images_ready = nullptr) {
   hipStream_t s = c->stream;
   const int W = c->cam.cols, H = c->cam.rows;
   // a persistent tracker launch of an EARLIER frame gave up waiting after admission (a protocol failure, sticky: every later launch of that
@@ -710,6 +724,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   // frame would run on the one-workgroup fallback — mode 1 is what such a context gets)
   const int overlap_mode = (c->overlap_mode == 2 && c->persistent == 1 && !c->use_graph) ? 1 : c->overlap_mode;
   if (overlap) EF_HIP(c, hipStreamWaitEvent(sb, overlap_mode == 2 ? c->ev_frame_done[c->frame_parity] : c->ev_track_done, 0));
+  if (images_ready) EF_HIP(c, hipStreamWaitEvent(sb, images_ready, 0));   // (the upload of a host-pointer frame, on copy_stream)
   // the frame images are referenced by later stages of this frame and by the next frame's tracker
   // (fill-in / predict read depth_filtered + rgb), so they are copied into context-owned buffers
   // Frames that are already in HBM are not copied by separate launches in the single-stream script: the bilateral filter
@@ -722,7 +737,6 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
     EF_HIP(c, hipMemcpyAsync(c->rgb, rgb_src, (size_t)W * H * 3, kind, sb));
     EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_src, (size_t)W * H * 2, kind, sb));
   }
-  if (kind == hipMemcpyHostToDevice) { EF_HIP(c, hipEventRecord(c->ev_staged, sb)); c->staged_pending = true; }
   timer_begin(c, "Preprocess");
   efm::preprocess_depth(depth_in, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb, 0u);
   timer_end(c, "Preprocess");
@@ -932,11 +946,20 @@ int ctx_init(ef_ctx* c) {
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_input_done, hipEventDisableTiming));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_track_done, hipEventDisableTiming));
   EF_HIP(c, hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming));
+  EF_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (int i = 0; i < ef_ctx::RING; ++i) {
+    EF_HIP(c, hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming));
+    EF_HIP(c, hipHostMalloc((void**)&c->h_rgb_ring[i], P * 3));
+    EF_HIP(c, hipHostMalloc((void**)&c->h_depth_ring[i], P * 2));
+    EF_ALLOC(c, c->d_rgb_ring[i], P * 3);
+    EF_ALLOC(c, c->d_depth_ring[i], P);
+  }
+  EF_HIP(c, hipHostMalloc((void**)&c->h_consumed, sizeof(unsigned), hipHostMallocMapped));
+  *c->h_consumed = 0u;
+  EF_HIP(c, hipHostGetDevicePointer((void**)&c->d_consumed, c->h_consumed, 0));
   EF_HIP(c, hipHostMalloc((void**)&c->h_abort, 4 * sizeof(unsigned), hipHostMallocMapped));
   memset(c->h_abort, 0, 4 * sizeof(unsigned));
   EF_HIP(c, hipHostGetDevicePointer((void**)&c->d_abort, c->h_abort, 0));
-  EF_HIP(c, hipHostMalloc((void**)&c->h_rgb, P * 3));
-  EF_HIP(c, hipHostMalloc((void**)&c->h_depth, P * 2));
   // tracker pyramids (zero-filled: the stale y/z planes of quirk Q3 are then deterministic)
   c->pyr.width = W;
   c->pyr.height = H;
@@ -1046,8 +1069,13 @@ void ctx_free(ef_ctx* c) {
     if (e) (void)hipEventDestroy(e);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->h_abort) (void)hipHostFree(c->h_abort);
-  if (c->h_rgb) (void)hipHostFree(c->h_rgb);
-  if (c->h_depth) (void)hipHostFree(c->h_depth);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+  for (int i = 0; i < ef_ctx::RING; ++i) {
+    if (c->ev_h2d[i]) (void)hipEventDestroy(c->ev_h2d[i]);
+    if (c->h_rgb_ring[i]) (void)hipHostFree(c->h_rgb_ring[i]);
+    if (c->h_depth_ring[i]) (void)hipHostFree(c->h_depth_ring[i]);
+  }
+  if (c->h_consumed) (void)hipHostFree(c->h_consumed);
   if (c->h_cons) (void)hipHostFree(c->h_cons);
   if (c->h_states) (void)hipHostFree(c->h_states);
   if (c->h_view) (void)hipHostFree(c->h_view);
@@ -1188,11 +1216,34 @@ int ef_process_frame(ef_ctx* c, const uint8_t* rgb, const uint16_t* depth, int64
   if (!c || !rgb || !depth) return EF_EINVAL;
   DeviceGuard dg_(c);
   const size_t P = (size_t)c->cam.cols * c->cam.rows;
-  // the pinned staging buffers may still be in flight from the previous frame's async copy: wait for that copy only
-  if (c->staged_pending) { EF_HIP(c, hipEventSynchronize(c->ev_staged)); c->staged_pending = false; }
-  memcpy(c->h_rgb, rgb, P * 3);
-  memcpy(c->h_depth, depth, P * 2);
-  return process_frame(c, c->h_rgb, c->h_depth, hipMemcpyHostToDevice, timestamp, wm, T);
+  // The reference uploads inside processFrame (ElasticFusion.cpp:278-280: three texture uploads, blocking).  Here (round 6): the caller's images go
+  // into slot r of a ring of pinned staging pairs, are uploaded on copy_stream into the ring's device landing pair — beside the previous
+  // frames' kernels — and the frame script reads the landing pair IN PLACE (the bilateral filter reads the depth, the intensity kernel reads the
+  // colours and keeps the context's copy: no device-side copy, exactly the device-pointer script).  The compute stream waits for the upload
+  // (one barrier packet); nothing waits on the host unless the caller is a whole ring ahead of the GPU: slot r is free once the frame that used
+  // it last has been read, which that frame's prediction launch reports through a host-mapped word (no event on the compute stream: an event
+  // record there costs a 6 us bubble, profiles/r06f_timeline_single_stream.txt).
+  const int r = (int)(c->host_seq % ef_ctx::RING);
+  if (c->host_seq >= (unsigned)ef_ctx::RING) {
+    const unsigned need = c->host_seq - ef_ctx::RING + 1u;   // the marker the last user of slot r leaves
+    volatile unsigned* seen = c->h_consumed;
+    int spins = 0;
+    while ((int)(*seen - need) < 0) {
+      if (++spins > 20000) {   // (~ms: that frame ended early on an error path, or the marker is not visible: join the streams instead)
+        EF_HIP(c, hipStreamSynchronize(c->stream));
+        break;
+      }
+      if (spins > 64) std::this_thread::yield();
+    }
+  }
+  memcpy(c->h_rgb_ring[r], rgb, P * 3);
+  memcpy(c->h_depth_ring[r], depth, P * 2);
+  EF_HIP(c, hipMemcpyAsync(c->d_depth_ring[r], c->h_depth_ring[r], P * 2, hipMemcpyHostToDevice, c->copy_stream));
+  EF_HIP(c, hipMemcpyAsync(c->d_rgb_ring[r], c->h_rgb_ring[r], P * 3, hipMemcpyHostToDevice, c->copy_stream));
+  EF_HIP(c, hipEventRecord(c->ev_h2d[r], c->copy_stream));
+  c->mark_value = c->host_seq + 1u;
+  c->host_seq++;
+  return process_frame(c, c->d_rgb_ring[r], c->d_depth_ring[r], hipMemcpyDeviceToDevice, timestamp, wm, T, c->ev_h2d[r]);
 }
 int ef_process_frame_dev(ef_ctx* c, const uint8_t* rgb_dev, const uint16_t* depth_dev, int64_t timestamp, float wm, const double* T) {
   if (!c || !rgb_dev || !depth_dev) return EF_EINVAL;

@@ -101,7 +101,10 @@ void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, co
                       FillMaps fill, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthroughImage,
                       unsigned* dense_counter, hipStream_t s,
                       // optional: *nonempty_flag = nonempty_value when the view shows at least one surfel (the caller stamps a fresh value per use)
-                      unsigned* nonempty_flag = nullptr, unsigned nonempty_value = 0);
+                      unsigned* nonempty_flag = nullptr, unsigned nonempty_value = 0,
+                      // optional: *consumed_mark = consumed_value (system scope, e.g. host-mapped memory) as soon as the splat launch starts, i.e. once
+                      // everything enqueued before it has finished
+                      unsigned* consumed_mark = nullptr, unsigned consumed_value = 0);
 // IndexMap::synthesizeDepth (splat.vert + depth_splat.frag): float depth of the nearest splat per pixel, 0 = none
 void synthesize_depth(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
                       float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s);

@@ -509,7 +509,11 @@ constexpr int SPLAT_GRID = 4096;   // workgroups; each strides over chunks of SP
 #endif
 __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const float* __restrict__ T16, SurfelSoA map,
                                                         const unsigned* __restrict__ count_dev, float maxDepth, float confThreshold,
-                                                        int time, int maxTime, int timeDelta, unsigned long long* zbuf) {
+                                                        int time, int maxTime, int timeDelta, unsigned long long* zbuf,
+                                                        unsigned* consumed_mark, unsigned consumed_value) {
+  // (host-pointer frames: every kernel that reads the frame's landing buffers precedes this launch in the stream — their ring slot is free)
+  if (consumed_mark && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(consumed_mark, consumed_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const rt34 T = rt34_load16(T16);
   const unsigned count = *count_dev;
   const unsigned sub = threadIdx.x % SPLAT_LANES;
@@ -1260,9 +1264,9 @@ void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSo
 void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
                       float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, PredictMaps out, FillMaps fill,
                       const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthroughImage, unsigned* dense_counter, hipStream_t s,
-                      unsigned* nonempty_flag, unsigned nonempty_value) {
+                      unsigned* nonempty_flag, unsigned nonempty_value, unsigned* consumed_mark, unsigned consumed_value) {
   hipLaunchKernelGGL(k_surface_splat, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
-                     time, maxTime, timeDelta, zbuf);
+                     time, maxTime, timeDelta, zbuf, consumed_mark, consumed_value);
   const dim3 g(ceil_div(cam.cols, 16), ceil_div(cam.rows, 16));   // 16 x 16 pixel tiles, 8 x 8 per wavefront
   if (fill.image)
     hipLaunchKernelGGL(k_surface_resolve<true>, g, dim3(BLK), 0, s, cam, T_cw16_dev, map, maxDepth, confThreshold, time, maxTime, timeDelta,
@@ -1274,7 +1278,7 @@ void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, co
 void synthesize_depth(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth, float confThreshold,
                       int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s) {
   hipLaunchKernelGGL(k_surface_splat, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
-                     time, maxTime, timeDelta, zbuf);
+                     time, maxTime, timeDelta, zbuf, (unsigned*)nullptr, 0u);
   const int n = cam.cols * cam.rows;
   hipLaunchKernelGGL(k_depth_resolve, dim3(ceil_div(n, BLK)), dim3(BLK), 0, s, cam.cols, cam.rows, zbuf, depth);
 }

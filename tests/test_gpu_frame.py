@@ -90,6 +90,41 @@ def test_tracking_and_fusion_sequence(hip, seq):
     ef.close()
 
 
+def test_host_pointer_frames_ride_a_ring_and_equal_the_device_pointer_path(hip, seq):
+    """ef_process_frame (the reference's processFrame signature: HOST pointers, ElasticFusion.cpp:270-280) stages every frame in a ring of three
+    pinned pairs, uploads it on a copy stream and lets the frame script read the landing buffers in place (round 6).  Thirty frames enqueued back
+    to back with no getter in between — the host runs ahead of the GPU until the ring is full and then waits for the oldest slot's consumption
+    marker — from ONE caller buffer that is overwritten right after every call (the call must have copied it): trajectory and map bit-identical
+    to the same frames handed over as device pointers (the path every oracle comparison of this file pins)."""
+    n = 30
+    frames = [seq.frame(k) for k in range(n)]
+    ref = hip.ElasticFusion()
+    dev = [(hip.DevBuf.from_array(r), hip.DevBuf.from_array(d)) for r, d, _ in frames]
+    for k in range(n):
+        ref.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
+    traj_ref, _ = ref.trajectory()
+    map_ref = ref.downloadMap()
+    ref.close()
+    for overlap in (0, 1):
+        ef = hip.ElasticFusion()
+        ef.setInputOverlap(overlap)
+        rgb_buf = np.empty_like(frames[0][0])
+        depth_buf = np.empty_like(frames[0][1])
+        for k in range(n):
+            rgb_buf[...] = frames[k][0]
+            depth_buf[...] = frames[k][1]
+            ef.processFrame(rgb_buf, depth_buf, k * 33333)
+            rgb_buf[...] = 0          # the caller's buffers are free as soon as the call returns
+            depth_buf[...] = 0
+        traj, _ = ef.trajectory()
+        assert len(traj) == n
+        for k in range(n):
+            assert np.array_equal(np.asarray(traj[k]), np.asarray(traj_ref[k])), (overlap, k)
+        assert np.array_equal(ef.downloadMap().view(np.uint32), map_ref.view(np.uint32)), overlap
+        assert ef.trackerFallbacks() == 0
+        ef.close()
+
+
 def test_pipelined_frames_match_oracle(hip, seq):
     """Frames enqueued back to back with no getter in between: frame k+1's input stage (copy-in, bilateral filter,
     frame pyramids) runs on the second stream while frame k is still being fused.  The whole trajectory and the

@@ -37,6 +37,9 @@ def main():
     dev = None
     for rep in range(a.reps):
         for spec in a.specs:
+            host = spec.endswith("+host")   # frames handed over as HOST pointers (ef_process_frame: pinned ring + upload on the copy stream)
+            if host:
+                spec = spec[:-5]
             nores = spec.endswith("+nores")   # round 5's streaming persistent launch (ef_set_resident_levels(ctx, 0))
             spec_ = spec[:-6] if nores else spec
             base, _, ov = spec_.partition("+ov")
@@ -57,15 +60,21 @@ def main():
                     ef.setInputCuMask(int(ov))
                 ef.setInputOverlap(1)
             first = 1 + a.preroll + 20
+            def step(k):
+                if host:
+                    ef.processFrame(frames[k][0], frames[k][1], k * 33333)
+                else:
+                    ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
             for k in range(k0, first):
-                ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
+                step(k)
             ef.synchronize()
             t0 = time.perf_counter()
             for k in range(first, first + a.steps):
-                ef.processFrameDevice(dev[k][0].p.value, dev[k][1].p.value, k * 33333)
+                step(k)
             ef.synchronize()
             dt = time.perf_counter() - t0
             fps = a.steps / dt
+            spec = spec + ("+host" if host else "")
             out.setdefault(spec, []).append(round(fps, 1))
             print(f"[{spec}] rep {rep}: {fps:.1f} frames/s ({1e3 * dt / a.steps:.4f} ms/frame), surfels {ef.lastCount()}, fallbacks {ef.trackerFallbacks()}", flush=True)
             ef.close()
