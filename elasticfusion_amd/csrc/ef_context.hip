@@ -107,6 +107,7 @@ struct ef_ctx {
   float* graph_dev = nullptr;
   int graph_nodes = 0, graph_is_fern = 0;
   float* synth_depth = nullptr;
+  float* rays = nullptr;           // efm::build_ray_table: the ray of every pixel (float4, column-major), for the surface splat
   // local loop closure, front half (ElasticFusion.cpp:447-527): a second tracker instance registers the view of the INACTIVE
   // part of the model against the ACTIVE one; buffers exist only when cfg.close_loops is set
   int icp_count_thresh = 35000;            // ElasticFusion.h:44-46
@@ -332,7 +333,7 @@ int do_predict(ef_ctx* c, bool count_dense = true) {
   efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence,
                         c->last_frame_recovery ? 0 : c->tick, c->tick, c->cfg.time_delta, c->zbuf, c->pm, c->fm, c->depth_filtered, c->rgb,
                         c->cfg.frame_to_frame_rgb != 0, count_dense ? &c->st->dense_count : nullptr, c->stream, nullptr, 0u,
-                        (count_dense && c->mark_value) ? c->d_consumed : nullptr, c->mark_value);
+                        (count_dense && c->mark_value) ? c->d_consumed : nullptr, c->mark_value, c->rays);
   if (count_dense) c->mark_value = 0;
   if (c->lost) efm::fill_in(c->cam, c->pm, c->depth_filtered, c->rgb, true, true, c->fm, c->stream);
   return EF_OK;
@@ -567,14 +568,15 @@ int local_loop_closure(ef_ctx* c, int log_slot, bool have_active) {
   // predict() of :387: the ACTIVE view at the pose just estimated (its fill-in only feeds the fern database: made by the caller then)
   if (!have_active)
     efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], count, c->maxDepthProcessed, c->cfg.confidence, c->tick, c->tick, c->cfg.time_delta,
-                          c->zbuf, c->pm, none, nullptr, nullptr, false, nullptr, s);
+                          c->zbuf, c->pm, none, nullptr, nullptr, false, nullptr, s, nullptr, 0u, nullptr, 0u, c->rays);
   // :451-459, IndexMap::INACTIVE: surfels last seen at or before tick - timeDelta
   // (the prediction stamps st2->model_view_stamp with this frame's value when it shows at least one surfel: the model-to-model tracker's
   // persistent launch leaves at once otherwise — nothing can be registered against an empty view, and the reference's tracker, which runs
   // all the same, ends on zero sums: the stamp only says which frames those are)
   const unsigned view_stamp = (unsigned)c->tick * 2u + 1u;
   efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], count, c->maxDepthProcessed, c->cfg.confidence, 0, c->tick - c->cfg.time_delta,
-                        c->cfg.time_delta, c->zbuf, c->old, none, nullptr, nullptr, false, nullptr, s, &c->st2->model_view_stamp, view_stamp);
+                        c->cfg.time_delta, c->zbuf, c->old, none, nullptr, nullptr, false, nullptr, s, &c->st2->model_view_stamp, view_stamp, nullptr, 0u,
+                        c->rays);
   eft::copy_pose(c->st2, c->st, s);                                                              // :469
   const float maxDepthRGB = 6.0f;                                                                // RGBDOdometry.cpp:42
   // :463 initICPModel(inactive view) + :464 initRGBModel(its image) + :466-467 initICP / initRGB(active view), fused (eft::init_model_pair)
@@ -897,7 +899,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       efm::Deformation def{c->graph_dev, c->graph_nodes, c->synth_depth, c->graph_is_fern, c->maxDepthProcessed};
       if (c->graph_nodes > 0 && !c->graph_is_fern)
         efm::synthesize_depth(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence, c->tick,
-                              c->tick - c->cfg.time_delta, 65535, c->zbuf, c->synth_depth, s);
+                              c->tick - c->cfg.time_delta, 65535, c->zbuf, c->synth_depth, s, c->rays);
       timer_begin(c, "Fuse::Copy");
       efm::clean(c->cam, c->st->T_cw, c->tick, c->im, c->cfg.confidence, c->cfg.time_delta, c->maps[c->cur], &c->st->map_counts[c->cur], c->cand,
                  c->winner, c->maps[c->cur ^ 1], &c->st->map_counts[c->cur ^ 1], c->capacity, c->cs, c->overflow, s,
@@ -998,6 +1000,7 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->zbuf, P, 0xFF);
   EF_ALLOC(c, c->graph_dev, 1024 * 16);     // GlobalModel::MAX_NODES x 16 (GlobalModel.cpp:24)
   EF_ALLOC(c, c->synth_depth, P);
+  EF_ALLOC(c, c->rays, P * 4);
   EF_ALLOC(c, c->overflow, 1);
   // global model
   c->capacity = g.max_surfels;
@@ -1053,6 +1056,7 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->traj, (size_t)c->traj_cap * 16);
   // T_wc = identity (ElasticFusion.h: T_wc_curr default) -> publish the float matrices
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->st, (W / 20) * (H / 20), W * H);
+  efm::build_ray_table(c->cam, c->rays, s);
   const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   eft::pose_injected(c->st, I16, false, 1.0f, false, nullptr, 0, s);
   eft::pose_injected(c->st, I16, true, 1.0f, false, nullptr, 0, s);   // previous pose = identity too

@@ -104,10 +104,15 @@ void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, co
                       unsigned* nonempty_flag = nullptr, unsigned nonempty_value = 0,
                       // optional: *consumed_mark = consumed_value (system scope, e.g. host-mapped memory) as soon as the splat launch starts, i.e. once
                       // everything enqueued before it has finished
-                      unsigned* consumed_mark = nullptr, unsigned consumed_value = 0);
+                      unsigned* consumed_mark = nullptr, unsigned consumed_value = 0,
+                      // optional: build_ray_table's table for this camera (cols x rows float4, column-major): the splat loads a fragment's ray instead of
+                      // evaluating it — the same value
+                      const float* rays4 = nullptr);
+void build_ray_table(const Cam& cam, float* rays4, hipStream_t s);
 // IndexMap::synthesizeDepth (splat.vert + depth_splat.frag): float depth of the nearest splat per pixel, 0 = none
 void synthesize_depth(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
-                      float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s);
+                      float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s,
+                      const float* rays4 = nullptr);
 void fill_in(const Cam& cam, PredictMaps pred, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthrough,
              bool passthroughImage, FillMaps out, hipStream_t s);
 // counts the (W/20)x(H/20) sample texels with r,g,b > 0 into *counter (Resize::image + denseEnough)

@@ -475,15 +475,31 @@ __device__ __forceinline__ Sprite make_sprite(const Cam& cam, const rt34& T, flo
   return S;
 }
 // combo_splat.frag:35-61 for one fragment; returns false when discarded
-__device__ __forceinline__ bool sprite_fragment(const Cam& cam, const Sprite& S, int px, int py, float& z) {
+__device__ __forceinline__ f3 pixel_ray(const Cam& cam, int px, int py) {
   const float fcx = (float)px + 0.5f, fcy = (float)py + 0.5f;
-  const f3 l = normalized(f3{(fcx - cam.cx) / cam.fx, (fcy - cam.cy) / cam.fy, 1.0f});
-  const float k = dot(S.p, S.n) / dot(l, S.n);
+  return normalized(f3{(fcx - cam.cx) / cam.fx, (fcy - cam.cy) / cam.fy, 1.0f});
+}
+// ... with the ray of the pixel and dot(S.p, S.n) given (the same operations on the same values wherever they were evaluated)
+__device__ __forceinline__ bool sprite_fragment_ray(const f3& Sp, const f3& Sn, float rad, float psn, const f3& l, float& z) {
+  const float k = psn / dot(l, Sn);
   const f3 cp{k * l.x, k * l.y, k * l.z};
-  const f3 diff = cp - S.p;
-  if (!(dot(diff, diff) <= S.rad * S.rad)) return false;
+  const f3 diff = cp - Sp;
+  if (!(dot(diff, diff) <= rad * rad)) return false;
   z = cp.z;
   return true;
+}
+__device__ __forceinline__ bool sprite_fragment(const Cam& cam, const Sprite& S, int px, int py, float& z) {
+  return sprite_fragment_ray(S.p, S.n, S.rad, dot(S.p, S.n), pixel_ray(cam, px, py), z);
+}
+// The ray of every pixel (column-major like the z-buffer: texel (x, y) at x * rows + y), built once per context: a fragment of the surface splat
+// then loads 16 bytes instead of evaluating two divisions, a square root and a reciprocal (52 of its ~90 instructions; the splat is VALU-bound,
+// round 6) — pixel_ray's own value, so the intersection is bit-identical.
+__global__ void k_ray_table(const Cam cam, float4* __restrict__ rays) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cam.cols * cam.rows) return;
+  const int px = i / cam.rows, py = i - px * cam.rows;
+  const f3 l = pixel_ray(cam, px, py);
+  rays[i] = make_float4(l.x, l.y, l.z, 0.f);
 }
 // SPLAT_LANES consecutive lanes share one surfel and take every SPLAT_LANES-th fragment of its sprite: sprite areas vary
 // from 1 to dozens of pixels, and with one surfel per lane a wave waits for its largest sprite
@@ -507,10 +523,16 @@ constexpr int SPLAT_GRID = SURFEL_GRID * SPLAT_LANES;
 constexpr int SPLAT_ROUNDS = 2, SPLAT_CHUNK = SPLAT_ROUNDS * (BLK / SPLAT_LANES), SPLAT_TILE = 4096;
 constexpr int SPLAT_GRID = 4096;   // workgroups; each strides over chunks of SPLAT_CHUNK ids (the count lives on the device)
 #endif
+// Round 6: a fragment's ray comes from the context's table (LUT; the operator tier, which has no context, evaluates it) and dot(S.p, S.n) is
+// taken out of the fragment loop.  (Measured and dropped in the same round: an early-z load before the atomic — 28.0 against 24.5 us, plain or
+// agent-scope: the atomics return nothing, the load makes every fragment wait — and one surfel per lane for the per-surfel part with the quad
+// working through its four sprites — 34-37 us: a quarter of the wavefronts, each with a four times longer serial chain;
+// profiles/r06i_*, r06k_*.)
+template <bool LUT>
 __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const float* __restrict__ T16, SurfelSoA map,
                                                         const unsigned* __restrict__ count_dev, float maxDepth, float confThreshold,
                                                         int time, int maxTime, int timeDelta, unsigned long long* zbuf,
-                                                        unsigned* consumed_mark, unsigned consumed_value) {
+                                                        unsigned* consumed_mark, unsigned consumed_value, const float4* __restrict__ rays) {
   // (host-pointer frames: every kernel that reads the frame's landing buffers precedes this launch in the stream — their ring slot is free)
   if (consumed_mark && blockIdx.x == 0 && threadIdx.x == 0)
     __hip_atomic_store(consumed_mark, consumed_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -529,15 +551,29 @@ __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const floa
     const int px0 = max(0, (int)ceilf(S.u - S.hs - 0.5f)), px1 = min(cam.cols - 1, (int)ceilf(S.u + S.hs - 0.5f) - 1);
     const int py0 = max(0, (int)ceilf(S.v - S.hs - 0.5f)), py1 = min(cam.rows - 1, (int)ceilf(S.v + S.hs - 0.5f) - 1);
     const int hgt = py1 - py0 + 1, nfrag = (px1 - px0 + 1) * hgt;
+    const float psn = dot(S.p, S.n);
     for (int f = (int)sub; f < nfrag; f += SPLAT_LANES) {   // (the sprite's fragments column by column: the lanes of a surfel stay in one cache line)
       const int fx = f / hgt, py = py0 + (f - fx * hgt), px = px0 + fx;
+      const int zi = px * cam.rows + py;   // column-major z-buffer: see k_surface_resolve
+      f3 l;
+      if (LUT) { const float4 r = rays[zi]; l = f3{r.x, r.y, r.z}; }
+      else l = pixel_ray(cam, px, py);
       float z;
-      if (!sprite_fragment(cam, S, px, py, z)) continue;
+      if (!sprite_fragment_ray(S.p, S.n, S.rad, psn, l, z)) continue;
       if (z != z) continue;
-      atomicMin(&zbuf[px * cam.rows + py], zkey(z, id));   // column-major z-buffer: see k_surface_resolve
+      unsigned long long* cell = &zbuf[zi];
+      const unsigned long long key = zkey(z, id);
+#if defined(EF_SPLAT_EARLYZ) && EF_SPLAT_EARLYZ == 1
+      // early z (A/B): a fragment that is not nearer than what the cell already shows cannot change it (keys only decrease: a stale value is safe)
+      if (*(volatile unsigned long long*)cell <= key) continue;
+#elif defined(EF_SPLAT_EARLYZ) && EF_SPLAT_EARLYZ == 2
+      if (__hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= key) continue;
+#endif
+      atomicMin(cell, key);
     }
   }
 #else
+  (void)rays;
   __shared__ unsigned long long tile[SPLAT_TILE];
   __shared__ int box[4];   // min x, min y, max x, max y of the chunk's sprites
   const unsigned group = threadIdx.x / SPLAT_LANES;
@@ -1264,9 +1300,16 @@ void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSo
 void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
                       float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, PredictMaps out, FillMaps fill,
                       const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthroughImage, unsigned* dense_counter, hipStream_t s,
-                      unsigned* nonempty_flag, unsigned nonempty_value, unsigned* consumed_mark, unsigned consumed_value) {
-  hipLaunchKernelGGL(k_surface_splat, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
-                     time, maxTime, timeDelta, zbuf, consumed_mark, consumed_value);
+                      unsigned* nonempty_flag, unsigned nonempty_value, unsigned* consumed_mark, unsigned consumed_value, const float* rays4) {
+#ifdef EF_SPLAT_NO_LUT
+  rays4 = nullptr;   // (A/B: every fragment evaluates its ray)
+#endif
+  if (rays4)
+    hipLaunchKernelGGL(k_surface_splat<true>, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
+                       time, maxTime, timeDelta, zbuf, consumed_mark, consumed_value, (const float4*)rays4);
+  else
+    hipLaunchKernelGGL(k_surface_splat<false>, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
+                       time, maxTime, timeDelta, zbuf, consumed_mark, consumed_value, (const float4*)nullptr);
   const dim3 g(ceil_div(cam.cols, 16), ceil_div(cam.rows, 16));   // 16 x 16 pixel tiles, 8 x 8 per wavefront
   if (fill.image)
     hipLaunchKernelGGL(k_surface_resolve<true>, g, dim3(BLK), 0, s, cam, T_cw16_dev, map, maxDepth, confThreshold, time, maxTime, timeDelta,
@@ -1276,11 +1319,18 @@ void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, co
                        zbuf, out, fill, depth_filtered, rgb3, passthroughImage, dense_counter, nonempty_flag, nonempty_value);
 }
 void synthesize_depth(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth, float confThreshold,
-                      int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s) {
-  hipLaunchKernelGGL(k_surface_splat, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
-                     time, maxTime, timeDelta, zbuf, (unsigned*)nullptr, 0u);
+                      int time, int maxTime, int timeDelta, unsigned long long* zbuf, float* depth, hipStream_t s, const float* rays4) {
+  if (rays4)
+    hipLaunchKernelGGL(k_surface_splat<true>, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
+                       time, maxTime, timeDelta, zbuf, (unsigned*)nullptr, 0u, (const float4*)rays4);
+  else
+    hipLaunchKernelGGL(k_surface_splat<false>, dim3(SPLAT_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, map, count_dev, maxDepth, confThreshold,
+                       time, maxTime, timeDelta, zbuf, (unsigned*)nullptr, 0u, (const float4*)nullptr);
   const int n = cam.cols * cam.rows;
   hipLaunchKernelGGL(k_depth_resolve, dim3(ceil_div(n, BLK)), dim3(BLK), 0, s, cam.cols, cam.rows, zbuf, depth);
+}
+void build_ray_table(const Cam& cam, float* rays4, hipStream_t s) {
+  hipLaunchKernelGGL(k_ray_table, dim3(ceil_div(cam.cols * cam.rows, BLK)), dim3(BLK), 0, s, cam, (float4*)rays4);
 }
 void fill_in(const Cam& cam, PredictMaps pred, const uint16_t* depth_filtered, const uint8_t* rgb3, bool passthrough, bool passthroughImage,
              FillMaps out, hipStream_t s) {

@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd /tmp
+for spec in d nolut un2; do
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/st_$spec -o st --output-format csv -- python $R/tools/ab_bench.py --steps 100 --reps 1 $spec 2>&1 | grep "rep 0"
+  f=$(find /tmp/st_$spec -name "st_kernel_stats.csv" | head -1)
+  cp $f $R/gpurun_out/r06k_kernel_stats_$spec.csv
+  grep "k_surface_splat" $f | cut -d, -f2-8
+done
