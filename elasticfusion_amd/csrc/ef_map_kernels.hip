@@ -21,12 +21,34 @@ constexpr int SURFEL_GRID = 1024;   // grid-stride workgroups for per-surfel pas
 constexpr int BLK = 256;
 constexpr int CLEAN_GRID = 4096;     // grid-stride workgroups of the clean passes (one 256-element row each)
 static_assert(CLEAN_ROW == BLK, "clean kernels run one element per thread");
+static_assert(CLEAN_GRID % 8 == 0, "xcd_row");
 
 __device__ __forceinline__ uint32_t depth_key(float z) {  // order-preserving float -> uint
   const uint32_t b = __float_as_uint(z);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 __device__ __forceinline__ unsigned long long zkey(float z, uint32_t id) { return ((unsigned long long)depth_key(z) << 32) | id; }
+// XCD-aware work order (round 6).  Workgroup b of a launch runs on XCD b % 8 and every XCD has its own L2.  The per-surfel and per-pixel passes
+// that read a NEIGHBOURHOOD of the index maps (clean's and fuse's taps) walk surfels / pixels in column-major order, so consecutive workgroups read
+// overlapping lines; dealt round-robin to the XCDs every such line is fetched into three L2s (k_clean_flags moved 2.4 x its unique bytes,
+// profiles/pmc_traffic.json).  These helpers give the workgroups of one XCD CONTIGUOUS stretches of the work instead — which workgroup computes
+// which element changes, no result does.
+//   xcd_block(): a bijection of [0, gridDim.x): the blocks of XCD x, in launch order, take the x-th eighth
+__device__ __forceinline__ unsigned xcd_block() {
+  const unsigned g = gridDim.x, x = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  return x * (g >> 3) + (x < (g & 7u) ? x : (g & 7u)) + slot;
+}
+//   xcd_row(nrows, it, r): row of this block's it-th trip when the rows are dealt to the XCDs in CHUNKS of XCD_CHUNK consecutive rows (chunk c to
+//   XCD c % 8; gridDim.x % 8 == 0): neighbouring rows — which read overlapping lines — share an L2, and the heavy and the light stretches of
+//   the map (old stable surfels at the front, candidate slots at the end) still spread over all XCDs (one contiguous eighth per XCD, measured:
+//   k_clean_flags 18.5 -> 22.4 us, 61 -> 108 us at 1280 x 960 — the XCDs that own the stable surfels finish last)
+constexpr unsigned XCD_CHUNK = 32;
+__device__ __forceinline__ bool xcd_row(unsigned nrows, unsigned it, unsigned& r) {
+  const unsigned x = blockIdx.x & 7u, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const unsigned local = slot + it * per;
+  r = (x + 8u * (local / XCD_CHUNK)) * XCD_CHUNK + (local % XCD_CHUNK);
+  return r < nrows;
+}
 
 // uv attribute (FeedbackBuffer.cpp:44-52, GlobalModel.cpp:109-117) and x = texcoord.x * cols
 __device__ __forceinline__ float pix_coord(int i, int n) {
@@ -772,7 +794,7 @@ struct FuseArgs {
 __global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates cand, uint32_t* winner, int colwalk) {
   const Cam cam = A.cam;
   const int qc = cam.cols / 2, qr = cam.rows / 2;
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = (int)(xcd_block() * blockDim.x + threadIdx.x);
   if (q >= qc * qr) return;
   // colwalk: consecutive lanes go down a column (the order of the candidate slots and of a column-major index map);
   // otherwise along a row (the order of the depth and colour images)
@@ -1129,7 +1151,8 @@ __global__ void __launch_bounds__(BLK) k_clean_flags(const CleanArgs A, SurfelSo
   const unsigned n = count + (unsigned)cand.n;
   const unsigned nrows = (n + CLEAN_ROW - 1) / CLEAN_ROW;
   const rt34 T = rt34_load16(A.T16);
-  for (unsigned r = blockIdx.x; r < nrows; r += gridDim.x) {
+  unsigned r;
+  for (unsigned it = 0; xcd_row(nrows, it, r); ++it) {   // (uniform per workgroup)
     const unsigned e = r * CLEAN_ROW + threadIdx.x;
     bool f = false;
     if (e < n) {
@@ -1157,7 +1180,8 @@ __global__ void __launch_bounds__(BLK) k_clean_scatter(SurfelSoA map, const unsi
   const unsigned count = *count_dev;
   const unsigned n = count + (unsigned)cand.n;
   const unsigned nrows = (n + CLEAN_ROW - 1) / CLEAN_ROW;
-  for (unsigned r = blockIdx.x; r < nrows; r += gridDim.x) {
+  unsigned r;
+  for (unsigned it = 0; xcd_row(nrows, it, r); ++it) {   // (uniform per workgroup)
     const unsigned e = r * CLEAN_ROW + threadIdx.x;
     const unsigned f = (e < n) ? flags[e] : 0u;
     float4 pc = make_float4(0, 0, 0, 0), ct = pc, nr = pc;
