@@ -589,8 +589,8 @@ def main():
         gpu.synchronize()
         value_200 = self_check / (time.perf_counter() - t1)
 
-    # the only collective: 32 B per rank over xGMI (RCCL all_gather)
-    allstats = multi.gather_stats([dt, float(a.steps), err_t, float(count)], device=stats_device)
+    # the only collective: 40 B per rank over xGMI (RCCL all_gather): seconds, frames, pose error, surfels, the sequence's seed
+    allstats = multi.gather_stats([dt, float(a.steps), err_t, float(count), float(seed)], device=stats_device)
     if rank != 0:
         ef.close()
         if world > 1:
@@ -641,7 +641,8 @@ def main():
                    "resolution": [w, h], "sequences": world, "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
                    "preroll_frames": a.preroll, "surfels_end": int(count),
                    "pose_err_vs_generating_traj_m": round(err_t, 5),
-                   "per_rank_fps": [round(x, 2) for x in agg["per_rank_fps"]]},
+                   "per_rank_fps": [round(x, 2) for x in agg["per_rank_fps"]],
+                   "sequence_seeds": [hex(int(x)) for x in allstats[:, 4]]},
         # the dominant kernel of the timed region (the persistent tracker launch); when the launch-per-step script was timed (--per-step-tracker,
         # --graph, rgbOnly) there is no such launch and the level-0 normal-equation kernel stands here
         "roofline": rtracker if rtracker is not None else roofline,

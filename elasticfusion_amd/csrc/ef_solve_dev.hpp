@@ -55,6 +55,7 @@ struct SolveScratch {     // LDS, one per workgroup that runs a solve
   float krkinv[9], kt[3];   // K R K^-1, K t of the coming iteration
   float Rcurr[9], tcurr[3]; // the new pose
   int broken;               // rgbOnly "break" flag after this step
+  int tail_pending;         // SPLIT_TAIL: 1 = resultRt is in Rt and the two tails (gn_tail_pose, gn_tail_krk) are still to be evaluated
 };
 // the per-lane part of that prefetch (registers until the update starts)
 struct SolvePrefetch {
@@ -269,11 +270,96 @@ struct SolveInputs {
   bool level_changes;
 };
 
+// The two tails of the update step behind resultRt (S.Rt): the float pose of the coming iteration, and its K R K^-1 / K t.  Each is called by ONE
+// converged wavefront; they read S.Rt / S.prevPose and write disjoint members, so two wavefronts may run them at the same time.
+__device__ __forceinline__ void gn_tail_pose(SolveScratch& S, eft::GNState* next, bool publish) {
+  const int lane = threadIdx.x & 63;
+  // ---- currentT = [Rprev|tprev] * rgbOdom^-1 in float, Isometry inverse = (R^T, -R^T t) (quirk Q13) ----
+  if (lane < 12) {
+    // iR = oR^T with oR = float(resultRt 3x3), ot = float(resultRt translation)
+    float iR[9], ot[3], it[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) iR[r * 3 + c] = (float)S.Rt[c * 4 + r];
+      ot[r] = (float)S.Rt[r * 4 + 3];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) it[r] = -(iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1] + iR[r * 3 + 2] * ot[2]);
+    const float* Rp = S.prevPose;
+    if (lane < 9) {
+      const int r = lane / 3, c = lane - r * 3;
+      // column c of iR = row c of float(resultRt), read from LDS with the lane's own index (selecting among the register copies
+      // makes the compiler index a private array, which lands in scratch when the alloca is not promoted to LDS)
+      const float i0 = (float)S.Rt[c * 4], i1 = (float)S.Rt[c * 4 + 1], i2 = (float)S.Rt[c * 4 + 2];
+      const float v = Rp[r * 3] * i0 + Rp[r * 3 + 1] * i1 + Rp[r * 3 + 2] * i2;
+      S.Rcurr[lane] = v;
+      if (publish) next->Rcurr[lane] = v;
+    } else {
+      const int r = lane - 9;
+      const float v = (Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2]) + S.prevPose[9 + r];
+      S.tcurr[r] = v;
+      if (publish) next->tcurr[r] = v;
+    }
+  }
+}
+__device__ __forceinline__ void gn_tail_krk(const eft::Intr knext, SolveScratch& S, eft::GNState* next, bool publish) {
+  const int lane = threadIdx.x & 63;
+  // ---- next iteration's K R K^-1 and K t (RGBDOdometry.cpp:395-417) ----
+  {
+    const eft::Intr k = knext;
+    const double K[9] = {k.fx, 0, k.cx, 0, k.fy, k.cy, 0, 0, 1};
+    // lanes 0..8: inverse of resultRt's 3x3 block; lanes 16..24: inverse of K (same code, different operand)
+    const bool second = lane >= 16;
+    double m[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) m[q] = second ? K[q] : S.Rt[(q / 3) * 4 + (q % 3)];
+    const int e = second ? lane - 16 : lane;
+    const double inv = m3_inverse_entry(m, (e >= 0 && e < 9) ? e : 0);
+    if (lane < 9) S.inv[0][lane] = inv;
+    else if (lane >= 16 && lane < 25) S.inv[1][lane - 16] = inv;
+    wave_sync();
+    // translation of the inverse: -(Ai * t)  (m4_affine_inverse)
+    if (lane < 3) {
+      const double* Ai = S.inv[0];
+      S.ti[lane] = Ai[lane * 3] * S.Rt[3] + Ai[lane * 3 + 1] * S.Rt[7] + Ai[lane * 3 + 2] * S.Rt[11];
+    }
+    // K * R
+    if (lane >= 16 && lane < 25) {
+      const int q = lane - 16, r = q / 3, c = q - r * 3;
+      // row r of K, selected without indexing a register array by a lane-dependent r
+      const double k0 = (r == 0) ? K[0] : 0.0, k1 = (r == 1) ? K[4] : 0.0, k2 = (r == 0) ? K[2] : (r == 1 ? K[5] : 1.0);
+      double s = 0;
+      s += k0 * S.inv[0][c];
+      s += k1 * S.inv[0][3 + c];
+      s += k2 * S.inv[0][6 + c];
+      S.KR[q] = s;
+    }
+    wave_sync();
+    if (lane < 9) {
+      const int r = lane / 3, c = lane - r * 3;
+      double s = 0;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) s += S.KR[r * 3 + kk] * S.inv[1][kk * 3 + c];
+      S.krkinv[lane] = (float)s;
+      if (publish) next->krkinv[lane] = (float)s;
+    } else if (lane >= 16 && lane < 19) {
+      const int r = lane - 16;
+      const double t0 = -S.ti[0], t1 = -S.ti[1], t2 = -S.ti[2];
+      const double k0 = (r == 0) ? K[0] : 0.0, k1 = (r == 1) ? K[4] : 0.0, k2 = (r == 0) ? K[2] : (r == 1 ? K[5] : 1.0);
+      const float v = (float)(k0 * t0 + k1 * t1 + k2 * t2);
+      S.kt[r] = v;
+      if (publish) next->kt[r] = v;
+    }
+  }
+  wave_sync();
+}
 // The update step proper.  sums: 58 floats in LDS (ICP members 0..28, RGB members 29..57).  Called by ONE converged
 // wavefront (lanes 0..63).  Leaves resultRt, Rcurr/tcurr, krkinv/kt in S; with `publish` also writes them into `next`
 // and lastA/lastb into st.
 // `stats`: also leave lastA / lastb in st (one workgroup does; in the persistent small-level kernel every workgroup publishes into its own
 // LDS copy of the state but only workgroup 0 writes the TrackState)
+template <bool SPLIT_TAIL = false>
 __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, eft::GNState* next, bool publish, const float* sums,
                                                          const SolveInputs in, SolveScratch& S, bool stats) {
   const int lane = threadIdx.x & 63;
@@ -349,82 +435,14 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, ef
   }
   wave_sync();
   if (publish && lane < 16) next->resultRt[lane] = S.Rt[lane];
-  // ---- currentT = [Rprev|tprev] * rgbOdom^-1 in float, Isometry inverse = (R^T, -R^T t) (quirk Q13) ----
-  if (lane < 12) {
-    // iR = oR^T with oR = float(resultRt 3x3), ot = float(resultRt translation)
-    float iR[9], ot[3], it[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) iR[r * 3 + c] = (float)S.Rt[c * 4 + r];
-      ot[r] = (float)S.Rt[r * 4 + 3];
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r) it[r] = -(iR[r * 3] * ot[0] + iR[r * 3 + 1] * ot[1] + iR[r * 3 + 2] * ot[2]);
-    const float* Rp = S.prevPose;
-    if (lane < 9) {
-      const int r = lane / 3, c = lane - r * 3;
-      // column c of iR = row c of float(resultRt), read from LDS with the lane's own index (selecting among the register copies
-      // makes the compiler index a private array, which lands in scratch when the alloca is not promoted to LDS)
-      const float i0 = (float)S.Rt[c * 4], i1 = (float)S.Rt[c * 4 + 1], i2 = (float)S.Rt[c * 4 + 2];
-      const float v = Rp[r * 3] * i0 + Rp[r * 3 + 1] * i1 + Rp[r * 3 + 2] * i2;
-      S.Rcurr[lane] = v;
-      if (publish) next->Rcurr[lane] = v;
-    } else {
-      const int r = lane - 9;
-      const float v = (Rp[r * 3] * it[0] + Rp[r * 3 + 1] * it[1] + Rp[r * 3 + 2] * it[2]) + S.prevPose[9 + r];
-      S.tcurr[r] = v;
-      if (publish) next->tcurr[r] = v;
-    }
+  if (SPLIT_TAIL) {   // the caller evaluates the two tails on two wavefronts side by side (round 6: they only share their input, Rt)
+    if (lane == 0) S.tail_pending = 1;
+    wave_sync();
+    return;
   }
+  gn_tail_pose(S, next, publish);
   EF_STAMP(st, 7);
-  // ---- next iteration's K R K^-1 and K t (RGBDOdometry.cpp:395-417) ----
-  {
-    const eft::Intr k = in.knext;
-    const double K[9] = {k.fx, 0, k.cx, 0, k.fy, k.cy, 0, 0, 1};
-    // lanes 0..8: inverse of resultRt's 3x3 block; lanes 16..24: inverse of K (same code, different operand)
-    const bool second = lane >= 16;
-    double m[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) m[q] = second ? K[q] : S.Rt[(q / 3) * 4 + (q % 3)];
-    const int e = second ? lane - 16 : lane;
-    const double inv = m3_inverse_entry(m, (e >= 0 && e < 9) ? e : 0);
-    if (lane < 9) S.inv[0][lane] = inv;
-    else if (lane >= 16 && lane < 25) S.inv[1][lane - 16] = inv;
-    wave_sync();
-    // translation of the inverse: -(Ai * t)  (m4_affine_inverse)
-    if (lane < 3) {
-      const double* Ai = S.inv[0];
-      S.ti[lane] = Ai[lane * 3] * S.Rt[3] + Ai[lane * 3 + 1] * S.Rt[7] + Ai[lane * 3 + 2] * S.Rt[11];
-    }
-    // K * R
-    if (lane >= 16 && lane < 25) {
-      const int q = lane - 16, r = q / 3, c = q - r * 3;
-      // row r of K, selected without indexing a register array by a lane-dependent r
-      const double k0 = (r == 0) ? K[0] : 0.0, k1 = (r == 1) ? K[4] : 0.0, k2 = (r == 0) ? K[2] : (r == 1 ? K[5] : 1.0);
-      double s = 0;
-      s += k0 * S.inv[0][c];
-      s += k1 * S.inv[0][3 + c];
-      s += k2 * S.inv[0][6 + c];
-      S.KR[q] = s;
-    }
-    wave_sync();
-    if (lane < 9) {
-      const int r = lane / 3, c = lane - r * 3;
-      double s = 0;
-#pragma unroll
-      for (int kk = 0; kk < 3; ++kk) s += S.KR[r * 3 + kk] * S.inv[1][kk * 3 + c];
-      S.krkinv[lane] = (float)s;
-      if (publish) next->krkinv[lane] = (float)s;
-    } else if (lane >= 16 && lane < 19) {
-      const int r = lane - 16;
-      const double t0 = -S.ti[0], t1 = -S.ti[1], t2 = -S.ti[2];
-      const double k0 = (r == 0) ? K[0] : 0.0, k1 = (r == 1) ? K[4] : 0.0, k2 = (r == 0) ? K[2] : (r == 1 ? K[5] : 1.0);
-      const float v = (float)(k0 * t0 + k1 * t1 + k2 * t2);
-      S.kt[r] = v;
-      if (publish) next->kt[r] = v;
-    }
-  }
+  gn_tail_krk(in.knext, S, next, publish);
   wave_sync();
   EF_STAMP(st, 8);
 }

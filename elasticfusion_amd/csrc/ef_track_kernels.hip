@@ -843,6 +843,7 @@ struct StepArgs {
   int it;                     // index of the iteration within the call (tag of the fused launch's record)
   int ng = 0;                 // fast order: group partials per accumulator the head's tree looks at
 };
+template <bool SPLIT_TAIL = false>
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* prev, GNState* next, bool publish, const float* sums,
                                                 const StepArgs& A, efs::SolveScratch& S, const efs::SolvePrefetch& PF, bool stats);
 template <int BLOCK, bool COHERENT = false>
@@ -1639,6 +1640,7 @@ constexpr int SOLVE_BLOCK = 512;
 // bookkeeping around the update (rgbOnly early exit, statistics); all lanes of wave 0 take the same path.  S receives what the
 // calling workgroup needs (krkinv, kt, Rcurr, tcurr, broken); with `publish` the whole GNState goes to `next` and the
 // statistics to st.
+template <bool SPLIT_TAIL>
 __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* prev, GNState* next, bool publish, const float* sums,
                                                 const StepArgs& A, efs::SolveScratch& S, const efs::SolvePrefetch& PF, bool stats) {
   const int lane = threadIdx.x & 63;
@@ -1658,6 +1660,7 @@ __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* p
   if (broken || brk) {
     // nothing of the pose changes; at a level change the flag clears and K R K^-1 / K t are re-evaluated for the new level
     if (lane == 0) {
+      S.tail_pending = 0;
       S.broken = A.level_changes ? 0 : 1;
       if (A.level_changes) {
         compute_krk(prev->resultRt, A.knext, S.krkinv, S.kt);
@@ -1700,7 +1703,7 @@ __device__ __forceinline__ void solve_step_wave(TrackState* st, const GNState* p
   }
   EF_STAMP(st, 3);
   efs::SolveInputs in{A.icp, A.rgb, A.rgbOnly, A.icpWeight, A.knext, A.level_changes};
-  efs::gauss_newton_update_wave(st, next, publish, sums, in, S, stats);
+  efs::gauss_newton_update_wave<SPLIT_TAIL>(st, next, publish, sums, in, S, stats);
 }
 // reduceSum over what k_se3_accum leaves: pairs[term][acc][block][pair] -> the rest of blockReduceSum's 8-warp tree (offsets 2, 1
 // over the four pair sums of a block: (p0 + p2) + (p1 + p3)), then reduceSum<<<1,1024>>> over the 64 block partials (two warp32

@@ -36,6 +36,27 @@ def test_bench_two_ranks_gloo_stand_in_engine():
     assert d["roofline"] is None and d["vs_baseline"] is None
 
 
+def test_bench_eight_ranks_gloo_the_real_width():
+    """the width the driver's scaling run uses, on this 8-core box — eight ranks, each forking the REAL frame generator
+    (tiny frames), each pinned to its own core share (multi.pin_rank_to_cores), the stand-in engine, one collective: ONE JSON line from rank 0,
+    the other seven silent, every exit code 0, the whole-job aggregate over eight sequences, and the per-rank seeds 0xEF0001 .. 0xEF0008 as
+    gathered by the collective itself (sequence k goes to GPU k)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "10", "--warmup", "2", "--preroll", "2", "--width", "64",
+           "--height", "48", "--stand-in-engine", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env, timeout=560)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 10 and d["scaling"] == "weak" and d["data"] == "stand-in"
+    assert d["config"]["sequences"] == 8 and d["config"]["rccl_world_size"] == 8 and len(d["config"]["per_rank_fps"]) == 8
+    assert d["config"]["sequence_seeds"] == [hex(0xEF0001 + k) for k in range(8)], d["config"]["sequence_seeds"]
+    assert abs(d["value"] - 80.0 / (d["ms_per_step"] * 10 / 1e3)) <= 0.02 * d["value"]
+    assert d["value"] <= 8 * 500.0 * 1.01
+
+
 def test_ranks_get_disjoint_contiguous_core_shares():
     from elasticfusion_amd import multi
     cores = list(range(3, 35))            # a 32-core cpuset that does not start at 0
