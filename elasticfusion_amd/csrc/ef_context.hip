@@ -1521,17 +1521,32 @@ int ef_get_tracker_fallbacks(ef_ctx* c, int* count) {
 }
 // developer instrumentation (tests/test_gpu_fallback.py): `workgroups` workgroups of 1024 threads and 128 registers per lane — each fills the
 // register file of a whole CU — spin for `microseconds` on a stream of their own: the chip is partly taken, as by another process
-__global__ void __launch_bounds__(1024) k_debug_occupy(unsigned long long ticks) {
+__global__ void __launch_bounds__(1024) k_debug_occupy(unsigned long long ticks, unsigned* started) {
   asm volatile("v_mov_b32 v127, 0" ::: "v127");
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const unsigned long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 int ef_debug_occupy(ef_ctx* c, int workgroups, int microseconds) {
   if (!c || workgroups < 1 || workgroups > 1024 || microseconds < 1 || microseconds > 2000000) return EF_EINVAL;
   DeviceGuard dg_(c);
-  if (!c->debug_stream) EF_HIP(c, hipStreamCreateWithFlags(&c->debug_stream, hipStreamNonBlocking));
-  hipLaunchKernelGGL(k_debug_occupy, dim3(workgroups), dim3(1024), 0, c->debug_stream, (unsigned long long)microseconds * 100ull);
+  // (a stream of ANOTHER priority: the runtime multiplexes the streams of a process onto a few hardware queues, and a spinner that sits in the
+  // queue the compute or the copy stream maps to holds up the frame itself — what the spinners stand for, another process, has queues of its own)
+  if (!c->debug_stream) {
+    int lo = 0, hi = 0;
+    EF_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    EF_HIP(c, hipStreamCreateWithPriority(&c->debug_stream, hipStreamNonBlocking, hi));
+  }
+  // The call returns once every spinner IS resident (they report in through a host-mapped word): a spinner needs a whole idle CU, and since round 6
+  // the frame script leaves no bubble in which one could slip in — enqueued right before a frame, the spinners would start behind it and the
+  // test would exercise nothing.  The compute stream is drained first so that they find the chip idle.
+  EF_HIP(c, hipStreamSynchronize(c->stream));
+  c->h_abort[3] = 0u;
+  hipLaunchKernelGGL(k_debug_occupy, dim3(workgroups), dim3(1024), 0, c->debug_stream, (unsigned long long)microseconds * 100ull, c->d_abort + 3);
   EF_HIP(c, hipGetLastError());
+  volatile unsigned* started = c->h_abort + 3;
+  for (int spin = 0; spin < 2000000 && *started < (unsigned)workgroups; ++spin) std::this_thread::yield();
+  if (*started < (unsigned)workgroups) { c->err = "ef_debug_occupy: the spinners did not become resident"; return EF_EHIP; }
   return EF_OK;
 }
 // test hook: raises the sticky abort flag of the frame tracker's persistent launches, as a wait that timed out would

@@ -314,7 +314,6 @@ __global__ void k_pyr_down_multi(const PyrJobs J) {
   else if (J.type[j] == 1) pyr_down_gauss_f_px((const float*)J.src[j], J.scols, J.srows, (float*)J.dst[j], x, y);
   else pyr_down_uchar_gauss_px((const uint8_t*)J.src[j], J.scols, J.srows, (uint8_t*)J.dst[j], x, y);
 }
-
 // verticesToDepthKernel, cudafuncs.cu:564-574
 __global__ void k_vertices_to_depth(const float4* __restrict__ vmaps_tmp, int cols, int rows, float cutOff, float* __restrict__ dst) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -2998,6 +2997,9 @@ void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, fl
   const int n = p.W(0) * p.H(0);
   hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 2), dim3(256), 0, s, rgb3, pred_image_rgba, fill_image_rgba, frameToFrameRGB, st,
                      n, p.nextImage[0], p.lastImage[0], rgb_keep, 0);
+  // (both pyramid steps as ONE launch — a workgroup computing the 36 x 36 level-1 pixels its 16 x 16 level-2 tile reads, then the tile — was
+  // built and measured in round 6: 25.2 us against 8.0 + 5.4 for the two launches: six dependent 25-tap trips per thread; dropped,
+  // profiles/r06q_kernel_stats_fused_pyramid_steps.csv)
   for (int i = 0; i + 1 < NUM_PYRS; ++i) {
     PyrJobs J;
     J.src[0] = i == 0 ? (const void*)depth_filtered : (const void*)p.depth_tmp[i]; J.dst[0] = p.depth_tmp[i + 1]; J.type[0] = 0;
