@@ -740,12 +740,14 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
     EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_src, (size_t)W * H * 2, kind, sb));
   }
   timer_begin(c, "Preprocess");
-  efm::preprocess_depth(depth_in, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb, 0u);
+  // (a tracked frame: the level-0 intensity image of the frame and — folded copies — the context's copy of the colours ride on this launch)
+  const uint8_t* rgb_in = fold_copies ? rgb_src : c->rgb;
+  efm::preprocess_depth(depth_in, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb, 0u,
+                        track_this ? rgb_in : nullptr, c->pyr.nextImage[0], fold_copies ? c->rgb : nullptr);
   timer_end(c, "Preprocess");
   if (overlap && overlap_mode == 2) EF_HIP(c, hipStreamWaitEvent(sb, c->ev_track_done, 0));
   if (track_this && overlap)   // the single-stream script builds all pyramids together below (eft::build_pyramids)
-    eft::build_pyramids_frame_side(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, fold_copies ? rgb_src : c->rgb, sb,
-                                   fold_copies ? c->rgb : nullptr);
+    eft::build_pyramids_frame_side(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, nullptr, sb, nullptr);
   if (overlap) EF_HIP(c, hipEventRecord(c->ev_input_done, sb));
 
   const bool rgbOnly = c->cfg.rgb_only != 0;
@@ -781,13 +783,13 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
       timer_begin(c, "odomInit");
       eft::init_icp_model(c->pyr, (const float*)c->pm.vertex, (const float*)c->pm.normal, (const float*)c->fm.vertex,
-                          (const float*)c->fm.normal, c->st, 6.0f /* maxDepthRGB, RGBDOdometry.cpp:42 */, s);
+                          (const float*)c->fm.normal, c->st, 6.0f /* maxDepthRGB, RGBDOdometry.cpp:42 */, s, (const uint8_t*)c->pm.image,
+                          (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0);
       if (overlap) {
-        eft::build_pyramids_model_side(c->pyr, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, c->st, s);
+        eft::build_pyramids_model_side(c->pyr, nullptr, nullptr, false, c->st, s);
         EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
       } else {
-        eft::build_pyramids(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, (const uint8_t*)c->pm.image, (const uint8_t*)c->fm.image,
-                            c->cfg.frame_to_frame_rgb != 0, fold_copies ? rgb_src : c->rgb, c->st, s, fold_copies ? c->rgb : nullptr, rgb);
+        eft::build_pyramids(c->pyr, c->depth_filtered, c->intr, c->maxDepthProcessed, nullptr, nullptr, false, nullptr, c->st, s, nullptr, rgb);
       }
       if (rgb && overlap) eft::init_rgb_sobel(c->pyr, s);
       timer_end(c, "odomInit");

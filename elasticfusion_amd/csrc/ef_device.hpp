@@ -36,6 +36,11 @@ __device__ __forceinline__ f3 normalized(f3 a) {
   const float rn = 1.0f / sqrtf(dot(a, a));
   return {a.x * rn, a.y * rn, a.z * rn};
 }
+// bgr2IntensityKernel's pixel function, cudafuncs.cu:593 (quirk Q5)
+__device__ __forceinline__ uint8_t intensity_of(float c0, float c1, float c2) {
+  const int value = (int)(c0 * 0.114f + c1 * 0.299f + c2 * 0.587f);
+  return (uint8_t)value;
+}
 struct m33 { f3 r[3]; };
 __device__ __forceinline__ f3 mul(const m33& m, f3 a) { return {dot(m.r[0], a), dot(m.r[1], a), dot(m.r[2], a)}; }
 __device__ __forceinline__ m33 m33_load(const float* p) {

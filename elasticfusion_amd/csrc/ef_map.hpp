@@ -77,8 +77,10 @@ void filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t*
 void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, hipStream_t s);
 // fused: bilateral + both metric conversions in one pass over the raw depth
 // extra_lds: unused dynamic LDS bytes added to the launch = an occupancy cap for when the kernel shares the GPU
+// rgb3 given: the frame's level-0 intensity image (next0) and, with rgb_keep, a copy of the colour image are written by the same launch
 void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric,
-                      float* metric_filtered, hipStream_t s, unsigned extra_lds = 0);
+                      float* metric_filtered, hipStream_t s, unsigned extra_lds = 0, const uint8_t* rgb3 = nullptr, uint8_t* next0 = nullptr,
+                      uint8_t* rgb_keep = nullptr);
 
 // ---- layout conversion at the API boundary ----
 void aos_to_soa(const float* aos, uint32_t count, SurfelSoA soa, hipStream_t s);

@@ -194,7 +194,8 @@ __global__ void k_bilateral_table(float* __restrict__ table) {
 template <bool WITH_METRIC>
 __global__ void __launch_bounds__(256) k_preprocess(const uint16_t* __restrict__ raw, int cols, int rows, unsigned maxv, const float* __restrict__ table,
                                                      uint16_t* __restrict__ filtered, float* __restrict__ metric,
-                                                     float* __restrict__ metric_filtered) {
+                                                     float* __restrict__ metric_filtered, const uint8_t* __restrict__ rgb3,
+                                                     uint8_t* __restrict__ next0, uint8_t* __restrict__ rgb_keep) {
   __shared__ __attribute__((aligned(16))) float tab[BIL_ROWS * BIL_COLS];
   __shared__ float tile[PRE_LH][PRE_LW];
   const int x0 = blockIdx.x * PRE_TW, y0 = blockIdx.y * PRE_TH;
@@ -217,6 +218,20 @@ __global__ void __launch_bounds__(256) k_preprocess(const uint16_t* __restrict__
   const int x = x0 + tx, ya = y0 + ty, yb = ya + 4;
   if (x >= cols) return;
   const bool in_a = ya < rows, in_b = yb < rows;
+  // Round 6: the frame's level-0 intensity image (bgr2IntensityKernel, cudafuncs.cu:584-596 — populateRGBDData(frame)) and the context's copy of
+  // the colour image ride along: six bytes per lane in the shadow of 169 LDS look-ups, one launch less per frame (k_intensity_both, 5 us).
+  if (rgb3) {
+    const int ys[2] = {ya, yb};
+    const bool ins[2] = {in_a, in_b};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!ins[q]) continue;
+      const size_t i = (size_t)ys[q] * cols + x;
+      const uint8_t r = rgb3[i * 3], g = rgb3[i * 3 + 1], b = rgb3[i * 3 + 2];
+      next0[i] = intensity_of((float)r, (float)g, (float)b);
+      if (rgb_keep) { rgb_keep[i * 3] = r; rgb_keep[i * 3 + 1] = g; rgb_keep[i * 3 + 2] = b; }
+    }
+  }
   const float2v value = {tile[ty + PRE_R][tx + PRE_R], tile[ty + 4 + PRE_R][tx + PRE_R]};
   const unsigned va = in_a ? (unsigned)value.x : 0u, vb = in_b ? (unsigned)value.y : 0u;
   const bool gate_a = in_a && !(va > maxv || va < 300U), gate_b = in_b && !(vb > maxv || vb < 300U);
@@ -1261,15 +1276,15 @@ const float* bilateral_table() {
 }
 void filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s) {
   hipLaunchKernelGGL(k_preprocess<false>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), bilateral_table(),
-                     filtered, (float*)nullptr, (float*)nullptr);
+                     filtered, (float*)nullptr, (float*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr);
 }
 void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_metricise, dim3(ceil_div(cols * rows, 256)), dim3(256), 0, s, in, cols * rows, (unsigned)(maxD * 1000.0f), out);
 }
 void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric, float* metric_filtered,
-                      hipStream_t s, unsigned extra_lds) {
+                      hipStream_t s, unsigned extra_lds, const uint8_t* rgb3, uint8_t* next0, uint8_t* rgb_keep) {
   hipLaunchKernelGGL(k_preprocess<true>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), extra_lds, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), bilateral_table(),
-                     filtered, metric, metric_filtered);
+                     filtered, metric, metric_filtered, rgb3, next0, rgb_keep);
 }
 namespace {
 __global__ void k_copy_map(SurfelSoA src, const unsigned* __restrict__ count_dev, SurfelSoA dst) {

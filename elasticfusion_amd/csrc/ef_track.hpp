@@ -200,8 +200,10 @@ void so3_step_op(const So3Args& a, const uint8_t* lastImage, const uint8_t* next
 void init_icp(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, hipStream_t s);
 // initICPModel + initRGBModel's depth half: predicted (or fill-in, chosen by the dense_count tally) float4 maps ->
 // world-frame planar pyramids + model depth L0.  RGBDOdometry.cpp:171-210, :217
+// (pred_image_rgba / fill_image_rgba given: the model's level-0 intensity image — populateRGBDData(model) — is written by the same launch)
 void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
-                    const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s);
+                    const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s, const uint8_t* pred_image_rgba = nullptr,
+                    const uint8_t* fill_image_rgba = nullptr, bool frameToFrameRGB = false);
 // the rest of populateRGBDData (RGBDOdometry.cpp:212-244, :275-279) in three independently enqueueable parts, so that
 // the part that only needs the new frame can run on the input stream while the previous frame is still being fused:
 //   model ("last"): Gaussian depth pyramid + intensity pyramid of the predicted (or fill-in) image

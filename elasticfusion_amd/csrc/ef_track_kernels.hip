@@ -322,10 +322,6 @@ __global__ void k_vertices_to_depth(const float4* __restrict__ vmaps_tmp, int co
   dst[y * cols + x] = (z > cutOff || z <= 0) ? qnan() : z;
 }
 
-__device__ __forceinline__ uint8_t intensity_of(float c0, float c1, float c2) {  // cudafuncs.cu:593 (Q5)
-  const int value = (int)(c0 * 0.114f + c1 * 0.299f + c2 * 0.587f);
-  return (uint8_t)value;
-}
 // bgr2IntensityKernel, cudafuncs.cu:584-596; CH = 4 (RGBA8 texel) or 3 (packed RGB as uploaded)
 template <int CH>
 __global__ void k_bgr_to_intensity(const uint8_t* __restrict__ src, int n, uint8_t* __restrict__ dst) {
@@ -497,6 +493,11 @@ struct ModelMapsArgs {
   int cols, rows;
   float maxDepthRGB;
   bool camera_frame;   // initICP(predictedVertices, predictedNormals): copyMaps + resize only, no tranformMaps
+  // optional (round 6): the model's level-0 intensity image rides along (k_intensity_both's model half: the same texels are in flight here)
+  const uint8_t* pred_image;
+  const uint8_t* fill_image;
+  bool force_fill_image;
+  uint8_t* last0;
 };
 // ALL_PLANES: level 0 (copyMaps NaNs x, y and z of an empty texel); the resized levels only get the
 // x-plane NaN that resizeMapKernel / tranformMapsKernel write (quirk Q3: y/z planes keep stale data).
@@ -544,6 +545,14 @@ __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const
   for (int r = 0; r < 4; ++r) {
     vs[r] = vsrc[(by * 4 + r) * cols + gx];
     ns[r] = nsrc[(by * 4 + r) * cols + gx];
+  }
+  if (A.last0) {   // populateRGBDData(model)'s level-0 intensity (k_model_intensity), same choice of source image
+    const uchar4* __restrict__ isrc = (const uchar4*)((A.force_fill_image || fill) ? A.fill_image : A.pred_image);
+    uchar4 cs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cs[r] = isrc[(by * 4 + r) * cols + gx];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) A.last0[(by * 4 + r) * cols + gx] = intensity_of((float)cs[r].x, (float)cs[r].y, (float)cs[r].z);
   }
   f3 v0[4], n0[4];
 #pragma unroll
@@ -2867,8 +2876,11 @@ static inline dim3 model_maps_grid(const Pyramid& p) {
   return dim3(ceil_div(p.W(0), 64), ceil_div(p.H(0) / 4, 4));
 }
 void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
-                    const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s) {
-  ModelMapsArgs A;
+                    const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s, const uint8_t* pred_image_rgba,
+                    const uint8_t* fill_image_rgba, bool frameToFrameRGB) {
+  ModelMapsArgs A{};
+  A.pred_image = pred_image_rgba; A.fill_image = fill_image_rgba; A.force_fill_image = frameToFrameRGB;
+  A.last0 = pred_image_rgba ? p.lastImage[0] : nullptr;
   A.pred_vertex = (const float4*)pred_vertex; A.pred_normal = (const float4*)pred_normal;
   A.fill_vertex = (const float4*)fill_vertex; A.fill_normal = (const float4*)fill_normal;
   for (int i = 0; i < NUM_PYRS; ++i) { A.vmap[i] = p.vmap_g_prev[i]; A.nmap[i] = p.nmap_g_prev[i]; }
@@ -2902,7 +2914,7 @@ void init_rgb_model(const Pyramid& p, const uint8_t* pred_image_rgba, const uint
 }
 void init_icp_maps(const Pyramid& p, const float* vertex, const float* normal, const uint8_t* image_rgba, const TrackState* st,
                    float maxDepthRGB, hipStream_t s) {
-  ModelMapsArgs A;
+  ModelMapsArgs A{};
   A.pred_vertex = A.fill_vertex = (const float4*)vertex;
   A.pred_normal = A.fill_normal = (const float4*)normal;
   for (int i = 0; i < NUM_PYRS; ++i) { A.vmap[i] = p.vmap_curr[i]; A.nmap[i] = p.nmap_curr[i]; }
@@ -2933,7 +2945,7 @@ __global__ void k_rgba_intensity_pair(const uint8_t* __restrict__ last_rgba, con
 // call: same results (rocprofv3, closed-loop bench: the separate launches were 4.3 + 4.3 + 2.1 per frame, ~76 us).
 void init_model_pair(const Pyramid& p, const float* model_vertex, const float* model_normal, const uint8_t* model_image_rgba, const float* cur_vertex,
                      const float* cur_normal, const uint8_t* cur_image_rgba, const TrackState* st, float maxDepthRGB, hipStream_t s) {
-  ModelMapsArgs A;
+  ModelMapsArgs A{};
   A.pred_vertex = A.fill_vertex = (const float4*)model_vertex;
   A.pred_normal = A.fill_normal = (const float4*)model_normal;
   for (int i = 0; i < NUM_PYRS; ++i) { A.vmap[i] = p.vmap_g_prev[i]; A.nmap[i] = p.nmap_g_prev[i]; }
@@ -2995,7 +3007,8 @@ void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, fl
                     const uint8_t* fill_image_rgba, bool frameToFrameRGB, const uint8_t* rgb3, const TrackState* st, hipStream_t s,
                     uint8_t* rgb_keep, bool with_sobel) {
   const int n = p.W(0) * p.H(0);
-  hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 2), dim3(256), 0, s, rgb3, pred_image_rgba, fill_image_rgba, frameToFrameRGB, st,
+  // (rgb3 == null: both level-0 intensity images are already there — the frame's from the pre-processing launch, the model's from k_model_maps)
+  if (rgb3) hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 2), dim3(256), 0, s, rgb3, pred_image_rgba, fill_image_rgba, frameToFrameRGB, st,
                      n, p.nextImage[0], p.lastImage[0], rgb_keep, 0);
   // (both pyramid steps as ONE launch — a workgroup computing the 36 x 36 level-1 pixels its 16 x 16 level-2 tile reads, then the tile — was
   // built and measured in round 6: 25.2 us against 8.0 + 5.4 for the two launches: six dependent 25-tap trips per thread; dropped,
@@ -3024,8 +3037,9 @@ void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, fl
 void build_pyramids_frame_side(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cutoff, const uint8_t* rgb3, hipStream_t s,
                                uint8_t* rgb_keep) {
   const int n = p.W(0) * p.H(0);
-  hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 1), dim3(256), 0, s, rgb3, (const uint8_t*)nullptr, (const uint8_t*)nullptr, false,
-                     (const TrackState*)nullptr, n, p.nextImage[0], p.lastImage[0], rgb_keep, 0);
+  if (rgb3)   // (null: the pre-processing launch wrote the frame's level-0 intensity)
+    hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 1), dim3(256), 0, s, rgb3, (const uint8_t*)nullptr, (const uint8_t*)nullptr, false,
+                       (const TrackState*)nullptr, n, p.nextImage[0], p.lastImage[0], rgb_keep, 0);
   for (int i = 0; i + 1 < NUM_PYRS; ++i) {
     PyrJobs J{};
     J.src[0] = i == 0 ? (const void*)depth_filtered : (const void*)p.depth_tmp[i]; J.dst[0] = p.depth_tmp[i + 1]; J.type[0] = 0;
@@ -3040,8 +3054,9 @@ void build_pyramids_frame_side(const Pyramid& p, const uint16_t* depth_filtered,
 void build_pyramids_model_side(const Pyramid& p, const uint8_t* pred_image_rgba, const uint8_t* fill_image_rgba, bool frameToFrameRGB,
                                const TrackState* st, hipStream_t s) {
   const int n = p.W(0) * p.H(0);
-  hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 1), dim3(256), 0, s, (const uint8_t*)nullptr, pred_image_rgba, fill_image_rgba,
-                     frameToFrameRGB, st, n, p.nextImage[0], p.lastImage[0], (uint8_t*)nullptr, 1);
+  if (pred_image_rgba)   // (null: k_model_maps wrote the model's level-0 intensity)
+    hipLaunchKernelGGL(k_intensity_both, dim3(ceil_div(n, 256), 1), dim3(256), 0, s, (const uint8_t*)nullptr, pred_image_rgba, fill_image_rgba,
+                       frameToFrameRGB, st, n, p.nextImage[0], p.lastImage[0], (uint8_t*)nullptr, 1);
   for (int i = 0; i + 1 < NUM_PYRS; ++i) {
     PyrJobs J{};
     J.src[0] = p.lastDepth[i]; J.dst[0] = p.lastDepth[i + 1]; J.type[0] = 1;
