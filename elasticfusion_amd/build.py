@@ -33,6 +33,16 @@ VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_
     "fast_clocks": ["-DEF_FAST_BUILD", "-DEF_STAGE_CLOCKS"],   # phase clocks of the fast build's persistent tracker (tools/fast_clocks.py)
     "ldlt_wave": ["-DEF_LDLT_WAVE"],                           # A/B: rounds 2-4's 6x6 factorisation, one matrix element per lane (ef_solve_dev.hpp)
     "ldlt_wave_clocks": ["-DEF_LDLT_WAVE", "-DEF_STAGE_CLOCKS"],
+    "nopairs": ["-DEF_NO_VISIT_PAIRS"],                        # A/B: one visit per lane in the normal-equation rows (rounds 1-5; round 6 evaluates two, packed)
+    "nopairs_clocks": ["-DEF_NO_VISIT_PAIRS", "-DEF_STAGE_CLOCKS"],
+    "p_icp": ["-DEF_RT_WITH_PAIRS_ICP"],                       # A/B: the level-resident parts of the persistent launch with two visits per lane (default: one)
+    "p_search": ["-DEF_RT_WITH_PAIRS_SEARCH"],
+    "p_rgb": ["-DEF_RT_WITH_PAIRS_RGB"],
+    "p_all": ["-DEF_RT_WITH_PAIRS_ICP", "-DEF_RT_WITH_PAIRS_SEARCH", "-DEF_RT_WITH_PAIRS_RGB"],
+    "shfl": ["-DEF_RT_SHFL_REDUCE"],                           # A/B: the wave-level sums of the persistent launch through ds_bpermute (rounds 1-5) instead of DPP / permlane moves
+    "sincos": ["-DEF_WAVE_SINCOS"],                            # A/B: cos(theta) and sin(theta) of the update step as one sincos call instead of two calls
+    "prep_late": ["-DEF_RT_PREPARE_LATE"],                     # A/B: the sigma-independent half of the photometric rows behind exchange A (rounds 1-5) instead of beside it
+    "p_nostream": ["-DEF_RT_NO_PAIRS_STREAM"],                 # ... and the streaming path with one
 }
 SHIM_LIB = os.path.join(HERE, "libefusion.so")          # class ElasticFusion (include/ElasticFusion.h) over the C ABI
 SOURCES = ["ef_track_kernels.hip", "ef_map_kernels.hip", "ef_context.hip", "ef_ferns.hip"]

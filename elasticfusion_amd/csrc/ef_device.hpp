@@ -61,6 +61,30 @@ __device__ __forceinline__ int f2i_rn(float x) {
   return (int)r;
 }
 
+// Gates on a Euclidean norm without the square root (round 6).  sqrtf is correctly rounded and monotone, so for a threshold T the set
+// {a >= 0 : sqrtf(a) <= T} is an initial segment of the floats: "sqrtf(a) <= T" is "a <= sq_le_max(T)" and "sqrtf(a) < T" is
+// "a <= sq_lt_max(T)", bit for bit on every input (NaN fails both forms, +inf passes neither unless T is +inf).  Evaluated once per call on the
+// host (glibc's sqrtf is correctly rounded too); an empty set is -1.
+__host__ __device__ inline float ef_next_up(float a) { unsigned u; __builtin_memcpy(&u, &a, 4); ++u; __builtin_memcpy(&a, &u, 4); return a; }     // a >= +0, finite
+__host__ __device__ inline float ef_next_down(float a) { unsigned u; __builtin_memcpy(&u, &a, 4); --u; __builtin_memcpy(&a, &u, 4); return a; }   // a > +0
+__host__ __device__ inline float sq_le_max(float T) {   // largest float a with sqrtf(a) <= T
+  if (!(T >= 0.0f)) return -1.0f;
+  if (T > 3.4028234664e38f) return T;   // +inf: every a up to +inf
+  float a = T * T;
+  if (a > 3.4028234664e38f) a = 3.4028234664e38f;
+  for (int i = 0; i < 8 && a > 0.0f && !(__builtin_sqrtf(a) <= T); ++i) a = ef_next_down(a);
+  for (int i = 0; i < 8 && a < 3.4028234664e38f && __builtin_sqrtf(ef_next_up(a)) <= T; ++i) a = ef_next_up(a);
+  return a;
+}
+__host__ __device__ inline float sq_lt_max(float T) {   // largest float a with sqrtf(a) < T
+  if (!(T > 0.0f)) return -1.0f;
+  float a = T > 3.4028234664e38f ? 3.4028234664e38f : T * T;
+  if (a > 3.4028234664e38f) a = 3.4028234664e38f;
+  for (int i = 0; i < 8 && a > 0.0f && !(__builtin_sqrtf(a) < T); ++i) a = ef_next_down(a);
+  for (int i = 0; i < 8 && a < 3.4028234664e38f && __builtin_sqrtf(ef_next_up(a)) < T; ++i) a = ef_next_up(a);
+  return a;
+}
+
 __device__ __forceinline__ float ef_expf(float x) {  // x <= 0
   if (x < -87.0f) return 0.0f;
   const float n = rintf(x * 1.44269504088896341f);

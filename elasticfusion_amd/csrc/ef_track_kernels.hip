@@ -631,8 +631,19 @@ struct IcpView {
   int cols, rows;
   Intr k;
   float distThres, angleThres;
+  float dist2Max, sine2Max;   // sq_le_max(distThres), sq_lt_max(angleThres): the two gates on squared norms (ef_device.hpp)
 };
 struct IcpPose { m33 Rcurr; f3 tcurr; m33 Rprev_inv; f3 tprev; };
+// The pose as 24 wave-uniform scalars (every caller's pose is the same in all lanes: kernel arguments or the workgroup's state).  Besides keeping
+// it in scalar registers, the read-first-lane results are values, not loads: the two-visit functions below broadcast pose components into
+// two-component vectors, and a broadcast of a LOADED scalar is rewritten by the compiler into a one-element vector load from the pose object,
+// which then can no longer be promoted to registers (it ended up in scratch memory, 160 bytes per lane).
+__device__ __forceinline__ float uniform_f(float x) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); }
+__device__ __forceinline__ f3 uniform_f3(f3 a) { return f3{uniform_f(a.x), uniform_f(a.y), uniform_f(a.z)}; }
+__device__ __forceinline__ m33 uniform_m33(const m33& m) { return m33{{uniform_f3(m.r[0]), uniform_f3(m.r[1]), uniform_f3(m.r[2])}}; }
+__device__ __forceinline__ IcpPose icp_pose_uniform(const IcpPose& P) {
+  return IcpPose{uniform_m33(P.Rcurr), uniform_f3(P.tcurr), uniform_m33(P.Rprev_inv), uniform_f3(P.tprev)};
+}
 
 // search() + getProducts(), reduce.cu:228-309: fills row[7]; returns found
 __device__ __forceinline__ bool icp_row(const IcpView& V, const IcpPose& P, int x, int y, float (&row)[7]) {
@@ -1280,6 +1291,128 @@ __device__ __forceinline__ void visit_stage2b(const IcpView& IV, const RgbView& 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// TWO visits per lane (round 6; the reference-rounding build).  The normal-equation kernels are bound by VALU issue, and the ISA of one
+// visit_stage2a + 2b showed why: ~325 VALU instructions per ICP row for ~210 floating-point operations — 80 v_mov (the compiler pairing scalars
+// for its own packed arithmetic and un-pairing them again), 34 of 64-bit address arithmetic, two IEEE square roots whose results are only ever
+// compared with a threshold, a branch with its exec-mask bookkeeping around every gate.  Here a lane evaluates the rows of two visits (steps
+// 2 u and 2 u + 1 of its virtual thread) at once, every value a two-component vector: the products and sums below compile to v_pk_mul_f32 /
+// v_pk_add_f32 (each component one IEEE multiply or add — exactly the scalar instruction's rounding), the gates are branch-free selects, the two
+// norms are compared as squares (IcpView::dist2Max / sine2Max: ef_device.hpp, sq_le_max — the same verdict on every input).  133 VALU
+// instructions per row.  Operation for operation icp_row / rgb_row: same operands, same order, same roundings; bit-identical rows.
+// ------------------------------------------------------------------------------------------
+#if defined(EF_NO_FMA) && !defined(EF_NO_VISIT_PAIRS)   // (-DEF_NO_VISIT_PAIRS: the A/B build, build.VARIANTS["nopairs"])
+#define EF_VISIT_PAIRS 1
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct p3 { f32x2 x, y, z; };   // a point / vector of each of the two visits
+__device__ __forceinline__ f32x2 both(float a) { return f32x2{a, a}; }
+__device__ __forceinline__ p3 operator-(p3 a, p3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ p3 operator-(p3 a, f3 b) { return {a.x - both(b.x), a.y - both(b.y), a.z - both(b.z)}; }
+__device__ __forceinline__ p3 operator+(p3 a, f3 b) { return {a.x + both(b.x), a.y + both(b.y), a.z + both(b.z)}; }
+// ef_device.hpp's dot / cross / mul with EF_FMA(a, b, c) = a * b + c
+__device__ __forceinline__ f32x2 dot(f3 a, p3 b) { return both(a.z) * b.z + (both(a.y) * b.y + both(a.x) * b.x); }
+__device__ __forceinline__ f32x2 dot(p3 a, p3 b) { return a.z * b.z + (a.y * b.y + a.x * b.x); }
+__device__ __forceinline__ p3 cross(p3 a, p3 b) { return {a.y * b.z + (-(a.z * b.y)), a.z * b.x + (-(a.x * b.z)), a.x * b.y + (-(a.y * b.x))}; }
+__device__ __forceinline__ p3 mul(const m33& m, p3 a) { return {dot(m.r[0], a), dot(m.r[1], a), dot(m.r[2], a)}; }
+
+// Loads go through buffer instructions: one VGPR byte offset per visit serves all six planes of a pixel (the plane stride rides in the
+// instruction's scalar offset), where a global_load needs a 64-bit address per plane — two to three VALU instructions each.
+typedef __amdgpu_buffer_rsrc_t bufrsrc;
+__device__ __forceinline__ bufrsrc buf_of(const void* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ float buf_f32(bufrsrc r, unsigned voff, unsigned soff) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0)); }
+__device__ __forceinline__ uint32_t buf_u32(bufrsrc r, unsigned voff) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0); }
+__device__ __forceinline__ int buf_i16(bufrsrc r, unsigned voff) { return (int)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)voff, 0, 0); }
+__device__ __forceinline__ p3 buf_p3(bufrsrc r, unsigned a4, unsigned b4, unsigned plane4) {   // planar float[3][plane] at byte offsets a4, b4
+  return p3{{buf_f32(r, a4, 0u), buf_f32(r, b4, 0u)}, {buf_f32(r, a4, plane4), buf_f32(r, b4, plane4)}, {buf_f32(r, a4, 2u * plane4), buf_f32(r, b4, 2u * plane4)}};
+}
+struct IcpLoads2 { p3 vcurr, ncurr; bool inb[2]; };
+struct IcpGathers2 { p3 vprev_g, nprev_g; int pidx[2]; };
+// visit_stage1's ICP half for the visits of pixels pa, pb (N: the visit does not exist)
+__device__ __forceinline__ IcpLoads2 icp2_stage1(const IcpView& IV, int pa, int pb, int N) {
+  IcpLoads2 L;
+  L.inb[0] = pa < N; L.inb[1] = pb < N;
+  const unsigned plane4 = (unsigned)(IV.cols * IV.rows) * 4u;
+  const unsigned a4 = (unsigned)(L.inb[0] ? pa : N - 1) * 4u, b4 = (unsigned)(L.inb[1] ? pb : N - 1) * 4u;
+  L.vcurr = buf_p3(buf_of(IV.vmap_curr, 3u * plane4), a4, b4, plane4);
+  L.ncurr = buf_p3(buf_of(IV.nmap_curr, 3u * plane4), a4, b4, plane4);
+  return L;
+}
+// the pose-dependent head of both stages: vcurr_g and s_cp (= visit_stage2a's vcurr_cp = visit_stage2b's s_cp: one expression)
+__device__ __forceinline__ void icp2_transform(const IcpPose& P, const IcpLoads2& L, p3& vcurr_g, p3& s_cp) {
+  vcurr_g = mul(P.Rcurr, L.vcurr) + P.tcurr;
+  s_cp = mul(P.Rprev_inv, vcurr_g - P.tprev);
+}
+// visit_stage2a's ICP half: the projective association and its gathers (a visit without one reads texel 0 and is discarded through pidx)
+__device__ __forceinline__ IcpGathers2 icp2_stage2a(const IcpView& IV, const IcpLoads2& L, const p3& s_cp) {
+  IcpGathers2 G;
+  const f32x2 px = s_cp.x * both(IV.k.fx) / s_cp.z + both(IV.k.cx);
+  const f32x2 py = s_cp.y * both(IV.k.fy) / s_cp.z + both(IV.k.cy);
+  unsigned g[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int ux = f2i_rn(px[e]), uy = f2i_rn(py[e]);
+    const bool ok = L.inb[e] && !(ux < 0 || uy < 0 || ux >= IV.cols || uy >= IV.rows || s_cp.z[e] < 0);
+    G.pidx[e] = ok ? uy * IV.cols + ux : -1;
+    g[e] = ok ? (unsigned)(uy * IV.cols + ux) : 0u;
+  }
+  const unsigned plane4 = (unsigned)(IV.cols * IV.rows) * 4u;
+  G.vprev_g = buf_p3(buf_of(IV.vmap_g_prev, 3u * plane4), g[0] * 4u, g[1] * 4u, plane4);
+  G.nprev_g = buf_p3(buf_of(IV.nmap_g_prev, 3u * plane4), g[0] * 4u, g[1] * 4u, plane4);
+  return G;
+}
+// visit_stage2b's ICP half: rows[e] = {row[0..6], found} of visit e
+__device__ __forceinline__ void icp2_stage2b(const IcpView& IV, const IcpPose& P, const IcpLoads2& L, const IcpGathers2& G, const p3& vcurr_g, const p3& s_cp,
+                                             float (&ra)[8], float (&rb)[8]) {
+  const p3 ncurr_g = mul(P.Rcurr, L.ncurr);
+  const p3 dv = G.vprev_g - vcurr_g;
+  const f32x2 dist2 = dot(dv, dv);             // norm(vprev_g - vcurr_g)^2 before the root
+  const p3 cr = cross(ncurr_g, G.nprev_g);
+  const f32x2 sine2 = dot(cr, cr);             // norm(cross(ncurr_g, nprev_g))^2 before the root
+  const p3 d_cp = mul(P.Rprev_inv, G.vprev_g - P.tprev);
+  const p3 n_cp = mul(P.Rprev_inv, G.nprev_g);
+  const p3 c = cross(s_cp, n_cp);
+  const f32x2 r6 = dot(n_cp, s_cp - d_cp);
+  bool f[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)   // sine < angleThres && dist <= distThres && !isnan(ncurr.x) && !isnan(nprev_g.x), reduce.cu:263-266
+    f[e] = G.pidx[e] >= 0 && sine2[e] <= IV.sine2Max && dist2[e] <= IV.dist2Max && !isnan(L.ncurr.x[e]) && !isnan(G.nprev_g.x[e]);
+  ra[0] = f[0] ? n_cp.x[0] : 0.f; ra[1] = f[0] ? n_cp.y[0] : 0.f; ra[2] = f[0] ? n_cp.z[0] : 0.f;
+  ra[3] = f[0] ? c.x[0] : 0.f; ra[4] = f[0] ? c.y[0] : 0.f; ra[5] = f[0] ? c.z[0] : 0.f;
+  ra[6] = f[0] ? r6[0] : 0.f; ra[7] = f[0] ? 1.f : 0.f;
+  rb[0] = f[1] ? n_cp.x[1] : 0.f; rb[1] = f[1] ? n_cp.y[1] : 0.f; rb[2] = f[1] ? n_cp.z[1] : 0.f;
+  rb[3] = f[1] ? c.x[1] : 0.f; rb[4] = f[1] ? c.y[1] : 0.f; rb[5] = f[1] ? c.z[1] : 0.f;
+  rb[6] = f[1] ? r6[1] : 0.f; rb[7] = f[1] ? 1.f : 0.f;
+}
+// visit_stage2b's photometric half (rgb_row<true>, reduce.cu:420-476) for two visits: corr = the packed correspondence (valid: bit 31), gx / gy the
+// Sobel gradients at the pixel, d0 the model depth at the correspondence
+__device__ __forceinline__ void rgb2_rows(const RgbView& RV, float sigma, const uint32_t (&corr)[2], const int (&gx)[2], const int (&gy)[2],
+                                          const float (&d0)[2], const bool (&valid)[2], float (&ra)[8], float (&rb)[8]) {
+  const f32x2 diff{(float)((int)((corr[0] >> 22) & 0x1FFu) - 255), (float)((int)((corr[1] >> 22) & 0x1FFu) - 255)};
+  const f32x2 ws = both(sigma) + f32x2{fabsf(diff[0]), fabsf(diff[1])};
+  f32x2 w{ws[0] > 1.19209290E-07F ? 1.0f / ws[0] : 1.0f, ws[1] > 1.19209290E-07F ? 1.0f / ws[1] : 1.0f};
+  if (sigma == -1) w = both(1.0f);
+  const f32x2 r6 = -w * diff;
+  // project_point(zx, zy, d0, 1 / fx, 1 / fy, cx, cy), cudafuncs.cu:670-688
+  const f32x2 zx{(float)(int)(corr[0] & 0x7FFu), (float)(int)(corr[1] & 0x7FFu)}, zy{(float)(int)((corr[0] >> 11) & 0x7FFu), (float)(int)((corr[1] >> 11) & 0x7FFu)};
+  const float invFx = 1.0f / RV.k.fx, invFy = 1.0f / RV.k.fy;
+  const f32x2 pz{d0[0], d0[1]};
+  const f32x2 px = (zx - both(RV.k.cx)) * pz * both(invFx), py = (zy - both(RV.k.cy)) * pz * both(invFy);
+  const f32x2 invz{(float)(1.0 / (double)pz[0]), (float)(1.0 / (double)pz[1])};
+  const f32x2 dI_dx_val = w * both(RV.sobelScale) * f32x2{(float)gx[0], (float)gx[1]};
+  const f32x2 dI_dy_val = w * both(RV.sobelScale) * f32x2{(float)gy[0], (float)gy[1]};
+  const f32x2 v0 = dI_dx_val * both(RV.k.fx) * invz;
+  const f32x2 v1 = dI_dy_val * both(RV.k.fy) * invz;
+  const f32x2 v2 = -(v0 * px + v1 * py) * invz;
+  const f32x2 r3 = -pz * v1 + py * v2, r4 = pz * v0 - px * v2, r5 = -py * v0 + px * v1;
+  ra[0] = valid[0] ? v0[0] : 0.f; ra[1] = valid[0] ? v1[0] : 0.f; ra[2] = valid[0] ? v2[0] : 0.f;
+  ra[3] = valid[0] ? r3[0] : 0.f; ra[4] = valid[0] ? r4[0] : 0.f; ra[5] = valid[0] ? r5[0] : 0.f;
+  ra[6] = valid[0] ? r6[0] : 0.f; ra[7] = valid[0] ? 1.f : 0.f;
+  rb[0] = valid[1] ? v0[1] : 0.f; rb[1] = valid[1] ? v1[1] : 0.f; rb[2] = valid[1] ? v2[1] : 0.f;
+  rb[3] = valid[1] ? r3[1] : 0.f; rb[4] = valid[1] ? r4[1] : 0.f; rb[5] = valid[1] ? r5[1] : 0.f;
+  rb[6] = valid[1] ? r6[1] : 0.f; rb[7] = valid[1] ? 1.f : 0.f;
+}
+#endif   // visit pairs
+
 // developer instrumentation (-DEF_ACCUM_CLOCKS, tools/accum_clocks.py): wall_clock64() (100 MHz) stamps of the first ICP wavefront of
 // every workgroup of the last level-0 launch
 #ifdef EF_ACCUM_CLOCKS
@@ -1316,6 +1449,92 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
     P.tprev = {in.tprev[0], in.tprev[1], in.tprev[2]};
   }
   __builtin_amdgcn_sched_barrier(0);   // keep the (scalar) pose loads ahead of the vector loads below: they overlap
+#ifdef EF_VISIT_PAIRS
+  if constexpr ((ICP || PACKED) && CH % 2 == 0) {   // two visits per lane: steps 2 u, 2 u + 1 of a chunk as one packed evaluation
+    constexpr int NP = CH / 2;
+    auto pixel = [&](int s) { const int k = 4 * s + jl; return (s < S && k < K) ? k * VTHREADS + g : N; };
+    float sigma = in.sigma_fixed;
+    if constexpr (ICP) {
+      const IcpPose Pu = icp_pose_uniform(P);
+      // the loads of the NEXT round are issued before this round's outer products (S <= CH: never — one round)
+      IcpLoads2 L[NP];
+#pragma unroll
+      for (int u = 0; u < NP; ++u) L[u] = icp2_stage1(IV, pixel(2 * u), pixel(2 * u + 1), N);
+#pragma unroll 1
+      for (int s0 = 0; s0 < S; s0 += CH) {
+        IcpGathers2 G[NP];
+        p3 vg[NP], scp[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+          icp2_transform(Pu, L[u], vg[u], scp[u]);
+          G[u] = icp2_stage2a(IV, L[u], scp[u]);
+        }
+        if (s0 == 0) EF_ASTAMP(1);
+        float rows[CH][8];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) icp2_stage2b(IV, Pu, L[u], G[u], vg[u], scp[u], rows[2 * u], rows[2 * u + 1]);
+        if (s0 == 0) EF_ASTAMP(2);
+        if (s0 + CH < S) {   // uniform
+#pragma unroll
+          for (int u = 0; u < NP; ++u) L[u] = icp2_stage1(IV, pixel(s0 + CH + 2 * u), pixel(s0 + CH + 2 * u + 1), N);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          if (s0 + u < S) quad_rows_accumulate(rows[u], s0 + u, K, c);   // uniform; phase B
+        }
+      }
+    } else {
+      const bufrsrc rc = buf_of(RV.corres, (unsigned)N * 4u), rdx = buf_of(RV.dIdx, (unsigned)N * 2u), rdy = buf_of(RV.dIdy, (unsigned)N * 2u),
+                    rd0 = buf_of(RV.lastDepth, (unsigned)N * 4u);
+      uint32_t corr[NP][2];
+      int gx[NP][2], gy[NP][2];
+      bool inb[NP][2];
+      auto load = [&](int s) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+          const int pa = pixel(s + 2 * u), pb = pixel(s + 2 * u + 1);
+          inb[u][0] = pa < N; inb[u][1] = pb < N;
+          const unsigned qa = (unsigned)(inb[u][0] ? pa : N - 1), qb = (unsigned)(inb[u][1] ? pb : N - 1);
+          corr[u][0] = buf_u32(rc, qa * 4u); corr[u][1] = buf_u32(rc, qb * 4u);
+          gx[u][0] = buf_i16(rdx, qa * 2u); gx[u][1] = buf_i16(rdx, qb * 2u);
+          gy[u][0] = buf_i16(rdy, qa * 2u); gy[u][1] = buf_i16(rdy, qb * 2u);
+        }
+      };
+      load(0);
+      if (with_slots) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          slot_a += __shfl_down(slot_a, off, 64);
+          slot_b += __shfl_down(slot_b, off, 64);
+        }
+        sigma = sigma_from_sums(__shfl(slot_b, 0, 64), __shfl(slot_a, 0, 64), in.rgbOnly);
+      }
+#pragma unroll 1
+      for (int s0 = 0; s0 < S; s0 += CH) {
+        bool valid[NP][2];
+        float d0[NP][2];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {   // visit_stage2a's photometric half: the model depth behind the correspondence
+            valid[u][e] = inb[u][e] && (corr[u][e] & 0x80000000u);
+            const unsigned zi = valid[u][e] ? ((corr[u][e] >> 11) & 0x7FFu) * (unsigned)RV.cols + (corr[u][e] & 0x7FFu) : 0u;
+            d0[u][e] = buf_f32(rd0, zi * 4u, 0u);
+          }
+        }
+        float rows[CH][8];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) rgb2_rows(RV, sigma, corr[u], gx[u], gy[u], d0[u], valid[u], rows[2 * u], rows[2 * u + 1]);
+        if (s0 + CH < S) load(s0 + CH);   // uniform: the next round's loads before this round's outer products
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          if (s0 + u < S) quad_rows_accumulate(rows[u], s0 + u, K, c);   // uniform; phase B
+        }
+      }
+    }
+    return;
+  }
+#endif
   VisitLoads L0[CH];
   if (ICP || PACKED) {
 #pragma unroll
@@ -2240,6 +2459,7 @@ struct PtArgs {
   int so3_cols, so3_rows;
   Intr kso3, kfirst;
   float icpWeight, distThres, angleThres;
+  float dist2Max, sine2Max;       // IcpView's gates on squared norms
   float* partials;                // two regions of PARTIAL_FLOATS + the PtSync
   int out_cur;                    // TrackState::gn buffer the launches that follow read
 };
@@ -2582,7 +2802,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
       for (int q = 0; q < 3; ++q) c[hf][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (active) {
       const int wbase = pt_vwarp(wg, 2 * task + wl) * 32;
-      const IcpView IV{Lv.vmap_curr, Lv.nmap_curr, Lv.vmap_g_prev, Lv.nmap_g_prev, cols, rows, Lv.k, A.distThres, A.angleThres};
+      const IcpView IV{Lv.vmap_curr, Lv.nmap_curr, Lv.vmap_g_prev, Lv.nmap_g_prev, cols, rows, Lv.k, A.distThres, A.angleThres, A.dist2Max, A.sine2Max};
       const RgbView RV{Lv.corres, Lv.lastDepth, nullptr, Lv.dIdx, Lv.dIdy, cols, rows, Lv.k, 1.0f / 8.0f};
       Se3Inputs in{G.Rcurr, G.tcurr, bg + 12, bg + 9, nullptr, nullptr, 0.f, false};
       if (HAS_ICP && !rgb_wave) accum_quads_halves<true>(IV, RV, in, wbase, N, K, 0, 0, false, c);
@@ -2780,6 +3000,17 @@ void launch_accum(const IcpView& IV, const RgbView& RV, const Se3Inputs& in, int
   // 75 passes = 19 steps = four dependent rounds.  CH = 10 there (two rounds, 231 registers: the launch runs two wavefronts per SIMD
   // anyway) was measured SLOWER: 28.4 vs 25.1 us (profiles/r03f_ab_fused_step_and_ch10.log) — twice the loads per round queue behind each
   // other in the CU's one address pipe for longer than the two saved round trips.
+#ifdef EF_VISIT_PAIRS
+  // (round 6: two visits per lane — a round is CH / 2 packed evaluations; 640x480: 5 steps = one round of CH = 6, the sixth step empty;
+  // 1280x960: 19 steps = five rounds of CH = 4)
+  if (HAS_ICP || PACKED) {
+    const int S = ((N + VTHREADS - 1) / VTHREADS + 3) >> 2;
+    if (S <= 2) hipExtLaunchKernelGGL((k_se3_accum<2, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
+    else if (S % 6 == 0 || S % 6 == 5 || !(S % 4 == 0 || S % 4 == 3)) hipExtLaunchKernelGGL((k_se3_accum<6, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
+    else hipExtLaunchKernelGGL((k_se3_accum<4, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
+    return;
+  }
+#endif
   if (N > 8 * VTHREADS) hipExtLaunchKernelGGL((k_se3_accum<5, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
   else hipExtLaunchKernelGGL((k_se3_accum<2, HAS_ICP, HAS_RGB, PACKED>), grid, block, 0, s, start, stop, 0, IV, RV, in, out);
 #endif
@@ -2808,7 +3039,7 @@ inline int so3_grid(int N) {
 
 void icp_step_op(const IcpArgs& a, const float* vmap_curr, const float* nmap_curr, const float* vmap_g_prev,
                  const float* nmap_g_prev, int cols, int rows, float* scratch, float* out29_dev, hipStream_t s) {
-  IcpView V{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, cols, rows, a.k, a.distThres, a.angleThres};
+  IcpView V{vmap_curr, nmap_curr, vmap_g_prev, nmap_g_prev, cols, rows, a.k, a.distThres, a.angleThres, sq_le_max(a.distThres), sq_lt_max(a.angleThres)};
   RgbView RV{};
   float* pose = scratch + SE3_ACCS * VWARPS;   // 24 floats of parameters behind the partials
   float h[24];
@@ -3154,7 +3385,7 @@ int launch_iteration(const Pyramid& p, TrackState* st, int level, Intr kl, const
   }
   }
   const GNState* g = &st->gn[cur];
-  IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres};
+  IcpView IV{p.vmap_curr[level], p.nmap_curr[level], p.vmap_g_prev[level], p.nmap_g_prev[level], cols, rows, kl, tp.distThres, tp.angleThres, sq_le_max(tp.distThres), sq_lt_max(tp.angleThres)};
   RgbView GV{p.corres[level], p.lastDepth[level], nullptr, p.dIdx[level], p.dIdy[level], cols, rows, kl, 1.0f / 8.0f};
   Se3Inputs in{g->Rcurr, g->tcurr, st->Rprev_inv, st->tprev, &st->rgb_slots[sp][0][0], &g->rgb_broken, 0.f, tp.rgbOnly};
   in.slots_zero = &st->rgb_slots[sp ^ 1][0][0];
@@ -3243,6 +3474,8 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
     FA.icpWeight = tp.icpWeight;
     FA.distThres = tp.distThres;
     FA.angleThres = tp.angleThres;
+    FA.dist2Max = sq_le_max(tp.distThres);
+    FA.sine2Max = sq_lt_max(tp.angleThres);
     FA.partials = p.partials;
     if (p.epoch > 0xFFFFFFFFu - 2u * FT_EPOCHS) p.epoch = 1;   // (a slot keeps a 2^32-launch-old tag only if nobody wrote it since)
     FA.epoch = p.epoch;
@@ -3348,6 +3581,8 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
     PA.icpWeight = tp.icpWeight;
     PA.distThres = tp.distThres;
     PA.angleThres = tp.angleThres;
+    PA.dist2Max = sq_le_max(tp.distThres);
+    PA.sine2Max = sq_lt_max(tp.angleThres);
     PA.partials = p.partials;
     PA.out_cur = 0;
     if (icp && rgb) hipLaunchKernelGGL((k_track_small<true, true>), dim3(PT_WGS), dim3(PT_BLOCK), 0, s, PA, st);

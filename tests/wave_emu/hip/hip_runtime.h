@@ -16,6 +16,7 @@
 #define __restrict__
 
 struct float4 { float x, y, z, w; };
+struct uchar4 { unsigned char x, y, z, w; };
 struct uint3e { unsigned x, y, z; };
 namespace emu {
 struct Lane {

@@ -17,7 +17,7 @@ extern "C" int run_model_maps(const float* pred_vertex, const float* pred_normal
                               float maxDepthRGB, int camera_frame, const float* R9, const float* t3, unsigned dense_count, int dense_samples,
                               float* vmap0, float* vmap1, float* vmap2, float* nmap0, float* nmap1, float* nmap2, float* depth0) {
   using namespace eft;
-  ModelMapsArgs A;
+  ModelMapsArgs A{};   // (no level-0 intensity image here: last0 = null)
   A.pred_vertex = (const float4*)pred_vertex; A.pred_normal = (const float4*)pred_normal;
   A.fill_vertex = (const float4*)fill_vertex; A.fill_normal = (const float4*)fill_normal;
   A.vmap[0] = vmap0; A.vmap[1] = vmap1; A.vmap[2] = vmap2;
