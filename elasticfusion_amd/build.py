@@ -40,7 +40,11 @@ VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_
     "p_rgb": ["-DEF_RT_WITH_PAIRS_RGB"],
     "p_all": ["-DEF_RT_WITH_PAIRS_ICP", "-DEF_RT_WITH_PAIRS_SEARCH", "-DEF_RT_WITH_PAIRS_RGB"],
     "shfl": ["-DEF_RT_SHFL_REDUCE"],                           # A/B: the wave-level sums of the persistent launch through ds_bpermute (rounds 1-5) instead of DPP / permlane moves
-    "sincos": ["-DEF_WAVE_SINCOS"],                            # A/B: cos(theta) and sin(theta) of the update step as one sincos call instead of two calls
+    "sepsc": ["-DEF_SEPARATE_SIN_COS"],                        # A/B: cos(theta) and sin(theta) of the update step as two calls (rounds 1-5) instead of one sincos
+    "shallow": ["-DEF_SHALLOW_PIPE"],                          # A/B: the multi-round normal-equation paths (1280x960) one round deep instead of two
+    "sepinputs": ["-DEF_SEPARATE_INPUTS"],                     # A/B: depth pre-processing and the tracker's model maps as two launches instead of one (k_frame_inputs)
+    "sepmerge": ["-DEF_SEPARATE_MERGE"],                       # A/B: the fusion's update pass as its own launch (k_merge) instead of riding on the second index splat
+    "pre_vpair": ["-DEF_PRE_VPAIR"],                           # A/B: the bilateral filter's two pixels per lane four rows apart (round 5) instead of side by side
     "prep_late": ["-DEF_RT_PREPARE_LATE"],                     # A/B: the sigma-independent half of the photometric rows behind exchange A (rounds 1-5) instead of beside it
     "p_nostream": ["-DEF_RT_NO_PAIRS_STREAM"],                 # ... and the streaming path with one
 }

@@ -113,6 +113,7 @@ struct ef_ctx {
   int icp_count_thresh = 35000;            // ElasticFusion.h:44-46
   float icp_err_thresh = 5e-05f, cov_thresh = 1e-05f;
   int deforms = 0;
+  const float* bil_table = nullptr;        // efm::bilateral_table() of this context's device, asked once at ef_create
   eft::Pyramid pyr2{};                     // RGBDOdometry modelToModel (ElasticFusion.h:280)
   eft::TrackState* st2 = nullptr;
   efm::PredictMaps old{};                  // IndexMap's oldImage/oldVertex/oldNormal/oldTime textures (IndexMap.h:114-128)
@@ -699,7 +700,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   // a persistent tracker launch of an EARLIER frame gave up waiting after admission (a protocol failure, sticky: every later launch of that
   // instance returns at once): k_track_end has copied the flag into host-mapped memory; reported here, where the front end calls
   // (class ElasticFusion::processFrame throws), without synchronising — ef_synchronize reports the same condition for the frames in flight
-  if (c->h_abort && (c->h_abort[0] | c->h_abort[1] | c->h_abort[2])) {
+  if ((c->h_abort && (c->h_abort[0] | c->h_abort[1] | c->h_abort[2])) || c->pyr.sticky_abort || c->pyr2.sticky_abort || c->pyr3.sticky_abort) {
     c->err = "a persistent tracker launch of an earlier frame timed out waiting for another workgroup after its whole grid had reported in (a protocol "
              "failure, not a busy chip: that case runs on one workgroup, ef_get_tracker_fallbacks): the poses and the map since then are invalid; "
              "recreate the context (ef_set_persistent_tracker(ctx, 0) selects the launch-per-step script)";
@@ -742,8 +743,18 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
   timer_begin(c, "Preprocess");
   // (a tracked frame: the level-0 intensity image of the frame and — folded copies — the context's copy of the colours ride on this launch)
   const uint8_t* rgb_in = fold_copies ? rgb_src : c->rgb;
-  efm::preprocess_depth(depth_in, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb, 0u,
-                        track_this ? rgb_in : nullptr, c->pyr.nextImage[0], fold_copies ? c->rgb : nullptr);
+  // Round 6: in the single-stream script of a tracked frame the pre-processing and the tracker's model-side maps are ONE launch (k_frame_inputs,
+  // at init_icp_model below): two independent kernels, one bound by LDS look-ups, the other by HBM.
+#ifdef EF_SEPARATE_INPUTS   // (A/B build "sepinputs")
+  const bool joint_inputs = false;
+#else
+  const bool joint_inputs = track_this && !overlap && !c->timing;
+#endif
+  if (!joint_inputs && !efm::preprocess_depth(depth_in, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, sb, 0u,
+                             track_this ? rgb_in : nullptr, c->pyr.nextImage[0], fold_copies ? c->rgb : nullptr, c->bil_table)) {
+    c->err = "bilateral weight table missing on this device";
+    return EF_EHIP;
+  }
   timer_end(c, "Preprocess");
   if (overlap && overlap_mode == 2) EF_HIP(c, hipStreamWaitEvent(sb, c->ev_track_done, 0));
   if (track_this && overlap)   // the single-stream script builds all pyramids together below (eft::build_pyramids)
@@ -782,9 +793,11 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
       tp.angleThres = sinf(20.f * 3.14159254f / 180.f);       // RGBDOdometry.h:42
       const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
       timer_begin(c, "odomInit");
+      const eft::FramePreprocess fp{depth_in, c->cfg.depth_cut, c->bil_table, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, rgb_in,
+                                    fold_copies ? c->rgb : nullptr};
       eft::init_icp_model(c->pyr, (const float*)c->pm.vertex, (const float*)c->pm.normal, (const float*)c->fm.vertex,
                           (const float*)c->fm.normal, c->st, 6.0f /* maxDepthRGB, RGBDOdometry.cpp:42 */, s, (const uint8_t*)c->pm.image,
-                          (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0);
+                          (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, joint_inputs ? &fp : nullptr);
       if (overlap) {
         eft::build_pyramids_model_side(c->pyr, nullptr, nullptr, false, c->st, s);
         EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
@@ -808,6 +821,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
         if (!g) {
           g = (c->tgraph[0].exec && c->tgraph[0].key != key) ? &c->tgraph[1] : &c->tgraph[0];
           if (g->exec) { (void)hipGraphExecDestroy(g->exec); g->exec = nullptr; }
+          eft::track_prepare(c->pyr, tp, s);   // (a script switch clears the exchange areas: outside the capture, not replayed with it — ADVICE r5)
           eft::Pyramid pyr_copy = c->pyr;   // track() swaps the copy's pointers; the real swap is done below
           hipGraph_t graph = nullptr;
           EF_HIP(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -888,13 +902,21 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
                            c->im, s, sample_splat ? &c->probe_splat : nullptr);
       timer_end(c, "indexMap");
       timer_begin(c, "Fuse::Data+Update");
+      // (the update pass — k_merge — rides on the splat of the second predictIndices: one launch less; with stage timers on it stays a launch of
+      // its own so that the reference's TICK / TOCK stages keep their meaning)
+#ifdef EF_SEPARATE_MERGE   // (A/B build "sepmerge")
+      const bool defer_merge = false;
+#else
+      const bool defer_merge = !c->timing;
+#endif
       efm::fuse(c->cam, c->st->pose_f, c->tick, c->rgb, c->depth_metric, c->depth_metric_filtered, c->im, c->maxDepthProcessed,
-                &c->st->weighting, c->maps[c->cur], &c->st->map_counts[c->cur], c->cand, c->winner, s);
-      if (c->reference_download) efm::copy_map(c->maps[c->cur], &c->st->map_counts[c->cur], c->shadow, s);
+                &c->st->weighting, c->maps[c->cur], &c->st->map_counts[c->cur], c->cand, c->winner, s, defer_merge);
+      if (c->reference_download && !defer_merge) efm::copy_map(c->maps[c->cur], &c->st->map_counts[c->cur], c->shadow, s);
       timer_end(c, "Fuse::Data+Update");
       timer_begin(c, "indexMap2");
       efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
-                           c->im, s);
+                           c->im, s, nullptr, defer_merge ? &c->cand : nullptr, c->winner);
+      if (c->reference_download && defer_merge) efm::copy_map(c->maps[c->cur], &c->st->map_counts[c->cur], c->shadow, s);
       timer_end(c, "indexMap2");
       // a pending deformation (ElasticFusion.cpp:558-585): re-predict the depth of the surfels outside the time window, then let
       // clean() move every kept surfel with the graph
@@ -1170,7 +1192,8 @@ int ef_create(const ef_config* cfg, ef_ctx** out) {
     if (e != hipSuccess) { g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e); delete c; return EF_EHIP; }
     c->own_stream = true;
   }
-  if (!efm::bilateral_table()) {   // the depth filter's weight table of this device (built once per process and device, here at the latest)
+  c->bil_table = efm::bilateral_table();
+  if (!c->bil_table) {   // the depth filter's weight table of this device (built once per process and device, here at the latest)
     g_create_error = "bilateral weight table: allocation or launch failed";
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1464,6 +1487,9 @@ int ef_set_resident_levels(ef_ctx* c, int on) { if (!c) return EF_EINVAL; c->no_
 int ef_set_persistent_tracker(ef_ctx* c, int on) {
   if (!c) return EF_EINVAL;
   c->persistent = on < 0 ? 0 : (on > 2 ? 1 : on);
+#ifdef EF_FAST_ORDER
+  if (c->persistent == 2) c->persistent = 1;   // (the fast order has no launch of the small levels: 2 means 1 there, also to process_frame's overlap rule)
+#endif
   for (auto& g : c->tgraph)   // captured tracker graphs hold the other script
     if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
   return EF_OK;
@@ -1699,7 +1725,11 @@ int ef_restore_state(ef_ctx* c, int tick, const double* q4_t3, const uint8_t* rg
   EF_HIP(c, hipMemcpyAsync(c->rgb, rgb_prev, (size_t)W * H * 3, hipMemcpyHostToDevice, s));
   EF_HIP(c, hipMemcpyAsync(c->depth_raw, depth_prev, (size_t)W * H * 2, hipMemcpyHostToDevice, s));
   EF_HIP(c, hipStreamSynchronize(s));   // the caller's buffers are pageable and only borrowed
-  efm::preprocess_depth(c->depth_raw, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, s, 0u);
+  if (!efm::preprocess_depth(c->depth_raw, W, H, c->cfg.depth_cut, c->depth_filtered, c->depth_metric, c->depth_metric_filtered, s, 0u, nullptr,
+                             nullptr, nullptr, c->bil_table)) {
+    c->err = "bilateral weight table missing on this device";
+    return EF_EHIP;
+  }
   // the frame's intensity pyramid where the next frame's SO(3) pre-alignment looks for it (lastNextImage: initFirstRGB's target and,
   // after every tracked frame, the swapped-in nextImage, RGBDOdometry.cpp:246-257,284-288)
   eft::init_first_rgb(c->pyr, c->rgb, s);
@@ -2268,7 +2298,7 @@ int ef_op_linalg(int which, const double* in, int n_in, double* out, int n_out) 
 
 // ---- operator tier: pre-processing + map ----
 int ef_op_filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, void* s) {
-  efm::filter_depth(raw, cols, rows, maxD, filtered, (hipStream_t)s);
+  if (!efm::filter_depth(raw, cols, rows, maxD, filtered, (hipStream_t)s)) return EF_EHIP;   // (no weight table: device ordinal >= 64, allocation or launch failure)
   OP_TAIL(s);
 }
 int ef_op_metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, void* s) {

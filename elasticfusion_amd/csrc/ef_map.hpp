@@ -73,14 +73,15 @@ struct CompactScratch {
 // the bilateral filter's weight table of the current device (built on first use, synchronously; null on a HIP error).  ef_create asks
 // for it so that no later call — possibly inside a stream capture — is the first
 const float* bilateral_table();
-void filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s);
+bool filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s);   // false: no weight table on this device
 void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, hipStream_t s);
 // fused: bilateral + both metric conversions in one pass over the raw depth
 // extra_lds: unused dynamic LDS bytes added to the launch = an occupancy cap for when the kernel shares the GPU
 // rgb3 given: the frame's level-0 intensity image (next0) and, with rgb_keep, a copy of the colour image are written by the same launch
-void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric,
+// table: bilateral_table()'s pointer when the caller holds it (null: asked here); returns false when the device has no table
+bool preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric,
                       float* metric_filtered, hipStream_t s, unsigned extra_lds = 0, const uint8_t* rgb3 = nullptr, uint8_t* next0 = nullptr,
-                      uint8_t* rgb_keep = nullptr);
+                      uint8_t* rgb_keep = nullptr, const float* table = nullptr);
 
 // ---- layout conversion at the API boundary ----
 void aos_to_soa(const float* aos, uint32_t count, SurfelSoA soa, hipStream_t s);
@@ -96,7 +97,9 @@ void seed_map(const Cam& cam, const uint8_t* rgb3, const float* depth_metric, co
 // ---- model prediction ----
 // T_cw16_dev: device pointer to the float 4x4 T_wc^-1; count_dev: device surfel count
 void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSoA map, const unsigned* count_dev, float maxDepth,
-                     int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s, eft::KernelProbe* probe = nullptr);
+                     int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s, eft::KernelProbe* probe = nullptr,
+                     // merge_cand / merge_winner given (behind fuse(..., defer_merge = true)): the update pass of the fusion rides on this splat
+                     const struct Candidates* merge_cand = nullptr, const uint32_t* merge_winner = nullptr);
 void combined_predict(const Cam& cam, const float* T_cw16_dev, SurfelSoA map, const unsigned* count_dev, float maxDepth,
                       float confThreshold, int time, int maxTime, int timeDelta, unsigned long long* zbuf, PredictMaps out,
                       // optional fused fill-in + denseEnough sampling (null fill.image => skipped)
@@ -124,7 +127,7 @@ void dense_count(const Cam& cam, const uchar4* image, unsigned* counter, hipStre
 // pose_f16_dev: float T_wc (cast<float>().matrix()); weighting_dev: device float
 void fuse(const Cam& cam, const float* pose_f16_dev, int time, const uint8_t* rgb3, const float* depth_metric,
           const float* depth_metric_filtered, IndexMaps im, float maxDepth, const float* weighting_dev, SurfelSoA map,
-          const unsigned* count_dev, Candidates cand, uint32_t* winner, hipStream_t s);
+          const unsigned* count_dev, Candidates cand, uint32_t* winner, hipStream_t s, bool defer_merge = false);
 // deformation graph handed to clean() after a loop closure (copy_unstable.vert:128-322): nodes x 16 floats sorted by time
 // {position 3, rotation 9 column-major, translation 3, time}; depth = synthesize_depth image (read unless is_fern)
 struct Deformation {

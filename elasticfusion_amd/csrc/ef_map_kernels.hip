@@ -146,41 +146,7 @@ __device__ __forceinline__ uint16_t bilateral_px(const uint16_t* __restrict__ ra
     }
   return (uint16_t)(unsigned)roundf(sum1 / sum2);
 }
-__device__ __forceinline__ float metric_px(unsigned value, unsigned maxv) {
-  return (value > maxv || value < 300U) ? 0.0f : (float)value / 1000.0f;
-}
-// Bilateral filter, the fast path (round 5: the weights come from a table).  The arithmetic of bilateral_px is kept operation for
-// operation (the filtered depth must be the oracle's, bit for bit); what changes is how it is fed and issued:
-//   * the weight of a tap, ef_expf(-(S + d * d * c)), depends on two small integers only: its squared distance dx^2 + dy^2 (27 distinct
-//     values in the 13 x 13 window) and |d| = |value - tmp| (depths are integers; beyond |d| = 395 the argument is below -87 and the weight is
-//     exactly +0 for every S).  A 27 x 400 table of these weights, each entry evaluated ONCE with the very expression of bilateral_px
-//     (k_bilateral_table: bit-identical by construction; rounds 1-4 evaluated 169 polynomial exps per pixel, 43 us of ALU), lives in HBM per
-//     device (43 KB) and is copied into LDS by every workgroup; a tap is then a subtraction, a clamp, a conversion and an LDS look-up;
-//   * the 76 x 20 neighbourhood of a 64 x 8 pixel tile is staged once in LDS as float (169 global loads per pixel -> 1);
-//   * every lane filters TWO pixels (rows y and y + 4); both loops fully unrolled, so the table row of a tap is an immediate offset;
-//   * taps outside the image read a sentinel far away from every depth: their |d| clamps to a zero column of the table, and
-//     x + sentinel * 0 == x exactly, so the two sums see the same sequence of non-trivial additions in the same order as the clipped
-//     loops of depth_bilateral.frag:49-72.
-typedef float float2v __attribute__((ext_vector_type(2)));
-constexpr int PRE_TW = 64, PRE_TH = 8, PRE_R = 6, PRE_LW = PRE_TW + 2 * PRE_R, PRE_LH = PRE_TH + 2 * PRE_R;
-constexpr int BIL_ROWS = 27, BIL_COLS = 400, BIL_ZERO = 396;   // columns >= BIL_ZERO hold +0 (|d| >= 396: 396^2 * 0.000555556 > 87)
-constexpr float BIL_OUTSIDE = 1.0e6f;                            // sentinel of a tap outside the image
-struct BilRows {   // (|dy|, |dx|) -> first float of the table row of dx^2 + dy^2
-  int distinct[BIL_ROWS];
-  int base[PRE_R + 1][PRE_R + 1];
-  constexpr BilRows() : distinct{}, base{} {
-    int n = 0;
-    for (int s2 = 0; s2 <= 2 * PRE_R * PRE_R; ++s2) {
-      bool hit = false;
-      for (int a = 0; a <= PRE_R; ++a)
-        for (int b = 0; b <= PRE_R; ++b)
-          if (a * a + b * b == s2) { hit = true; base[a][b] = n * BIL_COLS; }
-      if (hit) distinct[n++] = s2;
-    }
-  }
-};
-constexpr BilRows BIL{};
-static_assert(BIL.distinct[BIL_ROWS - 1] == 2 * PRE_R * PRE_R && BIL.base[PRE_R][PRE_R] == (BIL_ROWS - 1) * BIL_COLS, "27 distinct squared distances");
+#include "ef_preprocess.inc"
 __global__ void k_bilateral_table(float* __restrict__ table) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= BIL_ROWS * BIL_COLS) return;
@@ -196,71 +162,7 @@ __global__ void __launch_bounds__(256) k_preprocess(const uint16_t* __restrict__
                                                      uint16_t* __restrict__ filtered, float* __restrict__ metric,
                                                      float* __restrict__ metric_filtered, const uint8_t* __restrict__ rgb3,
                                                      uint8_t* __restrict__ next0, uint8_t* __restrict__ rgb_keep) {
-  __shared__ __attribute__((aligned(16))) float tab[BIL_ROWS * BIL_COLS];
-  __shared__ float tile[PRE_LH][PRE_LW];
-  const int x0 = blockIdx.x * PRE_TW, y0 = blockIdx.y * PRE_TH;
-  const int tx = threadIdx.x, ty = threadIdx.y, t = ty * 64 + tx;
-  {
-    const float4* src = (const float4*)table;
-    float4* dst = (float4*)tab;
-#pragma unroll
-    for (int i = 0; i < (BIL_ROWS * BIL_COLS / 4 + 255) / 256; ++i) {
-      const int q = t + i * 256;
-      if (q < BIL_ROWS * BIL_COLS / 4) dst[q] = src[q];
-    }
-  }
-  for (int i = t; i < PRE_LH * PRE_LW; i += 256) {
-    const int ly = i / PRE_LW, lx = i - ly * PRE_LW;
-    const int gx = x0 + lx - PRE_R, gy = y0 + ly - PRE_R;
-    tile[ly][lx] = (gx >= 0 && gx < cols && gy >= 0 && gy < rows) ? (float)raw[gy * cols + gx] : BIL_OUTSIDE;
-  }
-  __syncthreads();
-  const int x = x0 + tx, ya = y0 + ty, yb = ya + 4;
-  if (x >= cols) return;
-  const bool in_a = ya < rows, in_b = yb < rows;
-  // Round 6: the frame's level-0 intensity image (bgr2IntensityKernel, cudafuncs.cu:584-596 — populateRGBDData(frame)) and the context's copy of
-  // the colour image ride along: six bytes per lane in the shadow of 169 LDS look-ups, one launch less per frame (k_intensity_both, 5 us).
-  if (rgb3) {
-    const int ys[2] = {ya, yb};
-    const bool ins[2] = {in_a, in_b};
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (!ins[q]) continue;
-      const size_t i = (size_t)ys[q] * cols + x;
-      const uint8_t r = rgb3[i * 3], g = rgb3[i * 3 + 1], b = rgb3[i * 3 + 2];
-      next0[i] = intensity_of((float)r, (float)g, (float)b);
-      if (rgb_keep) { rgb_keep[i * 3] = r; rgb_keep[i * 3 + 1] = g; rgb_keep[i * 3 + 2] = b; }
-    }
-  }
-  const float2v value = {tile[ty + PRE_R][tx + PRE_R], tile[ty + 4 + PRE_R][tx + PRE_R]};
-  const unsigned va = in_a ? (unsigned)value.x : 0u, vb = in_b ? (unsigned)value.y : 0u;
-  const bool gate_a = in_a && !(va > maxv || va < 300U), gate_b = in_b && !(vb > maxv || vb < 300U);
-  float2v sum1 = (float2v)(0.0f), sum2 = (float2v)(0.0f);
-  if (gate_a || gate_b) {
-#pragma unroll
-    for (int dy = -PRE_R; dy <= PRE_R; ++dy) {
-#pragma unroll
-      for (int dx = -PRE_R; dx <= PRE_R; ++dx) {
-        const float* row = tab + BIL.base[dy < 0 ? -dy : dy][dx < 0 ? -dx : dx];   // (an immediate once both loops are unrolled)
-        const float2v tmp = {tile[ty + PRE_R + dy][tx + PRE_R + dx], tile[ty + 4 + PRE_R + dy][tx + PRE_R + dx]};
-        const float2v d = value - tmp;
-        const int ia = (int)fminf(fabsf(d.x), (float)BIL_ZERO), ib = (int)fminf(fabsf(d.y), (float)BIL_ZERO);
-        const float2v w = {row[ia], row[ib]};
-        sum1 = sum1 + tmp * w;
-        sum2 = sum2 + w;
-      }
-    }
-  }
-  if (in_a) {
-    const uint16_t f = gate_a ? (uint16_t)(unsigned)roundf(sum1.x / sum2.x) : (uint16_t)0;
-    filtered[ya * cols + x] = f;
-    if (WITH_METRIC) { metric[ya * cols + x] = metric_px(va, maxv); metric_filtered[ya * cols + x] = metric_px(f, maxv); }
-  }
-  if (in_b) {
-    const uint16_t f = gate_b ? (uint16_t)(unsigned)roundf(sum1.y / sum2.y) : (uint16_t)0;
-    filtered[yb * cols + x] = f;
-    if (WITH_METRIC) { metric[yb * cols + x] = metric_px(vb, maxv); metric_filtered[yb * cols + x] = metric_px(f, maxv); }
-  }
+  preprocess_tile<WITH_METRIC>((int)blockIdx.x, (int)blockIdx.y, raw, cols, rows, maxv, table, filtered, metric, metric_filtered, rgb3, next0, rgb_keep);
 }
 __global__ void k_metricise(const uint16_t* __restrict__ in, int n, unsigned maxv, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -422,15 +324,25 @@ __global__ void __launch_bounds__(BLK) k_seed_scatter(const SeedArgs A, const ui
 // ------------------------------------------------------------------------------------------
 // IndexMap::predictIndices (G4): 1-pixel splat -> resolve
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void merge_surfel(const Candidates& cand, int r, uint32_t id, const SurfelSoA& map, int time, float4& s, float4& sc);
+// MERGE (round 6): the frame's SECOND predictIndices (ElasticFusion.cpp:545) comes right behind the update pass (GlobalModel::fuse's second half,
+// update.vert) — whose work is per SURFEL too: surfel id is rewritten by the one candidate that won its association, winner[id].  The lane that
+// is about to splat surfel id merges that candidate into it first (merge_surfel: k_merge's arithmetic, in place) and splats what it wrote: one
+// launch less per frame (k_merge: 7.5 us for 96 bytes x matched candidates), no second read of the map's matched surfels.
+template <bool MERGE>
 __global__ void __launch_bounds__(BLK) k_index_splat(const Cam cam, const float* __restrict__ T16, int time, SurfelSoA map,
                                                       const unsigned* __restrict__ count_dev, float maxDepth, int timeDelta,
-                                                      unsigned long long* zbuf, int colmajor) {
+                                                      unsigned long long* zbuf, int colmajor, Candidates cand, const uint32_t* __restrict__ winner) {
   const rt34 T = rt34_load16(T16);
   const unsigned count = *count_dev;
   const float ftime = (float)time, ftd = (float)timeDelta;
   for (unsigned id = blockIdx.x * blockDim.x + threadIdx.x; id < count; id += gridDim.x * blockDim.x) {
-    const float4 pc = map.pos_conf[id];
-    const float4 ct = map.col_time[id];
+    float4 pc = map.pos_conf[id];
+    float4 ct = map.col_time[id];
+    if (MERGE) {
+      const uint32_t r = winner[id];
+      if (r != WINNER_EMPTY) merge_surfel(cand, (int)r, id, map, time, pc, ct);
+    }
     const f3 p = xform(T, f3{pc.x, pc.y, pc.z});
     if (p.z > maxDepth || p.z < 0 || ftime - ct.w > ftd) continue;
     const float u = ((cam.fx * p.x) / p.z) + cam.cx;
@@ -897,15 +809,12 @@ __global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates 
   cand.col_time[r] = c_col;
 }
 // update.vert:37-92, in place, only for the surfels that won an association
-__global__ void __launch_bounds__(BLK) k_merge(Candidates cand, const uint32_t* __restrict__ winner, SurfelSoA map, int time) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= cand.n) return;
+// update.vert:37-92 for ONE surfel: candidate r (which won the association) merged into surfel id, in place; s / sc: the surfel's position +
+// confidence and colour + times as they stand afterwards
+__device__ __forceinline__ void merge_surfel(const Candidates& cand, int r, uint32_t id, const SurfelSoA& map, int time, float4& s, float4& sc) {
   const float4 ucol = cand.col_time[r];
-  if (ucol.w != -1.0f) return;
-  const uint32_t id = cand.best[r];
-  if (winner[id] != (uint32_t)r) return;
   const float4 u = cand.pos_conf[r], un = cand.nrm_rad[r];
-  float4 s = map.pos_conf[id], sc = map.col_time[id], sn = map.nrm_rad[id];
+  float4 sn = map.nrm_rad[id];
   const float c_k = s.w, a = u.w, ftime = (float)time;
   if (un.w < (1.0f + 0.5f) * sn.w) {
     s.x = ((c_k * s.x) + (a * u.x)) / (c_k + a);
@@ -930,6 +839,15 @@ __global__ void __launch_bounds__(BLK) k_merge(Candidates cand, const uint32_t* 
     map.pos_conf[id] = s;
     map.col_time[id] = sc;
   }
+}
+__global__ void __launch_bounds__(BLK) k_merge(Candidates cand, const uint32_t* __restrict__ winner, SurfelSoA map, int time) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= cand.n) return;
+  if (cand.col_time[r].w != -1.0f) return;
+  const uint32_t id = cand.best[r];
+  if (winner[id] != (uint32_t)r) return;
+  float4 s = map.pos_conf[id], sc = map.col_time[id];
+  merge_surfel(cand, r, id, map, time, s, sc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1274,17 +1192,27 @@ const float* bilateral_table() {
   }
   return tables[dev];
 }
-void filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s) {
-  hipLaunchKernelGGL(k_preprocess<false>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), bilateral_table(),
+bool filter_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, hipStream_t s) {
+  const float* table = bilateral_table();
+  if (!table) return false;   // (device ordinal >= 64, allocation or launch failure: an error to the caller, not a null dereference on the device)
+  hipLaunchKernelGGL(k_preprocess<false>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), 0, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), table,
                      filtered, (float*)nullptr, (float*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr);
+  return true;
 }
 void metricise_depth(const uint16_t* in, int cols, int rows, float maxD, float* out, hipStream_t s) {
   hipLaunchKernelGGL(k_metricise, dim3(ceil_div(cols * rows, 256)), dim3(256), 0, s, in, cols * rows, (unsigned)(maxD * 1000.0f), out);
 }
-void preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric, float* metric_filtered,
-                      hipStream_t s, unsigned extra_lds, const uint8_t* rgb3, uint8_t* next0, uint8_t* rgb_keep) {
-  hipLaunchKernelGGL(k_preprocess<true>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), extra_lds, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), bilateral_table(),
+bool preprocess_depth(const uint16_t* raw, int cols, int rows, float maxD, uint16_t* filtered, float* metric, float* metric_filtered,
+                      hipStream_t s, unsigned extra_lds, const uint8_t* rgb3, uint8_t* next0, uint8_t* rgb_keep, const float* table) {
+  if (!table) table = bilateral_table();   // (a context hands in the pointer it asked for at ef_create: no process-wide lock per frame)
+  if (!table) return false;
+  // static + dynamic LDS of a launch that never asked for more than the default 64 KB: beyond it the launch would fail silently
+  constexpr unsigned STATIC_LDS = sizeof(float) * (BIL_ROWS * BIL_COLS + PRE_LH * PRE_LW);
+  static_assert(STATIC_LDS < 65536u, "k_preprocess fits the default LDS limit");
+  if (extra_lds > 65536u - STATIC_LDS) extra_lds = 65536u - STATIC_LDS;
+  hipLaunchKernelGGL(k_preprocess<true>, dim3(ceil_div(cols, PRE_TW), ceil_div(rows, PRE_TH)), dim3(64, 4), extra_lds, s, raw, cols, rows, (unsigned)(maxD * 1000.0f), table,
                      filtered, metric, metric_filtered, rgb3, next0, rgb_keep);
+  return true;
 }
 namespace {
 __global__ void k_copy_map(SurfelSoA src, const unsigned* __restrict__ count_dev, SurfelSoA dst) {
@@ -1326,13 +1254,20 @@ void seed_map(const Cam& cam, const uint8_t* rgb3, const float* dm, const float*
 }
 
 void predict_indices(const Cam& cam, const float* T_cw16_dev, int time, SurfelSoA map, const unsigned* count_dev, float maxDepth,
-                     int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s, eft::KernelProbe* probe) {
+                     int timeDelta, unsigned long long* zbuf, IndexMaps out, hipStream_t s, eft::KernelProbe* probe, const Candidates* merge_cand,
+                     const uint32_t* merge_winner) {
+  if (merge_cand) {   // fuse(..., defer_merge = true) in front of this call: the update pass rides on the splat
+    hipLaunchKernelGGL(k_index_splat<true>, dim3(SURFEL_GRID), dim3(BLK), 0, s, cam, T_cw16_dev, time, map, count_dev, maxDepth, timeDelta, zbuf,
+                       out.colmajor, *merge_cand, merge_winner);
+    hipLaunchKernelGGL(k_index_resolve, dim3(ceil_div(cam.cols * cam.rows, BLK)), dim3(BLK), 0, s, cam, T_cw16_dev, map, zbuf, out);
+    return;
+  }
   // the probe's events receive the kernel's own begin / end timestamps (what rocprofv3 --kernel-trace reports as its duration)
   const bool sample = probe && probe->used < probe->capacity;
   hipEvent_t e0 = sample ? probe->start[probe->used] : nullptr, e1 = sample ? probe->stop[probe->used] : nullptr;
   if (sample) probe->used++;
-  hipExtLaunchKernelGGL(k_index_splat, dim3(SURFEL_GRID), dim3(BLK), 0, s, e0, e1, 0, cam, T_cw16_dev, time, map, count_dev, maxDepth, timeDelta,
-                        zbuf, out.colmajor);
+  hipExtLaunchKernelGGL(k_index_splat<false>, dim3(SURFEL_GRID), dim3(BLK), 0, s, e0, e1, 0, cam, T_cw16_dev, time, map, count_dev, maxDepth, timeDelta,
+                        zbuf, out.colmajor, Candidates{}, (const uint32_t*)nullptr);
   hipLaunchKernelGGL(k_index_resolve, dim3(ceil_div(cam.cols * cam.rows, BLK)), dim3(BLK), 0, s, cam, T_cw16_dev, map, zbuf, out);
 }
 
@@ -1383,12 +1318,13 @@ void dense_count(const Cam& cam, const uchar4* image, unsigned* counter, hipStre
 
 void fuse(const Cam& cam, const float* pose_f16_dev, int time, const uint8_t* rgb3, const float* dm, const float* dmf, IndexMaps im,
           float maxDepth, const float* weighting_dev, SurfelSoA map, const unsigned* count_dev, Candidates cand, uint32_t* winner,
-          hipStream_t s) {
+          hipStream_t s, bool defer_merge) {
   (void)count_dev;
   FuseArgs A{cam, pose_f16_dev, time, rgb3, dm, dmf, im, maxDepth, weighting_dev};
   // column-major index maps: walking columns measured 24.7 us vs 34.8 us for walking rows (profiles/, round 1)
   hipLaunchKernelGGL(k_associate, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, A, cand, winner, im.colmajor ? 1 : 0);
-  hipLaunchKernelGGL(k_merge, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, cand, (const uint32_t*)winner, map, time);
+  // (defer_merge: the caller's next launch is predict_indices(..., &cand, winner), whose splat merges every surfel before it projects it)
+  if (!defer_merge) hipLaunchKernelGGL(k_merge, dim3(ceil_div(cand.n, BLK)), dim3(BLK), 0, s, cand, (const uint32_t*)winner, map, time);
 }
 
 void clean(const Cam& cam, const float* T_cw16_dev, int time, IndexMaps im, float confThreshold, int timeDelta, SurfelSoA map,

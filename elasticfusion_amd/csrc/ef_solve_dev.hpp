@@ -404,10 +404,10 @@ __device__ __forceinline__ void gauss_newton_update_wave(eft::TrackState* st, ef
       const int k = r * 3 + c;
       val = (r == c) ? 1.0 : 0.0;
       if (theta >= DBL_EPSILON) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(EF_WAVE_SINCOS)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(EF_SEPARATE_SIN_COS)
         // one sincos instead of cos and sin apart (155 against 294 VALU instructions of one dependent double-precision chain on the critical path of
-        // every iteration): ocml's sincos returns, bit for bit, what its sin and its cos return (tools/probe/sincos_probe.hip: 2^24 arguments from
-        // subnormal to 1e300, zero differences)
+        // every iteration): ocml's sincos returns, bit for bit, what its sin and its cos return (tools/probe/sincos_probe.hip on MI355X: 2^24 arguments from
+        // subnormal to 1e300, zero differences — profiles/r06x_sincos_probe.json)
         double sn, cs;
         sincos(theta, &sn, &cs);
         const double c1 = 1. - cs;

@@ -126,6 +126,9 @@ struct Pyramid {               // one RGBDOdometry instance's device buffers (RG
   float* partials;                 // PARTIAL_ALLOC_FLOATS: region 0 (what the per-step kernels use), region 1, PtSync (zero-filled at allocation)
   unsigned epoch = 1;              // next unused exchange epoch of this instance's persistent launches (host side; 0 = "never written")
   int last_mode = 0;               // host side: 1 = the exchange areas hold a 256-workgroup persistent launch's granules (k_track_fast / k_track_ref)
+  // host side: what the sticky words of the exchange areas held when a context switched scripts (the areas are cleared at a switch: ADVICE r5) —
+  // tracker_aborted / tracker_fallbacks add them to what the device holds now
+  unsigned sticky_abort = 0, fallbacks_base = 0;
   int W(int l) const { return width >> l; }
   int H(int l) const { return height >> l; }
 };
@@ -201,9 +204,21 @@ void init_icp(const Pyramid& p, const uint16_t* depth_filtered, Intr k, float cu
 // initICPModel + initRGBModel's depth half: predicted (or fill-in, chosen by the dense_count tally) float4 maps ->
 // world-frame planar pyramids + model depth L0.  RGBDOdometry.cpp:171-210, :217
 // (pred_image_rgba / fill_image_rgba given: the model's level-0 intensity image — populateRGBDData(model) — is written by the same launch)
+// `with` given: the depth pre-processing of the new frame (efm::preprocess_depth's work, with the frame's level-0 intensity) is part of the same
+// launch — the two read nothing of each other's (round 6: k_frame_inputs)
+struct FramePreprocess {
+  const uint16_t* raw;          // the frame's raw depth
+  float maxD;                   // depth cut-off in metres
+  const float* table;           // efm::bilateral_table()
+  uint16_t* filtered;
+  float* metric;
+  float* metric_filtered;
+  const uint8_t* rgb3;          // the frame's colours -> Pyramid::nextImage[0]
+  uint8_t* rgb_keep;            // copy of the colours, or null
+};
 void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
                     const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s, const uint8_t* pred_image_rgba = nullptr,
-                    const uint8_t* fill_image_rgba = nullptr, bool frameToFrameRGB = false);
+                    const uint8_t* fill_image_rgba = nullptr, bool frameToFrameRGB = false, const FramePreprocess* with = nullptr);
 // the rest of populateRGBDData (RGBDOdometry.cpp:212-244, :275-279) in three independently enqueueable parts, so that
 // the part that only needs the new frame can run on the input stream while the previous frame is still being fused:
 //   model ("last"): Gaussian depth pyramid + intensity pyramid of the predicted (or fill-in) image
@@ -254,6 +269,9 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
 // 1 when a persistent launch of this tracker instance gave up waiting in a grid barrier (its workgroups were not co-resident), 0
 // otherwise, < 0 on a HIP error; synchronises the stream
 int tracker_aborted(const Pyramid& p, hipStream_t s);
+// the script track() will run with these parameters on a stream that is NOT capturing; switches the instance over to it (clearing the exchange
+// areas, carrying their sticky words over) — for a caller that is about to capture track() and must not have the clear inside its graph
+void track_prepare(Pyramid& p, const TrackParams& tp, hipStream_t s);
 // fast order: persistent launches of this tracker instance that found the chip partly taken (admission failed) and ran on ONE workgroup
 // instead — same results, ~25x the time; < 0 on a HIP error; synchronises the stream
 int tracker_fallbacks(const Pyramid& p, hipStream_t s);

@@ -527,8 +527,8 @@ __device__ __forceinline__ f3 qx2(f3 v) { return f3{qx2(v.x), qx2(v.y), qx2(v.z)
 __device__ __forceinline__ f3 box4(f3 a, f3 b, f3 c, f3 d) {
   return f3{(a.x + b.x + c.x + d.x) / 4, (a.y + b.y + c.y + d.y) / 4, (a.z + b.z + c.z + d.z) / 4};
 }
-__global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const TrackState* __restrict__ st) {
-  const int gx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
+// (gx: the lane's pixel column; by: its row of 4 x 4 blocks — k_model_maps takes them from its own grid, k_frame_inputs from its share of a joint one)
+__device__ __forceinline__ void model_maps_lane(const ModelMapsArgs& A, const TrackState* __restrict__ st, int gx, int by) {
   const int cols = A.cols, rows = A.rows;
   if (gx >= cols || by * 4 >= rows) return;   // cols is a multiple of 4: a quad is in or out as a whole
   const int j = gx & 3, bx = gx >> 2;
@@ -619,6 +619,9 @@ __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const
       store_planar<false>(A.nmap[2], c2, r2, bx, by, nok2 && !isnan(na.x), mul(R, na));
     }
   }
+}
+__global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const TrackState* __restrict__ st) {
+  model_maps_lane(A, st, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(blockIdx.y * blockDim.y + threadIdx.y));
 }
 // ------------------------------------------------------------------------------------------
 // per-pixel Jacobian rows
@@ -1452,31 +1455,67 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
 #ifdef EF_VISIT_PAIRS
   if constexpr ((ICP || PACKED) && CH % 2 == 0) {   // two visits per lane: steps 2 u, 2 u + 1 of a chunk as one packed evaluation
     constexpr int NP = CH / 2;
+#ifdef EF_SHALLOW_PIPE
+    constexpr bool DEEP = false;
+#else
+    constexpr bool DEEP = CH <= 4;
+#endif
+    // (CH = 6 serves the levels of ONE round: nothing to pipeline, and a third set of loads would not fit the registers)
     auto pixel = [&](int s) { const int k = 4 * s + jl; return (s < S && k < K) ? k * VTHREADS + g : N; };
     float sigma = in.sigma_fixed;
+    // A round = CH steps = NP packed evaluations.  Two rounds deep (round 6): while round r's rows go through their outer
+    // products, round r + 1's GATHERS (behind its loads and the projective association) and round r + 2's LOADS are in flight — 1280 x 960 has
+    // five dependent rounds of two memory round trips each, and with a prefetch distance of one load they were the kernel's length.
     if constexpr (ICP) {
       const IcpPose Pu = icp_pose_uniform(P);
-      // the loads of the NEXT round are issued before this round's outer products (S <= CH: never — one round)
-      IcpLoads2 L[NP];
+      IcpLoads2 L[NP], Ln[DEEP ? NP : 1];
+      IcpGathers2 G[NP];
+      p3 vg[NP], scp[NP];
 #pragma unroll
       for (int u = 0; u < NP; ++u) L[u] = icp2_stage1(IV, pixel(2 * u), pixel(2 * u + 1), N);
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        icp2_transform(Pu, L[u], vg[u], scp[u]);
+        G[u] = icp2_stage2a(IV, L[u], scp[u]);
+      }
+      EF_ASTAMP(1);
+      if constexpr (DEEP) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) Ln[u] = L[u];
+        if (CH < S) {   // uniform
+#pragma unroll
+          for (int u = 0; u < NP; ++u) Ln[u] = icp2_stage1(IV, pixel(CH + 2 * u), pixel(CH + 2 * u + 1), N);
+        }
+      }
 #pragma unroll 1
       for (int s0 = 0; s0 < S; s0 += CH) {
-        IcpGathers2 G[NP];
-        p3 vg[NP], scp[NP];
+        if (!DEEP && s0 > 0) {   // (one round deep: this round's gathers behind its loads, issued before the previous round's outer products)
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-          icp2_transform(Pu, L[u], vg[u], scp[u]);
-          G[u] = icp2_stage2a(IV, L[u], scp[u]);
+          for (int u = 0; u < NP; ++u) {
+            icp2_transform(Pu, L[u], vg[u], scp[u]);
+            G[u] = icp2_stage2a(IV, L[u], scp[u]);
+          }
         }
-        if (s0 == 0) EF_ASTAMP(1);
         float rows[CH][8];
 #pragma unroll
         for (int u = 0; u < NP; ++u) icp2_stage2b(IV, Pu, L[u], G[u], vg[u], scp[u], rows[2 * u], rows[2 * u + 1]);
         if (s0 == 0) EF_ASTAMP(2);
         if (s0 + CH < S) {   // uniform
+          if constexpr (DEEP) {   // the next round's gathers, the round after's loads
 #pragma unroll
-          for (int u = 0; u < NP; ++u) L[u] = icp2_stage1(IV, pixel(s0 + CH + 2 * u), pixel(s0 + CH + 2 * u + 1), N);
+            for (int u = 0; u < NP; ++u) {
+              L[u] = Ln[u];
+              icp2_transform(Pu, L[u], vg[u], scp[u]);
+              G[u] = icp2_stage2a(IV, L[u], scp[u]);
+            }
+            if (s0 + 2 * CH < S) {
+#pragma unroll
+              for (int u = 0; u < NP; ++u) Ln[u] = icp2_stage1(IV, pixel(s0 + 2 * CH + 2 * u), pixel(s0 + 2 * CH + 2 * u + 1), N);
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) L[u] = icp2_stage1(IV, pixel(s0 + CH + 2 * u), pixel(s0 + CH + 2 * u + 1), N);
+          }
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -1486,21 +1525,39 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
     } else {
       const bufrsrc rc = buf_of(RV.corres, (unsigned)N * 4u), rdx = buf_of(RV.dIdx, (unsigned)N * 2u), rdy = buf_of(RV.dIdy, (unsigned)N * 2u),
                     rd0 = buf_of(RV.lastDepth, (unsigned)N * 4u);
-      uint32_t corr[NP][2];
-      int gx[NP][2], gy[NP][2];
-      bool inb[NP][2];
-      auto load = [&](int s) {
+      struct Rgb2 { uint32_t corr[2]; int gx[2], gy[2]; bool inb[2]; };
+      auto load = [&](int s, auto& X) {
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
           const int pa = pixel(s + 2 * u), pb = pixel(s + 2 * u + 1);
-          inb[u][0] = pa < N; inb[u][1] = pb < N;
-          const unsigned qa = (unsigned)(inb[u][0] ? pa : N - 1), qb = (unsigned)(inb[u][1] ? pb : N - 1);
-          corr[u][0] = buf_u32(rc, qa * 4u); corr[u][1] = buf_u32(rc, qb * 4u);
-          gx[u][0] = buf_i16(rdx, qa * 2u); gx[u][1] = buf_i16(rdx, qb * 2u);
-          gy[u][0] = buf_i16(rdy, qa * 2u); gy[u][1] = buf_i16(rdy, qb * 2u);
+          X[u].inb[0] = pa < N; X[u].inb[1] = pb < N;
+          const unsigned qa = (unsigned)(X[u].inb[0] ? pa : N - 1), qb = (unsigned)(X[u].inb[1] ? pb : N - 1);
+          X[u].corr[0] = buf_u32(rc, qa * 4u); X[u].corr[1] = buf_u32(rc, qb * 4u);
+          X[u].gx[0] = buf_i16(rdx, qa * 2u); X[u].gx[1] = buf_i16(rdx, qb * 2u);
+          X[u].gy[0] = buf_i16(rdy, qa * 2u); X[u].gy[1] = buf_i16(rdy, qb * 2u);
         }
       };
-      load(0);
+      bool valid[NP][2];
+      float d0[NP][2];
+      auto gather = [&](const auto& X) {   // visit_stage2a's photometric half: the model depth behind the correspondence
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            valid[u][e] = X[u].inb[e] && (X[u].corr[e] & 0x80000000u);
+            const unsigned zi = valid[u][e] ? ((X[u].corr[e] >> 11) & 0x7FFu) * (unsigned)RV.cols + (X[u].corr[e] & 0x7FFu) : 0u;
+            d0[u][e] = buf_f32(rd0, zi * 4u, 0u);
+          }
+        }
+      };
+      Rgb2 X[NP], Xn[DEEP ? NP : 1];
+      load(0, X);
+      gather(X);
+      if constexpr (DEEP) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) Xn[u] = X[u];
+        if (CH < S) load(CH, Xn);   // uniform
+      }
       if (with_slots) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -1511,21 +1568,20 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
       }
 #pragma unroll 1
       for (int s0 = 0; s0 < S; s0 += CH) {
-        bool valid[NP][2];
-        float d0[NP][2];
-#pragma unroll
-        for (int u = 0; u < NP; ++u) {
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {   // visit_stage2a's photometric half: the model depth behind the correspondence
-            valid[u][e] = inb[u][e] && (corr[u][e] & 0x80000000u);
-            const unsigned zi = valid[u][e] ? ((corr[u][e] >> 11) & 0x7FFu) * (unsigned)RV.cols + (corr[u][e] & 0x7FFu) : 0u;
-            d0[u][e] = buf_f32(rd0, zi * 4u, 0u);
-          }
-        }
+        if (!DEEP && s0 > 0) gather(X);
         float rows[CH][8];
 #pragma unroll
-        for (int u = 0; u < NP; ++u) rgb2_rows(RV, sigma, corr[u], gx[u], gy[u], d0[u], valid[u], rows[2 * u], rows[2 * u + 1]);
-        if (s0 + CH < S) load(s0 + CH);   // uniform: the next round's loads before this round's outer products
+        for (int u = 0; u < NP; ++u) rgb2_rows(RV, sigma, X[u].corr, X[u].gx, X[u].gy, d0[u], valid[u], rows[2 * u], rows[2 * u + 1]);
+        if (s0 + CH < S) {   // uniform
+          if constexpr (DEEP) {   // the next round's gathers, the round after's loads
+#pragma unroll
+            for (int u = 0; u < NP; ++u) X[u] = Xn[u];
+            gather(X);
+            if (s0 + 2 * CH < S) load(s0 + 2 * CH, Xn);
+          } else {
+            load(s0 + CH, X);
+          }
+        }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
           if (s0 + u < S) quad_rows_accumulate(rows[u], s0 + u, K, c);   // uniform; phase B
@@ -2925,6 +2981,40 @@ __global__ void __launch_bounds__(PT_BLOCK) k_track_small(const PtArgs A, TrackS
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The two INDEPENDENT launches at the head of a tracked frame as one (round 6): the depth pre-processing of the new frame (k_preprocess:
+// LDS look-ups, 2.3 wavefronts per SIMD, hardly any HBM traffic) and the model-side maps of the tracker (k_model_maps: 20 MB streamed at
+// 2.6 TB/s) read nothing of each other's — one grid carries the tiles of both, the second kind filling the issue slots and the memory pipe the
+// first leaves idle, and a launch boundary goes.  Same device functions as the two kernels: same results.
+// ------------------------------------------------------------------------------------------
+namespace pre {
+#include "ef_preprocess.inc"
+}
+struct PreArgs {
+  const uint16_t* raw;
+  int cols, rows;
+  unsigned maxv;
+  const float* table;
+  uint16_t* filtered;
+  float* metric;
+  float* metric_filtered;
+  const uint8_t* rgb3;
+  uint8_t* next0;
+  uint8_t* rgb_keep;
+  int tiles_x, tiles;   // the filter's tiles: the first `tiles` workgroups of the grid, tiles_x per row
+  int mm_x;             // the model maps' workgroups behind them: mm_x per row (k_model_maps' own grid, row-major)
+};
+__global__ void __launch_bounds__(256) k_frame_inputs(const PreArgs P, const ModelMapsArgs A, const TrackState* __restrict__ st) {
+  const int b = (int)blockIdx.x;
+  if (b < P.tiles) {   // (uniform per workgroup)
+    pre::preprocess_tile<true>(b % P.tiles_x, b / P.tiles_x, P.raw, P.cols, P.rows, P.maxv, P.table, P.filtered, P.metric, P.metric_filtered, P.rgb3,
+                               P.next0, P.rgb_keep);
+  } else {
+    const int m = b - P.tiles, mx = m % P.mm_x, my = m / P.mm_x;
+    model_maps_lane(A, st, mx * 64 + (int)threadIdx.x, my * 4 + (int)threadIdx.y);
+  }
+}
+
 #include "ef_track_exchange.inc"
 #ifdef EF_FAST_ORDER
 #include "ef_track_fast_persistent.inc"
@@ -3108,7 +3198,7 @@ static inline dim3 model_maps_grid(const Pyramid& p) {
 }
 void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
                     const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s, const uint8_t* pred_image_rgba,
-                    const uint8_t* fill_image_rgba, bool frameToFrameRGB) {
+                    const uint8_t* fill_image_rgba, bool frameToFrameRGB, const FramePreprocess* with) {
   ModelMapsArgs A{};
   A.pred_image = pred_image_rgba; A.fill_image = fill_image_rgba; A.force_fill_image = frameToFrameRGB;
   A.last0 = pred_image_rgba ? p.lastImage[0] : nullptr;
@@ -3119,7 +3209,19 @@ void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pre
   A.cols = p.W(0); A.rows = p.H(0);
   A.maxDepthRGB = maxDepthRGB;
   A.camera_frame = false;
-  hipLaunchKernelGGL(k_model_maps, model_maps_grid(p), dim3(64, 4), 0, s, A, st);
+  const dim3 mg = model_maps_grid(p);
+  if (with) {   // the frame's depth pre-processing rides on this launch (k_frame_inputs)
+    PreArgs P{};
+    P.raw = with->raw; P.cols = p.W(0); P.rows = p.H(0); P.maxv = (unsigned)(with->maxD * 1000.0f); P.table = with->table;
+    P.filtered = with->filtered; P.metric = with->metric; P.metric_filtered = with->metric_filtered;
+    P.rgb3 = with->rgb3; P.next0 = p.nextImage[0]; P.rgb_keep = with->rgb_keep;
+    P.tiles_x = (P.cols + pre::PRE_TW - 1) / pre::PRE_TW;
+    P.tiles = P.tiles_x * ((P.rows + pre::PRE_TH - 1) / pre::PRE_TH);
+    P.mm_x = (int)mg.x;
+    hipLaunchKernelGGL(k_frame_inputs, dim3(P.tiles + (int)(mg.x * mg.y)), dim3(64, 4), 0, s, P, A, st);
+    return;
+  }
+  hipLaunchKernelGGL(k_model_maps, mg, dim3(64, 4), 0, s, A, st);
 }
 
 namespace {
@@ -3412,6 +3514,36 @@ void persistent_chain_forget(hipStream_t s) {
     if (g_chain_has[d] && g_chain_last[d] == s) { g_chain_has[d] = false; g_chain_last[d] = nullptr; }
 }
 
+// Which script a call runs decides what the exchange areas (Pyramid::partials) hold: 1 = the granules of a 256-workgroup persistent launch, 0 = the
+// per-step kernels' plain partials / k_track_small's barrier words.  A context that changes scripts gets the areas cleared (tags must never match
+// by accident; the other script's words start from zeros) — and the sticky words they hold, the abort flag and the fallback count, carried over
+// on the host first (a clear used to erase them silently): one synchronisation per switch, which happens when an option is toggled or
+// a sampled frame leaves a graph-replaying context's script, never in a steady replay.  Under a CALLER's capture nothing can be read back: the
+// clear is recorded (the caller's graph then runs the launch-per-step script, which keeps no sticky word).
+static void switch_script(Pyramid& p, int target, hipStream_t s, bool capturing) {
+  if (p.last_mode == target) return;
+  if (p.partials) {
+    if (!capturing) {
+      if (tracker_aborted(p, s) > 0) p.sticky_abort = 1u;
+      const int f = tracker_fallbacks(p, s);
+      if (f > 0) p.fallbacks_base = (unsigned)f;   // (tracker_fallbacks already includes the earlier base)
+    }
+    (void)hipMemsetAsync(p.partials, 0, sizeof(float) * PARTIAL_ALLOC_FLOATS, s);
+  }
+  p.last_mode = target;
+}
+static int script_of(const TrackParams& tp, bool capturing, int n_total) {
+#ifdef EF_FAST_ORDER
+  const int pmode = (tp.persistent && !capturing) ? 1 : 0;
+#else
+  const int pmode = capturing ? 0 : tp.persistent;
+#endif
+  return (pmode == 1 && !tp.rgbOnly && n_total <= FT_MAX_ITER) ? 1 : 0;
+}
+void track_prepare(Pyramid& p, const TrackParams& tp, hipStream_t s) {
+  const int n_total = (tp.fastOdom ? 3 : 10) + (tp.pyramid ? 9 : 0);
+  switch_script(p, script_of(tp, false, n_total), s, false);
+}
 TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipStream_t s, KernelProbe* probe, KernelProbe* probe_all) {
   const bool icp = !tp.rgbOnly && tp.icpWeight > 0;       // RGBDOdometry.cpp:266-267
   const bool rgb = tp.rgbOnly || tp.icpWeight < 100;
@@ -3423,12 +3555,21 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
   for (int i = NUM_PYRS - 1; i >= 0; --i)
     if (iterations[i] > 0) { first_level = i; break; }
   const int so3_level = 2;
+  // (a caller capturing `s` into a graph of its own gets the launch-per-step script: the persistent launches take a fresh epoch per launch
+  // and wait for the device's chain event, neither of which a replayed graph can carry)
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(s, &capture) == hipSuccess && capture != hipStreamCaptureStatusNone;
+#ifdef EF_FAST_ORDER
+  const int pmode = (tp.persistent && !capturing) ? 1 : 0;
+#else
+  const int pmode = capturing ? 0 : tp.persistent;
+#endif
   // The persistent launch takes k_track_begin, the SO(3) loop and the leading iterations whose level fits (coarse to fine: once a
   // level is too large, it and everything after it run one launch per step).  rgbOnly keeps the per-step script (its per-level
   // "break" bookkeeping is not in the persistent kernel).
   int n_small = 0;
   PtArgs PA{};
-  if (tp.persistent == 2 && !tp.rgbOnly) {   // (reference-order builds only: the fast order has no launch of the small levels)
+  if (pmode == 2 && !tp.rgbOnly) {   // (reference-order builds only: the fast order has no launch of the small levels)
     bool fits = true;
     for (int i = NUM_PYRS - 1; i >= 0 && fits; --i) {
       if (iterations[i] == 0) continue;
@@ -3442,20 +3583,8 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
   // off / rgbOnly (whose per-level "break" bookkeeping is not in the kernels), nothing: then every step is its own launch, in the same order
   // of additions.  (Reference-order builds: persistent == 2 asks for round 3's launch of the small levels, k_track_small, below.)
   const int n_total = iterations[0] + iterations[1] + iterations[2];
-  // (a caller capturing `s` into a graph of its own gets the launch-per-step script: the persistent launches take a fresh epoch per launch
-  // and wait for the device's chain event, neither of which a replayed graph can carry)
-  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-  const bool capturing = hipStreamIsCapturing(s, &capture) == hipSuccess && capture != hipStreamCaptureStatusNone;
-#ifdef EF_FAST_ORDER
-  const int pmode = (tp.persistent && !capturing) ? 1 : 0;
-#else
-  const int pmode = capturing ? 0 : tp.persistent;
-#endif
   if (pmode == 1 && !tp.rgbOnly && n_total <= FT_MAX_ITER) {
-    if (p.last_mode != 1) {   // another script of this instance may have left anything in the exchange areas: tags must never match by accident
-      (void)hipMemsetAsync(p.partials, 0, sizeof(float) * PARTIAL_ALLOC_FLOATS, s);
-      p.last_mode = 1;
-    }
+    switch_script(p, 1, s, capturing);   // another script of this instance may have left anything in the exchange areas: tags must never match by accident
     FtArgs FA{};
     for (int i = 0; i < NUM_PYRS; ++i)
       FA.L[i] = PtLevel{p.vmap_curr[i], p.nmap_curr[i], p.vmap_g_prev[i], p.nmap_g_prev[i], p.rgbMask[i], p.lastDepth[i], p.nextDepth[i],
@@ -3552,10 +3681,7 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
 #endif
     return tail;
   }
-  if (p.last_mode == 1) {   // (the per-step kernels' plain partials and k_track_small's barrier words start from zeros)
-    (void)hipMemsetAsync(p.partials, 0, sizeof(float) * PARTIAL_ALLOC_FLOATS, s);
-    p.last_mode = 0;
-  }
+  switch_script(p, 0, s, capturing);   // (the per-step kernels' plain partials and k_track_small's barrier words start from zeros)
 #ifdef EF_FAST_ORDER
   n_small = 0;
   hipLaunchKernelGGL(k_track_begin, dim3(1), dim3(64), 0, s, st, tp.so3, intr_level(k, so3_level), intr_level(k, first_level));
@@ -3566,7 +3692,7 @@ TrackTail track(Pyramid& p, TrackState* st, Intr k, const TrackParams& tp, hipSt
                          intr_level(k, so3_level), intr_level(k, first_level), i, st, p.partials);
   }
 #else
-  if (tp.persistent == 2 && !tp.rgbOnly && (n_small > 0 || tp.so3)) {
+  if (pmode == 2 && !tp.rgbOnly && (n_small > 0 || tp.so3)) {   // (pmode, not tp.persistent: a capturing caller gets the launch-per-step script)
     for (int i = 0; i < NUM_PYRS; ++i)
       PA.L[i] = PtLevel{p.vmap_curr[i], p.nmap_curr[i], p.vmap_g_prev[i], p.nmap_g_prev[i], p.rgbMask[i], p.lastDepth[i], p.nextDepth[i],
                         p.lastImage[i], p.nextImage[i], p.corres[i], p.dIdx[i], p.dIdy[i], p.W(i), p.H(i), intr_level(k, i)};
@@ -3633,6 +3759,7 @@ int tracker_small_clocks(const Pyramid& p, unsigned long long* out32, hipStream_
   return hipMemset(src, 0, n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 int tracker_aborted(const Pyramid& p, hipStream_t s) {
+  if (p.sticky_abort) return 1;   // (carried over a script switch)
   if (!p.partials) return 0;
 #ifndef EF_FAST_ORDER
   if (p.last_mode != 1) {   // round 3's launch of the small levels (k_track_small) keeps its flag in PtSync
@@ -3648,11 +3775,11 @@ int tracker_aborted(const Pyramid& p, hipStream_t s) {
   return flag != 0 ? 1 : 0;
 }
 int tracker_fallbacks(const Pyramid& p, hipStream_t s) {
-  if (!p.partials || p.last_mode != 1) return 0;
+  if (!p.partials || p.last_mode != 1) return (int)p.fallbacks_base;   // (what earlier persistent launches of this instance counted)
   unsigned n = 0;
   if (hipMemcpyAsync(&n, (const char*)(p.partials + FT_SY_OFF) + offsetof(FtSync, fallbacks), sizeof(n), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
-  return (int)n;
+  return (int)(n + p.fallbacks_base);
 }
 void track_swap(Pyramid& p, const TrackParams& tp) {
   if (tp.so3)

@@ -73,3 +73,45 @@ def test_a_protocol_failure_is_reported_where_the_front_end_calls(seq, which):
         ef.close()
     finally:
         api.use_library(None)
+
+
+def test_sticky_words_survive_a_script_switch(seq):
+    """switching a context between tracker scripts (ef_set_persistent_tracker, graph replay, a sampled frame) clears the exchange
+    areas — and used to erase the sticky abort flag and the fallback count that live in them.  (a) An abort injected before the FIRST tracked
+    frame sits in the per-step scripts' word; the first persistent launch's switch must carry it over, and the context must report it.
+    (b) The fallbacks counted by persistent launches must still be there after the context moved to the launch-per-step script and back."""
+    from elasticfusion_amd import api
+    ef = api.ElasticFusion()
+    rgb, depth, _ = seq.frame(0)
+    ef.processFrame(rgb, depth, 0)
+    ef.synchronize()
+    ef.debugInjectTrackerAbort()                           # (no tracked frame yet: the word of the launch-per-step scripts)
+    rgb, depth, _ = seq.frame(1)
+    with pytest.raises(api.EFError, match="persistent tracker launch"):
+        ef.processFrame(rgb, depth, 33333)                 # the switch to the persistent script reads the word before it clears the areas ...
+        ef.processFrame(rgb, depth, 66666)                 # ... and the context reports it at the latest on the next call
+    with pytest.raises(api.EFError):
+        ef.synchronize()
+    ef.close()
+
+    ef = api.ElasticFusion()
+    for k in range(3):
+        rgb, depth, _ = seq.frame(k)
+        if k == 2:
+            ef.debugOccupy(96, 30000)
+        ef.processFrame(rgb, depth, k * 33333)
+    ef.synchronize()
+    n = ef.trackerFallbacks()
+    assert n >= 1
+    ef.setPersistentTracker(0)
+    for k in range(3, 5):
+        rgb, depth, _ = seq.frame(k)
+        ef.processFrame(rgb, depth, k * 33333)
+    ef.synchronize()
+    assert ef.trackerFallbacks() == n                      # (the per-step script counts none and forgets none)
+    ef.setPersistentTracker(1)
+    rgb, depth, _ = seq.frame(5)
+    ef.processFrame(rgb, depth, 5 * 33333)
+    ef.synchronize()
+    assert ef.trackerFallbacks() == n
+    ef.close()
