@@ -41,7 +41,8 @@ VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_
     "p_all": ["-DEF_RT_WITH_PAIRS_ICP", "-DEF_RT_WITH_PAIRS_SEARCH", "-DEF_RT_WITH_PAIRS_RGB"],
     "shfl": ["-DEF_RT_SHFL_REDUCE"],                           # A/B: the wave-level sums of the persistent launch through ds_bpermute (rounds 1-5) instead of DPP / permlane moves
     "sepsc": ["-DEF_SEPARATE_SIN_COS"],                        # A/B: cos(theta) and sin(theta) of the update step as two calls (rounds 1-5) instead of one sincos
-    "shallow": ["-DEF_SHALLOW_PIPE"],                          # A/B: the multi-round normal-equation paths (1280x960) one round deep instead of two
+    "pyrstages": ["-DEF_PYR_STAGES"],                          # A/B: one launch per pyramid stage (step l -> l + 1 with the maps + Sobel of level l) instead of two steps + one maps / Sobel launch (measured no faster: off)
+    "deep": ["-DEF_DEEP_PIPE"],                                # A/B: k_se3_accum's multi-round path (1280x960) two rounds deep instead of one (measured slower: off)
     "sepinputs": ["-DEF_SEPARATE_INPUTS"],                     # A/B: depth pre-processing and the tracker's model maps as two launches instead of one (k_frame_inputs)
     "sepmerge": ["-DEF_SEPARATE_MERGE"],                       # A/B: the fusion's update pass as its own launch (k_merge) instead of riding on the second index splat
     "pre_vpair": ["-DEF_PRE_VPAIR"],                           # A/B: the bilateral filter's two pixels per lane four rows apart (round 5) instead of side by side

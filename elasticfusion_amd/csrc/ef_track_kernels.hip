@@ -457,6 +457,30 @@ __global__ void k_vn_sobel_levels(const VNLevels V, const SobelLevels S) {
   else sobel_mask_px(S, z - NUM_PYRS, x, y);
 }
 
+// One STAGE of the frame's pyramids as one launch (round 6; A/B build "pyrstages", not the default: see build_pyramids): the pyramid step level
+// l -> l + 1 of up to four images AND the vertex / normal maps and the Sobel + photometric gates of level l — which read level l only, i.e. what
+// the previous stage (or, for l = 0, the input launch) wrote.  blockIdx.z: 0 .. n_pyr - 1 pyramid jobs, then the maps, then the Sobel.
+struct StageJobs {
+  PyrJobs J;
+  int n_pyr;
+  VNLevels V;
+  SobelLevels S;
+  int level;
+};
+__global__ void k_pyramid_stage(const StageJobs A) {
+  const int z = blockIdx.z, x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (z < A.n_pyr) {
+    if (x >= A.J.scols / 2 || y >= A.J.srows / 2) return;
+    if (A.J.type[z] == 0) pyr_down_u16_px((const uint16_t*)A.J.src[z], A.J.scols, A.J.srows, (uint16_t*)A.J.dst[z], x, y);
+    else if (A.J.type[z] == 1) pyr_down_gauss_f_px((const float*)A.J.src[z], A.J.scols, A.J.srows, (float*)A.J.dst[z], x, y);
+    else pyr_down_uchar_gauss_px((const uint8_t*)A.J.src[z], A.J.scols, A.J.srows, (uint8_t*)A.J.dst[z], x, y);
+  } else if (z == A.n_pyr) {
+    vmap_nmap_px(A.V, A.level, x, y);
+  } else {
+    sobel_mask_px(A.S, A.level, x, y);
+  }
+}
+
 // projectPointsKernel, cudafuncs.cu:670-688
 __device__ __forceinline__ f3 project_point(int x, int y, float z, float invFx, float invFy, float cx, float cy) {
   return {(float)((x - cx) * z * invFx), (float)((y - cy) * z * invFy), z};
@@ -1455,17 +1479,17 @@ __device__ __forceinline__ void accum_quads(const IcpView& IV, const RgbView& RV
 #ifdef EF_VISIT_PAIRS
   if constexpr ((ICP || PACKED) && CH % 2 == 0) {   // two visits per lane: steps 2 u, 2 u + 1 of a chunk as one packed evaluation
     constexpr int NP = CH / 2;
-#ifdef EF_SHALLOW_PIPE
-    constexpr bool DEEP = false;
-#else
+    // DEEP: two rounds in flight instead of one.  Built and measured at 1280 x 960 (five rounds of CH = 4): k_se3_accum 22.9 us against 21.5 with
+    // one (profiles/r07c_1280x960_kernel_stats*.csv) — a third set of loads queues behind the others in the CU's one address pipe (the same
+    // finding as CH = 10 in round 3) and costs a register copy per value and round.  Off; the code stays for the A/B (-DEF_DEEP_PIPE).
+#ifdef EF_DEEP_PIPE
     constexpr bool DEEP = CH <= 4;
+#else
+    constexpr bool DEEP = false;
 #endif
-    // (CH = 6 serves the levels of ONE round: nothing to pipeline, and a third set of loads would not fit the registers)
     auto pixel = [&](int s) { const int k = 4 * s + jl; return (s < S && k < K) ? k * VTHREADS + g : N; };
     float sigma = in.sigma_fixed;
-    // A round = CH steps = NP packed evaluations.  Two rounds deep (round 6): while round r's rows go through their outer
-    // products, round r + 1's GATHERS (behind its loads and the projective association) and round r + 2's LOADS are in flight — 1280 x 960 has
-    // five dependent rounds of two memory round trips each, and with a prefetch distance of one load they were the kernel's length.
+    // A round = CH steps = NP packed evaluations; the next round's loads are issued before this round's outer products.
     if constexpr (ICP) {
       const IcpPose Pu = icp_pose_uniform(P);
       IcpLoads2 L[NP], Ln[DEEP ? NP : 1];
@@ -3346,6 +3370,39 @@ void build_pyramids(const Pyramid& p, const uint16_t* depth_filtered, Intr k, fl
   // (both pyramid steps as ONE launch — a workgroup computing the 36 x 36 level-1 pixels its 16 x 16 level-2 tile reads, then the tile — was
   // built and measured in round 6: 25.2 us against 8.0 + 5.4 for the two launches: six dependent 25-tap trips per thread; dropped,
   // profiles/r06q_kernel_stats_fused_pyramid_steps.csv)
+  // (one launch per pyramid STAGE — the step level l -> l + 1 together with the vertex / normal maps and the Sobel of level l, which read level l
+  // only: k_pyramid_stage — was built and measured in round 6: 1934 against 1939 frames/s same box, 3 x 18.7 us against 2 x 13.5 + 25.5 at
+  // 1280 x 960, profiles/r07d_ab_pyramid_stages.log: the level-0 maps no longer wait for two launches, but the two small stages cost what the one
+  // joint launch of all levels cost; off, kept as the A/B build "pyrstages")
+#ifdef EF_PYR_STAGES
+  {
+    StageJobs A{};
+    for (int i = 0; i < NUM_PYRS; ++i) {
+      A.V.depth[i] = i == 0 ? depth_filtered : p.depth_tmp[i];
+      A.V.vmap[i] = p.vmap_curr[i]; A.V.nmap[i] = p.nmap_curr[i];
+      A.V.cols[i] = p.W(i); A.V.rows[i] = p.H(i);
+      A.V.k[i] = intr_level(k, i);
+    }
+    A.V.cutoff = cutoff;
+    A.S = sobel_levels_of(p);
+    for (int i = 0; i < NUM_PYRS; ++i) {   // stage i: level i -> i + 1 (not behind the last level), maps + Sobel of level i
+      A.level = i;
+      A.n_pyr = 0;
+      if (i + 1 < NUM_PYRS) {
+        A.J.src[0] = i == 0 ? (const void*)depth_filtered : (const void*)p.depth_tmp[i]; A.J.dst[0] = p.depth_tmp[i + 1]; A.J.type[0] = 0;
+        A.J.src[1] = p.lastDepth[i]; A.J.dst[1] = p.lastDepth[i + 1]; A.J.type[1] = 1;
+        A.J.src[2] = p.lastImage[i]; A.J.dst[2] = p.lastImage[i + 1]; A.J.type[2] = 2;
+        A.J.src[3] = p.nextImage[i]; A.J.dst[3] = p.nextImage[i + 1]; A.J.type[3] = 2;
+        A.J.scols = p.W(i); A.J.srows = p.H(i);
+        A.n_pyr = 4;
+      }
+      dim3 g = tile_grid(p.W(i), p.H(i));
+      g.z = A.n_pyr + 1 + (with_sobel ? 1 : 0);
+      hipLaunchKernelGGL(k_pyramid_stage, g, tile_block(), 0, s, A);
+    }
+    return;
+  }
+#endif
   for (int i = 0; i + 1 < NUM_PYRS; ++i) {
     PyrJobs J;
     J.src[0] = i == 0 ? (const void*)depth_filtered : (const void*)p.depth_tmp[i]; J.dst[0] = p.depth_tmp[i + 1]; J.type[0] = 0;
