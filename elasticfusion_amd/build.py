@@ -48,6 +48,9 @@ VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_
     "pre_vpair": ["-DEF_PRE_VPAIR"],                           # A/B: the bilateral filter's two pixels per lane four rows apart (round 5) instead of side by side
     "prep_late": ["-DEF_RT_PREPARE_LATE"],                     # A/B: the sigma-independent half of the photometric rows behind exchange A (rounds 1-5) instead of beside it
     "p_nostream": ["-DEF_RT_NO_PAIRS_STREAM"],                 # ... and the streaming path with one
+    "sepscan": ["-DEF_SEPARATE_SCAN"],                         # A/B: clean()'s scan of the rows' counts as its own launch (rounds 1-5) instead of inside the scatter's workgroups
+    "endwave": ["-DEF_END_ONE_WAVE"],                          # A/B: k_track_ref_end's two tails behind resultRt on one wavefront (round 5) instead of two
+    "r6m": ["-DEF_SEPARATE_SCAN", "-DEF_END_ONE_WAVE"],        # A/B: both of the above = the launches of commit 7b89629
 }
 SHIM_LIB = os.path.join(HERE, "libefusion.so")          # class ElasticFusion (include/ElasticFusion.h) over the C ABI
 SOURCES = ["ef_track_kernels.hip", "ef_map_kernels.hip", "ef_context.hip", "ef_ferns.hip"]

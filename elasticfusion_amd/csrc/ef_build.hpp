@@ -10,7 +10,7 @@
 //   -DEF_FORCE_FAST_ORDER               no                    the fast order       libefusion_hip_nofma_fast.so   parity factorial (tools/parity_factorial.py)
 //
 // Why the default is the reference rounding (round 5, profiles/r05_parity_factorial.json): one tracked frame from IDENTICAL state, 113
-// checkpoints — FMA + reference order leaves the 1e-4 bar on 19, FMA + fast order on 19, no FMA + fast order on 2 (median 9e-7 m): it is the
+// checkpoints — FMA + reference order leaves the 1e-4 bar on 15, FMA + fast order on 15, no FMA + fast order on 2 (the record's summary): it is the
 // fused multiply-adds inside the per-pixel geometry (projective association, gates) that move the pose, and only the build that shares the
 // reference's rounding meets the bar on every frame.
 #pragma once

@@ -925,6 +925,7 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
         efm::synthesize_depth(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence, c->tick,
                               c->tick - c->cfg.time_delta, 65535, c->zbuf, c->synth_depth, s, c->rays);
       timer_begin(c, "Fuse::Copy");
+      c->cs.flip ^= 1;   // (CompactScratch::group_sum: this call's half was cleared by the call before it)
       efm::clean(c->cam, c->st->T_cw, c->tick, c->im, c->cfg.confidence, c->cfg.time_delta, c->maps[c->cur], &c->st->map_counts[c->cur], c->cand,
                  c->winner, c->maps[c->cur ^ 1], &c->st->map_counts[c->cur ^ 1], c->capacity, c->cs, c->overflow, s,
                  c->graph_nodes > 0 ? &def : nullptr);
@@ -1044,6 +1045,8 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->cs.chunk_count, c->cs.max_chunks);
   EF_ALLOC(c, c->cs.chunk_offset, c->cs.max_chunks);
   EF_ALLOC(c, c->cs.totals, 8);
+  c->cs.max_groups = c->cs.max_chunks / efm::CLEAN_GROUP + 2;
+  EF_ALLOC(c, c->cs.group_sum, 2 * (size_t)c->cs.max_groups * efm::CLEAN_GSTRIDE);   // (zero-filled: what the first clean() expects of its half)
   if (g.close_loops) {
     c->pyr2.width = W;
     c->pyr2.height = H;

@@ -67,7 +67,17 @@ struct CompactScratch {
   uint32_t* chunk_offset;  // exclusive scan
   uint32_t* totals;        // small scratch (>= 4 u32)
   int max_chunks;
+  // clean() without its scan launch (round 6): kept elements per GROUP of CLEAN_GROUP rows, added up by k_clean_flags (integer atomics: exact
+  // in any order) and read by k_clean_scatter, whose workgroups find their row's offset themselves.  Two halves of max_groups words: a call
+  // adds into half `flip` and zeroes the other one for the call after it (the owner flips before every clean()).  Null: the scan launch.
+  // One sum per 128-byte line (CLEAN_GSTRIDE words apart): with the sums side by side every row's atomic of a frame queued on one or two lines
+  // (k_clean_flags 16.9 -> 20.9 us, profiles/r08a_bench_kernel_stats.csv).
+  uint32_t* group_sum = nullptr;
+  int max_groups = 0;
+  int flip = 0;
 };
+constexpr int CLEAN_GROUP = 32;     // rows per group of CompactScratch::group_sum
+constexpr int CLEAN_GSTRIDE = 32;   // words between two group sums
 
 // ---- pre-processing (ComputePack FILTER / METRIC / METRIC_FILTERED, ElasticFusion.cpp:655-673) ----
 // the bilateral filter's weight table of the current device (built on first use, synchronously; null on a HIP error).  ef_create asks

@@ -1076,14 +1076,18 @@ __global__ void __launch_bounds__(BLK) k_clean_deform(const CleanArgs A, const D
 
 // one element per thread, one CLEAN_ROW-element compaction chunk per workgroup iteration: everything a row needs
 // is in flight at once (the element count is device-resident, hence the grid-stride over rows)
+// gsum_now / gsum_zero (CompactScratch::group_sum, or null): the row's count is also added to its group's sum, and the other half is cleared
 __global__ void __launch_bounds__(BLK) k_clean_flags(const CleanArgs A, SurfelSoA map, const unsigned* __restrict__ count_dev,
                                                       Candidates cand, uint32_t* winner, uint8_t* __restrict__ flags,
-                                                      uint32_t* __restrict__ chunk_count) {
+                                                      uint32_t* __restrict__ chunk_count, uint32_t* gsum_now, uint32_t* __restrict__ gsum_zero,
+                                                      int max_groups) {
   __shared__ unsigned lds[BLK / 64];
   const unsigned count = *count_dev;
   const unsigned n = count + (unsigned)cand.n;
   const unsigned nrows = (n + CLEAN_ROW - 1) / CLEAN_ROW;
   const rt34 T = rt34_load16(A.T16);
+  if (gsum_zero)
+    for (int i = blockIdx.x * BLK + threadIdx.x; i < max_groups; i += gridDim.x * BLK) gsum_zero[(size_t)i * CLEAN_GSTRIDE] = 0u;
   unsigned r;
   for (unsigned it = 0; xcd_row(nrows, it, r); ++it) {   // (uniform per workgroup)
     const unsigned e = r * CLEAN_ROW + threadIdx.x;
@@ -1102,30 +1106,81 @@ __global__ void __launch_bounds__(BLK) k_clean_flags(const CleanArgs A, SurfelSo
 #pragma unroll
       for (int i = 0; i < BLK / 64; ++i) tot += lds[i];
       chunk_count[r] = tot;
+      if (gsum_now && tot) atomicAdd(&gsum_now[(size_t)(r / CLEAN_GROUP) * CLEAN_GSTRIDE], tot);
     }
     __syncthreads();
   }
 }
+// block_excl_scan of v together with the workgroup's sum of a second value (same two barriers)
+__device__ __forceinline__ unsigned block_excl_scan_and_sum(unsigned v, unsigned a, unsigned* lds, unsigned& total, unsigned& asum) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  unsigned x = v, y = a;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned u = __shfl_up(x, off, 64);
+    if (lane >= off) x += u;
+    y += __shfl_xor(y, off, 64);
+  }
+  __syncthreads();
+  if (lane == 63) { lds[w] = x; lds[BLK / 64 + w] = y; }
+  __syncthreads();
+  unsigned base = 0, tot = 0, as = 0;
+#pragma unroll
+  for (int i = 0; i < BLK / 64; ++i) {
+    const unsigned s = lds[i];
+    if (i < w) base += s;
+    tot += s;
+    as += lds[BLK / 64 + i];
+  }
+  total = tot;
+  asum = as;
+  return base + x - v;
+}
+// gsum given (CompactScratch::group_sum): no scan launch in front of this one — the workgroup adds up the groups and the rows in front of its row
+// itself (<= max_groups + CLEAN_GROUP - 1 words, one or two loads per thread, in flight with the row's elements), and the workgroup of the
+// LAST row leaves the totals k_scan_chunks left (total_out, the clamped count_out, the overflow flag)
 __global__ void __launch_bounds__(BLK) k_clean_scatter(SurfelSoA map, const unsigned* __restrict__ count_dev, Candidates cand,
                                                         const uint8_t* __restrict__ flags, const uint32_t* __restrict__ chunk_offset,
-                                                        int time, SurfelSoA out, uint32_t capacity) {
-  __shared__ unsigned lds[BLK / 64];
+                                                        int time, SurfelSoA out, uint32_t capacity, const uint32_t* __restrict__ gsum,
+                                                        const uint32_t* __restrict__ chunk_count, uint32_t* total_out, unsigned* count_out,
+                                                        int* overflow_flag) {
+  __shared__ unsigned lds[2 * BLK / 64];
   const unsigned count = *count_dev;
   const unsigned n = count + (unsigned)cand.n;
   const unsigned nrows = (n + CLEAN_ROW - 1) / CLEAN_ROW;
+  if (gsum && nrows == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    *total_out = 0u;
+    if (count_out) *count_out = 0u;
+  }
   unsigned r;
   for (unsigned it = 0; xcd_row(nrows, it, r); ++it) {   // (uniform per workgroup)
     const unsigned e = r * CLEAN_ROW + threadIdx.x;
     const unsigned f = (e < n) ? flags[e] : 0u;
+    unsigned before = 0;
+    if (gsum) {
+      const unsigned g = r / CLEAN_GROUP;
+      for (unsigned i = threadIdx.x; i < g; i += BLK) before += gsum[(size_t)i * CLEAN_GSTRIDE];
+      for (unsigned i = g * CLEAN_GROUP + threadIdx.x; i < r; i += BLK) before += chunk_count[i];
+    }
     float4 pc = make_float4(0, 0, 0, 0), ct = pc, nr = pc;
     if (f) load_element(map, cand, count, e, pc, ct, nr);
-    unsigned tot;
-    const unsigned pos = chunk_offset[r] + block_excl_scan(f, lds, tot);
+    unsigned tot, row0;
+    unsigned pos = block_excl_scan_and_sum(f, before, lds, tot, row0);
+    if (!gsum) row0 = chunk_offset[r];
+    pos += row0;
     if (f && pos < capacity) {
       if (ct.w == -2.0f) ct.w = (float)time;  // copy_unstable.vert:114-117
       out.pos_conf[pos] = pc;
       out.col_time[pos] = ct;
       out.nrm_rad[pos] = nr;
+    }
+    if (gsum && r == nrows - 1 && threadIdx.x == 0) {
+      unsigned all = row0 + tot;
+      *total_out = all;
+      if (count_out) {
+        if (all > capacity) { all = capacity; if (overflow_flag) *overflow_flag = 1; }
+        *count_out = all;
+      }
     }
     __syncthreads();
   }
@@ -1331,16 +1386,27 @@ void clean(const Cam& cam, const float* T_cw16_dev, int time, IndexMaps im, floa
            const unsigned* count_dev, Candidates cand, uint32_t* winner, SurfelSoA out, unsigned* count_out_dev, uint32_t capacity,
            const CompactScratch& cs, int* overflow_flag, hipStream_t s, const Deformation* deform) {
   CleanArgs A{cam, T_cw16_dev, time, im, confThreshold, timeDelta};
+#ifdef EF_SEPARATE_SCAN   // (A/B build "sepscan": rounds 1-5's three launches)
+  const bool fold = false;
+#else
+  const bool fold = cs.group_sum != nullptr;
+#endif
+  uint32_t* const gnow = fold ? cs.group_sum + (size_t)(cs.flip & 1) * cs.max_groups * CLEAN_GSTRIDE : nullptr;
+  uint32_t* const gzero = fold ? cs.group_sum + (size_t)((cs.flip & 1) ^ 1) * cs.max_groups * CLEAN_GSTRIDE : nullptr;
   hipLaunchKernelGGL(k_clean_flags, dim3(CLEAN_GRID), dim3(BLK), 0, s, A, map, count_dev, cand, winner, cs.flags,
-                     cs.chunk_count);
+                     cs.chunk_count, gnow, gzero, cs.max_groups);
   if (deform && deform->nodes > 0) {
     const DeformArgs D{deform->graph_dev, deform->nodes, deform->depth_dev, deform->is_fern, deform->max_depth};
     hipLaunchKernelGGL(k_clean_deform, dim3(CLEAN_GRID), dim3(BLK), 0, s, A, D, map, count_dev, cand, (const uint8_t*)cs.flags);
   }
-  hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, (const uint32_t*)cs.chunk_count, (const unsigned*)count_dev, (unsigned)cand.n,
-                     cs.chunk_offset, cs.totals, count_out_dev, capacity, overflow_flag, (unsigned)CLEAN_ROW);
+  // (the scan of the rows' counts: with CompactScratch::group_sum every workgroup of the scatter finds its own row's offset — one launch of one
+  // workgroup less on the frame's chain)
+  if (!fold)
+    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, s, (const uint32_t*)cs.chunk_count, (const unsigned*)count_dev, (unsigned)cand.n,
+                       cs.chunk_offset, cs.totals, count_out_dev, capacity, overflow_flag, (unsigned)CLEAN_ROW);
   hipLaunchKernelGGL(k_clean_scatter, dim3(CLEAN_GRID), dim3(BLK), 0, s, map, count_dev, cand, (const uint8_t*)cs.flags,
-                     (const uint32_t*)cs.chunk_offset, time, out, capacity);
+                     (const uint32_t*)cs.chunk_offset, time, out, capacity, (const uint32_t*)gnow, (const uint32_t*)cs.chunk_count, cs.totals,
+                     count_out_dev, overflow_flag);
 }
 
 void candidates_to_aos(Candidates cand, float* aos, unsigned* count_dev, const CompactScratch& cs, hipStream_t s) {
