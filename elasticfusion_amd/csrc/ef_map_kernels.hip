@@ -889,7 +889,16 @@ __device__ __forceinline__ bool clean_test(const CleanArgs& A, const rt34& T, fl
   const float y = ((cam.fy * localPos.y) / localPos.z) + cam.cy;
   const f3 localNorm = normalized(mul(T.R, f3{nr.x, nr.y, nr.z}));
   int cnt = 0, zCount = 0;
-  if (ftime - ct.w < ftd && localPos.z > 0 && x > 0 && y > 0 && x < (float)cam.cols && y < (float)cam.rows) {
+  // (round 6) the taps only ever turn a 1 into a 0, and the two time rules below override them: an element they send away whatever the taps say
+  // — a matched candidate (tag -1: most candidate slots of a mature map), an old unstable surfel — does not ask for its 27 texels
+  const float tagTime = ct.w == -2 ? ftime : ct.w;
+#ifdef EF_CLEAN_ALL_TAPS   // (A/B build "alltaps": rounds 1-5)
+  const bool decided = false;
+  (void)tagTime;
+#else
+  const bool decided = tagTime == -1 || ((ftime - tagTime) > 20 && pc.w < A.confThreshold);
+#endif
+  if (!decided && ftime - ct.w < ftd && localPos.z > 0 && x > 0 && y > 0 && x < (float)cam.cols && y < (float)cam.rows) {
     const Taps3 tx = dedupe_taps(x, cam.cols - 1), ty = dedupe_taps(y, cam.rows - 1);
     uint32_t idx[9];
     float4 vcs[9], c2s[9];
