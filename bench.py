@@ -219,7 +219,10 @@ def rooflines(lib, ef, w, h, where):
         # HBM-side bytes per launch: rocprofv3 PMC passes cannot run inside this process, so this is the measurement
         # COMMITTED under profiles/ by tools/pmc_traffic.sh for this kernel and workload (see traffic_source), not a live value
         traffic, traffic_source = pmc_traffic_of(kt.name.decode().split(" ")[0], w, h)
-        straffic, ssource = pmc_traffic_of("k_index_splat", w, h)
+        # (the sampled launch is the FIRST predictIndices of a frame, k_index_splat<false>; the second one, <true>, also carries the fusion's update pass)
+        straffic, ssource = pmc_traffic_of("k_index_splat<false>", w, h)
+        if straffic is None:
+            straffic, ssource = pmc_traffic_of("k_index_splat", w, h)
         roofline = {"bound": "hbm", "kernel": kt.name.decode(), "achieved": round(achieved_survey, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved_survey / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_us": round(float(kt.avg_us), 3), "timer": "dispatch begin/end timestamps (hipExtLaunchKernelGGL start/stop events) of every level-0 launch of the " + where,

@@ -58,10 +58,11 @@ for t, wanted in ((tag, None), (args[1] if len(args) > 1 else None, ("k_se3_accu
         w = write.get(k, (0, 0.0))[1]
         rec = {"dispatches": n, "FETCH_SIZE_KB_per_dispatch": round(f, 3), "WRITE_SIZE_KB_per_dispatch": round(w, 3),
                "traffic_bytes_per_launch": int(round(f * cf + w * cw)), "source": f"tools/pmc_traffic.sh {t}"}
-        if name.startswith("k_se3_accum<5"):
-            # bench.py runs the launch-per-step script on the frames behind its timed region: the <5, ...> instance is every launch over more than
-            # 8 x 16384 pixels — at 640x480 exactly the level-0 launches, at 1280x960 levels 0 AND 1 (10 : 5 launches a frame)
-            rec["launches_are"] = "level 0" if "1280" not in out_path else "levels 0 and 1 (10 : 5 per frame; level 1 carries a quarter of level 0's pixels)"
+        if name.startswith("k_se3_accum<"):
+            # bench.py runs the launch-per-step script on the frames behind its timed region.  Round 6's instances: <6, ...> = a level of ONE round of
+            # six steps (640x480: level 0; 1280x960: level 1), <4, ...> = the multi-round path (1280x960: level 0), <2, ...> = the small levels;
+            # the instance with the most bytes per dispatch is kept below: the level-0 launches at either size
+            rec["launches_are"] = "level 0 (the instance with the most bytes per dispatch: <6, ...> at 640x480, <4, ...> at 1280x960)"
         if name in doc["kernels"] and doc["kernels"][name]["traffic_bytes_per_launch"] >= rec["traffic_bytes_per_launch"]:
             continue   # (templated kernels: keep the instance with the most bytes per dispatch)
         doc["kernels"][name] = rec
