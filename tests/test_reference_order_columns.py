@@ -24,7 +24,7 @@ CSRC = os.path.join(ROOT, "elasticfusion_amd", "csrc")
 def lib(tmp_path_factory):
     tmp = str(tmp_path_factory.mktemp("rtcols"))
     src = open(os.path.join(CSRC, "ef_track_ref_persistent.inc")).read()
-    a, b = src.index("__device__ __forceinline__ int rt_column("), src.index("// the rest of the reference's tree over one accumulator's 256 column sums")
+    a, b = src.index("__device__ __forceinline__ int rt_column("), src.index("// warpReduceSum over each 32-lane half of the wavefront")   # (the wave-level sums behind it are DPP moves: device only)
     cut = src[a:b]
     assert "rt_vwarp" in cut and "rt_pixel" in cut
     wgs = int(re.search(r"constexpr int FT_WGS = (\d+)", open(os.path.join(CSRC, "ef_track_exchange.inc")).read()).group(1))
