@@ -51,6 +51,8 @@ VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_
     "sepscan": ["-DEF_SEPARATE_SCAN"],                         # A/B: clean()'s scan of the rows' counts as its own launch (rounds 1-5) instead of inside the scatter's workgroups
     "endwave": ["-DEF_END_ONE_WAVE"],                          # A/B: k_track_ref_end's two tails behind resultRt on one wavefront (round 5) instead of two
     "pre_pertap": ["-DEF_PRE_SCALE_PER_TAP"],                  # A/B: the bilateral filter scales the tile value back at every tap instead of once behind the loop
+    "assoc_late": ["-DEF_ASSOC_LATE_LOADS"],                   # A/B: k_associate asks for the filtered depth, the colour and the index-map texels behind its test on the raw depth (rounds 1-5)
+    "splat_early": ["-DEF_SPLAT_EARLY_LOADS"],                 # A/B: the surface splat asks for all three streams of a surfel at once (default: colour / time and normal only for stable surfels)
     "alltaps": ["-DEF_CLEAN_ALL_TAPS"],                        # A/B: clean()'s keep-test asks for the taps of elements the time rules decide anyway (rounds 1-5)
     "r6m": ["-DEF_SEPARATE_SCAN", "-DEF_END_ONE_WAVE"],        # A/B: both of the above = the launches of commit 7b89629
 }

@@ -492,9 +492,15 @@ __global__ void __launch_bounds__(BLK) k_surface_splat(const Cam cam, const floa
   const unsigned stride = gridDim.x * blockDim.x / SPLAT_LANES;
   for (unsigned id = (blockIdx.x * blockDim.x + threadIdx.x) / SPLAT_LANES; id < count; id += stride) {
     const float4 pc = map.pos_conf[id];
+#ifdef EF_SPLAT_EARLY_LOADS   // (A/B build "splat_early": all three streams of a surfel in one round trip, whatever its confidence)
+    const float4 ct = map.col_time[id];
+    const float4 nr = map.nrm_rad[id];
+    if (pc.w < confThreshold) continue;
+#else
     if (pc.w < confThreshold) continue;  // unstable surfels (the bulk of a young map) never reach the normal stream
     const float4 ct = map.col_time[id];
     const float4 nr = map.nrm_rad[id];
+#endif
     const Sprite S = make_sprite(cam, T, pc, ct, nr, maxDepth, confThreshold, (float)time, (float)maxTime, (float)timeDelta);
     if (!S.ok) continue;
     const int px0 = max(0, (int)ceilf(S.u - S.hs - 0.5f)), px1 = min(cam.cols - 1, (int)ceilf(S.u + S.hs - 0.5f) - 1);
@@ -739,13 +745,51 @@ __global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates 
     const f3 vPosLocal = getVertexF(DR, i, j, x, y, cx, cy, inv_fx, inv_fy);
     const bool sel = ((int)x % 2 == (int)ftime % 2 && (int)y % 2 == (int)ftime % 2);
     const bool nb = !(DR.at(i - 1, j) == 0 || DR.at(i, j - 1) == 0 || DR.at(i + 1, j) == 0 || DR.at(i, j + 1) == 0);
+#ifndef EF_ASSOC_LATE_LOADS
+    // Round 6: everything the pixel reads — the filtered depth's cross, its colour, the 27 words of its 9 index-map texels — has an address that
+    // depends on (i, j) only, so it is asked for HERE, beside the raw depth, not behind the test on the raw depth (a second dependent round
+    // trip for every pixel that passes; clamped addresses: a pixel that fails the test reads valid memory it does not use)
+    const float zf_c = DF.at(i, j), zf_xf = DF.at(i + 1, j), zf_xb = DF.at(i - 1, j), zf_yf = DF.at(i, j + 1), zf_yb = DF.at(i, j - 1);
+    const uint8_t* c = A.rgb3 + (size_t)(j * cam.cols + i) * 3;
+    const uint8_t c0 = c[0], c1 = c[1], c2 = c[2];
+    const float weighting = *A.weighting;
+    uint32_t idx9[3][3];
+    float4 vc9[3][3], nr9[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int tx = clampi(i + a - 1, 0, cam.cols - 1);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int ty = clampi(j + b - 1, 0, cam.rows - 1);
+        const int ti = im_texel(A.im, cam, tx, ty);
+        idx9[a][b] = A.im.index[ti];
+        vc9[a][b] = A.im.vert_conf[ti];
+        nr9[a][b] = A.im.norm_rad[ti];
+      }
+    }
+    const rt34 pose = rt34_load16(A.pose16);
+#endif
     if (sel && nb && vPosLocal.z > 0 && vPosLocal.z <= A.maxDepth) {
+#ifdef EF_ASSOC_LATE_LOADS
       const rt34 pose = rt34_load16(A.pose16);
+#endif
       const f3 vPos = xform(pose, vPosLocal);
+#ifndef EF_ASSOC_LATE_LOADS
+      // getVertexF / getNormalF (geometry.glsl:21-40) on the values loaded above: the same expressions
+      auto vtx = [&](float z, float xx, float yy) { return f3{(xx - cx) * z * inv_fx, (yy - cy) * z * inv_fy, z}; };
+      const f3 vPosition_f = vtx(zf_c, x, y);
+      const f3 col{(float)c0 / 255.0f, (float)c1 / 255.0f, (float)c2 / 255.0f};
+      const f3 xf = vtx(zf_xf, x + 1, y), xb = vtx(zf_xb, x - 1, y), yf = vtx(zf_yf, x, y + 1), yb = vtx(zf_yb, x, y - 1);
+      const f3 del_x = half_sum(xb, vPosition_f) - half_sum(xf, vPosition_f);
+      const f3 del_y = half_sum(yb, vPosition_f) - half_sum(yf, vPosition_f);
+      const f3 vNormLocal = normalized(cross(del_x, del_y));
+#else
       const f3 vPosition_f = getVertexF(DF, i, j, x, y, cx, cy, inv_fx, inv_fy);
       const uint8_t* c = A.rgb3 + (size_t)(j * cam.cols + i) * 3;
       const f3 col{(float)c[0] / 255.0f, (float)c[1] / 255.0f, (float)c[2] / 255.0f};
       const f3 vNormLocal = getNormalF(DF, vPosition_f, i, j, x, y, cx, cy, inv_fx, inv_fy);
+      const float weighting = *A.weighting;
+#endif
       const f3 nW = mul(pose.R, vNormLocal);
       int counter = 0;
       uint32_t best = 0;
@@ -759,6 +803,7 @@ __global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates 
       // texels) are issued up front, unconditionally — inside the conditionals of the tap loop they formed chains of up to 48 DEPENDENT
       // round trips (index -> vertex -> normal, tap after tap: the compiler cannot speculate a load across a branch); the 16 taps are then
       // evaluated on registers in the reference's order (a duplicate tap never changes `best`: dist < bestDist is strict)
+#ifdef EF_ASSOC_LATE_LOADS
       uint32_t idx9[3][3];
       float4 vc9[3][3], nr9[3][3];
 #pragma unroll
@@ -773,6 +818,7 @@ __global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates 
           nr9[a][b] = A.im.norm_rad[ti];
         }
       }
+#endif
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const int a3 = a == 0 ? 0 : (a == 3 ? 2 : 1);
@@ -799,7 +845,7 @@ __global__ void __launch_bounds__(BLK) k_associate(const FuseArgs A, Candidates 
         }
       }
       const float tag = counter > 0 ? -1.0f : -2.0f;
-      cand.pos_conf[r] = make_float4(vPos.x, vPos.y, vPos.z, confidence(x, y, cx, cy, *A.weighting));
+      cand.pos_conf[r] = make_float4(vPos.x, vPos.y, vPos.z, confidence(x, y, cx, cy, weighting));
       cand.nrm_rad[r] = make_float4(nW.x, nW.y, nW.z, getRadius(vPosition_f.z, vNormLocal.z, inv_fx, inv_fy));
       c_col = make_float4(encodeColor(col), 0.f, ftime, tag);
       cand.best[r] = best;
