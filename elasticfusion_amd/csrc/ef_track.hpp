@@ -34,7 +34,8 @@ constexpr int PARTIAL_FLOATS = 2 * SE3_ACCS * SE3_PAIRS > SO3_ACCS * VWARPS ? 2 
 // alternate between two partial regions, and a small synchronisation record (PtSync) sits behind them.
 constexpr int PT_WGS = 128, PT_BLOCK = 512, PT_MAX_ITER = 16, PT_MAX_PIXELS = 8 * VTHREADS, PT_SYNC_FLOATS = 1024;
 // (the fast order's persistent tracker lays its exchange areas over the same allocation: FT_*_OFF in ef_track_fast.inc, 45.8 K floats)
-constexpr int PARTIAL_ALLOC_FLOATS = (2 * PARTIAL_FLOATS + PT_SYNC_FLOATS) > 49152 ? (2 * PARTIAL_FLOATS + PT_SYNC_FLOATS) : 49152;
+// (round 6: + the copies of the reference-order launch's all-to-all areas behind float 49152: FT_G2R_OFF / FT_GAR_OFF, 512 + 64 KB)
+constexpr int PARTIAL_ALLOC_FLOATS = (2 * PARTIAL_FLOATS + PT_SYNC_FLOATS) > 196608 ? (2 * PARTIAL_FLOATS + PT_SYNC_FLOATS) : 196608;
 constexpr int FT_EPOCHS = 64;        // exchange epochs one launch of the persistent tracker may use (<= 10 SO(3) + 2 x 24 iterations)
 
 struct Intr { float fx, fy, cx, cy; };
