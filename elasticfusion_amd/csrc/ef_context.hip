@@ -100,6 +100,13 @@ struct ef_ctx {
   std::vector<int64_t> stamps;
   int tick = 1;
   std::vector<void*> allocs;
+  // denseEnough()'s tally (ElasticFusion.cpp:256-268): taken by the model-map workgroups of the next tracked frame from the predicted image
+  // (eft::ModelMapsArgs::tally_image) instead of one atomic per sample from the prediction's resolve pass
+  // (set at ef_create: up to 1 024 samples — 640 x 480 has 768: the resolve pass 13.5 -> 10.3 us, 2072 -> 2091 frames/s; at 1280 x 960, 3 072
+  // samples, every model-map workgroup reading them all costs more than the atomics, which hide behind that size's 139 MB: 1029 against 1034,
+  // profiles/r08o_*, r08p_*.  -DEF_RESOLVE_TALLY, the A/B build "resolvetally": never)
+  bool tally_by_consumer = false;
+  bool tally_pending = false;
   // timing
   bool timing = false;
   std::vector<StageTimer> timers;
@@ -333,9 +340,10 @@ int do_predict(ef_ctx* c, bool count_dense = true) {
   // (a host-pointer frame: this launch, behind every reader of the frame's landing buffers, tells the host that their ring slot is free again)
   efm::combined_predict(c->cam, c->st->T_cw, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.confidence,
                         c->last_frame_recovery ? 0 : c->tick, c->tick, c->cfg.time_delta, c->zbuf, c->pm, c->fm, c->depth_filtered, c->rgb,
-                        c->cfg.frame_to_frame_rgb != 0, count_dense ? &c->st->dense_count : nullptr, c->stream, nullptr, 0u,
+                        c->cfg.frame_to_frame_rgb != 0, (count_dense && !c->tally_by_consumer) ? &c->st->dense_count : nullptr, c->stream, nullptr, 0u,
                         (count_dense && c->mark_value) ? c->d_consumed : nullptr, c->mark_value, c->rays);
   if (count_dense) c->mark_value = 0;
+  if (count_dense && c->tally_by_consumer) c->tally_pending = true;   // (the next tracked frame's model maps count the samples of this prediction)
   if (c->lost) efm::fill_in(c->cam, c->pm, c->depth_filtered, c->rgb, true, true, c->fm, c->stream);
   return EF_OK;
 }
@@ -797,7 +805,8 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
                                     fold_copies ? c->rgb : nullptr};
       eft::init_icp_model(c->pyr, (const float*)c->pm.vertex, (const float*)c->pm.normal, (const float*)c->fm.vertex,
                           (const float*)c->fm.normal, c->st, 6.0f /* maxDepthRGB, RGBDOdometry.cpp:42 */, s, (const uint8_t*)c->pm.image,
-                          (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, joint_inputs ? &fp : nullptr);
+                          (const uint8_t*)c->fm.image, c->cfg.frame_to_frame_rgb != 0, joint_inputs ? &fp : nullptr, c->tally_pending);
+      c->tally_pending = false;
       if (overlap) {
         eft::build_pyramids_model_side(c->pyr, nullptr, nullptr, false, c->st, s);
         EF_HIP(c, hipStreamWaitEvent(s, c->ev_input_done, 0));
@@ -1083,6 +1092,9 @@ int ctx_init(ef_ctx* c) {
   EF_ALLOC(c, c->traj, (size_t)c->traj_cap * 16);
   // T_wc = identity (ElasticFusion.h: T_wc_curr default) -> publish the float matrices
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(64), 0, s, c->st, (W / 20) * (H / 20), W * H);
+#ifndef EF_RESOLVE_TALLY
+  c->tally_by_consumer = (W / 20) * (H / 20) <= 1024;
+#endif
   efm::build_ray_table(c->cam, c->rays, s);
   const double I16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   eft::pose_injected(c->st, I16, false, 1.0f, false, nullptr, 0, s);

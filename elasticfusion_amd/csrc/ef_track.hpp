@@ -219,7 +219,8 @@ struct FramePreprocess {
 };
 void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
                     const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s, const uint8_t* pred_image_rgba = nullptr,
-                    const uint8_t* fill_image_rgba = nullptr, bool frameToFrameRGB = false, const FramePreprocess* with = nullptr);
+                    const uint8_t* fill_image_rgba = nullptr, bool frameToFrameRGB = false, const FramePreprocess* with = nullptr,
+                    bool tally = false /* take denseEnough()'s tally from pred_image_rgba first (ModelMapsArgs::tally_image) */);
 // the rest of populateRGBDData (RGBDOdometry.cpp:212-244, :275-279) in three independently enqueueable parts, so that
 // the part that only needs the new frame can run on the input stream while the previous frame is still being fused:
 //   model ("last"): Gaussian depth pyramid + intensity pyramid of the predicted (or fill-in) image

@@ -522,7 +522,33 @@ struct ModelMapsArgs {
   const uint8_t* fill_image;
   bool force_fill_image;
   uint8_t* last0;
+  // optional (round 6): denseEnough()'s tally (ElasticFusion.cpp:256-268) taken HERE, by every workgroup for itself, from the predicted image's
+  // (W / 20) x (H / 20) sample texels — instead of one atomicAdd per sample from the prediction's resolve pass: 768 (640 x 480) / 3 072
+  // (1280 x 960) device-scope atomics on ONE word, which the memory side retires one after the other (≈ 12 ns each: 9 / 37 us, the length of
+  // that launch).  Null: TrackState::dense_count stands (a prediction that was not to be counted, the operator tier).
+  const uint8_t* tally_image;
+  unsigned* tally_out;   // TrackState::dense_count: written by the launch's first model-map workgroup for whoever reads it later
 };
+// the workgroup's decision "tracking reads the fill-in maps" (uniform); called by all 256 threads of a model-map workgroup before any of them leaves
+__device__ __forceinline__ bool model_maps_use_fill(const ModelMapsArgs& A, const TrackState* __restrict__ st, bool first_wg) {
+  if (!A.tally_image) return use_fill_in(st);
+  __shared__ unsigned tally_s[4];
+  const int t = (int)(threadIdx.y * blockDim.x + threadIdx.x);
+  const int dc = A.cols / 20, dr = A.rows / 20;
+  unsigned cnt = 0;
+  for (int i = t; i < dc * dr; i += 256) {   // Resize::image: dest (a, b) <- source texel (20 a + 10, 20 b + 10) (k_dense_count, ef_map_kernels.hip)
+    const int b = i / dc, a = i - b * dc;
+    const uchar4 px = ((const uchar4*)A.tally_image)[(20 * b + 10) * A.cols + (20 * a + 10)];
+    cnt += (px.x > 0 && px.y > 0 && px.z > 0) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if ((t & 63) == 0) tally_s[t >> 6] = cnt;
+  __syncthreads();
+  const unsigned total = tally_s[0] + tally_s[1] + tally_s[2] + tally_s[3];
+  if (first_wg && t == 0) *A.tally_out = total;
+  return !((float)total / (float)st->dense_samples > 0.75f);
+}
 // ALL_PLANES: level 0 (copyMaps NaNs x, y and z of an empty texel); the resized levels only get the
 // x-plane NaN that resizeMapKernel / tranformMapsKernel write (quirk Q3: y/z planes keep stale data).
 template <bool ALL_PLANES>
@@ -552,12 +578,11 @@ __device__ __forceinline__ f3 box4(f3 a, f3 b, f3 c, f3 d) {
   return f3{(a.x + b.x + c.x + d.x) / 4, (a.y + b.y + c.y + d.y) / 4, (a.z + b.z + c.z + d.z) / 4};
 }
 // (gx: the lane's pixel column; by: its row of 4 x 4 blocks — k_model_maps takes them from its own grid, k_frame_inputs from its share of a joint one)
-__device__ __forceinline__ void model_maps_lane(const ModelMapsArgs& A, const TrackState* __restrict__ st, int gx, int by) {
+__device__ __forceinline__ void model_maps_lane(const ModelMapsArgs& A, const TrackState* __restrict__ st, int gx, int by, bool fill) {
   const int cols = A.cols, rows = A.rows;
   if (gx >= cols || by * 4 >= rows) return;   // cols is a multiple of 4: a quad is in or out as a whole
   const int j = gx & 3, bx = gx >> 2;
   const bool even = (j & 1) == 0, leftpair = j < 2;
-  const bool fill = use_fill_in(st);
   const float4* __restrict__ vsrc = fill ? A.fill_vertex : A.pred_vertex;
   const float4* __restrict__ nsrc = fill ? A.fill_normal : A.pred_normal;
   const m33 R = m33_load(st->R_wc_f);
@@ -645,7 +670,8 @@ __device__ __forceinline__ void model_maps_lane(const ModelMapsArgs& A, const Tr
   }
 }
 __global__ void __launch_bounds__(256) k_model_maps(const ModelMapsArgs A, const TrackState* __restrict__ st) {
-  model_maps_lane(A, st, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(blockIdx.y * blockDim.y + threadIdx.y));
+  const bool fill = model_maps_use_fill(A, st, blockIdx.x == 0 && blockIdx.y == 0);
+  model_maps_lane(A, st, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(blockIdx.y * blockDim.y + threadIdx.y), fill);
 }
 // ------------------------------------------------------------------------------------------
 // per-pixel Jacobian rows
@@ -3029,13 +3055,15 @@ struct PreArgs {
   int mm_x;             // the model maps' workgroups behind them: mm_x per row (k_model_maps' own grid, row-major)
 };
 __global__ void __launch_bounds__(256) k_frame_inputs(const PreArgs P, const ModelMapsArgs A, const TrackState* __restrict__ st) {
+  // (the model maps' workgroups dispatched IN FRONT of the filter's tiles instead of behind them: measured, 2077 against 2091 frames/s — profiles/r08p_*)
   const int b = (int)blockIdx.x;
   if (b < P.tiles) {   // (uniform per workgroup)
     pre::preprocess_tile<true>(b % P.tiles_x, b / P.tiles_x, P.raw, P.cols, P.rows, P.maxv, P.table, P.filtered, P.metric, P.metric_filtered, P.rgb3,
                                P.next0, P.rgb_keep);
   } else {
     const int m = b - P.tiles, mx = m % P.mm_x, my = m / P.mm_x;
-    model_maps_lane(A, st, mx * 64 + (int)threadIdx.x, my * 4 + (int)threadIdx.y);
+    const bool fill = model_maps_use_fill(A, st, m == 0);
+    model_maps_lane(A, st, mx * 64 + (int)threadIdx.x, my * 4 + (int)threadIdx.y, fill);
   }
 }
 
@@ -3222,9 +3250,11 @@ static inline dim3 model_maps_grid(const Pyramid& p) {
 }
 void init_icp_model(const Pyramid& p, const float* pred_vertex, const float* pred_normal, const float* fill_vertex,
                     const float* fill_normal, const TrackState* st, float maxDepthRGB, hipStream_t s, const uint8_t* pred_image_rgba,
-                    const uint8_t* fill_image_rgba, bool frameToFrameRGB, const FramePreprocess* with) {
+                    const uint8_t* fill_image_rgba, bool frameToFrameRGB, const FramePreprocess* with, bool tally) {
   ModelMapsArgs A{};
   A.pred_image = pred_image_rgba; A.fill_image = fill_image_rgba; A.force_fill_image = frameToFrameRGB;
+  A.tally_image = (tally && pred_image_rgba) ? pred_image_rgba : nullptr;
+  A.tally_out = const_cast<unsigned*>(&st->dense_count);
   A.last0 = pred_image_rgba ? p.lastImage[0] : nullptr;
   A.pred_vertex = (const float4*)pred_vertex; A.pred_normal = (const float4*)pred_normal;
   A.fill_vertex = (const float4*)fill_vertex; A.fill_normal = (const float4*)fill_normal;
