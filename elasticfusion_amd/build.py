@@ -54,6 +54,8 @@ VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_
     "assoc_late": ["-DEF_ASSOC_LATE_LOADS"],                   # A/B: k_associate asks for the filtered depth, the colour and the index-map texels behind its test on the raw depth (rounds 1-5)
     "splat_early": ["-DEF_SPLAT_EARLY_LOADS"],                 # A/B: the surface splat asks for all three streams of a surfel at once (default: colour / time and normal only for stable surfels)
     "resolvetally": ["-DEF_RESOLVE_TALLY"],                    # A/B: denseEnough()'s tally by one atomicAdd per sample from the prediction's resolve pass (rounds 1-5) instead of by the next frame's model-map workgroups
+    "modeone": ["-DEF_FT_MODE_ONE"],                           # A/B: the admission verdict of the persistent launch polled on one word (rounds 4-5) instead of 64 copies
+    "modeone_clocks": ["-DEF_FT_MODE_ONE", "-DEF_STAGE_CLOCKS"],
     "norepl": ["-DEF_FT_REPL=1", "-DEF_FT_REPL_A=1"],          # A/B: one copy of the all-to-all exchange areas of the persistent launch (rounds 4-5) instead of 64 (totals) / 2 (records)
     "norepl_clocks": ["-DEF_FT_REPL=1", "-DEF_FT_REPL_A=1", "-DEF_STAGE_CLOCKS"],
     "lanesweep": ["-DEF_FT_LANE_SWEEP"],                       # A/B: the sweeps of the exchanges with every lane on its own four granules (rounds 4-5) instead of every load instruction on 64 consecutive ones
