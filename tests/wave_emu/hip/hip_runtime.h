@@ -54,6 +54,10 @@ typedef void* hipEvent_t;
 inline void __syncthreads() { std::abort(); }
 inline int __shfl_down(int, int, int) { std::abort(); }
 inline float __shfl_down(float, int, int) { std::abort(); }
+inline unsigned __shfl_down(unsigned, int, int) { std::abort(); }   // (model_maps_use_fill's tally: never taken here, tally_image is null)
+#ifndef __shared__
+#define __shared__ static
+#endif
 inline int atomicAdd(int*, int) { std::abort(); }
 
 // ---- a whole wavefront: 64 host threads that meet at every cross-lane operation (emu::wave) ----
