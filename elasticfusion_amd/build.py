@@ -52,6 +52,7 @@ VARIANTS = {   # python -m elasticfusion_amd.build --variant <name>: libefusion_
     "endwave": ["-DEF_END_ONE_WAVE"],                          # A/B: k_track_ref_end's two tails behind resultRt on one wavefront (round 5) instead of two
     "pre_pertap": ["-DEF_PRE_SCALE_PER_TAP"],                  # A/B: the bilateral filter scales the tile value back at every tap instead of once behind the loop
     "assoc_late": ["-DEF_ASSOC_LATE_LOADS"],                   # A/B: k_associate asks for the filtered depth, the colour and the index-map texels behind its test on the raw depth (rounds 1-5)
+    "resolveall": ["-DEF_RESOLVE_ALL_MAPS"],                   # A/B: the frame's first predictIndices resolves all four index maps (rounds 1-5) instead of the three the association taps
     "splat_early": ["-DEF_SPLAT_EARLY_LOADS"],                 # A/B: the surface splat asks for all three streams of a surfel at once (default: colour / time and normal only for stable surfels)
     "resolvetally": ["-DEF_RESOLVE_TALLY"],                    # A/B: denseEnough()'s tally by one atomicAdd per sample from the prediction's resolve pass (rounds 1-5) instead of by the next frame's model-map workgroups
     "modeone": ["-DEF_FT_MODE_ONE"],                           # A/B: the admission verdict of the persistent launch polled on one word (rounds 4-5) instead of 64 copies

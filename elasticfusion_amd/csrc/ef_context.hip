@@ -907,8 +907,12 @@ int process_frame(ef_ctx* c, const uint8_t* rgb_src, const uint16_t* depth_src, 
     if (!rgbOnly && c->tracking_ok && !c->lost && !c->track_only) {  // ElasticFusion.cpp:536-585
       timer_begin(c, "indexMap");
       const bool sample_splat = c->ktime_every > 0 && (c->tick % c->ktime_every) == 0 && c->probe_splat.start;
+      efm::IndexMaps im_assoc = c->im;   // what the association taps: no colour / time stream (the second predictIndices below writes all four maps)
+#ifndef EF_RESOLVE_ALL_MAPS   // (A/B build "resolveall")
+      im_assoc.color_time = nullptr;
+#endif
       efm::predict_indices(c->cam, c->st->T_cw, c->tick, c->maps[c->cur], &c->st->map_counts[c->cur], c->maxDepthProcessed, c->cfg.time_delta, c->zbuf,
-                           c->im, s, sample_splat ? &c->probe_splat : nullptr);
+                           im_assoc, s, sample_splat ? &c->probe_splat : nullptr);
       timer_end(c, "indexMap");
       timer_begin(c, "Fuse::Data+Update");
       // (the update pass — k_merge — rides on the splat of the second predictIndices: one launch less; with stage timers on it stays a launch of

@@ -361,10 +361,12 @@ __global__ void __launch_bounds__(BLK) k_index_resolve(const Cam cam, const floa
   const int pi = blockIdx.x * blockDim.x + threadIdx.x;
   if (pi >= cam.cols * cam.rows) return;
   const unsigned long long key = zbuf[pi];
+  // (out.color_time null — the frame's FIRST predictIndices, whose only reader is the association: it taps index, vertex + confidence and
+  // normal + radius — : the colour / time stream is neither gathered nor written, a quarter of this launch's bytes)
   if (key == ZBUF_EMPTY) {
     out.index[pi] = 0u;
     out.vert_conf[pi] = make_float4(0, 0, 0, 0);
-    out.color_time[pi] = make_float4(0, 0, 0, 0);
+    if (out.color_time) out.color_time[pi] = make_float4(0, 0, 0, 0);
     out.norm_rad[pi] = make_float4(0, 0, 0, 0);
     return;
   }
@@ -377,7 +379,7 @@ __global__ void __launch_bounds__(BLK) k_index_resolve(const Cam cam, const floa
   const f3 n = normalized(mul(T.R, f3{nr.x, nr.y, nr.z}));
   out.index[pi] = id;
   out.vert_conf[pi] = make_float4(p.x, p.y, p.z, pc.w);
-  out.color_time[pi] = map.col_time[id];
+  if (out.color_time) out.color_time[pi] = map.col_time[id];
   out.norm_rad[pi] = make_float4(n.x, n.y, n.z, nr.w);
 }
 
